@@ -1,0 +1,203 @@
+/*
+ * mhap_hip.h — C ABI of libmhaphip.so, the MI355X (gfx950) MinHash overlap engine.
+ *
+ * This is the drop-in boundary for MHAP's hot path.  The reference (marbl/MHAP, Java)
+ * has no FFI; its only operator seam is the abstract class
+ *   J/impl/AbstractMatchSearch.java:47   (J/ = src/main/java/edu/umd/marbl/mhap/)
+ * with MinHashSearch as the sole implementation.  Per-read JNI calls would serialise
+ * the GPU, so every entry point below is batch-granular.  Each entry point cites the
+ * reference interface it replaces.  INTEGRATION.md shows the JNI stub + the Java
+ * subclass (HipMinHashSearch extends AbstractMatchSearch) a maintainer would add.
+ *
+ * Conventions: C linkage, plain pointers and sizes, no exceptions cross the boundary.
+ * Every call returns 0 on success or a negative MHAP_E_* code; the message is
+ * available from mhap_last_error().  A handle is NOT re-entrant: the caller
+ * serialises calls on one handle (the library overlaps work on its own HIP stream).
+ * There is no CPU fallback: without a usable HIP device mhap_create() fails.
+ */
+#ifndef MHAP_HIP_H
+#define MHAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHAP_OK 0
+#define MHAP_E_INVALID (-1)     /* bad argument / unsupported option (MhapRuntimeException analogue) */
+#define MHAP_E_HIP (-2)         /* HIP runtime error, no device, kernel failure */
+#define MHAP_E_NOMEM (-3)
+#define MHAP_E_STATE (-4)       /* call sequence error (e.g. search before index) */
+
+/* Per-strand sketch status (mirrors the streamer's skip rules). */
+#define MHAP_STRAND_OK 0
+#define MHAP_STRAND_ZERO_NGRAMS 1 /* ZeroNGramsFoundException, J/impl/SequenceSketchStreamer.java:235-238 */
+#define MHAP_STRAND_TOO_SHORT 2   /* L < --min-olap-length,    J/impl/SequenceSketchStreamer.java:129-133 */
+
+/* Flag table of J/main/MhapMain.java:67-125 that reaches the hot path. */
+typedef struct mhap_params {
+  int32_t kmer_size;           /* -k                      (16)   MhapMain.java:75,107  */
+  int32_t num_hashes;          /* --num-hashes            (512)  :87,108               */
+  int32_t ordered_kmer_size;   /* --ordered-kmer-size     (12)   :89,116               */
+  int32_t ordered_sketch_size; /* --ordered-sketch-size   (1536) :91,117               */
+  int32_t num_min_matches;     /* --num-min-matches       (3)    :83,112               */
+  int32_t min_store_length;    /* --min-store-length      (0)    :79,118               */
+  int32_t min_olap_length;     /* --min-olap-length       (116)  :81,119               */
+  int32_t device;              /* HIP device ordinal; -1 = current device              */
+  double threshold;            /* --threshold             (0.78) :67,109               */
+  double max_shift;            /* --max-shift             (0.2)  :77,111               */
+  double repeat_weight;        /* --repeat-weight         (0.9)  :69,114               */
+} mhap_params;
+
+/* One overlap = the fields of J/impl/MatchResult.java:46-65 (before text formatting). */
+typedef struct mhap_record {
+  int64_t from_id, to_id;  /* SequenceId.getHeaderId()  */
+  double score;            /* OverlapInfo.score (identity); the text column is 1-min(score,1) */
+  double raw;              /* OverlapInfo.rawScore = number of valid shared k-mers */
+  int32_t a1, a2, alen;    /* query interval + full length (fromLength)       */
+  int32_t b1, b2, blen;    /* match interval (already flipped if to_rc) + toLength */
+  int32_t to_rc;           /* 0 fwd / 1 reverse-complement entry              */
+  int32_t pad;
+} mhap_record;
+
+/* Counters behind MhapMain.outputFinalStat (J/main/MhapMain.java:572-590). */
+typedef struct mhap_stats {
+  int64_t strands_indexed;        /* MinHashSearch.size()                        */
+  int64_t queries_searched;       /* getNumberSequencesSearched()                */
+  int64_t candidates_compared;    /* getNumberSequencesFullyCompared()           */
+  int64_t matches_found;          /* getMatchesProcessed()                       */
+  int64_t slot_compares;          /* brute-force slot comparisons performed      */
+} mhap_stats;
+
+/* Per-kernel HIP-event timings accumulated on the handle's stream (for bench/roofline). */
+#define MHAP_K_HASH 0      /* k-mer murmur3_x64_128 + murmur3_x86_32            */
+#define MHAP_K_DEDUP 1     /* per-strand k-mer multiplicity (tf weight)          */
+#define MHAP_K_MINHASH 2   /* weighted xorshift MinHash                          */
+#define MHAP_K_ORDERED 3   /* bottom-S select + sort                             */
+#define MHAP_K_CANDIDATE 4 /* all-pairs slot-equality count                      */
+#define MHAP_K_OVERLAP 5   /* second-stage getOverlapInfo                        */
+#define MHAP_K_COUNT 6
+typedef struct mhap_kernel_times {
+  double ms[MHAP_K_COUNT];      /* summed kernel time, milliseconds */
+  int64_t launches[MHAP_K_COUNT];
+} mhap_kernel_times;
+
+typedef struct mhap_handle mhap_handle;
+
+/* Record sink: called from the calling thread, one batch at a time; `recs` is owned by
+ * the library and valid only during the call.  Replaces AbstractMatchSearch.outputResults
+ * (J/impl/AbstractMatchSearch.java:316-338).  Return non-zero to abort the search. */
+typedef int (*mhap_record_sink)(const mhap_record* recs, int64_t n, void* user);
+
+/* Replaces `new MinHashSearch(...)` argument plumbing (J/impl/MinHashSearch.java:63-98). */
+int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t errcap);
+void mhap_destroy(mhap_handle* h);
+const char* mhap_last_error(const mhap_handle* h);
+void mhap_default_params(mhap_params* p);
+
+/* Host-built repeat filter = J/sketch/FrequencyCounts.java:63-229 after parsing.
+ * hashes[i] = murmur3_x64_128 h1 of the (canonicalised per --no-rc) k-mer, fractions[i] its
+ * column-2 value; entries with fraction < filter_cutoff are dropped here (:176-184).
+ * offset = repeat_weight if 0<=rw<1 else 0 (MhapMain.java:346-350); range = --repeat-idf-scale.
+ * Only --supress-noise 0 is supported.  n == 0 clears the filter. */
+int mhap_set_filter(mhap_handle* h, const int64_t* hashes, const double* fractions, int64_t n,
+                    double filter_cutoff, double offset, double range, int no_tf);
+
+/* Sketch `n` reads (both strands) and append them to the index.  Replaces
+ * SequenceSketchStreamer.enqueue/getSketch (J/impl/SequenceSketchStreamer.java:123-177,262-266)
+ * + MinHashSearch.addSequence (J/impl/MinHashSearch.java:100-147).
+ * bases: concatenated upper-cased sequence bytes (one byte per Java char);
+ * offsets[i]/lengths[i] locate read i; ids[i] = SequenceId.getHeaderId (1-based FASTA order).
+ * Every read takes two entries (fwd = 2*j, rc = 2*j+1, j = running read count); entries that
+ * the reference would skip are kept as non-matchable placeholders (see mhap_index_status). */
+int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths,
+                         const int64_t* ids, int64_t n);
+
+/* Sketch only (no index change); outputs to caller-allocated HOST arrays, any may be NULL:
+ * minhash[2n][max(1,H)], ordered[2n][S][2] (hash,pos), ordered_size[2n], status[2n].
+ * Strand order: 2*i = forward, 2*i+1 = reverse complement.  Used by parity tests and the
+ * `.dat` writer (J/impl/SequenceSketch.java:123-148). */
+int mhap_sketch_batch(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n,
+                      int32_t* minhash, int32_t* ordered, int32_t* ordered_size, uint8_t* status);
+
+/* Ingest precomputed sketches (from `.dat`, J/impl/SequenceSketch.java:61-96): `m` entries, host arrays.
+ * is_fwd[e], seq_length[e] = full base length, ordered_seqlen[e] = L-k2+1 as stored in the file. */
+int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* is_fwd, const int32_t* seq_length,
+                            const int32_t* minhash, const int32_t* ordered, const int32_t* ordered_size,
+                            const int32_t* ordered_seqlen, int64_t m);
+
+/* Index introspection: number of entries (incl. placeholders); copy-out of the tables (any NULL). */
+int mhap_index_size(mhap_handle* h, int64_t* entries);
+int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids, uint8_t* is_fwd, int32_t* seq_length,
+                      int32_t* minhash, int32_t* ordered, int32_t* ordered_size, int32_t* ordered_seqlen,
+                      uint8_t* status);
+int mhap_index_clear(mhap_handle* h);
+
+/* Multi-GPU plumbing (one process per GPU): the per-rank shard tables live in device memory
+ * owned by the CALLER (e.g. torch tensors that RCCL all-gathers over xGMI).
+ *  - mhap_sketch_reads_device: sketch n reads into caller device buffers
+ *      d_minhash int32[2n][Hrow], d_ordered int32[2n][S][2], d_meta int32[2n][4] =
+ *      {ordered_size, ordered_seqlen, seq_length, status}; Hrow = max(1,H).
+ *  - mhap_index_set_device: adopt (no copy) gathered tables of `m` entries as the index;
+ *      ids/is_fwd are host arrays.  The buffers must outlive the handle's use of them. */
+int mhap_sketch_reads_device(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths,
+                             int64_t n, void* d_minhash, void* d_ordered, void* d_meta);
+int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_fwd, void* d_minhash,
+                          void* d_ordered, void* d_meta, int64_t m);
+
+/* Self-overlap: every forward entry in [q_first, q_first+q_count) is searched against the whole
+ * index with toSelf=true.  Replaces AbstractMatchSearch.findMatches()
+ * (J/impl/AbstractMatchSearch.java:121-199) + MinHashSearch.findMatches(sketch,true)
+ * (J/impl/MinHashSearch.java:150-251).  q_count < 0 means "to the end".  Entry indices, not ids. */
+int mhap_find_matches_self(mhap_handle* h, int64_t q_first, int64_t q_count, mhap_record_sink sink, void* user);
+
+/* Index-vs-stream (-q mode, toSelf=false): sketch the `n` query reads (forward only,
+ * J/impl/AbstractMatchSearch.java:203-285) and search them against the index. */
+int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths,
+                            const int64_t* ids, int64_t n, mhap_record_sink sink, void* user);
+
+int mhap_get_stats(mhap_handle* h, mhap_stats* out);
+int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out);
+int mhap_reset_kernel_times(mhap_handle* h);
+/* Use an externally created hipStream_t (e.g. torch's current stream); NULL = library stream. */
+int mhap_set_stream(mhap_handle* h, void* hip_stream);
+int mhap_synchronize(mhap_handle* h);
+
+/* ---- host-side helpers (no GPU): the reference's IO conventions --------------------------- */
+
+/* Java String.format("%s %s %.6f %.6f %d %d %d %d %d %d %d %d") of MatchResult.toString
+ * (J/impl/MatchResult.java:98-113) with numeric headers; returns bytes written (no NUL counted). */
+int mhap_format_record(const mhap_record* r, char* out, size_t cap);
+
+/* FASTA ingest with FastaData semantics (J/impl/FastaData.java:125-204): lines concatenated,
+ * upper-cased, ids = 1-based running count of non-empty records (+id_offset).  The returned
+ * object owns the arrays; free with mhap_fasta_free. */
+typedef struct mhap_fasta {
+  char* bases; int64_t* offsets; int32_t* lengths; int64_t* ids; int64_t n; int64_t total_bases;
+} mhap_fasta;
+int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* err, size_t errcap);
+void mhap_fasta_free(mhap_fasta* f);
+
+/* Deterministic synthetic PacBio-style reads: xoshiro256** seeded by
+ * splitmix64(seed), random genome of n*len/coverage bp, reads at uniform positions/strands with
+ * i.i.d. errors (ins:del:sub = 0.1188:0.0183:0.0129 scaled to error_rate), exactly `len` bases each.
+ * bases must hold n*len bytes. */
+int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, char* bases);
+
+/* murmur3_x64_128(seed 0).h1 of one k-mer line of a `-f` filter file, canonicalised when do_rc != 0
+ * (HashUtils.computeSequenceHashesLong(str, len, 0, doRC)[0], J/sketch/FrequencyCounts.java:169). */
+int mhap_hash_kmer(const char* kmer, int32_t len, int32_t do_rc, int64_t* out);
+
+/* ---- test hooks: the kernels' __host__ __device__ arithmetic executed on the host (never used by the
+ * product path; lets a GPU-less container check the hash and second-stage lane logic) --------------------- */
+int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t k2, int64_t* out64, int32_t* out32);
+/* out8 = {empty, valid(rawScore), a1, a2, b1, b2, inter, k} */
+int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const int32_t* B, int32_t nB, int32_t lenB,
+                               double max_shift, int32_t stride, int32_t* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHAP_HIP_H */

@@ -1,0 +1,407 @@
+"""Host-side mirror of MHAP's operator interface over the libmhaphip C ABI (include/mhap_hip.h).
+
+Names follow the reference (J/ = src/main/java/edu/umd/marbl/mhap/):
+  MinHashSearch   <- J/impl/MinHashSearch.java + J/impl/AbstractMatchSearch.java (addData/findMatches)
+  FastaData       <- J/impl/FastaData.java
+  FrequencyCounts <- J/sketch/FrequencyCounts.java (file parsing; the table is applied on the GPU)
+  MatchResult     <- J/impl/MatchResult.java (record + text format)
+Error behaviour: every failure raises MhapError (the MhapRuntimeException analogue).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libmhaphip.so")
+_lib = None
+
+KERNEL_NAMES = ["hash_kmers", "kmer_weight", "minhash", "ordered", "candidate", "overlap"]
+
+
+class MhapError(RuntimeError):
+    """MhapRuntimeException analogue (J/impl/MhapRuntimeException.java:32)."""
+
+
+class _Params(C.Structure):
+    _fields_ = [("kmer_size", C.c_int32), ("num_hashes", C.c_int32), ("ordered_kmer_size", C.c_int32),
+                ("ordered_sketch_size", C.c_int32), ("num_min_matches", C.c_int32), ("min_store_length", C.c_int32),
+                ("min_olap_length", C.c_int32), ("device", C.c_int32), ("threshold", C.c_double),
+                ("max_shift", C.c_double), ("repeat_weight", C.c_double)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("strands_indexed", C.c_int64), ("queries_searched", C.c_int64), ("candidates_compared", C.c_int64),
+                ("matches_found", C.c_int64), ("slot_compares", C.c_int64)]
+
+
+class _KTimes(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6)]
+
+
+class _Fasta(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p), ("ids", C.c_void_p),
+                ("n", C.c_int64), ("total_bases", C.c_int64)]
+
+
+RECORD_DTYPE = np.dtype([("from_id", "<i8"), ("to_id", "<i8"), ("score", "<f8"), ("raw", "<f8"), ("a1", "<i4"),
+                         ("a2", "<i4"), ("alen", "<i4"), ("b1", "<i4"), ("b2", "<i4"), ("blen", "<i4"),
+                         ("to_rc", "<i4"), ("pad", "<i4")])
+_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+
+# every symbol include/mhap_hip.h declares
+EXPORTED_SYMBOLS = [
+    "mhap_create", "mhap_destroy", "mhap_last_error", "mhap_default_params", "mhap_set_filter", "mhap_index_add_reads",
+    "mhap_sketch_batch", "mhap_index_add_sketches", "mhap_index_size", "mhap_index_export", "mhap_index_clear",
+    "mhap_sketch_reads_device", "mhap_index_set_device", "mhap_find_matches_self", "mhap_find_matches_reads",
+    "mhap_get_stats", "mhap_get_kernel_times", "mhap_reset_kernel_times", "mhap_set_stream", "mhap_synchronize",
+    "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
+    "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane",
+]
+
+
+def load_library(build_if_missing=True):
+    """Load libmhaphip.so (building it in-tree with hipcc if absent). Fails loudly: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        if not build_if_missing:
+            raise MhapError(f"{_LIB_PATH} is missing: run `python -m mhap_amd.build`")
+        from . import build as _b
+        _b.build()
+    try:
+        lib = C.CDLL(_LIB_PATH)
+    except OSError as e:
+        raise MhapError(f"cannot load the HIP extension {_LIB_PATH}: {e}") from e
+    lib.mhap_last_error.restype = C.c_char_p
+    lib.mhap_last_error.argtypes = [C.c_void_p]
+    lib.mhap_destroy.restype = None
+    lib.mhap_destroy.argtypes = [C.c_void_p]
+    lib.mhap_fasta_free.restype = None
+    lib.mhap_default_params.restype = None
+    for name in EXPORTED_SYMBOLS:
+        getattr(lib, name)  # AttributeError here = header/library mismatch
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class MhapParams:
+    """Flag table of J/main/MhapMain.java:67-125 (defaults identical)."""
+
+    def __init__(self, kmer_size=16, num_hashes=512, ordered_kmer_size=12, ordered_sketch_size=1536, num_min_matches=3,
+                 min_store_length=0, min_olap_length=116, threshold=0.78, max_shift=0.2, repeat_weight=0.9, device=-1):
+        self.kmer_size = kmer_size
+        self.num_hashes = num_hashes
+        self.ordered_kmer_size = ordered_kmer_size
+        self.ordered_sketch_size = ordered_sketch_size
+        self.num_min_matches = num_min_matches
+        self.min_store_length = min_store_length
+        self.min_olap_length = min_olap_length
+        self.threshold = threshold
+        self.max_shift = max_shift
+        self.repeat_weight = repeat_weight
+        self.device = device
+
+    def _c(self):
+        return _Params(self.kmer_size, self.num_hashes, self.ordered_kmer_size, self.ordered_sketch_size,
+                       self.num_min_matches, self.min_store_length, self.min_olap_length, self.device,
+                       self.threshold, self.max_shift, self.repeat_weight)
+
+
+class FastaData:
+    """Reads (upper-cased, concatenated) + 1-based ids, as J/impl/FastaData.java:125-204 produces them."""
+
+    def __init__(self, bases, offsets, lengths, ids):
+        self.bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        self.lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+        self.ids = np.ascontiguousarray(ids, dtype=np.int64)
+
+    def __len__(self):
+        return int(self.lengths.shape[0])
+
+    @classmethod
+    def from_file(cls, path, id_offset=0):
+        lib = load_library()
+        f = _Fasta()
+        err = C.create_string_buffer(512)
+        rc = lib.mhap_fasta_read(path.encode(), C.c_int64(id_offset), C.byref(f), err, C.c_size_t(512))
+        if rc != 0:
+            raise MhapError(err.value.decode() or f"mhap_fasta_read failed ({rc})")
+        try:
+            n, tb = f.n, f.total_bases
+            bases = np.ctypeslib.as_array(C.cast(f.bases, C.POINTER(C.c_uint8)), shape=(max(tb, 1),))[:tb].copy()
+            offsets = np.ctypeslib.as_array(C.cast(f.offsets, C.POINTER(C.c_int64)), shape=(max(n, 1),))[:n].copy()
+            lengths = np.ctypeslib.as_array(C.cast(f.lengths, C.POINTER(C.c_int32)), shape=(max(n, 1),))[:n].copy()
+            ids = np.ctypeslib.as_array(C.cast(f.ids, C.POINTER(C.c_int64)), shape=(max(n, 1),))[:n].copy()
+        finally:
+            lib.mhap_fasta_free(C.byref(f))
+        return cls(bases, offsets, lengths, ids)
+
+    @classmethod
+    def from_strings(cls, seqs, id_offset=0):
+        """Ids count only non-empty records, 1-based (FastaData.java:180-181)."""
+        seqs = [s.upper() for s in seqs if len(s) > 0]
+        lengths = np.array([len(s) for s in seqs], dtype=np.int32)
+        offsets = np.zeros(len(seqs), dtype=np.int64)
+        if len(seqs):
+            offsets[1:] = np.cumsum(lengths[:-1], dtype=np.int64)
+        bases = np.frombuffer("".join(seqs).encode("latin-1"), dtype=np.uint8).copy() if seqs else np.zeros(0, np.uint8)
+        ids = np.arange(1, len(seqs) + 1, dtype=np.int64) + id_offset
+        return cls(bases, offsets, lengths, ids)
+
+    def sequence(self, i):
+        o, n = int(self.offsets[i]), int(self.lengths[i])
+        return self.bases[o:o + n].tobytes().decode("latin-1")
+
+    def subset(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        lengths = self.lengths[idx]
+        offsets = np.zeros(len(idx), dtype=np.int64)
+        if len(idx):
+            offsets[1:] = np.cumsum(lengths[:-1], dtype=np.int64)
+        bases = np.empty(int(lengths.sum()), dtype=np.uint8)
+        for j, i in enumerate(idx):
+            bases[offsets[j]:offsets[j] + lengths[j]] = self.bases[self.offsets[i]:self.offsets[i] + self.lengths[i]]
+        return FastaData(bases, offsets, lengths, self.ids[idx])
+
+
+def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15):
+    """Deterministic synthetic PacBio-style reads as a FastaData."""
+    lib = load_library()
+    bases = np.empty(n * length, dtype=np.uint8)
+    rc = lib.mhap_synth_reads(C.c_uint64(seed), C.c_int64(n), C.c_int32(length), C.c_double(coverage),
+                              C.c_double(error_rate), _ptr(bases))
+    if rc != 0:
+        raise MhapError(f"mhap_synth_reads failed ({rc})")
+    offsets = np.arange(n, dtype=np.int64) * length
+    lengths = np.full(n, length, dtype=np.int32)
+    return FastaData(bases, offsets, lengths, np.arange(1, n + 1, dtype=np.int64))
+
+
+class FrequencyCounts:
+    """Parsed `-f` filter file (J/sketch/FrequencyCounts.java:63-229): k-mer hash -> fraction."""
+
+    def __init__(self, hashes, fractions, filter_cutoff=1.0e-5, offset=0.0, repeat_idf_scale=3.0, no_tf=False):
+        self.hashes = np.ascontiguousarray(hashes, dtype=np.int64)
+        self.fractions = np.ascontiguousarray(fractions, dtype=np.float64)
+        self.filter_cutoff = filter_cutoff
+        self.offset = offset
+        self.range = repeat_idf_scale
+        self.no_tf = no_tf
+
+    @classmethod
+    def from_file(cls, path, filter_cutoff=1.0e-5, repeat_weight=0.9, repeat_idf_scale=3.0, no_tf=False, do_rc=True,
+                  supress_noise=0):
+        if supress_noise != 0:
+            raise MhapError("--supress-noise 1|2 (Guava BloomFilter whitelist) is not supported")
+        lib = load_library()
+        offset = repeat_weight if 0.0 <= repeat_weight < 1.0 else 0.0   # MhapMain.java:346-350
+        hs, fr = [], []
+        out = C.c_int64()
+        with open(path, "r") as fh:
+            fh.readline()  # "sizeBloom sizeRepeat" (FrequencyCounts.java:102-104)
+            for line in fh:
+                parts = line.split(None, 2)
+                if len(parts) < 2:
+                    continue
+                kmer = parts[0].encode("latin-1")
+                if lib.mhap_hash_kmer(kmer, C.c_int32(len(kmer)), C.c_int32(1 if do_rc else 0), C.byref(out)) != 0:
+                    raise MhapError("cannot hash filter k-mer " + parts[0])
+                hs.append(out.value)
+                fr.append(float(parts[1]))
+        return cls(np.array(hs, dtype=np.int64), np.array(fr, dtype=np.float64), filter_cutoff, offset,
+                   repeat_idf_scale, no_tf)
+
+
+class MatchResult:
+    """One overlap record (J/impl/MatchResult.java)."""
+    __slots__ = ("from_id", "to_id", "score", "raw", "a1", "a2", "alen", "b1", "b2", "blen", "to_rc")
+
+    def __init__(self, rec):
+        for k in self.__slots__:
+            setattr(self, k, rec[k].item() if hasattr(rec[k], "item") else rec[k])
+
+    def __str__(self):
+        return format_record(self)
+
+
+def format_record(rec):
+    """MatchResult.toString (J/impl/MatchResult.java:98-113) through the library's Java-compatible formatter."""
+    lib = load_library()
+    arr = np.zeros(1, dtype=RECORD_DTYPE)
+    for k in RECORD_DTYPE.names:
+        if k != "pad":
+            arr[0][k] = rec[k] if not isinstance(rec, MatchResult) else getattr(rec, k)
+    buf = C.create_string_buffer(256)
+    n = lib.mhap_format_record(_ptr(arr), buf, C.c_size_t(256))
+    if n < 0:
+        raise MhapError("mhap_format_record failed")
+    return buf.value.decode()
+
+
+def records_to_lines(records):
+    lib = load_library()
+    records = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+    buf = C.create_string_buffer(256)
+    out = []
+    base = records.ctypes.data
+    for i in range(records.shape[0]):
+        lib.mhap_format_record(C.c_void_p(base + i * RECORD_DTYPE.itemsize), buf, C.c_size_t(256))
+        out.append(buf.value.decode())
+    return out
+
+
+class MinHashSearch:
+    """GPU counterpart of J/impl/MinHashSearch.java (+ the drivers of AbstractMatchSearch.java).
+
+    add_data(fasta)            ~ new MinHashSearch(streamer, ...) / addData   (sketch fwd+rc, index)
+    find_matches()             ~ AbstractMatchSearch.findMatches()            (self, toSelf=true)
+    find_matches_stream(fasta) ~ AbstractMatchSearch.findMatches(streamer)    (-q, toSelf=false)
+    """
+
+    def __init__(self, params=None, kmer_filter=None):
+        self._lib = load_library()
+        self.params = params or MhapParams()
+        self._h = C.c_void_p()
+        err = C.create_string_buffer(512)
+        p = self.params._c()
+        rc = self._lib.mhap_create(C.byref(p), C.byref(self._h), err, C.c_size_t(512))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise MhapError(err.value.decode() or f"mhap_create failed ({rc})")
+        if kmer_filter is not None:
+            self.set_filter(kmer_filter)
+
+    # -- lifetime -------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.mhap_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MhapError(f"{self._lib.mhap_last_error(self._h).decode()} (code {rc})")
+
+    # -- configuration --------------------------------------------------------------------------
+    def set_filter(self, fc):
+        self._chk(self._lib.mhap_set_filter(self._h, _ptr(fc.hashes), _ptr(fc.fractions), C.c_int64(len(fc.hashes)),
+                                            C.c_double(fc.filter_cutoff), C.c_double(fc.offset), C.c_double(fc.range),
+                                            C.c_int(1 if fc.no_tf else 0)))
+
+    def set_stream(self, hip_stream_ptr):
+        self._chk(self._lib.mhap_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    # -- index ----------------------------------------------------------------------------------
+    def add_data(self, fasta):
+        self._chk(self._lib.mhap_index_add_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
+                                                 _ptr(fasta.ids), C.c_int64(len(fasta))))
+
+    def size(self):
+        n = C.c_int64()
+        self._chk(self._lib.mhap_index_size(self._h, C.byref(n)))
+        return n.value
+
+    def clear(self):
+        self._chk(self._lib.mhap_index_clear(self._h))
+
+    def sketch(self, fasta):
+        """SequenceSketchStreamer.getSketch for a batch: returns dict of host arrays (both strands)."""
+        n = len(fasta)
+        H, S = max(1, self.params.num_hashes), self.params.ordered_sketch_size
+        mh = np.zeros((2 * n, H), dtype=np.int32)
+        od = np.zeros((2 * n, S, 2), dtype=np.int32)
+        osz = np.zeros(2 * n, dtype=np.int32)
+        st = np.zeros(2 * n, dtype=np.uint8)
+        self._chk(self._lib.mhap_sketch_batch(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
+                                              C.c_int64(n), _ptr(mh), _ptr(od), _ptr(osz), _ptr(st)))
+        return {"minhash": mh, "ordered": od, "ordered_size": osz, "status": st}
+
+    def export(self, first=0, count=None):
+        total = self.size()
+        count = total - first if count is None else count
+        H, S = max(1, self.params.num_hashes), self.params.ordered_sketch_size
+        out = {"ids": np.zeros(count, np.int64), "is_fwd": np.zeros(count, np.uint8), "seq_length": np.zeros(count, np.int32),
+               "minhash": np.zeros((count, H), np.int32), "ordered": np.zeros((count, S, 2), np.int32),
+               "ordered_size": np.zeros(count, np.int32), "ordered_seqlen": np.zeros(count, np.int32),
+               "status": np.zeros(count, np.uint8)}
+        self._chk(self._lib.mhap_index_export(self._h, C.c_int64(first), C.c_int64(count), _ptr(out["ids"]), _ptr(out["is_fwd"]),
+                                              _ptr(out["seq_length"]), _ptr(out["minhash"]), _ptr(out["ordered"]),
+                                              _ptr(out["ordered_size"]), _ptr(out["ordered_seqlen"]), _ptr(out["status"])))
+        return out
+
+    def add_sketches(self, sk):
+        m = len(sk["ids"])
+        a = {k: np.ascontiguousarray(v) for k, v in sk.items()}
+        self._chk(self._lib.mhap_index_add_sketches(self._h, _ptr(a["ids"].astype(np.int64)), _ptr(a["is_fwd"].astype(np.uint8)),
+                                                    _ptr(a["seq_length"].astype(np.int32)), _ptr(a["minhash"].astype(np.int32)),
+                                                    _ptr(a["ordered"].astype(np.int32)), _ptr(a["ordered_size"].astype(np.int32)),
+                                                    _ptr(a["ordered_seqlen"].astype(np.int32)), C.c_int64(m)))
+
+    # -- multi-GPU plumbing (device pointers owned by the caller, e.g. torch tensors) -----------
+    def sketch_reads_device(self, fasta, d_minhash_ptr, d_ordered_ptr, d_meta_ptr):
+        self._chk(self._lib.mhap_sketch_reads_device(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
+                                                     C.c_int64(len(fasta)), C.c_void_p(d_minhash_ptr), C.c_void_p(d_ordered_ptr),
+                                                     C.c_void_p(d_meta_ptr)))
+
+    def set_device_index(self, ids, is_fwd, d_minhash_ptr, d_ordered_ptr, d_meta_ptr):
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        is_fwd = np.ascontiguousarray(is_fwd, dtype=np.uint8)
+        self._chk(self._lib.mhap_index_set_device(self._h, _ptr(ids), _ptr(is_fwd), C.c_void_p(d_minhash_ptr),
+                                                  C.c_void_p(d_ordered_ptr), C.c_void_p(d_meta_ptr), C.c_int64(len(ids))))
+
+    # -- search ---------------------------------------------------------------------------------
+    def _collect(self, call):
+        chunks = []
+
+        def sink(recs, n, user):
+            a = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(n * RECORD_DTYPE.itemsize,))
+            chunks.append(a.view(RECORD_DTYPE).copy())
+            return 0
+
+        cb = _SINK(sink)
+        self._chk(call(cb))
+        return np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+
+    def find_matches(self, q_first=0, q_count=-1):
+        """Self overlap of forward entries [q_first, q_first+q_count) against the whole index."""
+        return self._collect(lambda cb: self._lib.mhap_find_matches_self(self._h, C.c_int64(q_first), C.c_int64(q_count), cb, None))
+
+    def find_matches_stream(self, fasta):
+        return self._collect(lambda cb: self._lib.mhap_find_matches_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets),
+                                                                          _ptr(fasta.lengths), _ptr(fasta.ids),
+                                                                          C.c_int64(len(fasta)), cb, None))
+
+    # -- counters -------------------------------------------------------------------------------
+    def stats(self):
+        s = _Stats()
+        self._chk(self._lib.mhap_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    def kernel_times(self):
+        t = _KTimes()
+        self._chk(self._lib.mhap_get_kernel_times(self._h, C.byref(t)))
+        return {KERNEL_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(6)}
+
+    def reset_kernel_times(self):
+        self._chk(self._lib.mhap_reset_kernel_times(self._h))
+
+    def synchronize(self):
+        self._chk(self._lib.mhap_synchronize(self._h))

@@ -1,0 +1,203 @@
+// host_util.cpp — host-side helpers of libmhaphip.so that need no GPU: the reference's IO conventions
+// (FASTA ingest, overlap-record text format) and the deterministic synthetic read generator.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mhap_hip.h"
+
+namespace {
+
+// ---- Java Formatter "%.6f": shortest round-trip decimal digits, then HALF_UP at 6 places -------
+// (JDK 8 java.util.Formatter -> sun.misc.FormattedFloatingDecimal; J/impl/MatchResult.java:100).
+int fmt6(double v, char* out, size_t cap) {
+  if (std::isnan(v)) return snprintf(out, cap, "NaN");
+  if (std::isinf(v)) return snprintf(out, cap, v > 0 ? "Infinity" : "-Infinity");
+  const bool neg = std::signbit(v);
+  const double a = std::fabs(v);
+  // shortest digit string d1.d2...dn x 10^e that parses back to a
+  char sci[40];
+  int nd = 1;
+  for (; nd <= 17; nd++) {
+    snprintf(sci, sizeof sci, "%.*e", nd - 1, a);
+    if (strtod(sci, nullptr) == a) break;
+  }
+  char digs[24];
+  int n = 0;
+  const char* epos = strchr(sci, 'e');
+  for (const char* p = sci; p < epos; p++) if (*p != '.') digs[n++] = *p;
+  const int e10 = atoi(epos + 1);
+  // decimal expansion: integer part has (e10+1) digits when e10 >= 0
+  std::string ip, fp;
+  for (int i = 0; i <= e10; i++) ip.push_back(i < n ? digs[i] : '0');
+  if (ip.empty()) ip = "0";
+  for (int i = -1; i > e10; i--) fp.push_back('0');          // leading zeros of a pure fraction
+  for (int i = std::max(0, e10 + 1); i < n; i++) fp.push_back(digs[i]);
+  bool carry = false;
+  if (fp.size() > 6) { carry = fp[6] >= '5'; fp.resize(6); }   // HALF_UP on the decimal digits
+  while (fp.size() < 6) fp.push_back('0');
+  if (carry) {
+    std::string all = ip + fp;
+    int i = (int)all.size() - 1;
+    for (; i >= 0; i--) { if (all[i] == '9') all[i] = '0'; else { all[i]++; break; } }
+    if (i < 0) all.insert(all.begin(), '1');
+    ip = all.substr(0, all.size() - 6);
+    fp = all.substr(all.size() - 6);
+  }
+  return snprintf(out, cap, "%s%s.%s", neg ? "-" : "", ip.c_str(), fp.c_str());
+}
+
+// ---- deterministic PRNG -------------------------------------------------------------------------
+struct SplitMix64 { uint64_t s; uint64_t next() { uint64_t z = (s += 0x9e3779b97f4a7c15ULL); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); } };
+struct Xoshiro256ss {
+  uint64_t s[4];
+  explicit Xoshiro256ss(uint64_t seed) { SplitMix64 sm{seed}; for (auto& x : s) x = sm.next(); }
+  static uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+  uint64_t next() {
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3]; s[2] ^= t; s[3] = rotl(s[3], 45);
+    return r;
+  }
+  double unit() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  uint64_t below(uint64_t n) { return (uint64_t)(unit() * (double)n); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int mhap_format_record(const mhap_record* r, char* out, size_t cap) {
+  if (!r || !out || cap == 0) return -1;
+  const double score = r->score > 1.0 ? 1.0 : r->score;            // MatchResult.java:61-64
+  char e[48], s[48];
+  fmt6(1.0 - score, e, sizeof e);
+  fmt6(r->raw, s, sizeof s);
+  return snprintf(out, cap, "%lld %lld %s %s %d %d %d %d %d %d %d %d", (long long)r->from_id, (long long)r->to_id, e, s, 0, r->a1, r->a2,
+                  r->alen, r->to_rc ? 1 : 0, r->b1, r->b2, r->blen);   // MatchResult.java:98-113
+}
+
+// FastaData.enqueueNextSequenceInFile (J/impl/FastaData.java:125-204).  Deviation (documented in DESIGN.md):
+// an empty record is skipped instead of stopping a worker thread (reference behaviour is thread-count dependent).
+int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* err, size_t errcap) {
+  auto seterr = [&](const std::string& m) { if (err && errcap) snprintf(err, errcap, "%s", m.c_str()); };
+  if (!path || !out) { seterr("null argument"); return MHAP_E_INVALID; }
+  memset(out, 0, sizeof *out);
+  FILE* f = fopen(path, "rb");
+  if (!f) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
+  std::string data;
+  {
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+    fclose(f);
+  }
+  std::string bases;
+  bases.reserve(data.size());
+  std::vector<int64_t> offs, ids;
+  std::vector<int32_t> lens;
+  size_t pos = 0;
+  const size_t N = data.size();
+  int64_t count = 0;
+  bool have_record = false;
+  int64_t rec_start = 0;
+  bool first_line = true;
+  auto close_record = [&]() {
+    if (!have_record) return;
+    const int64_t len = (int64_t)bases.size() - rec_start;
+    if (len > 0) { count++; offs.push_back(rec_start); lens.push_back((int32_t)len); ids.push_back(count + id_offset); }   // :180-181
+    have_record = false;
+  };
+  while (pos < N) {
+    // BufferedReader.readLine: a line ends at \n, \r or \r\n
+    size_t e = pos;
+    while (e < N && data[e] != '\n' && data[e] != '\r') e++;
+    const char* line = data.data() + pos;
+    const size_t ll = e - pos;
+    if (ll > 0 && line[0] == '>') {
+      close_record();
+      have_record = true;
+      rec_start = (int64_t)bases.size();
+    } else {
+      if (first_line || !have_record) { seterr("Next sequence does not start with >. Invalid format."); return MHAP_E_INVALID; }   // :150-151
+      for (size_t i = 0; i < ll; i++) {
+        char c = line[i];
+        if (c >= 'a' && c <= 'z') c = (char)(c - 'a' + 'A');       // toUpperCase(Locale.ENGLISH) :194
+        bases.push_back(c);
+      }
+    }
+    first_line = false;
+    pos = e;
+    if (pos < N) { if (data[pos] == '\r' && pos + 1 < N && data[pos + 1] == '\n') pos += 2; else pos += 1; }
+  }
+  close_record();
+  out->n = (int64_t)offs.size();
+  out->total_bases = (int64_t)bases.size();
+  out->bases = (char*)malloc(std::max<size_t>(bases.size(), 1));
+  out->offsets = (int64_t*)malloc(std::max<size_t>(offs.size(), 1) * 8);
+  out->lengths = (int32_t*)malloc(std::max<size_t>(offs.size(), 1) * 4);
+  out->ids = (int64_t*)malloc(std::max<size_t>(offs.size(), 1) * 8);
+  if (!out->bases || !out->offsets || !out->lengths || !out->ids) { mhap_fasta_free(out); seterr("out of memory"); return MHAP_E_NOMEM; }
+  memcpy(out->bases, bases.data(), bases.size());
+  if (!offs.empty()) { memcpy(out->offsets, offs.data(), offs.size() * 8); memcpy(out->lengths, lens.data(), lens.size() * 4); memcpy(out->ids, ids.data(), ids.size() * 8); }
+  return MHAP_OK;
+}
+
+void mhap_fasta_free(mhap_fasta* f) {
+  if (!f) return;
+  free(f->bases); free(f->offsets); free(f->lengths); free(f->ids);
+  memset(f, 0, sizeof *f);
+}
+
+// Synthetic PacBio-style reads.  Circular random genome of n*len/coverage bp; every read
+// has its own generator seeded from (seed, index) so generation is order- and thread-independent.
+int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, char* bases) {
+  if (n < 0 || len <= 0 || !bases || coverage <= 0.0 || error_rate < 0.0 || error_rate >= 1.0) return MHAP_E_INVALID;
+  if (n == 0) return MHAP_OK;
+  const int64_t G = std::max<int64_t>((int64_t)((double)n * (double)len / coverage), (int64_t)len + 1);
+  std::vector<uint8_t> genome((size_t)G);
+  {
+    Xoshiro256ss g(SplitMix64{seed}.next());
+    for (int64_t i = 0; i < G; i += 32) {
+      uint64_t r = g.next();
+      for (int j = 0; j < 32 && i + j < G; j++) genome[(size_t)(i + j)] = (uint8_t)((r >> (2 * j)) & 3);
+    }
+  }
+  // ins:del:sub = 0.1188:0.0183:0.0129 (J/utils/RandomSequenceGenerator.java:93-96), scaled to error_rate
+  const double p_ins = error_rate * (0.1188 / 0.15), p_del = error_rate * (0.0183 / 0.15), p_sub = error_rate * (0.0129 / 0.15);
+  static const char ALPHA[4] = {'A', 'C', 'G', 'T'};
+  unsigned hc = std::thread::hardware_concurrency();
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(hc ? hc : 1u, 32u), n));
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) {
+    th.emplace_back([&, t]() {
+      std::vector<uint8_t> tmp((size_t)len);
+      for (int64_t r = t; r < n; r += nthreads) {
+        Xoshiro256ss g(SplitMix64{seed ^ (0x9e3779b97f4a7c15ULL * (uint64_t)(r + 1))}.next());
+        int64_t gp = (int64_t)g.below((uint64_t)G);
+        const bool rev = (g.next() >> 63) != 0;
+        int w = 0;
+        while (w < len) {
+          const double u = g.unit();
+          if (u < p_ins) { tmp[(size_t)w++] = (uint8_t)(g.next() >> 62); continue; }
+          const uint8_t b = genome[(size_t)gp];
+          gp++; if (gp == G) gp = 0;
+          if (u < p_ins + p_del) continue;
+          if (u < p_ins + p_del + p_sub) { tmp[(size_t)w++] = (uint8_t)((b + 1 + (g.next() >> 62) % 3) & 3); continue; }
+          tmp[(size_t)w++] = b;
+        }
+        char* dst = bases + r * (int64_t)len;
+        if (!rev) for (int i = 0; i < len; i++) dst[i] = ALPHA[tmp[(size_t)i]];
+        else for (int i = 0; i < len; i++) dst[i] = ALPHA[3 - tmp[(size_t)(len - 1 - i)]];
+      }
+    });
+  }
+  for (auto& x : th) x.join();
+  return MHAP_OK;
+}
+
+}  // extern "C"

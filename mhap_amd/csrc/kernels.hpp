@@ -1,0 +1,74 @@
+// kernels.hpp — launch interface between the C-ABI orchestration (mhap_capi.hip) and the gfx950 kernels.
+#pragma once
+#include "device_common.hpp"
+
+namespace mhap {
+
+constexpr int HASH_TILE = 1024;      // window starts per hash workgroup
+constexpr int WEIGHT_THREADS = 512;  // threads per k-mer-weight workgroup
+constexpr int MH_U = 4;              // k-mers per lane per row in the MinHash hot loop
+constexpr int ORD_THREADS = 256;
+constexpr int ORD_BINS = 2048;
+constexpr int CAND_TQ = 128;         // queries per candidate tile
+constexpr int CAND_TM = 128;         // index entries per candidate tile
+constexpr int CAND_KS = 32;          // slots staged per LDS chunk
+constexpr int OVL_THREADS = 128;     // lanes per second-stage workgroup
+
+struct StrandInfo { int32_t valid; int32_t heavy; };
+
+// Host-built FrequencyCounts table (open addressing; vals[slot]==0.0 marks empty; vals = scaledIdf).
+struct FilterTable {
+  const int64_t* keys;
+  const double* vals;
+  uint32_t mask;
+  uint32_t size;
+  int32_t enabled;
+  int32_t no_tf;
+  double range;
+};
+
+// Per-entry metadata row: {ordered_size, ordered_seqlen (L-k2+1), seq_length (bases), status}
+constexpr int META_W = 4;
+
+// Candidate pair produced by the all-pairs count and consumed by the second stage.
+struct Candidate { int32_t q; int32_t m; };
+
+// Device-side accepted overlap (entry indices; host maps to ids/lengths, MatchResult.java:46-65).
+struct DevRecord { int32_t q, m; double score; int32_t raw, a1, a2, b1, b2, pad; };
+
+struct SearchParams {
+  int32_t H, S, k2;
+  int32_t num_min_matches, min_store_length;
+  int32_t to_self;
+  double max_shift, threshold;
+};
+
+// ---- sketch_kernels.hip ----
+void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store, int64_t* keys,
+                       int32_t* h32, int k, int k2);
+void launch_kmer_weights(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, uint32_t* wts,
+                         uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
+                         double repeat_weight, StrandInfo* info);
+void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
+                    int32_t* out_status, int64_t status_stride);
+void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
+size_t ordered_lds_bytes(int cap);
+void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, const int32_t* h32, int k2, int S, int cap,
+                    int32_t* out_rows, int64_t out_stride, int32_t* out_meta, int64_t meta_stride);
+
+// ---- search_kernels.hip ----
+// All-pairs slot-equality count between query entries qlist[0..nq) and index entries [0..ne).
+// rowstart != NULL enables triangular tile skipping (device array of ntq+1 linear tile offsets).
+// Appends (q,m) with count >= num_min_matches that pass the MinHashSearch filters to cand[] via *cand_count.
+void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* qminhash, int64_t qrow_stride,
+                       const int32_t* qlist, int nq, int ne, const int64_t* ids, const int64_t* qids, const int32_t* meta,
+                       const int32_t* qmeta, const SearchParams& sp, const long long* rowstart, long long nblocks_tri, Candidate* cand,
+                       unsigned long long* cand_count, unsigned long long cand_cap);
+// Second stage: one lane per candidate.
+void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
+                    const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
+                    const int32_t* qmeta, const SearchParams& sp, const double* score_table, int32_t* scratch, int64_t scratch_per_lane,
+                    DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared);
+
+}  // namespace mhap

@@ -1,0 +1,760 @@
+// mhap_capi.hip — C-ABI implementation (include/mhap_hip.h): handle, HBM tables, batch orchestration.
+// No CPU fallback lives here: every compute entry point launches the gfx950 kernels or fails.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mhap_hip.h"
+#include "kernels.hpp"
+#include "overlap_lane.hpp"
+
+using namespace mhap;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes, bool keep = false, hipStream_t st = nullptr) {
+    if (bytes <= cap) return hipSuccess;
+    size_t ncap = std::max(bytes, keep ? cap * 2 : cap);
+    void* np = nullptr;
+    hipError_t e = hipMalloc(&np, ncap);
+    if (e != hipSuccess) return e;
+    if (keep && p && cap) {
+      e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) { (void)hipFree(np); return e; }
+    }
+    if (p) (void)hipFree(p);
+    p = np; cap = ncap;
+    return hipSuccess;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+struct TimedLaunch { hipEvent_t a, b; int kind; };
+
+inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
+
+void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t)>& fn) {
+  if (n <= 0) return;
+  nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n));
+  if (nthreads == 1) { fn(0, n); return; }
+  std::vector<std::thread> th;
+  int64_t chunk = (n + nthreads - 1) / nthreads;
+  for (int t = 0; t < nthreads; t++) {
+    int64_t lo = t * chunk, hi = std::min(n, lo + chunk);
+    if (lo >= hi) break;
+    th.emplace_back([=, &fn]() { fn(lo, hi); });
+  }
+  for (auto& t : th) t.join();
+}
+
+int host_threads() {
+  const char* e = getenv("MHAP_HOST_THREADS");
+  if (e && atoi(e) > 0) return atoi(e);
+  unsigned hc = std::thread::hardware_concurrency();
+  return (int)std::max(1u, std::min(hc, 32u));
+}
+
+}  // namespace
+
+struct mhap_handle {
+  mhap_params P;
+  int device = 0;
+  int num_cus = 256;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  std::string err;
+  int Hrow = 1;      // minhash row stride (ints)
+  int ord_cap = 0;   // ordered-kernel sort capacity
+
+  // filter
+  DevBuf f_keys, f_vals;
+  FilterTable ft{};
+  DevBuf score_tbl;
+
+  // index (owned or external)
+  bool external = false;
+  int64_t n_entries = 0;
+  DevBuf own_minhash, own_ordered, own_meta;
+  int32_t *d_minhash = nullptr, *d_ordered = nullptr, *d_meta = nullptr;
+  DevBuf d_ids;
+  std::vector<int64_t> ids;
+  std::vector<uint8_t> fwd;
+  std::vector<int32_t> seqlen;   // full base length per entry (host mirror)
+  std::vector<uint8_t> status;   // per entry status (host mirror)
+
+  // sketch scratch
+  DevBuf store, descs, keys, wts, h32, info, slabs, counters;
+  std::vector<uint8_t> h_store;
+  std::vector<ReadDesc> h_descs;
+
+  // query tables for -q mode
+  DevBuf q_minhash, q_ordered, q_meta, q_ids;
+
+  // search scratch
+  DevBuf qlist, rowstart, cand, recs, ovl_scratch;
+  std::vector<DevRecord> h_recs;
+  std::vector<mhap_record> out_recs;
+
+  // timing
+  std::vector<TimedLaunch> pending;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+  mhap_kernel_times ktimes{};
+  mhap_stats stats{};
+};
+
+namespace {
+
+int fail(mhap_handle* h, int code, const std::string& msg) { h->err = msg; return code; }
+
+#define HIPCHK(h, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t _e = (expr);                                                                          \
+    if (_e != hipSuccess)                                                                            \
+      return fail((h), _e == hipErrorOutOfMemory ? MHAP_E_NOMEM : MHAP_E_HIP,                        \
+                  std::string(#expr) + ": " + hipGetErrorString(_e));                                \
+  } while (0)
+
+void time_begin(mhap_handle* h, int kind) {
+  TimedLaunch t; t.kind = kind;
+  if (!h->free_events.empty()) { t.a = h->free_events.back().first; t.b = h->free_events.back().second; h->free_events.pop_back(); }
+  else { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
+  (void)hipEventRecord(t.a, h->stream);
+  h->pending.push_back(t);
+}
+void time_end(mhap_handle* h) { (void)hipEventRecord(h->pending.back().b, h->stream); }
+
+// call after the stream is synchronised
+void time_collect(mhap_handle* h) {
+  for (auto& t : h->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { h->ktimes.ms[t.kind] += ms; h->ktimes.launches[t.kind]++; }
+    h->free_events.emplace_back(t.a, t.b);
+  }
+  h->pending.clear();
+}
+
+int sync_stream(mhap_handle* h) {
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  time_collect(h);
+  return MHAP_OK;
+}
+
+// identity score for every reachable (inter, k): BottomOverlapSketch.jaccardToIdentity
+// (J/sketch/BottomOverlapSketch.java:391-395) evaluated on the host so libm lives in one place.
+int build_score_table(mhap_handle* h) {
+  const int S = h->P.ordered_sketch_size;
+  const int64_t n = score_index(S, S) + 1;
+  std::vector<double> tbl((size_t)n);
+  const int k2 = h->P.ordered_kmer_size;
+  parallel_for(S + 1, host_threads(), [&](int64_t lo, int64_t hi) {
+    for (int64_t kk = lo; kk < hi; kk++)
+      for (int64_t it = 0; it <= kk; it++) {
+        double j = (kk == 0) ? 0.0 : (double)it / (double)kk;
+        double d = -1.0 / (double)k2 * std::log(2.0 * j / (1.0 + j));
+        tbl[(size_t)score_index((int)it, (int)kk)] = std::exp(-d);
+      }
+  });
+  HIPCHK(h, h->score_tbl.ensure((size_t)n * 8));
+  HIPCHK(h, hipMemcpy(h->score_tbl.p, tbl.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+  return MHAP_OK;
+}
+
+inline int code_of(char c) {
+  switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return -1; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sketch `n` reads into device rows [row0, row0+2n) of the given tables.
+// ------------------------------------------------------------------------------------------------
+int sketch_into(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, bool fwd_only,
+                int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
+  if (n <= 0) return MHAP_OK;
+  const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
+  int64_t batch_bases = 256LL << 20;
+  if (const char* e = getenv("MHAP_BATCH_BASES")) { long long v = atoll(e); if (v > 0) batch_bases = v; }
+  const int nthreads = host_threads();
+  int64_t r0 = 0;
+  while (r0 < n) {
+    // ---- choose batch [r0, r1) ----
+    int64_t r1 = r0, tot = 0;
+    while (r1 < n && (r1 == r0 || tot + lengths[r1] <= batch_bases) && (r1 - r0) < (1 << 22)) { tot += std::max(0, lengths[r1]); r1++; }
+    const int64_t nb = r1 - r0;
+    // ---- descriptors + storage layout ----
+    h->h_descs.resize((size_t)nb);
+    int64_t store_bytes = 0, key_elems = 0, h2_elems = 0;
+    int max_len = 0;
+    std::vector<uint8_t> israw((size_t)nb);
+    parallel_for(nb, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; i++) {
+        const char* s = bases + offsets[r0 + i];
+        const int L = lengths[r0 + i];
+        uint8_t raw = 0;
+        for (int j = 0; j < L; j++) if (code_of(s[j]) < 0) { raw = 1; break; }
+        israw[(size_t)i] = raw;
+      }
+    });
+    for (int64_t i = 0; i < nb; i++) {
+      ReadDesc& d = h->h_descs[(size_t)i];
+      const int L = std::max(0, lengths[r0 + i]);
+      d.length = L;
+      d.flags = 0;
+      if (L < h->P.min_olap_length) d.flags |= MHAP_RD_SKIP;          // SequenceSketchStreamer.java:129-133
+      if (israw[(size_t)i]) d.flags |= MHAP_RD_RAW;
+      if (fwd_only) d.flags |= MHAP_RD_FWDONLY;
+      d.base_off = store_bytes;
+      if (!(d.flags & MHAP_RD_SKIP)) store_bytes += (d.flags & MHAP_RD_RAW) ? align4(L) : align4((L + 3) / 4);
+      const int64_t nk = align4(std::max(0, L - k + 1)), nk2 = align4(std::max(0, L - k2 + 1));
+      d.key_off = key_elems; d.key_stride = (int32_t)nk;
+      d.h2_off = h2_elems; d.h2_stride = (int32_t)nk2;
+      if (!(d.flags & MHAP_RD_SKIP)) { key_elems += 2 * nk; h2_elems += 2 * nk2; max_len = std::max(max_len, L); }
+    }
+    h->h_store.assign((size_t)std::max<int64_t>(store_bytes, 4), 0);
+    parallel_for(nb, nthreads, [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; i++) {
+        const ReadDesc& d = h->h_descs[(size_t)i];
+        if (d.flags & MHAP_RD_SKIP) continue;
+        const char* s = bases + offsets[r0 + i];
+        uint8_t* dst = h->h_store.data() + d.base_off;
+        if (d.flags & MHAP_RD_RAW) memcpy(dst, s, (size_t)d.length);
+        else
+          for (int j = 0; j < d.length; j++) dst[j >> 2] |= (uint8_t)(code_of(s[j]) << (2 * (j & 3)));
+      }
+    });
+    const int64_t nstr = 2 * nb;
+    // ---- device scratch ----
+    HIPCHK(h, h->store.ensure((size_t)h->h_store.size()));
+    HIPCHK(h, h->descs.ensure((size_t)nb * sizeof(ReadDesc)));
+    HIPCHK(h, h->keys.ensure((size_t)std::max<int64_t>(key_elems, 4) * 8));
+    HIPCHK(h, h->wts.ensure((size_t)std::max<int64_t>(key_elems, 4) * 4));
+    HIPCHK(h, h->h32.ensure((size_t)std::max<int64_t>(h2_elems, 4) * 4));
+    HIPCHK(h, h->info.ensure((size_t)nstr * sizeof(StrandInfo)));
+    HIPCHK(h, h->counters.ensure(256));
+    const int wblocks = (int)std::min<int64_t>(nstr, (int64_t)h->num_cus * 4);
+    int64_t slab_entries = 64;
+    while (slab_entries < 2LL * std::max(1, max_len - k + 1)) slab_entries <<= 1;
+    HIPCHK(h, h->slabs.ensure((size_t)wblocks * (size_t)slab_entries * 2 * 4));
+    HIPCHK(h, hipMemcpyAsync(h->store.p, h->h_store.data(), h->h_store.size(), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
+
+    int32_t* mh_rows = d_minhash + (2 * r0) * mh_stride;
+    int32_t* ord_rows = d_ordered + (2 * r0) * ord_stride;
+    int32_t* meta_rows = d_meta + (2 * r0) * META_W;
+    unsigned long long* ctr = h->counters.as<unsigned long long>();
+
+    time_begin(h, MHAP_K_HASH);
+    launch_hash_kmers(h->stream, h->descs.as<ReadDesc>(), nstr, max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2);
+    time_end(h);
+    time_begin(h, MHAP_K_DEDUP);
+    launch_kmer_weights(h->stream, wblocks, h->descs.as<ReadDesc>(), nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
+                        h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>());
+    time_end(h);
+    time_begin(h, MHAP_K_MINHASH);
+    const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * 8);
+    launch_minhash(h->stream, mblocks, h->descs.as<ReadDesc>(), nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(),
+                   k, k2, H, ctr + 1, mh_rows, mh_stride, meta_rows + 3, META_W);
+    time_end(h);
+    time_begin(h, MHAP_K_ORDERED);
+    launch_ordered(h->stream, h->descs.as<ReadDesc>(), nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
+    time_end(h);
+    launch_fix_status(h->stream, meta_rows, nb);
+    HIPCHK(h, hipGetLastError());
+    int rc = sync_stream(h);
+    if (rc != MHAP_OK) return rc;
+    r0 = r1;
+  }
+  return MHAP_OK;
+}
+
+int ensure_index_capacity(mhap_handle* h, int64_t entries) {
+  if (h->external) return fail(h, MHAP_E_STATE, "index tables are externally owned (mhap_index_set_device); clear the index first");
+  const int S = h->P.ordered_sketch_size;
+  HIPCHK(h, h->own_minhash.ensure((size_t)entries * h->Hrow * 4, true, h->stream));
+  HIPCHK(h, h->own_ordered.ensure((size_t)entries * S * 8, true, h->stream));
+  HIPCHK(h, h->own_meta.ensure((size_t)entries * META_W * 4, true, h->stream));
+  HIPCHK(h, h->d_ids.ensure((size_t)entries * 8, true, h->stream));
+  h->d_minhash = h->own_minhash.as<int32_t>();
+  h->d_ordered = h->own_ordered.as<int32_t>();
+  h->d_meta = h->own_meta.as<int32_t>();
+  return MHAP_OK;
+}
+
+// pull meta rows [first, first+count) into the host mirrors
+int mirror_meta(mhap_handle* h, const int32_t* d_meta, int64_t first, int64_t count) {
+  std::vector<int32_t> m((size_t)count * META_W);
+  HIPCHK(h, hipMemcpy(m.data(), d_meta + first * META_W, m.size() * 4, hipMemcpyDeviceToHost));
+  if ((int64_t)h->seqlen.size() < first + count) { h->seqlen.resize((size_t)(first + count)); h->status.resize((size_t)(first + count)); }
+  for (int64_t e = 0; e < count; e++) { h->seqlen[(size_t)(first + e)] = m[(size_t)e * META_W + 2]; h->status[(size_t)(first + e)] = (uint8_t)m[(size_t)e * META_W + 3]; }
+  return MHAP_OK;
+}
+
+struct QuerySide {
+  const int32_t* d_minhash; int64_t mh_stride;
+  const int32_t* d_ordered; int64_t ord_stride;
+  const int32_t* d_meta;
+  const int64_t* d_ids;
+  const int64_t* h_ids; const int32_t* h_seqlen;
+};
+
+// Run candidate + second stage for the query entries in `ql` (entry indices into the query side).
+int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>& ql, bool to_self, bool triangular_ok,
+                mhap_record_sink sink, void* user) {
+  if (ql.empty() || h->n_entries == 0) return MHAP_OK;
+  const int S = h->P.ordered_sketch_size;
+  SearchParams sp;
+  sp.H = h->P.num_hashes; sp.S = S; sp.k2 = h->P.ordered_kmer_size;
+  sp.num_min_matches = h->P.num_min_matches; sp.min_store_length = h->P.min_store_length; sp.to_self = to_self ? 1 : 0;
+  sp.max_shift = h->P.max_shift; sp.threshold = h->P.threshold;
+  const int ne = (int)h->n_entries;
+  int64_t qchunk = 16384;
+  if (const char* e = getenv("MHAP_QUERY_CHUNK")) { long long v = atoll(e); if (v >= CAND_TQ) qchunk = (v / CAND_TQ) * CAND_TQ; }
+  HIPCHK(h, h->qlist.ensure(ql.size() * 4));
+  HIPCHK(h, hipMemcpyAsync(h->qlist.p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, h->counters.ensure(256));
+  unsigned long long* ctr = h->counters.as<unsigned long long>();
+  size_t cand_cap = std::max<size_t>(h->cand.cap / sizeof(Candidate), (size_t)4 << 20);
+  const int oblocks = h->num_cus * 2;
+  const int64_t lanes = (int64_t)oblocks * OVL_THREADS;
+  const int64_t per_lane = 3LL * (2LL * S + 2);
+  HIPCHK(h, h->ovl_scratch.ensure((size_t)lanes * (size_t)per_lane * 4));
+  const int ntu = (ne + CAND_TM - 1) / CAND_TM;
+
+  for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
+    const int nq = (int)std::min<int64_t>(qchunk, (int64_t)ql.size() - c0);
+    const int ntq = (nq + CAND_TQ - 1) / CAND_TQ;
+    const long long* d_rowstart = nullptr;
+    long long nblocks_tri = 0;
+    if (triangular_ok) {
+      std::vector<long long> rs((size_t)ntq + 1);
+      long long acc = 0;
+      for (int t = 0; t < ntq; t++) {
+        rs[(size_t)t] = acc;
+        const int32_t maxq = ql[(size_t)(c0 + std::min<int64_t>((int64_t)(t + 1) * CAND_TQ, nq) - 1)];
+        acc += std::min<long long>(ntu, ((long long)maxq + CAND_TM - 1) / CAND_TM);
+      }
+      rs[(size_t)ntq] = acc; nblocks_tri = acc;
+      HIPCHK(h, h->rowstart.ensure(rs.size() * 8));
+      HIPCHK(h, hipMemcpyAsync(h->rowstart.p, rs.data(), rs.size() * 8, hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipStreamSynchronize(h->stream));  // rs is a stack vector
+      d_rowstart = h->rowstart.as<long long>();
+      if (nblocks_tri == 0) continue;
+    }
+    unsigned long long ncand = 0;
+    for (;;) {
+      HIPCHK(h, h->cand.ensure(cand_cap * sizeof(Candidate)));
+      HIPCHK(h, hipMemsetAsync(ctr, 0, 64, h->stream));
+      time_begin(h, MHAP_K_CANDIDATE);
+      launch_candidates(h->stream, h->d_minhash, h->Hrow, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq, ne,
+                        h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, d_rowstart, nblocks_tri, h->cand.as<Candidate>(),
+                        ctr + 0, (unsigned long long)cand_cap);
+      time_end(h);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
+      int rc = sync_stream(h);
+      if (rc != MHAP_OK) return rc;
+      if (ncand <= cand_cap) break;
+      cand_cap = (size_t)ncand + (size_t)(ncand / 4) + 1024;   // overflow: grow and redo this chunk
+    }
+    {
+      const long long tiles = triangular_ok ? nblocks_tri : (long long)ntq * ntu;
+      h->stats.slot_compares += tiles * (long long)CAND_TQ * CAND_TM * sp.H;
+    }
+    h->stats.queries_searched += nq;
+    if (ncand == 0) continue;
+    HIPCHK(h, h->recs.ensure((size_t)ncand * sizeof(DevRecord)));
+    time_begin(h, MHAP_K_OVERLAP);
+    launch_overlap(h->stream, oblocks, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
+                   qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
+                   h->recs.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2);
+    time_end(h);
+    HIPCHK(h, hipGetLastError());
+    unsigned long long counts[3] = {0, 0, 0};
+    HIPCHK(h, hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
+    int rc = sync_stream(h);
+    if (rc != MHAP_OK) return rc;
+    const unsigned long long nrec = counts[1];
+    h->stats.candidates_compared += (int64_t)counts[2];
+    if (nrec == 0) continue;
+    h->h_recs.resize((size_t)nrec);
+    HIPCHK(h, hipMemcpy(h->h_recs.data(), h->recs.p, (size_t)nrec * sizeof(DevRecord), hipMemcpyDeviceToHost));
+    h->out_recs.resize((size_t)nrec);
+    parallel_for((int64_t)nrec, host_threads(), [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; i++) {
+        const DevRecord& d = h->h_recs[(size_t)i];
+        mhap_record& r = h->out_recs[(size_t)i];
+        r.from_id = qs.h_ids[d.q]; r.to_id = h->ids[(size_t)d.m];
+        r.score = d.score; r.raw = (double)d.raw;
+        r.alen = qs.h_seqlen[d.q]; r.blen = h->seqlen[(size_t)d.m];
+        r.a1 = d.a1; r.a2 = d.a2;                                        // from is always a forward entry
+        r.to_rc = h->fwd[(size_t)d.m] ? 0 : 1;
+        if (r.to_rc) { r.b1 = r.blen - d.b2 - 1; r.b2 = r.blen - d.b1 - 1; }   // MatchResult.java:56-57
+        else { r.b1 = d.b1; r.b2 = d.b2; }
+        r.pad = 0;
+      }
+    });
+    h->stats.matches_found += (int64_t)nrec;
+    if (sink) { if (sink(h->out_recs.data(), (int64_t)nrec, user) != 0) return fail(h, MHAP_E_STATE, "record sink aborted the search"); }
+  }
+  return MHAP_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+void mhap_default_params(mhap_params* p) {
+  p->kmer_size = 16; p->num_hashes = 512; p->ordered_kmer_size = 12; p->ordered_sketch_size = 1536;
+  p->num_min_matches = 3; p->min_store_length = 0; p->min_olap_length = 116; p->device = -1;
+  p->threshold = 0.78; p->max_shift = 0.2; p->repeat_weight = 0.9;
+}
+
+int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t errcap) {
+  auto seterr = [&](const std::string& m) { if (err && errcap) snprintf(err, errcap, "%s", m.c_str()); };
+  if (!params || !out) { seterr("null argument"); return MHAP_E_INVALID; }
+  const mhap_params& P = *params;
+  if (P.kmer_size < 1 || P.kmer_size > 255) { seterr("k-mer size must be in [1,255]"); return MHAP_E_INVALID; }
+  if (P.ordered_kmer_size < 1 || P.ordered_kmer_size > 255) { seterr("ordered k-mer size must be in [1,255]"); return MHAP_E_INVALID; }
+  if (P.num_hashes < 1 || P.num_hashes > 8192) { seterr("num-hashes must be in [1,8192]"); return MHAP_E_INVALID; }
+  if (P.ordered_sketch_size < 1 || P.ordered_sketch_size > 8192) { seterr("ordered-sketch-size must be in [1,8192]"); return MHAP_E_INVALID; }
+  if (P.num_min_matches < 1) { seterr("Minimum number of matches must be positive."); return MHAP_E_INVALID; }
+  if (P.min_store_length < 0) { seterr("The minimum read length stored must be >=0."); return MHAP_E_INVALID; }
+  if (P.max_shift < -1.0) { seterr("The minimum shift must be greater than -1."); return MHAP_E_INVALID; }
+  if (P.threshold < 0.0 || P.threshold > 1.0) { seterr("The second stage filter threshold must be 0<=threshold<=1.0."); return MHAP_E_INVALID; }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) { seterr(std::string("no HIP device available: ") + hipGetErrorString(e)); return MHAP_E_HIP; }
+  mhap_handle* h = new mhap_handle();
+  h->P = P;
+  int dev = P.device;
+  if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+  if (dev >= ndev) { seterr("device ordinal out of range"); delete h; return MHAP_E_INVALID; }
+  h->device = dev;
+  if ((e = hipSetDevice(dev)) != hipSuccess) { seterr(hipGetErrorString(e)); delete h; return MHAP_E_HIP; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = std::max(1, prop.multiProcessorCount);
+  if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { seterr(hipGetErrorString(e)); delete h; return MHAP_E_HIP; }
+  h->stream = h->own_stream;
+  h->Hrow = std::max(1, P.num_hashes);
+  int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
+  h->ord_cap = cap;
+  h->ft = FilterTable{nullptr, nullptr, 0, 0, 0, 0, 3.0};
+  int rc = build_score_table(h);
+  if (rc != MHAP_OK) { seterr(h->err); mhap_destroy(h); return rc; }
+  *out = h;
+  return MHAP_OK;
+}
+
+void mhap_destroy(mhap_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
+                    &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
+                    &h->qlist, &h->rowstart, &h->cand, &h->recs, &h->ovl_scratch};
+  for (DevBuf* b : bufs) b->release();
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  delete h;
+}
+
+const char* mhap_last_error(const mhap_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int mhap_set_filter(mhap_handle* h, const int64_t* hashes, const double* fractions, int64_t n, double filter_cutoff, double offset,
+                    double range, int no_tf) {
+  if (!h) return MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  if (n <= 0 && !hashes) { h->ft = FilterTable{nullptr, nullptr, 0, 0, 0, 0, range}; return MHAP_OK; }
+  if (offset < 0.0 || offset >= 1.0) return fail(h, MHAP_E_INVALID, "Offset can only be between 0 and 1.0.");   // FrequencyCounts.java:74-75
+  // FrequencyCounts.java:176-184 keep fraction >= cutoff; maxValue = max kept fraction
+  std::vector<int64_t> kk; std::vector<double> ff;
+  double maxv = -INFINITY;
+  for (int64_t i = 0; i < n; i++) if (fractions[i] >= filter_cutoff) { kk.push_back(hashes[i]); ff.push_back(fractions[i]); maxv = std::max(maxv, fractions[i]); }
+  const double minv = filter_cutoff;
+  auto idf = [&](double f) { return std::log(maxv / f - offset); };   // :250-254
+  const double minIdf = idf(maxv), maxIdf = idf(minv);                // :226-227
+  uint32_t ts = 16; while (ts < 2 * kk.size() + 2) ts <<= 1;
+  std::vector<int64_t> tk(ts, 0); std::vector<double> tv(ts, 0.0);
+  for (size_t i = 0; i < kk.size(); i++) {
+    double id = idf(ff[i]);
+    double scale = (maxIdf - minIdf) / (double)(range - 1.0);
+    double v = 1.0 + (id - minIdf) / scale;                            // scaledIdf :290-311
+    if (v == 0.0) v = 4.9406564584124654e-324;                         // keep 0.0 reserved for "empty"
+    uint32_t slot = (uint32_t)fmix64((uint64_t)kk[i]) & (ts - 1);
+    for (;;) {
+      if (tv[slot] == 0.0) { tk[slot] = kk[i]; tv[slot] = v; break; }
+      if (tk[slot] == kk[i]) { tv[slot] = v; break; }                  // duplicate k-mer line: last writer wins (:181-184)
+      slot = (slot + 1) & (ts - 1);
+    }
+  }
+  HIPCHK(h, h->f_keys.ensure((size_t)ts * 8));
+  HIPCHK(h, h->f_vals.ensure((size_t)ts * 8));
+  HIPCHK(h, hipMemcpy(h->f_keys.p, tk.data(), (size_t)ts * 8, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->f_vals.p, tv.data(), (size_t)ts * 8, hipMemcpyHostToDevice));
+  h->ft.keys = h->f_keys.as<int64_t>(); h->ft.vals = h->f_vals.as<double>();
+  h->ft.mask = ts - 1; h->ft.size = (uint32_t)kk.size(); h->ft.enabled = 1; h->ft.no_tf = no_tf ? 1 : 0; h->ft.range = range;
+  return MHAP_OK;
+}
+
+int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n) {
+  if (!h || (n > 0 && (!bases || !offsets || !lengths || !ids))) return h ? fail(h, MHAP_E_INVALID, "null argument") : MHAP_E_INVALID;
+  if (n <= 0) return MHAP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
+  for (int64_t i = 0; i < n; i++) if (lengths[i] < 0) return fail(h, MHAP_E_INVALID, "negative read length");
+  int rc = ensure_index_capacity(h, h->n_entries + 2 * n);
+  if (rc != MHAP_OK) return rc;
+  const int64_t first = h->n_entries;
+  const int S = h->P.ordered_sketch_size;
+  rc = sketch_into(h, bases, offsets, lengths, n, false, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S,
+                   h->d_meta + first * META_W);
+  if (rc != MHAP_OK) return rc;
+  h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
+  for (int64_t i = 0; i < n; i++) {
+    h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
+    h->fwd[(size_t)(first + 2 * i)] = 1; h->fwd[(size_t)(first + 2 * i + 1)] = 0;
+  }
+  HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)(2 * n) * 8, hipMemcpyHostToDevice));
+  rc = mirror_meta(h, h->d_meta, first, 2 * n);
+  if (rc != MHAP_OK) return rc;
+  h->n_entries = first + 2 * n;
+  h->stats.strands_indexed = 0;
+  for (int64_t e = 0; e < h->n_entries; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
+  return MHAP_OK;
+}
+
+int mhap_sketch_batch(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, int32_t* minhash,
+                      int32_t* ordered, int32_t* ordered_size, uint8_t* status) {
+  if (!h) return MHAP_E_INVALID;
+  if (n <= 0) return MHAP_OK;
+  if (!bases || !offsets || !lengths) return fail(h, MHAP_E_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  const int S = h->P.ordered_sketch_size;
+  HIPCHK(h, h->q_minhash.ensure((size_t)(2 * n) * h->Hrow * 4));
+  HIPCHK(h, h->q_ordered.ensure((size_t)(2 * n) * S * 8));
+  HIPCHK(h, h->q_meta.ensure((size_t)(2 * n) * META_W * 4));
+  int rc = sketch_into(h, bases, offsets, lengths, n, false, h->q_minhash.as<int32_t>(), h->Hrow, h->q_ordered.as<int32_t>(), 2LL * S,
+                       h->q_meta.as<int32_t>());
+  if (rc != MHAP_OK) return rc;
+  std::vector<int32_t> meta((size_t)(2 * n) * META_W);
+  HIPCHK(h, hipMemcpy(meta.data(), h->q_meta.p, meta.size() * 4, hipMemcpyDeviceToHost));
+  if (minhash) HIPCHK(h, hipMemcpy(minhash, h->q_minhash.p, (size_t)(2 * n) * h->Hrow * 4, hipMemcpyDeviceToHost));
+  if (ordered) HIPCHK(h, hipMemcpy(ordered, h->q_ordered.p, (size_t)(2 * n) * S * 8, hipMemcpyDeviceToHost));
+  for (int64_t e = 0; e < 2 * n; e++) {
+    if (ordered_size) ordered_size[e] = meta[(size_t)e * META_W + 3] == 0 ? meta[(size_t)e * META_W + 0] : 0;
+    if (status) status[e] = (uint8_t)meta[(size_t)e * META_W + 3];
+  }
+  return MHAP_OK;
+}
+
+int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* is_fwd, const int32_t* seq_length, const int32_t* minhash,
+                            const int32_t* ordered, const int32_t* ordered_size, const int32_t* ordered_seqlen, int64_t m) {
+  if (!h) return MHAP_E_INVALID;
+  if (m <= 0) return MHAP_OK;
+  if (!ids || !is_fwd || !seq_length || !minhash || !ordered || !ordered_size || !ordered_seqlen) return fail(h, MHAP_E_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  int rc = ensure_index_capacity(h, h->n_entries + m);
+  if (rc != MHAP_OK) return rc;
+  const int64_t first = h->n_entries;
+  const int S = h->P.ordered_sketch_size;
+  std::vector<int32_t> meta((size_t)m * META_W);
+  for (int64_t e = 0; e < m; e++) {
+    if (ordered_size[e] < 0 || ordered_size[e] > S) return fail(h, MHAP_E_INVALID, "ordered sketch larger than --ordered-sketch-size");
+    meta[(size_t)e * META_W + 0] = ordered_size[e]; meta[(size_t)e * META_W + 1] = ordered_seqlen[e];
+    meta[(size_t)e * META_W + 2] = seq_length[e]; meta[(size_t)e * META_W + 3] = 0;
+  }
+  HIPCHK(h, hipMemcpy(h->d_minhash + first * h->Hrow, minhash, (size_t)m * h->Hrow * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_ordered + first * 2LL * S, ordered, (size_t)m * S * 8, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->d_meta + first * META_W, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+  h->ids.resize((size_t)(first + m)); h->fwd.resize((size_t)(first + m));
+  for (int64_t e = 0; e < m; e++) { h->ids[(size_t)(first + e)] = ids[e]; h->fwd[(size_t)(first + e)] = is_fwd[e] ? 1 : 0; }
+  HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)m * 8, hipMemcpyHostToDevice));
+  rc = mirror_meta(h, h->d_meta, first, m);
+  if (rc != MHAP_OK) return rc;
+  h->n_entries = first + m;
+  h->stats.strands_indexed += m;
+  return MHAP_OK;
+}
+
+int mhap_index_size(mhap_handle* h, int64_t* entries) {
+  if (!h || !entries) return MHAP_E_INVALID;
+  *entries = h->n_entries;
+  return MHAP_OK;
+}
+
+int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids, uint8_t* is_fwd, int32_t* seq_length, int32_t* minhash,
+                      int32_t* ordered, int32_t* ordered_size, int32_t* ordered_seqlen, uint8_t* status) {
+  if (!h) return MHAP_E_INVALID;
+  if (first < 0 || count < 0 || first + count > h->n_entries) return fail(h, MHAP_E_INVALID, "export range outside the index");
+  if (count == 0) return MHAP_OK;
+  (void)hipSetDevice(h->device);
+  const int S = h->P.ordered_sketch_size;
+  std::vector<int32_t> meta((size_t)count * META_W);
+  HIPCHK(h, hipMemcpy(meta.data(), h->d_meta + first * META_W, meta.size() * 4, hipMemcpyDeviceToHost));
+  if (minhash) HIPCHK(h, hipMemcpy(minhash, h->d_minhash + first * h->Hrow, (size_t)count * h->Hrow * 4, hipMemcpyDeviceToHost));
+  if (ordered) HIPCHK(h, hipMemcpy(ordered, h->d_ordered + first * 2LL * S, (size_t)count * S * 8, hipMemcpyDeviceToHost));
+  for (int64_t e = 0; e < count; e++) {
+    if (ids) ids[e] = h->ids[(size_t)(first + e)];
+    if (is_fwd) is_fwd[e] = h->fwd[(size_t)(first + e)];
+    if (seq_length) seq_length[e] = meta[(size_t)e * META_W + 2];
+    if (ordered_size) ordered_size[e] = meta[(size_t)e * META_W + 0];
+    if (ordered_seqlen) ordered_seqlen[e] = meta[(size_t)e * META_W + 1];
+    if (status) status[e] = (uint8_t)meta[(size_t)e * META_W + 3];
+  }
+  return MHAP_OK;
+}
+
+int mhap_index_clear(mhap_handle* h) {
+  if (!h) return MHAP_E_INVALID;
+  h->n_entries = 0; h->external = false;
+  h->ids.clear(); h->fwd.clear(); h->seqlen.clear(); h->status.clear();
+  h->d_minhash = h->own_minhash.as<int32_t>(); h->d_ordered = h->own_ordered.as<int32_t>(); h->d_meta = h->own_meta.as<int32_t>();
+  h->stats = mhap_stats{};
+  return MHAP_OK;
+}
+
+int mhap_sketch_reads_device(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_minhash,
+                             void* d_ordered, void* d_meta) {
+  if (!h) return MHAP_E_INVALID;
+  if (n <= 0) return MHAP_OK;
+  if (!bases || !offsets || !lengths || !d_minhash || !d_ordered || !d_meta) return fail(h, MHAP_E_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  return sketch_into(h, bases, offsets, lengths, n, false, (int32_t*)d_minhash, h->Hrow, (int32_t*)d_ordered, 2LL * h->P.ordered_sketch_size,
+                     (int32_t*)d_meta);
+}
+
+int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_fwd, void* d_minhash, void* d_ordered, void* d_meta, int64_t m) {
+  if (!h) return MHAP_E_INVALID;
+  if (m < 0 || (m > 0 && (!ids || !is_fwd || !d_minhash || !d_ordered || !d_meta))) return fail(h, MHAP_E_INVALID, "null argument");
+  if (m > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
+  (void)hipSetDevice(h->device);
+  mhap_index_clear(h);
+  h->external = true;
+  h->d_minhash = (int32_t*)d_minhash; h->d_ordered = (int32_t*)d_ordered; h->d_meta = (int32_t*)d_meta;
+  h->ids.assign(ids, ids + m); h->fwd.assign(is_fwd, is_fwd + m);
+  HIPCHK(h, h->d_ids.ensure((size_t)std::max<int64_t>(m, 1) * 8));
+  if (m > 0) HIPCHK(h, hipMemcpy(h->d_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
+  if (m > 0) { int rc = mirror_meta(h, h->d_meta, 0, m); if (rc != MHAP_OK) return rc; }
+  h->n_entries = m;
+  for (int64_t e = 0; e < m; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
+  return MHAP_OK;
+}
+
+int mhap_find_matches_self(mhap_handle* h, int64_t q_first, int64_t q_count, mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  if (q_first < 0 || q_first > h->n_entries) return fail(h, MHAP_E_INVALID, "query range outside the index");
+  int64_t q_end = (q_count < 0) ? h->n_entries : std::min(h->n_entries, q_first + q_count);
+  std::vector<int32_t> ql;
+  for (int64_t e = q_first; e < q_end; e++) if (h->fwd[(size_t)e] && h->status[(size_t)e] == 0) ql.push_back((int32_t)e);   // AbstractMatchSearch.java:128-129
+  bool mono = true;
+  for (int64_t e = 1; e < h->n_entries && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
+  // tile skipping needs: ids sorted with entry order, every entry "long" (minStore == 0 -> only m.id < q.id survives)
+  const bool tri = mono && h->P.min_store_length == 0 && !getenv("MHAP_NO_TRIANGULAR");
+  QuerySide qs{h->d_minhash, h->Hrow, h->d_ordered, 2LL * h->P.ordered_sketch_size, h->d_meta, h->d_ids.as<int64_t>(), h->ids.data(), h->seqlen.data()};
+  return search_core(h, qs, ql, true, tri, sink, user);
+}
+
+int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n,
+                            mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  if (n <= 0) return MHAP_OK;
+  if (!bases || !offsets || !lengths || !ids) return fail(h, MHAP_E_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  const int S = h->P.ordered_sketch_size;
+  HIPCHK(h, h->q_minhash.ensure((size_t)(2 * n) * h->Hrow * 4));
+  HIPCHK(h, h->q_ordered.ensure((size_t)(2 * n) * S * 8));
+  HIPCHK(h, h->q_meta.ensure((size_t)(2 * n) * META_W * 4));
+  HIPCHK(h, h->q_ids.ensure((size_t)(2 * n) * 8));
+  int rc = sketch_into(h, bases, offsets, lengths, n, true, h->q_minhash.as<int32_t>(), h->Hrow, h->q_ordered.as<int32_t>(), 2LL * S,
+                       h->q_meta.as<int32_t>());
+  if (rc != MHAP_OK) return rc;
+  std::vector<int32_t> meta((size_t)(2 * n) * META_W);
+  HIPCHK(h, hipMemcpy(meta.data(), h->q_meta.p, meta.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int64_t> qids((size_t)(2 * n));
+  std::vector<int32_t> qlen((size_t)(2 * n));
+  std::vector<int32_t> ql;
+  for (int64_t i = 0; i < n; i++) {
+    qids[(size_t)(2 * i)] = qids[(size_t)(2 * i + 1)] = ids[i];
+    qlen[(size_t)(2 * i)] = qlen[(size_t)(2 * i + 1)] = lengths[i];
+    if (meta[(size_t)(2 * i) * META_W + 3] == 0) ql.push_back((int32_t)(2 * i));   // forward only (AbstractMatchSearch.java:225,236)
+  }
+  HIPCHK(h, hipMemcpy(h->q_ids.p, qids.data(), qids.size() * 8, hipMemcpyHostToDevice));
+  QuerySide qs{h->q_minhash.as<int32_t>(), h->Hrow, h->q_ordered.as<int32_t>(), 2LL * S, h->q_meta.as<int32_t>(), h->q_ids.as<int64_t>(),
+               qids.data(), qlen.data()};
+  return search_core(h, qs, ql, false, false, sink, user);
+}
+
+int mhap_get_stats(mhap_handle* h, mhap_stats* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->stats; return MHAP_OK; }
+int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->ktimes; return MHAP_OK; }
+int mhap_reset_kernel_times(mhap_handle* h) { if (!h) return MHAP_E_INVALID; h->ktimes = mhap_kernel_times{}; return MHAP_OK; }
+int mhap_set_stream(mhap_handle* h, void* hip_stream) {
+  if (!h) return MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return MHAP_OK;
+}
+int mhap_synchronize(mhap_handle* h) { if (!h) return MHAP_E_INVALID; (void)hipSetDevice(h->device); return sync_stream(h); }
+
+}  // extern "C"
+
+// =================================================================================================
+// Host-side entry points that share the kernels' __host__ __device__ arithmetic.
+// =================================================================================================
+extern "C" {
+
+// murmur3_x64_128(seed 0).h1 of one k-mer string, canonicalised when do_rc != 0 exactly like
+// HashUtils.computeSequenceHashesLong(str, len, 0, doRC)[0] (J/sketch/HashUtils.java:237-258).  This is what
+// the host driver uses to hash the lines of a `-f` filter file (J/sketch/FrequencyCounts.java:169).
+int mhap_hash_kmer(const char* kmer, int32_t len, int32_t do_rc, int64_t* out) {
+  if (!kmer || !out || len < 1 || len > 4096) return MHAP_E_INVALID;
+  std::string s(kmer, (size_t)len);
+  if (do_rc) {
+    std::string r((size_t)len, 'N');
+    for (int i = 0; i < len; i++) r[(size_t)i] = (char)rc_char((uint32_t)(uint8_t)s[(size_t)(len - 1 - i)]);
+    if (r.compare(s) < 0) s = r;   // String.compareTo < 0 -> use the reverse complement (:246-251)
+  }
+  std::vector<uint32_t> W((size_t)len / 4 + 3, 0u);
+  memcpy(W.data(), s.data(), (size_t)len);
+  *out = (int64_t)murmur128_h1_chars<0>(W.data(), 0, len);
+  return MHAP_OK;
+}
+
+// Test hooks: run the SAME __host__ __device__ functions the kernels use on the host, so that the hash and
+// second-stage lane logic can be checked in a GPU-less container.  Never called by the product path.
+int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t k2, int64_t* out64, int32_t* out32) {
+  if (!seq || len < 0 || k < 1 || k2 < 1) return MHAP_E_INVALID;
+  std::vector<uint32_t> W((size_t)len / 4 + 3, 0u);
+  memcpy(W.data(), seq, (size_t)len);
+  if (out64) for (int p = 0; p + k <= len; p++) out64[p] = (k == 16) ? (int64_t)murmur128_h1_chars<16>(W.data(), p, k) : (int64_t)murmur128_h1_chars<0>(W.data(), p, k);
+  if (out32) for (int p = 0; p + k2 <= len; p++) out32[p] = (k2 == 12) ? (int32_t)murmur32_chars<12>(W.data(), p, k2) : (int32_t)murmur32_chars<0>(W.data(), p, k2);
+  return MHAP_OK;
+}
+
+// out8 = {empty, valid, a1, a2, b1, b2, inter, k}
+int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const int32_t* B, int32_t nB, int32_t lenB, double max_shift,
+                               int32_t stride, int32_t* out8) {
+  if (!A || !B || !out8 || stride < 1) return MHAP_E_INVALID;
+  const int maxrec = 2 * std::max(nA, nB) + 2;
+  std::vector<int32_t> scratch((size_t)3 * (size_t)maxrec * (size_t)stride, 0);
+  LaneScratch sc; sc.base = scratch.data(); sc.stride = stride; sc.maxrec = maxrec;
+  const LaneOverlap r = lane_overlap(A, nA, lenA, B, nB, lenB, max_shift, sc);
+  out8[0] = r.empty; out8[1] = r.valid; out8[2] = r.a1; out8[3] = r.a2; out8[4] = r.b1; out8[5] = r.b2; out8[6] = r.inter; out8[7] = r.kk;
+  return MHAP_OK;
+}
+
+}  // extern "C"

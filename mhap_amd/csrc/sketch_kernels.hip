@@ -1,0 +1,474 @@
+// sketch_kernels.hip — gfx950 kernels for MHAP sketch construction (hot loops A-D of SURVEY §3.1).
+//
+//   hash_kmers_kernel   : murmur3_x64_128 of every k-mer + murmur3_x86_32 of every k2-mer
+//                         (J/sketch/HashUtils.java:213-258), both strands, chars staged in LDS.
+//   kmer_weight_kernel  : per-strand k-mer multiplicity / tf-idf weight, first-occurrence flag
+//                         (J/sketch/MinHashSketch.java:66-81,98-128).
+//   minhash_kernel      : weighted xorshift MinHash, one wavefront per strand, per-slot threshold
+//                         in LDS, ballot-driven rare update path (J/sketch/MinHashSketch.java:130-154).
+//   ordered_kernel      : bottom-S (signed hash, pos) select + sort
+//                         (J/sketch/BottomOverlapSketch.java:525-559).
+#include "kernels.hpp"
+
+namespace mhap {
+
+// =============================================================================================
+// K-mer hashing.  grid = (nstrands, max tiles), block = 256.  A tile is HASH_TILE consecutive
+// window starts of one strand; the chars it needs are decoded once into LDS (packed 2-bit or raw
+// bytes -> ASCII, reverse-complemented on the fly for odd strands).
+// =============================================================================================
+template <int KT, int K2T>
+__global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restrict__ descs, const uint8_t* __restrict__ store,
+                                                         int64_t* __restrict__ keys, int32_t* __restrict__ h32, int k_rt,
+                                                         int k2_rt) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_chars[];
+  const int k = KT > 0 ? KT : k_rt, k2 = K2T > 0 ? K2T : k2_rt;
+  const int strand = blockIdx.x;
+  const ReadDesc rd = descs[strand >> 1];
+  const int rcs = strand & 1;
+  if (strand_skipped(rd, rcs)) return;
+  const int L = rd.length;
+  const int nk = L - k + 1, nk2 = L - k2 + 1;
+  const int nmax = nk > nk2 ? nk : nk2;
+  const int t0 = blockIdx.y * HASH_TILE;
+  if (t0 >= nmax) return;
+  const int halo = (k > k2 ? k : k2) - 1;
+  const int nchars = HASH_TILE + halo;
+  const int nwords = (nchars + 3) / 4 + 1;
+  for (int wj = threadIdx.x; wj < nwords; wj += 256) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      int i = t0 + 4 * wj + b;
+      uint32_t c = (i < L) ? strand_char(store, rd, rcs, i) : 0u;
+      d |= c << (8 * b);
+    }
+    lds_chars[wj] = d;
+  }
+  __syncthreads();
+  int64_t* kout = keys + rd.key_off + (rcs ? rd.key_stride : 0);
+  int32_t* hout = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
+  for (int pp = threadIdx.x; pp < HASH_TILE; pp += 256) {
+    const int p = t0 + pp;
+    if (p < nk) kout[p] = (int64_t)murmur128_h1_chars<KT>(lds_chars, pp, k);
+    if (p < nk2) hout[p] = (int32_t)murmur32_chars<K2T>(lds_chars, pp, k2);
+  }
+}
+
+void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store,
+                       int64_t* keys, int32_t* h32, int k, int k2) {
+  if (nstrands <= 0) return;
+  int kmin = k < k2 ? k : k2;
+  int nmax = max_len - kmin + 1;
+  if (nmax < 1) return;
+  dim3 grid((unsigned)nstrands, (unsigned)((nmax + HASH_TILE - 1) / HASH_TILE));
+  int halo = (k > k2 ? k : k2) - 1;
+  size_t lds = (size_t)(((HASH_TILE + halo + 3) / 4 + 2) * 4);
+  if (k == 16 && k2 == 12)
+    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2);
+  else
+    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2);
+}
+
+// =============================================================================================
+// K-mer multiplicity -> weight.  Persistent workgroups; each takes strands from an atomic counter
+// and owns a private open-addressing table slab in HBM (stays in L2/MALL): pos[TS] holds
+// (first position + 1) of the k-mer that owns the slot, cnt[TS] its multiplicity.
+// Output wts[i] = weight of k-mer i if i is the first occurrence of its key, else 0.
+// =============================================================================================
+__device__ inline uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline bool filter_lookup(const FilterTable& ft, int64_t key, double& val) {
+  uint64_t h = fmix64((uint64_t)key);
+  uint32_t slot = (uint32_t)h & ft.mask;
+  for (;;) {
+    double v = ft.vals[slot];
+    if (v == 0.0) return false;
+    if (ft.keys[slot] == key) { val = v; return true; }
+    slot = (slot + 1) & ft.mask;
+  }
+}
+
+__global__ __launch_bounds__(WEIGHT_THREADS) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
+                                                                     const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
+                                                                     uint32_t* __restrict__ slabs, int64_t slab_entries,
+                                                                     unsigned long long* __restrict__ counter, int k,
+                                                                     FilterTable ft, double repeat_weight,
+                                                                     StrandInfo* __restrict__ info) {
+  __shared__ long long s_strand;
+  __shared__ unsigned int s_valid, s_heavy;
+  uint32_t* tpos = slabs + (size_t)blockIdx.x * (size_t)slab_entries * 2;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) { s_strand = (long long)atomicAdd(counter, 1ULL); s_valid = 0; s_heavy = 0; }
+    __syncthreads();
+    const int64_t strand = s_strand;
+    if (strand >= nstrands) break;
+    const ReadDesc rd = descs[strand >> 1];
+    const int rcs = (int)(strand & 1);
+    const int nk = rd.length - k + 1;
+    if (strand_skipped(rd, rcs) || nk < 1) {
+      if (threadIdx.x == 0) { info[strand].valid = 0; info[strand].heavy = 0; }
+      continue;
+    }
+    const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
+    uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
+    uint32_t ts = 64;
+    while (ts < 2u * (uint32_t)nk) ts <<= 1;
+    const uint32_t mask = ts - 1;
+    uint32_t* tcnt = tpos + ts;
+    for (uint32_t j = threadIdx.x; j < 2 * ts; j += WEIGHT_THREADS) tpos[j] = 0;
+    __threadfence();
+    __syncthreads();
+    // insert
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const int64_t key = kp[i];
+      uint32_t slot = (uint32_t)(uint64_t)key & mask;
+      for (;;) {
+        uint32_t e = ld_agent(&tpos[slot]);
+        if (e == 0) {
+          uint32_t old = atomicCAS(&tpos[slot], 0u, (uint32_t)i + 1u);
+          if (old == 0) { atomicAdd(&tcnt[slot], 1u); break; }
+          e = old;
+        }
+        if (kp[e - 1] == key) { atomicMin(&tpos[slot], (uint32_t)i + 1u); atomicAdd(&tcnt[slot], 1u); break; }
+        slot = (slot + 1) & mask;
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    // finalize: weight of first occurrences
+    unsigned int myvalid = 0, myheavy = 0;
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const int64_t key = kp[i];
+      uint32_t slot = (uint32_t)(uint64_t)key & mask;
+      uint32_t e;
+      for (;;) {
+        e = ld_agent(&tpos[slot]);
+        if (e != 0 && kp[e - 1] == key) break;
+        slot = (slot + 1) & mask;
+      }
+      uint32_t w = 0;
+      if (e == (uint32_t)i + 1u) {
+        const int count = (int)ld_agent(&tcnt[slot]);
+        int weight = count;                                   // tf weight (MinHashSketch.java:98)
+        if (repeat_weight < 0.0) {                            // :101-107
+          weight = 1;
+          double v;
+          if (ft.size > 0 && filter_lookup(ft, key, v)) weight = 0;
+        } else if (ft.enabled && repeat_weight < 1.0) {       // :109-124
+          double idf = ft.range, v;
+          if (ft.size > 0 && filter_lookup(ft, key, v)) idf = v;
+          double tf = ft.no_tf ? 1.0 : (double)count;
+          weight = (int)java_round(tf * idf);
+          if (weight < 1) weight = 1;
+        }
+        if (weight > 0) { w = (uint32_t)weight; myvalid = 1; if (weight > 1) myheavy = 1; }
+      }
+      wp[i] = w;
+    }
+    if (myvalid) atomicOr(&s_valid, 1u);
+    if (myheavy) atomicOr(&s_heavy, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) { info[strand].valid = (int)s_valid; info[strand].heavy = (int)s_heavy; }
+  }
+}
+
+void launch_kmer_weights(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, uint32_t* wts,
+                         uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
+                         double repeat_weight, StrandInfo* info) {
+  if (nstrands <= 0) return;
+  hipLaunchKernelGGL(kmer_weight_kernel, dim3(nblocks), dim3(WEIGHT_THREADS), 0, st, descs, nstrands, keys, wts, slabs, slab_entries,
+                     counter, k, ft, repeat_weight, info);
+}
+
+// =============================================================================================
+// Weighted MinHash.  One wavefront per strand (strands pulled from an atomic counter), 4 waves per
+// workgroup.  Each lane owns MH_U k-mers per row and walks their xorshift chains through all H
+// slots; the per-slot running minimum lives in LDS (best[s], bpos[s]) and is wave-private.  The hot
+// loop only compares the high dword of x against the slot's current minimum (uniform LDS read);
+// a ballot sends the wave into the exact 64-bit update path, which becomes rare after the first
+// rows (expected ~ln(#rows) updates per slot).
+// Ties (x equal, different k-mers; 2^-64) resolve to the earlier first-occurrence position, which
+// is the reference's insertion order.
+// =============================================================================================
+__device__ inline void minhash_update(volatile int64_t* best, volatile int32_t* bpos, int s, const int64_t* xv, const int* pv,
+                                      const bool* act, int n, int lane) {
+  int64_t cur = best[s];
+  int32_t curpos = bpos[s];
+  bool changed = false;
+  for (int u = 0; u < n; u++) {
+    const int64_t x = xv[u];
+    const int p = pv[u];
+    bool c = act[u] && (x < cur || (x == cur && p < curpos));
+    unsigned long long m = __ballot(c);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1;
+      cur = __shfl(x, l);
+      curpos = __shfl(p, l);
+      changed = true;
+      c = act[u] && (x < cur || (x == cur && p < curpos));
+      m = __ballot(c);
+    }
+  }
+  if (changed && lane == 0) { best[s] = cur; bpos[s] = curpos; }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
+                                                      const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
+                                                      const StrandInfo* __restrict__ info, int k, int k2, int H,
+                                                      unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
+                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const size_t per_wave = (size_t)H * 12;
+  volatile int64_t* best = (volatile int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
+  volatile int32_t* bpos = (volatile int32_t*)(best + H);
+  for (;;) {
+    long long sidx = 0;
+    if (lane == 0) sidx = (long long)atomicAdd(counter, 1ULL);
+    sidx = __shfl(sidx, 0);
+    if (sidx >= nstrands) break;
+    const ReadDesc rd = descs[sidx >> 1];
+    const int rcs = (int)(sidx & 1);
+    const int nk = rd.length - k + 1;
+    int32_t* orow = out_rows + sidx * out_stride;
+    const StrandInfo si = info[sidx];
+    if (strand_skipped(rd, rcs) || nk < 1 || rd.length - k2 + 1 < 1 || !si.valid) {
+      // too short (status 2) or ZeroNGramsFoundException from either sketch (status 1)
+      for (int s = lane; s < H; s += 64) orow[s] = 0;
+      if (lane == 0) out_status[sidx * status_stride] = strand_skipped(rd, rcs) ? 2 : 1;
+      continue;
+    }
+    const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
+    const uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
+    for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- pass 1: weight == 1 k-mers, U per lane ----
+    for (int base = 0; base < nk; base += 64 * U) {
+      uint64_t x[U];
+      int pv[U];
+      bool act[U];
+      bool anyact = false;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int i = base + u * 64 + lane;
+        pv[u] = i;
+        act[u] = false;
+        x[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
+        if (i < nk && wp[i] == 1u) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
+      }
+      if (!__any(anyact)) continue;
+      for (int s = 0; s < H; s++) {
+        const int32_t bh = ((volatile int32_t*)best)[2 * s + 1];
+        bool hit = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          x[u] = xorshift_step(x[u]);
+          hit |= ((int32_t)(x[u] >> 32) <= bh);
+        }
+        if (__any(hit)) {
+          int64_t xs[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) xs[u] = (int64_t)x[u];
+          minhash_update(best, bpos, s, xs, pv, act, U, lane);
+        }
+      }
+    }
+    // ---- pass 2: k-mers with weight > 1 (repeats / tf-idf), one per lane, w steps per slot ----
+    if (si.heavy) {
+      for (int base = 0; base < nk; base += 64) {
+        const int i = base + lane;
+        uint32_t wt = (i < nk) ? wp[i] : 0u;
+        const bool heavy = wt > 1u;
+        if (!__any(heavy)) continue;
+        uint32_t wmax = heavy ? wt : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(wmax, off); wmax = o > wmax ? o : wmax; }
+        uint64_t x = heavy ? (uint64_t)kp[i] : 0ULL;
+        for (int s = 0; s < H; s++) {
+          int64_t mn = INT64_MAX;
+          for (uint32_t c = 0; c < wmax; c++) {
+            if (heavy && c < wt) { x = xorshift_step(x); mn = (int64_t)x < mn ? (int64_t)x : mn; }
+          }
+          const int32_t bh = ((volatile int32_t*)best)[2 * s + 1];
+          const bool hit = heavy && ((int32_t)(mn >> 32) <= bh);
+          if (__any(hit)) {
+            int64_t xs[1] = {mn};
+            int pp[1] = {i};
+            bool aa[1] = {heavy};
+            minhash_update(best, bpos, s, xs, pp, aa, 1, lane);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int s = lane; s < H; s += 64) {
+      const int32_t p = bpos[s];
+      int32_t v = 0;
+      if (p != INT32_MIN) {
+        const uint64_t key = (uint64_t)kp[p];
+        v = (s & 1) ? (int32_t)(uint32_t)(key >> 32) : (int32_t)(uint32_t)key;   // MinHashSketch.java:147-150
+      }
+      orow[s] = v;
+    }
+    if (lane == 0) out_status[sidx * status_stride] = 0;
+  }
+}
+
+void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
+                    int32_t* out_status, int64_t status_stride) {
+  if (nstrands <= 0) return;
+  size_t per_wave = (((size_t)H * 12) + 15) & ~(size_t)15;
+  size_t lds = per_wave * 4;
+  hipLaunchKernelGGL((minhash_kernel<MH_U>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter,
+                     out_rows, out_stride, out_status, status_stride);
+}
+
+// =============================================================================================
+// Ordered bottom-S sketch.  One workgroup per strand.  Composite key = (hash ^ 0x80000000) << 32 | pos
+// orders exactly like (signed hash asc, pos asc) = fastutil's stable radixSortIndirect.  A multi-level
+// radix select (11/11/10 bits of hash, then 11/11/10 bits of pos) narrows the S smallest keys down to
+// at most CAP candidates, which are then bitonic-sorted in LDS.
+// =============================================================================================
+__device__ inline uint64_t okey(int32_t h, int pos) { return ((uint64_t)((uint32_t)h ^ 0x80000000u) << 32) | (uint32_t)pos; }
+
+__global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
+                                                              const int32_t* __restrict__ h32, int k2, int S, int cap,
+                                                              int32_t* __restrict__ out_rows, int64_t out_stride,
+                                                              int32_t* __restrict__ out_meta, int64_t meta_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* hist = (uint32_t*)smem;                       // ORD_BINS
+  uint32_t* part = hist + ORD_BINS;                       // ORD_THREADS partial sums
+  uint32_t* svars = part + ORD_THREADS;                   // 4 scalars (kept in the dynamic region: 16-B aligned base)
+  uint64_t* buf = (uint64_t*)(svars + 4);                 // cap keys
+  uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
+  const int64_t strand = blockIdx.x;
+  if (strand >= nstrands) return;
+  const ReadDesc rd = descs[strand >> 1];
+  const int rcs = (int)(strand & 1);
+  const int n = rd.length - k2 + 1;
+  int32_t* meta = out_meta + strand * meta_stride;
+  if (strand_skipped(rd, rcs) || n < 1) {
+    if (threadIdx.x == 0) { meta[0] = 0; meta[1] = n; meta[2] = rd.length; }
+    return;
+  }
+  const int32_t* hp = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
+  const int K = S < n ? S : n;   // BottomOverlapSketch.java:548
+  if (threadIdx.x == 0) { meta[0] = K; meta[1] = n; meta[2] = rd.length; }
+  if (K <= 0) return;
+
+  uint64_t bound = ~0ULL;  // select all keys <= bound
+  if (n > cap) {
+    const int shifts[6] = {53, 42, 32, 21, 10, 0};
+    const int widths[6] = {11, 11, 10, 11, 11, 10};
+    uint64_t prefix = 0;      // high bits fixed so far
+    uint64_t prefmask = 0;
+    uint32_t below = 0;       // keys strictly below the current prefix bin
+    for (int lv = 0; lv < 6; lv++) {
+      const int sh = shifts[lv];
+      const uint32_t nb = 1u << widths[lv];
+      for (uint32_t j = threadIdx.x; j < ORD_BINS; j += ORD_THREADS) hist[j] = 0;
+      __syncthreads();
+      for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
+        const uint64_t key = okey(hp[i], i);
+        if ((key & prefmask) == prefix) atomicAdd(&hist[(uint32_t)(key >> sh) & (nb - 1)], 1u);
+      }
+      __syncthreads();
+      // find the bin holding rank (K-1-below) among keys matching the prefix
+      const uint32_t target = (uint32_t)(K - 1) - below;
+      const int per = ORD_BINS / ORD_THREADS;
+      uint32_t loc = 0;
+      for (int j = 0; j < per; j++) loc += hist[threadIdx.x * per + j];
+      part[threadIdx.x] = loc;
+      __syncthreads();
+      // exclusive scan of part[] (Hillis-Steele, ORD_THREADS elements)
+      for (int off = 1; off < ORD_THREADS; off <<= 1) {
+        uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+      }
+      const uint32_t incl = part[threadIdx.x];
+      const uint32_t excl = incl - loc;
+      if (target >= excl && target < incl) {
+        uint32_t run = excl;
+        for (int j = 0; j < per; j++) {
+          const uint32_t c = hist[threadIdx.x * per + j];
+          if (target < run + c) { s_bin = threadIdx.x * per + j; s_below = run; s_cnt = c; break; }
+          run += c;
+        }
+      }
+      __syncthreads();
+      const uint32_t bin = s_bin, binbelow = s_below, bincnt = s_cnt;
+      __syncthreads();
+      below += binbelow;
+      prefix |= (uint64_t)bin << sh;
+      prefmask |= (uint64_t)(nb - 1) << sh;
+      bound = prefix | (sh > 0 ? ((1ULL << sh) - 1) : 0ULL);
+      if (below + bincnt <= (uint32_t)cap) break;   // candidates (<= bound) fit the sort buffer
+    }
+  }
+  // compact candidates into LDS, pad, sort
+  if (threadIdx.x == 0) s_fill = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
+    const uint64_t key = okey(hp[i], i);
+    if (key <= bound) { uint32_t slot = atomicAdd(&s_fill, 1u); if (slot < (uint32_t)cap) buf[slot] = key; }
+  }
+  __syncthreads();
+  const uint32_t m = s_fill < (uint32_t)cap ? s_fill : (uint32_t)cap;
+  uint32_t np2 = 1;
+  while (np2 < m) np2 <<= 1;
+  for (uint32_t j = m + threadIdx.x; j < np2; j += ORD_THREADS) buf[j] = ~0ULL;
+  __syncthreads();
+  for (uint32_t size = 2; size <= np2; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = threadIdx.x; t < (np2 >> 1); t += ORD_THREADS) {
+        const uint32_t lo = 2 * t - (t & (stride - 1));
+        const uint32_t hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const uint64_t a = buf[lo], b = buf[hi];
+        if ((a > b) == up) { buf[lo] = b; buf[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  int32_t* orow = out_rows + strand * out_stride;
+  for (int j = threadIdx.x; j < K; j += ORD_THREADS) {
+    const uint64_t key = buf[j];
+    orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+    orow[2 * j + 1] = (int32_t)(uint32_t)key;
+  }
+}
+
+size_t ordered_lds_bytes(int cap) { return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8; }
+
+// A read whose forward sketch throws ZeroNGramsFoundException is dropped entirely
+// (J/impl/SequenceSketchStreamer.java:123-156,235-238): propagate the forward status to the rc entry.
+__global__ void fix_status_kernel(int32_t* __restrict__ meta, int64_t nreads) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nreads) return;
+  const int32_t fs = meta[(2 * i) * META_W + 3];
+  if (fs != 0 && meta[(2 * i + 1) * META_W + 3] == 0) meta[(2 * i + 1) * META_W + 3] = fs;
+}
+
+void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads) {
+  if (nreads <= 0) return;
+  hipLaunchKernelGGL(fix_status_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, meta, nreads);
+}
+
+void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, const int32_t* h32, int k2, int S, int cap,
+                    int32_t* out_rows, int64_t out_stride, int32_t* out_meta, int64_t meta_stride) {
+  if (nstrands <= 0) return;
+  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap), st, descs, nstrands, h32,
+                     k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
+}
+
+}  // namespace mhap

@@ -1,0 +1,156 @@
+"""CPU tests of the product's host logic: the C-ABI library loads and exports every symbol the header declares,
+the kernels' __host__ __device__ arithmetic (hash windows, second-stage lane) equals the oracle, and the reference's
+IO conventions (FASTA ids, record text format) hold.  No compute entry point is called here (no GPU)."""
+import ctypes as C
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import mhap_amd
+from mhap_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = mhap_amd.load_library()
+    hdr = open(os.path.join(ROOT, "include", "mhap_hip.h")).read()
+    declared = set(re.findall(r"\b(mhap_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"mhap_record_sink"}
+    assert declared, "no declarations parsed"
+    assert declared == set(api.EXPORTED_SYMBOLS)
+    for name in sorted(declared):
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(api._Params) == 8 * 4 + 3 * 8
+    assert api.RECORD_DTYPE.itemsize == 64
+    assert O.ORC_RECORD.itemsize == 64
+
+
+def test_create_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mhap_amd.MhapError):
+        mhap_amd.MinHashSearch(mhap_amd.MhapParams())
+
+
+def _hash_windows(seq, k, k2):
+    lib = mhap_amd.load_library()
+    s = seq.encode("latin-1")
+    o64 = np.zeros(max(len(s) - k + 1, 1), dtype=np.int64)
+    o32 = np.zeros(max(len(s) - k2 + 1, 1), dtype=np.int32)
+    assert lib.mhap_selftest_hash_windows(s, C.c_int32(len(s)), C.c_int32(k), C.c_int32(k2), api._ptr(o64), api._ptr(o32)) == 0
+    return o64[:max(len(s) - k + 1, 0)], o32[:max(len(s) - k2 + 1, 0)]
+
+
+@pytest.mark.parametrize("k,k2", [(16, 12), (16, 14), (15, 13), (21, 11), (8, 5), (24, 12), (13, 16), (1, 1), (7, 3)])
+def test_kernel_hash_arithmetic_matches_oracle(k, k2):
+    rnd = random.Random(k * 100 + k2)
+    seq = "".join(rnd.choice("ACGTNRY") for _ in range(211))
+    h64, h32 = _hash_windows(seq, k, k2)
+    assert h64.tolist() == O.kmer_hashes64(seq, k).tolist()
+    assert h32.tolist() == O.kmer_hashes32(seq, k2).tolist()
+
+
+def test_filter_kmer_hash_is_canonical_when_rc():
+    lib = mhap_amd.load_library()
+    out = C.c_int64()
+    for kmer in ("ACGTACGTACGTACGT", "TTTTTTTTTTTTTTTT", "GATTACAGATTACAGA", "ACGTN"):
+        for do_rc in (0, 1):
+            assert lib.mhap_hash_kmer(kmer.encode(), C.c_int32(len(kmer)), C.c_int32(do_rc), C.byref(out)) == 0
+            assert out.value == int(O.kmer_hashes64(kmer, len(kmer), bool(do_rc))[0])
+
+
+def _lane(A, lenA, B, lenB, max_shift=0.2, stride=1):
+    lib = mhap_amd.load_library()
+    A = np.ascontiguousarray(A, dtype=np.int32)
+    B = np.ascontiguousarray(B, dtype=np.int32)
+    out = np.zeros(8, dtype=np.int32)
+    assert lib.mhap_selftest_overlap_lane(api._ptr(A), C.c_int32(A.shape[0]), C.c_int32(lenA), api._ptr(B), C.c_int32(B.shape[0]),
+                                          C.c_int32(lenB), C.c_double(max_shift), C.c_int32(stride), api._ptr(out)) == 0
+    return dict(zip(["empty", "raw", "a1", "a2", "b1", "b2", "inter", "k"], out.tolist()))
+
+
+def test_second_stage_lane_matches_oracle():
+    rnd = random.Random(99)
+    nonempty = 0
+    for trial in range(40):
+        la, lb = rnd.randint(300, 3000), rnd.randint(300, 3000)
+        g = "".join(rnd.choice("ACGT") for _ in range(max(la, lb) + 600))
+        off = rnd.randint(0, 500)
+        err = rnd.choice([0.0, 0.01, 0.04, 0.08])
+
+        def noisy(s):
+            return "".join((rnd.choice("ACGT") if rnd.random() < err else c) for c in s)
+        a, b = noisy(g[:la]), noisy(g[off:off + lb])
+        if trial % 7 == 0:
+            b = O.rc(b)                                   # wrong strand: (nearly) EMPTY
+        if trial % 5 == 1:
+            rep = "".join(rnd.choice("ACGT") for _ in range(12))
+            a = a[:150] + rep * rnd.randint(3, 30) + a[150:]
+            b = b[:90] + rep * rnd.randint(3, 30) + b[90:]
+        if trial % 9 == 4:
+            a, b = "A" * 400 + a, "A" * 300 + b           # long equal-hash runs
+        S = rnd.choice([32, 128, 1536])
+        _, A, lenA = O.ordered(a, 12, S)
+        _, B, lenB = O.ordered(b, 12, S)
+        ms = rnd.choice([0.2, 0.05, 0.5])
+        want = O.overlap(A, lenA, B, lenB, max_shift=ms)
+        got = _lane(A, lenA, B, lenB, max_shift=ms, stride=rnd.choice([1, 3, 64]))
+        assert got["empty"] == want["empty"], trial
+        if not want["empty"]:
+            nonempty += 1
+            for key in ("a1", "a2", "b1", "b2", "inter", "k"):
+                assert got[key] == want[key], (trial, key)
+            assert float(got["raw"]) == want["raw"]
+    assert nonempty >= 15
+
+
+def test_record_text_format_matches_java_semantics():
+    rnd = random.Random(1)
+    rec = {"from_id": 12, "to_id": 7, "score": 0.78, "raw": 57.0, "a1": 3, "a2": 4000, "alen": 5000, "b1": 10, "b2": 3900,
+           "blen": 4800, "to_rc": 1}
+    assert mhap_amd.format_record(rec) == "12 7 0.220000 57.000000 0 3 4000 5000 1 10 3900 4800"
+    rec["score"] = 1.0 - 5e-7      # error column 5e-7 (approx): compare with the oracle's formatter
+    for _ in range(300):
+        rec["score"] = rnd.choice([rnd.random(), 1.0, 1.2, 0.0, 1 - 1e-6 * rnd.randint(0, 9) - 5e-7])
+        rec["raw"] = float(rnd.randint(0, 3000))
+        assert mhap_amd.format_record(rec) == O.format_record(rec)
+    assert mhap_amd.format_record({**rec, "score": 1.5}).split()[2] == "0.000000"      # clamp (MatchResult.java:61-64)
+
+
+def test_fasta_reader_follows_fastadata(tmp_path):
+    p = tmp_path / "x.fasta"
+    p.write_bytes(b">r1 desc\nacgt\nACGN\n>empty\n>r2\r\nTTTT\r\n\r\nGG\n>r3\nA")
+    fa = mhap_amd.FastaData.from_file(str(p))
+    assert len(fa) == 3
+    assert [fa.sequence(i) for i in range(3)] == ["ACGTACGN", "TTTTGG", "A"]
+    assert fa.ids.tolist() == [1, 2, 3]            # empty record does not consume an id (FastaData.java:180-181)
+    fa = mhap_amd.FastaData.from_file(str(p), id_offset=10)
+    assert fa.ids.tolist() == [11, 12, 13]
+    bad = tmp_path / "bad.fasta"
+    bad.write_bytes(b"ACGT\n>r\nAC\n")
+    with pytest.raises(mhap_amd.MhapError):
+        mhap_amd.FastaData.from_file(str(bad))
+    g = mhap_amd.FastaData.from_file(os.path.join(ROOT, "tests", "golden", "small_reads.fasta"))
+    assert len(g) == 30 and g.sequence(7) == g.sequence(7).upper()
+
+
+def test_synthetic_reads_are_deterministic_and_overlap():
+    a = mhap_amd.synth_reads(50, 2000, seed=123)
+    b = mhap_amd.synth_reads(50, 2000, seed=123)
+    c = mhap_amd.synth_reads(50, 2000, seed=124)
+    assert np.array_equal(a.bases, b.bases) and not np.array_equal(a.bases, c.bases)
+    assert set(np.unique(a.bases).tolist()) <= set(b"ACGT")
+    assert a.lengths.tolist() == [2000] * 50 and a.ids.tolist() == list(range(1, 51))
+    # 30x coverage of a 3.3 kb genome at 5 % error: the oracle must find many overlaps between these reads
+    d = mhap_amd.synth_reads(50, 2000, seed=123, error_rate=0.05)
+    res = O.run_self(d, H=128, S=512, nthreads=4)
+    assert len(res["records"]) > 50
