@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — MHAP hot path on MI355X: self-overlap of synthetic PacBio-style reads (BASELINE.json configs[1]).
+
+A "step" is ONE full pass of the hot path over the whole data set: sketch every read (both strands: k-mer
+murmur hashes, tf weights, weighted MinHash, ordered bottom-S sketch), build the index tables in HBM, all-pairs
+candidate count, second-stage overlap scoring, accepted records delivered to the host.  The packed reads are
+resident in HBM before the timed region starts (mhap_stage_reads); record text formatting is outside it.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+N > 1 (strong scaling, same 100k reads): rank r sketches reads r, r+N, ...; the per-rank sketch tables are
+all-gathered with RCCL over xGMI; every rank searches its round-robin query shard against the full index.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import mhap_amd  # noqa: E402
+from mhap_amd import MhapParams, MinHashSearch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x max clock = 78.6e12 int lane-ops/s
+
+
+def sketch_bytes_per_read(L, H, S, k2):
+    """packed read once + both MinHash rows + both ordered rows."""
+    sp = min(S, L - k2 + 1)
+    return (L + 3) // 4 + 2 * 4 * H + 2 * 8 * sp
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100000)
+    ap.add_argument("--length", type=int, default=10000)
+    ap.add_argument("--hashes", type=int, default=512)
+    ap.add_argument("--error-rate", type=float, default=0.15)
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_total, L, H, S, k, k2 = args.reads, args.length, args.hashes, 1536, 16, 12
+    p = MhapParams(kmer_size=k, num_hashes=H, ordered_kmer_size=k2, ordered_sketch_size=S, device=local_rank)
+    seed = 0x4D484150 ^ 2
+    t_gen = time.time()
+    fa = mhap_amd.synth_reads(n_total, L, seed=seed, error_rate=args.error_rate, shard=rank, nshards=world)
+    n_local = len(fa)
+    n_pad = (n_total + world - 1) // world      # equal shard size for the all-gather (pad = zero-length reads)
+    if n_local < n_pad:
+        pad = n_pad - n_local
+        fa = mhap_amd.FastaData(fa.bases, np.concatenate([fa.offsets, np.zeros(pad, np.int64)]),
+                                np.concatenate([fa.lengths, np.zeros(pad, np.int32)]),
+                                np.concatenate([fa.ids, np.arange(n_total + 1, n_total + pad + 1, dtype=np.int64)]))
+    t_gen = time.time() - t_gen
+
+    ms = MinHashSearch(p)
+    ms.stage(fa)                                  # packed reads now resident in HBM
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        loc_mh = torch.zeros((2 * n_pad, H), dtype=torch.int32, device=dev)
+        loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
+        loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
+        all_mh = torch.empty((world, n_pad, 2, H), dtype=torch.int32, device=dev)
+        all_od = torch.empty((world, n_pad, 2, S * 2), dtype=torch.int32, device=dev)
+        all_mt = torch.empty((world, n_pad, 2, 4), dtype=torch.int32, device=dev)
+        # global read order r = j*world + rank  ->  entry 2r+s
+        gids = np.repeat(np.arange(1, n_pad * world + 1, dtype=np.int64), 2)
+        gfwd = np.tile(np.array([1, 0], dtype=np.uint8), n_pad * world)
+
+    def step():
+        ms.clear()
+        if world == 1:
+            ms.add_staged()
+            recs = ms.find_matches()
+        else:
+            ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+            dist.all_gather_into_tensor(all_mh.view(world, -1), loc_mh.view(1, -1))
+            dist.all_gather_into_tensor(all_od.view(world, -1), loc_od.view(1, -1))
+            dist.all_gather_into_tensor(all_mt.view(world, -1), loc_mt.view(1, -1))
+            g_mh = all_mh.permute(1, 0, 2, 3).contiguous()     # [j][rank][strand] = global read order
+            g_od = all_od.permute(1, 0, 2, 3).contiguous()
+            g_mt = all_mt.permute(1, 0, 2, 3).contiguous()
+            torch.cuda.synchronize()
+            ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
+            recs = ms.find_matches_shard(rank, world)
+            step.keep = (g_mh, g_od, g_mt)
+        return recs
+
+    def fence():
+        ms.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ms.reset_kernel_times()
+    fence()
+    t0 = time.perf_counter()
+    nrec = 0
+    for _ in range(args.steps):
+        recs = step()
+        nrec = len(recs)
+    fence()
+    elapsed = time.perf_counter() - t0
+    st = ms.stats()
+    kt = ms.kernel_times()
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot_rec = torch.tensor([nrec], dtype=torch.int64, device=dev)
+    kms = torch.tensor([kt[kname]["ms"] for kname in mhap_amd.KERNEL_NAMES], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_rec, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    total_records = int(tot_rec.item())
+    sec_per_step = elapsed / max(args.steps, 1)
+
+    if rank == 0:
+        K = max(args.steps, 1)
+        kernel_ms_per_step = {kname: float(kms[i].item()) / K for i, kname in enumerate(mhap_amd.KERNEL_NAMES)}
+        sketch_ms = sum(kernel_ms_per_step[x] for x in ("hash_kmers", "kmer_weight", "minhash", "ordered"))
+        search_ms = kernel_ms_per_step["candidate"] + kernel_ms_per_step["overlap"]
+        # dominant kernel roofline
+        dom = max(kernel_ms_per_step, key=kernel_ms_per_step.get)
+        launches = max(kt[dom]["launches"], 1)
+        avg_launch_s = kt[dom]["ms"] / launches / 1e3
+        reads_per_launch = n_local * K / launches if dom in ("hash_kmers", "kmer_weight", "minhash", "ordered") else None
+        if dom == "candidate":
+            alg_bytes = (n_total + 2 * n_total) * 4 * H / world * K / launches      # §8(d): every sketch row read once per pass
+        elif dom == "overlap":
+            alg_bytes = st["candidates_compared"] / launches * 8 * S * 2
+        else:
+            alg_bytes = sketch_bytes_per_read(L, H, S, k2) * reads_per_launch
+        achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches)}
+        # integer-VALU view of the MinHash kernel (the path is integer min-reduction work, not HBM-bound: SURVEY F12)
+        steps_per_read = 2 * (L - k + 1) * H
+        mh_s = kernel_ms_per_step["minhash"] / 1e3
+        xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
+        valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1), "lane_ops_per_step": 11,
+                "frac_of_int_valu_peak": round(xs_rate * 11 / VALU_LANE_OPS_PEAK, 4)}
+        if kernel_ms_per_step["candidate"] > 0:
+            valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / K / (kernel_ms_per_step["candidate"] / 1e3), 1)
+
+        out = {
+            "metric": "overlaps/sec", "value": round(total_records / sec_per_step, 2), "unit": "overlaps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{n_total} synthetic PacBio-style reads x {L} bp (30x, {args.error_rate:.0%} error), k={k}, "
+                                   f"--num-hashes {H}, ordered sketch k2={k2} S={S}, self-overlap (BASELINE configs[1])",
+                       "parallelism": f"reads round-robin over {world} GPU(s); RCCL all-gather of sketch tables" if world > 1 else "1 GPU"},
+            "records_per_step": total_records,
+            "sketches_per_sec": round(2 * n_total / (sketch_ms / 1e3), 1) if sketch_ms > 0 else None,
+            "sketches_per_sec_note": "strands / summed sketch-kernel time (rank max)",
+            "overlaps_per_sec_search_only": round(total_records / (search_ms / 1e3), 1) if search_ms > 0 else None,
+            "kernel_ms_per_step": {kk: round(v, 3) for kk, v in kernel_ms_per_step.items()},
+            "candidates_per_step": int(st["candidates_compared"] // K) if world == 1 else None,
+            "roofline": roofline, "valu": valu,
+            "input_gen_s": round(t_gen, 2),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, L, H, S, k, k2)
+        print(json.dumps(out), flush=True)
+    ms.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, L, H, S, k, k2):
+    """The CPU oracle (a C++ restatement of the reference's Java, kind "port") timed on this box's host cores on a
+    bounded sample of the same workload: same read length, coverage, error model and flags, fewer reads."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    n = args.cpu_sample_reads
+    if n <= 0:
+        # ~2*(L-k+1)*H xorshift steps per read at ~1.5e9 steps/s/core; aim at ~15 s
+        per_read_s = 2.0 * (L - k + 1) * H / 1.5e9
+        n = int(max(200, min(20000, 15.0 * cores / per_read_s)))
+    fa = mhap_amd.synth_reads(n, L, seed=(0x4D484150 ^ 2) + 1, error_rate=args.error_rate)
+    t = time.perf_counter()
+    res = O.run_self(fa, k=k, H=H, k2=k2, S=S, nthreads=cores, cap=1 << 24)
+    wall = time.perf_counter() - t
+    nrec = len(res["records"])
+    busy = res["sketch_s"] + res["search_s"]
+    return {"value": round(nrec / busy, 2) if busy > 0 else None, "unit": "overlaps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} reads x {L} bp at the same 30x coverage/error model (own genome), same flags; "
+                      f"{nrec} records in {busy:.2f} s ({res['sketch_s']:.2f} s sketch + {res['search_s']:.2f} s search)",
+            "sketches_per_sec": round(2 * n / res["sketch_s"], 1) if res["sketch_s"] > 0 else None,
+            "reads_per_sec": round(n / busy, 2) if busy > 0 else None, "wall_s": round(wall, 2),
+            "note": "C++ restatement of MHAP's Java path (no JVM on this box), std::thread on all host cores"}
+
+
+if __name__ == "__main__":
+    main()

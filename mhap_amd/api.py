@@ -56,7 +56,8 @@ EXPORTED_SYMBOLS = [
     "mhap_sketch_reads_device", "mhap_index_set_device", "mhap_find_matches_self", "mhap_find_matches_reads",
     "mhap_get_stats", "mhap_get_kernel_times", "mhap_reset_kernel_times", "mhap_set_stream", "mhap_synchronize",
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
-    "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane",
+    "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
+    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard",
 ]
 
 
@@ -70,6 +71,12 @@ def load_library(build_if_missing=True):
             raise MhapError(f"{_LIB_PATH} is missing: run `python -m mhap_amd.build`")
         from . import build as _b
         _b.build()
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Importing torch first makes the
+        # process use ONE HIP/HSA runtime; loading ours first and torch later leaves the second runtime without devices.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     try:
         lib = C.CDLL(_LIB_PATH)
     except OSError as e:
@@ -171,17 +178,21 @@ class FastaData:
         return FastaData(bases, offsets, lengths, self.ids[idx])
 
 
-def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15):
-    """Deterministic synthetic PacBio-style reads as a FastaData."""
+def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15, shard=0, nshards=1):
+    """Deterministic synthetic PacBio-style reads as a FastaData.
+
+    With nshards > 1 only reads shard, shard+nshards, ... of the same n-read data set are generated (ids kept)."""
     lib = load_library()
-    bases = np.empty(n * length, dtype=np.uint8)
-    rc = lib.mhap_synth_reads(C.c_uint64(seed), C.c_int64(n), C.c_int32(length), C.c_double(coverage),
-                              C.c_double(error_rate), _ptr(bases))
+    idx = np.arange(shard, n, nshards, dtype=np.int64)
+    m = len(idx)
+    bases = np.empty(max(m * length, 1), dtype=np.uint8)
+    rc = lib.mhap_synth_reads_shard(C.c_uint64(seed), C.c_int64(n), C.c_int32(length), C.c_double(coverage),
+                                    C.c_double(error_rate), C.c_int64(shard), C.c_int64(nshards), _ptr(bases))
     if rc != 0:
         raise MhapError(f"mhap_synth_reads failed ({rc})")
-    offsets = np.arange(n, dtype=np.int64) * length
-    lengths = np.full(n, length, dtype=np.int32)
-    return FastaData(bases, offsets, lengths, np.arange(1, n + 1, dtype=np.int64))
+    offsets = np.arange(m, dtype=np.int64) * length
+    lengths = np.full(m, length, dtype=np.int32)
+    return FastaData(bases[:m * length], offsets, lengths, idx + 1)
 
 
 class FrequencyCounts:
@@ -314,6 +325,18 @@ class MinHashSearch:
         self._chk(self._lib.mhap_index_add_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
                                                  _ptr(fasta.ids), C.c_int64(len(fasta))))
 
+    def stage(self, fasta):
+        """Pack + upload reads so that they are resident in HBM (bench: outside the timed region)."""
+        self._chk(self._lib.mhap_stage_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
+                                             _ptr(fasta.ids), C.c_int64(len(fasta))))
+
+    def add_staged(self):
+        self._chk(self._lib.mhap_index_add_staged(self._h))
+
+    def sketch_staged_device(self, d_minhash_ptr, d_ordered_ptr, d_meta_ptr):
+        self._chk(self._lib.mhap_sketch_staged_device(self._h, C.c_void_p(d_minhash_ptr), C.c_void_p(d_ordered_ptr),
+                                                      C.c_void_p(d_meta_ptr)))
+
     def size(self):
         n = C.c_int64()
         self._chk(self._lib.mhap_index_size(self._h, C.byref(n)))
@@ -383,6 +406,10 @@ class MinHashSearch:
     def find_matches(self, q_first=0, q_count=-1):
         """Self overlap of forward entries [q_first, q_first+q_count) against the whole index."""
         return self._collect(lambda cb: self._lib.mhap_find_matches_self(self._h, C.c_int64(q_first), C.c_int64(q_count), cb, None))
+
+    def find_matches_shard(self, shard, nshards):
+        """This rank's share of the self overlap (reads with ordinal % nshards == shard are the queries)."""
+        return self._collect(lambda cb: self._lib.mhap_find_matches_self_shard(self._h, C.c_int64(shard), C.c_int64(nshards), cb, None))
 
     def find_matches_stream(self, fasta):
         return self._collect(lambda cb: self._lib.mhap_find_matches_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets),

@@ -156,7 +156,14 @@ void mhap_fasta_free(mhap_fasta* f) {
 // Synthetic PacBio-style reads.  Circular random genome of n*len/coverage bp; every read
 // has its own generator seeded from (seed, index) so generation is order- and thread-independent.
 int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, char* bases) {
+  return mhap_synth_reads_shard(seed, n, len, coverage, error_rate, 0, 1, bases);
+}
+
+// Reads r = shard, shard+nshards, ... of the n-read data set (identical bytes to the full generation).
+int mhap_synth_reads_shard(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, int64_t shard, int64_t nshards,
+                           char* bases) {
   if (n < 0 || len <= 0 || !bases || coverage <= 0.0 || error_rate < 0.0 || error_rate >= 1.0) return MHAP_E_INVALID;
+  if (nshards < 1 || shard < 0 || shard >= nshards) return MHAP_E_INVALID;
   if (n == 0) return MHAP_OK;
   const int64_t G = std::max<int64_t>((int64_t)((double)n * (double)len / coverage), (int64_t)len + 1);
   std::vector<uint8_t> genome((size_t)G);
@@ -176,7 +183,8 @@ int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, dou
   for (int t = 0; t < nthreads; t++) {
     th.emplace_back([&, t]() {
       std::vector<uint8_t> tmp((size_t)len);
-      for (int64_t r = t; r < n; r += nthreads) {
+      for (int64_t q = t; shard + q * nshards < n; q += nthreads) {
+        const int64_t r = shard + q * nshards;
         Xoshiro256ss g(SplitMix64{seed ^ (0x9e3779b97f4a7c15ULL * (uint64_t)(r + 1))}.next());
         int64_t gp = (int64_t)g.below((uint64_t)G);
         const bool rev = (g.next() >> 63) != 0;
@@ -190,7 +198,7 @@ int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, dou
           if (u < p_ins + p_del + p_sub) { tmp[(size_t)w++] = (uint8_t)((b + 1 + (g.next() >> 62) % 3) & 3); continue; }
           tmp[(size_t)w++] = b;
         }
-        char* dst = bases + r * (int64_t)len;
+        char* dst = bases + q * (int64_t)len;
         if (!rev) for (int i = 0; i < len; i++) dst[i] = ALPHA[tmp[(size_t)i]];
         else for (int i = 0; i < len; i++) dst[i] = ALPHA[3 - tmp[(size_t)(len - 1 - i)]];
       }

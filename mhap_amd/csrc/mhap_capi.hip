@@ -98,6 +98,9 @@ struct mhap_handle {
   DevBuf store, descs, keys, wts, h32, info, slabs, counters;
   std::vector<uint8_t> h_store;
   std::vector<ReadDesc> h_descs;
+  std::vector<ReadDesc> st_descs;   // staged reads (base_off/length/flags); packed bases resident in `store`
+  std::vector<int64_t> st_ids;
+  int64_t st_n = 0, st_bytes = 0;
 
   // query tables for -q mode
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
@@ -176,65 +179,82 @@ inline int code_of(char c) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Sketch `n` reads into device rows [row0, row0+2n) of the given tables.
+// Staging: pack reads (2 bits/base; raw bytes for reads with non-ACGT chars) and upload them once.
+// After staging the packed reads are resident in HBM; sketch_staged() only launches kernels.
 // ------------------------------------------------------------------------------------------------
-int sketch_into(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, bool fwd_only,
-                int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
+int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, bool fwd_only) {
+  const int nthreads = host_threads();
+  h->st_descs.resize((size_t)n);
+  h->st_n = n;
+  std::vector<uint8_t> israw((size_t)n);
+  parallel_for(n, nthreads, [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      const char* s = bases + offsets[i];
+      const int L = lengths[i];
+      uint8_t raw = 0;
+      for (int j = 0; j < L; j++) if (code_of(s[j]) < 0) { raw = 1; break; }
+      israw[(size_t)i] = raw;
+    }
+  });
+  int64_t store_bytes = 0;
+  for (int64_t i = 0; i < n; i++) {
+    ReadDesc& d = h->st_descs[(size_t)i];
+    const int L = std::max(0, lengths[i]);
+    d.length = L;
+    d.flags = 0;
+    if (L < h->P.min_olap_length) d.flags |= MHAP_RD_SKIP;          // SequenceSketchStreamer.java:129-133
+    if (israw[(size_t)i]) d.flags |= MHAP_RD_RAW;
+    if (fwd_only) d.flags |= MHAP_RD_FWDONLY;
+    d.base_off = store_bytes;
+    d.key_off = d.h2_off = 0; d.key_stride = d.h2_stride = 0;
+    if (!(d.flags & MHAP_RD_SKIP)) store_bytes += (d.flags & MHAP_RD_RAW) ? align4(L) : align4((L + 3) / 4);
+  }
+  h->h_store.assign((size_t)std::max<int64_t>(store_bytes, 4), 0);
+  parallel_for(n, nthreads, [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      const ReadDesc& d = h->st_descs[(size_t)i];
+      if (d.flags & MHAP_RD_SKIP) continue;
+      const char* s = bases + offsets[i];
+      uint8_t* dst = h->h_store.data() + d.base_off;
+      if (d.flags & MHAP_RD_RAW) memcpy(dst, s, (size_t)d.length);
+      else
+        for (int j = 0; j < d.length; j++) dst[j >> 2] |= (uint8_t)(code_of(s[j]) << (2 * (j & 3)));
+    }
+  });
+  HIPCHK(h, h->store.ensure(h->h_store.size()));
+  HIPCHK(h, hipMemcpyAsync(h->store.p, h->h_store.data(), h->h_store.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->st_bytes = (int64_t)h->h_store.size();
+  std::vector<uint8_t>().swap(h->h_store);
+  return MHAP_OK;
+}
+
+// Sketch the staged reads into device rows [0, 2*st_n) of the given tables (kernels only + tiny descriptor uploads).
+int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
+  const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
   int64_t batch_bases = 256LL << 20;
   if (const char* e = getenv("MHAP_BATCH_BASES")) { long long v = atoll(e); if (v > 0) batch_bases = v; }
-  const int nthreads = host_threads();
   int64_t r0 = 0;
   while (r0 < n) {
     // ---- choose batch [r0, r1) ----
     int64_t r1 = r0, tot = 0;
-    while (r1 < n && (r1 == r0 || tot + lengths[r1] <= batch_bases) && (r1 - r0) < (1 << 22)) { tot += std::max(0, lengths[r1]); r1++; }
+    while (r1 < n && (r1 == r0 || tot + h->st_descs[(size_t)r1].length <= batch_bases) && (r1 - r0) < (1 << 22)) { tot += h->st_descs[(size_t)r1].length; r1++; }
     const int64_t nb = r1 - r0;
-    // ---- descriptors + storage layout ----
-    h->h_descs.resize((size_t)nb);
-    int64_t store_bytes = 0, key_elems = 0, h2_elems = 0;
+    // ---- per-batch scratch layout ----
+    h->h_descs.assign(h->st_descs.begin() + r0, h->st_descs.begin() + r1);
+    int64_t key_elems = 0, h2_elems = 0;
     int max_len = 0;
-    std::vector<uint8_t> israw((size_t)nb);
-    parallel_for(nb, nthreads, [&](int64_t lo, int64_t hi) {
-      for (int64_t i = lo; i < hi; i++) {
-        const char* s = bases + offsets[r0 + i];
-        const int L = lengths[r0 + i];
-        uint8_t raw = 0;
-        for (int j = 0; j < L; j++) if (code_of(s[j]) < 0) { raw = 1; break; }
-        israw[(size_t)i] = raw;
-      }
-    });
     for (int64_t i = 0; i < nb; i++) {
       ReadDesc& d = h->h_descs[(size_t)i];
-      const int L = std::max(0, lengths[r0 + i]);
-      d.length = L;
-      d.flags = 0;
-      if (L < h->P.min_olap_length) d.flags |= MHAP_RD_SKIP;          // SequenceSketchStreamer.java:129-133
-      if (israw[(size_t)i]) d.flags |= MHAP_RD_RAW;
-      if (fwd_only) d.flags |= MHAP_RD_FWDONLY;
-      d.base_off = store_bytes;
-      if (!(d.flags & MHAP_RD_SKIP)) store_bytes += (d.flags & MHAP_RD_RAW) ? align4(L) : align4((L + 3) / 4);
+      const int L = d.length;
       const int64_t nk = align4(std::max(0, L - k + 1)), nk2 = align4(std::max(0, L - k2 + 1));
       d.key_off = key_elems; d.key_stride = (int32_t)nk;
       d.h2_off = h2_elems; d.h2_stride = (int32_t)nk2;
       if (!(d.flags & MHAP_RD_SKIP)) { key_elems += 2 * nk; h2_elems += 2 * nk2; max_len = std::max(max_len, L); }
     }
-    h->h_store.assign((size_t)std::max<int64_t>(store_bytes, 4), 0);
-    parallel_for(nb, nthreads, [&](int64_t lo, int64_t hi) {
-      for (int64_t i = lo; i < hi; i++) {
-        const ReadDesc& d = h->h_descs[(size_t)i];
-        if (d.flags & MHAP_RD_SKIP) continue;
-        const char* s = bases + offsets[r0 + i];
-        uint8_t* dst = h->h_store.data() + d.base_off;
-        if (d.flags & MHAP_RD_RAW) memcpy(dst, s, (size_t)d.length);
-        else
-          for (int j = 0; j < d.length; j++) dst[j >> 2] |= (uint8_t)(code_of(s[j]) << (2 * (j & 3)));
-      }
-    });
     const int64_t nstr = 2 * nb;
-    // ---- device scratch ----
-    HIPCHK(h, h->store.ensure((size_t)h->h_store.size()));
     HIPCHK(h, h->descs.ensure((size_t)nb * sizeof(ReadDesc)));
     HIPCHK(h, h->keys.ensure((size_t)std::max<int64_t>(key_elems, 4) * 8));
     HIPCHK(h, h->wts.ensure((size_t)std::max<int64_t>(key_elems, 4) * 4));
@@ -245,7 +265,6 @@ int sketch_into(mhap_handle* h, const char* bases, const int64_t* offsets, const
     int64_t slab_entries = 64;
     while (slab_entries < 2LL * std::max(1, max_len - k + 1)) slab_entries <<= 1;
     HIPCHK(h, h->slabs.ensure((size_t)wblocks * (size_t)slab_entries * 2 * 4));
-    HIPCHK(h, hipMemcpyAsync(h->store.p, h->h_store.data(), h->h_store.size(), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
 
@@ -271,12 +290,23 @@ int sketch_into(mhap_handle* h, const char* bases, const int64_t* offsets, const
     time_end(h);
     launch_fix_status(h->stream, meta_rows, nb);
     HIPCHK(h, hipGetLastError());
-    int rc = sync_stream(h);
+    int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
     r0 = r1;
   }
   return MHAP_OK;
 }
+
+int sketch_into(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, bool fwd_only,
+                int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
+  if (n <= 0) return MHAP_OK;
+  int rc = stage_reads(h, bases, offsets, lengths, n, fwd_only);
+  if (rc != MHAP_OK) return rc;
+  rc = sketch_staged(h, d_minhash, mh_stride, d_ordered, ord_stride, d_meta);
+  h->st_n = 0;   // staging consumed (explicit mhap_stage_reads keeps it; see mhap_index_add_staged)
+  return rc;
+}
+
 
 int ensure_index_capacity(mhap_handle* h, int64_t entries) {
   if (h->external) return fail(h, MHAP_E_STATE, "index tables are externally owned (mhap_index_set_device); clear the index first");
@@ -509,6 +539,8 @@ int mhap_set_filter(mhap_handle* h, const int64_t* hashes, const double* fractio
   return MHAP_OK;
 }
 
+static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n);
+
 int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n) {
   if (!h || (n > 0 && (!bases || !offsets || !lengths || !ids))) return h ? fail(h, MHAP_E_INVALID, "null argument") : MHAP_E_INVALID;
   if (n <= 0) return MHAP_OK;
@@ -522,18 +554,54 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
   rc = sketch_into(h, bases, offsets, lengths, n, false, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S,
                    h->d_meta + first * META_W);
   if (rc != MHAP_OK) return rc;
+  return finish_add(h, first, ids, n);
+}
+
+// shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
+static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
   for (int64_t i = 0; i < n; i++) {
     h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
     h->fwd[(size_t)(first + 2 * i)] = 1; h->fwd[(size_t)(first + 2 * i + 1)] = 0;
   }
   HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)(2 * n) * 8, hipMemcpyHostToDevice));
-  rc = mirror_meta(h, h->d_meta, first, 2 * n);
+  int rc = mirror_meta(h, h->d_meta, first, 2 * n);
   if (rc != MHAP_OK) return rc;
   h->n_entries = first + 2 * n;
   h->stats.strands_indexed = 0;
   for (int64_t e = 0; e < h->n_entries; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
   return MHAP_OK;
+}
+
+int mhap_stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n) {
+  if (!h || n < 0 || (n > 0 && (!bases || !offsets || !lengths || !ids))) return h ? fail(h, MHAP_E_INVALID, "null argument") : MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  for (int64_t i = 0; i < n; i++) if (lengths[i] < 0) return fail(h, MHAP_E_INVALID, "negative read length");
+  h->st_ids.assign(ids, ids + n);
+  if (n == 0) { h->st_n = 0; return MHAP_OK; }
+  return stage_reads(h, bases, offsets, lengths, n, false);
+}
+
+int mhap_index_add_staged(mhap_handle* h) {
+  if (!h) return MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  const int64_t n = h->st_n;
+  if (n <= 0 || (int64_t)h->st_ids.size() != n) return fail(h, MHAP_E_STATE, "no staged reads (call mhap_stage_reads first)");
+  if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
+  int rc = ensure_index_capacity(h, h->n_entries + 2 * n);
+  if (rc != MHAP_OK) return rc;
+  const int64_t first = h->n_entries;
+  const int S = h->P.ordered_sketch_size;
+  rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
+  if (rc != MHAP_OK) return rc;
+  return finish_add(h, first, h->st_ids.data(), n);
+}
+
+int mhap_sketch_staged_device(mhap_handle* h, void* d_minhash, void* d_ordered, void* d_meta) {
+  if (!h || !d_minhash || !d_ordered || !d_meta) return h ? fail(h, MHAP_E_INVALID, "null argument") : MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  if (h->st_n <= 0) return fail(h, MHAP_E_STATE, "no staged reads (call mhap_stage_reads first)");
+  return sketch_staged(h, (int32_t*)d_minhash, h->Hrow, (int32_t*)d_ordered, 2LL * h->P.ordered_sketch_size, (int32_t*)d_meta);
 }
 
 int mhap_sketch_batch(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, int32_t* minhash,
@@ -653,19 +721,35 @@ int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_
   return MHAP_OK;
 }
 
-int mhap_find_matches_self(mhap_handle* h, int64_t q_first, int64_t q_count, mhap_record_sink sink, void* user) {
-  if (!h) return MHAP_E_INVALID;
+static int self_search(mhap_handle* h, int64_t q_first, int64_t q_count, int64_t shard, int64_t nshards, mhap_record_sink sink, void* user) {
   (void)hipSetDevice(h->device);
   if (q_first < 0 || q_first > h->n_entries) return fail(h, MHAP_E_INVALID, "query range outside the index");
+  if (nshards < 1 || shard < 0 || shard >= nshards) return fail(h, MHAP_E_INVALID, "bad shard");
   int64_t q_end = (q_count < 0) ? h->n_entries : std::min(h->n_entries, q_first + q_count);
   std::vector<int32_t> ql;
-  for (int64_t e = q_first; e < q_end; e++) if (h->fwd[(size_t)e] && h->status[(size_t)e] == 0) ql.push_back((int32_t)e);   // AbstractMatchSearch.java:128-129
+  int64_t ordinal = 0;   // running count of forward entries = the read's position in the index
+  for (int64_t e = 0; e < q_end; e++) {
+    if (!h->fwd[(size_t)e]) continue;
+    const int64_t o = ordinal++;
+    if (e < q_first || (o % nshards) != shard) continue;
+    if (h->status[(size_t)e] == 0) ql.push_back((int32_t)e);   // AbstractMatchSearch.java:128-129
+  }
   bool mono = true;
   for (int64_t e = 1; e < h->n_entries && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
   // tile skipping needs: ids sorted with entry order, every entry "long" (minStore == 0 -> only m.id < q.id survives)
   const bool tri = mono && h->P.min_store_length == 0 && !getenv("MHAP_NO_TRIANGULAR");
   QuerySide qs{h->d_minhash, h->Hrow, h->d_ordered, 2LL * h->P.ordered_sketch_size, h->d_meta, h->d_ids.as<int64_t>(), h->ids.data(), h->seqlen.data()};
   return search_core(h, qs, ql, true, tri, sink, user);
+}
+
+int mhap_find_matches_self(mhap_handle* h, int64_t q_first, int64_t q_count, mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  return self_search(h, q_first, q_count, 0, 1, sink, user);
+}
+
+int mhap_find_matches_self_shard(mhap_handle* h, int64_t shard, int64_t nshards, mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  return self_search(h, 0, -1, shard, nshards, sink, user);
 }
 
 int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n,

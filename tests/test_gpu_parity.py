@@ -1,0 +1,251 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same inputs — bit-exact."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import mhap_amd
+from mhap_amd import FastaData, MhapParams, MinHashSearch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _rand_seq(rnd, n, alphabet="ACGT"):
+    return "".join(rnd.choice(alphabet) for _ in range(n))
+
+
+def _assert_sketch_parity(fa, p, flt=None, oflt=None):
+    with MinHashSearch(p, kmer_filter=flt) as ms:
+        sk = ms.sketch(fa)
+    for i in range(len(fa)):
+        seq = fa.sequence(i)
+        for strand, s in ((0, seq), (1, O.rc(seq))):
+            e = 2 * i + strand
+            if len(seq) < p.min_olap_length:
+                assert sk["status"][e] == 2, (i, strand)
+                continue
+            rc1, mh = O.minhash(s, p.kmer_size, p.num_hashes, p.repeat_weight, oflt)
+            rc2, od, _ = O.ordered(s, p.ordered_kmer_size, p.ordered_sketch_size)
+            if strand == 1 and sk["status"][e - 1] != 0:
+                assert sk["status"][e] != 0        # forward failed -> read dropped
+                continue
+            if rc1 or rc2:
+                assert sk["status"][e] == 1, (i, strand)
+                continue
+            assert sk["status"][e] == 0, (i, strand)
+            assert sk["minhash"][e].tolist() == mh.tolist(), ("minhash", i, strand)
+            n = sk["ordered_size"][e]
+            assert n == od.shape[0], ("ordered size", i, strand)
+            assert sk["ordered"][e, :n].tolist() == od.tolist(), ("ordered", i, strand)
+
+
+def test_sketch_parity_golden_fasta():
+    fa = FastaData.from_file(os.path.join(GOLD, "small_reads.fasta"))
+    _assert_sketch_parity(fa, MhapParams(num_hashes=64, ordered_sketch_size=256))
+    _assert_sketch_parity(fa, MhapParams())   # defaults: H=512, S=1536 > n for these reads
+
+
+def test_sketch_parity_edge_cases():
+    rnd = random.Random(17)
+    seqs = [
+        _rand_seq(rnd, 5000),
+        _rand_seq(rnd, 13),                    # >= k2, < k  -> ZeroNGrams from MinHash
+        _rand_seq(rnd, 16),                    # exactly one k-mer
+        _rand_seq(rnd, 11),                    # < k2
+        _rand_seq(rnd, 1025), _rand_seq(rnd, 1039), _rand_seq(rnd, 1040), _rand_seq(rnd, 2063),   # hash tile edges
+        "A" * 3000,                            # one k-mer with weight 2985; all ordered hashes equal (ties by position)
+        ("ACGTTGCA" * 400),                    # few distinct k-mers with large tf weights
+        _rand_seq(rnd, 2000) * 2,              # every k-mer twice
+        _rand_seq(rnd, 3000, "ACGTN"),         # non-ACGT chars: raw-byte path + rc translate table
+        _rand_seq(rnd, 700, "ACGTRYKMBDHVSWN-*"),
+        _rand_seq(rnd, 30000),
+        _rand_seq(rnd, 1),
+    ]
+    fa = FastaData.from_strings(seqs)
+    _assert_sketch_parity(fa, MhapParams(num_hashes=128, ordered_sketch_size=1536, min_olap_length=0))
+    _assert_sketch_parity(fa, MhapParams(num_hashes=48, ordered_sketch_size=100, min_olap_length=116))
+    _assert_sketch_parity(fa, MhapParams(num_hashes=33, ordered_sketch_size=64, min_olap_length=0, repeat_weight=-1.0))
+
+
+def test_sketch_parity_other_kmer_sizes():
+    rnd = random.Random(23)
+    fa = FastaData.from_strings([_rand_seq(rnd, rnd.randint(200, 3000)) for _ in range(12)] + ["ACGT" * 200])
+    for k, k2 in ((15, 13), (21, 14), (9, 7), (24, 17)):
+        _assert_sketch_parity(fa, MhapParams(kmer_size=k, ordered_kmer_size=k2, num_hashes=64, ordered_sketch_size=300, min_olap_length=50))
+
+
+def _self_lines(fa, p, flt=None):
+    with MinHashSearch(p, kmer_filter=flt) as ms:
+        ms.add_data(fa)
+        recs = ms.find_matches()
+        st = ms.stats()
+    return sorted(mhap_amd.records_to_lines(recs)), st
+
+
+def test_self_overlap_golden_records():
+    g = json.load(open(os.path.join(GOLD, "small_reads.json")))
+    fa = FastaData.from_file(os.path.join(GOLD, "small_reads.fasta"))
+    pp = g["params"]
+    p = MhapParams(kmer_size=pp["k"], num_hashes=pp["H"], ordered_kmer_size=pp["k2"], ordered_sketch_size=pp["S"],
+                   min_olap_length=pp["min_olap_length"])
+    lines, st = _self_lines(fa, p)
+    assert lines == g["sorted_records"]
+    assert st["matches_found"] == len(g["sorted_records"])
+
+
+@pytest.mark.parametrize("err,H,S", [(0.15, 256, 1536), (0.05, 512, 1536), (0.08, 100, 400)])
+def test_self_overlap_matches_oracle_config1(err, H, S):
+    """BASELINE configs[0] shape: 1k x 5kb reads, k=16, --num-hashes 256 (plus two variants)."""
+    n = 1000 if H == 256 else 300
+    fa = mhap_amd.synth_reads(n, 5000, seed=0x4D484150 ^ 1, error_rate=err)
+    p = MhapParams(num_hashes=H, ordered_sketch_size=S)
+    want = O.run_self(fa, H=H, S=S, nthreads=8)
+    lines, st = _self_lines(fa, p)
+    assert len(want["records"]) > 100
+    assert lines == O.record_lines(want["records"])
+    assert st["candidates_compared"] == want["compared"]
+    assert st["strands_indexed"] == want["strands"]
+
+
+def test_self_overlap_filters_and_thresholds():
+    fa = mhap_amd.synth_reads(200, 3000, seed=77, error_rate=0.06)
+    # mix lengths so --min-store-length splits the reads into short and long
+    idx = np.arange(200)
+    fa.lengths[idx % 3 == 0] = 1500
+    for kw in (dict(min_store_length=2000), dict(num_min_matches=1, threshold=0.0), dict(threshold=0.95, max_shift=0.05),
+               dict(num_min_matches=6, max_shift=0.5)):
+        p = MhapParams(num_hashes=128, ordered_sketch_size=512, **kw)
+        want = O.run_self(fa, H=128, S=512, nthreads=8, num_min_matches=p.num_min_matches, min_store_length=p.min_store_length,
+                          threshold=p.threshold, max_shift=p.max_shift)
+        lines, _ = _self_lines(fa, p)
+        assert lines == O.record_lines(want["records"]), kw
+
+
+def test_self_overlap_with_repeat_filter():
+    """tf-idf weighted MinHash (-f file, J/sketch/FrequencyCounts.java) incl. the repeat-weight < 0 (v1.0) mode."""
+    rnd = random.Random(5)
+    fa = mhap_amd.synth_reads(150, 3000, seed=31, error_rate=0.05)
+    # plant a repeat so that some k-mers are frequent, then list the most frequent k-mers as the filter
+    rep = _rand_seq(rnd, 300)
+    seqs = [fa.sequence(i) for i in range(len(fa))]
+    seqs = [s[:500] + rep + s[800:] if i % 2 == 0 else s for i, s in enumerate(seqs)]
+    fa = FastaData.from_strings(seqs)
+    counts = {}
+    for s in seqs:
+        for i in range(len(s) - 15):
+            counts[s[i:i + 16]] = counts.get(s[i:i + 16], 0) + 1
+    total = sum(counts.values())
+    top = sorted(counts.items(), key=lambda kv: -kv[1])[:400]
+    kmers = [k for k, _ in top]
+    fracs = np.array([c / total for _, c in top])
+    hashes = np.array([int(O.kmer_hashes64(k, 16, True)[0]) for k in kmers], dtype=np.int64)   # canonical (doRC default)
+    for rw, no_tf in ((0.9, False), (0.5, True), (-1.0, False), (1.0, False)):
+        cutoff = 1e-5
+        offset = rw if 0.0 <= rw < 1.0 else 0.0
+        flt = mhap_amd.FrequencyCounts(hashes, fracs, cutoff, offset, 3.0, no_tf)
+        oflt = O.Filter(hashes, fracs, cutoff, offset, 3.0, no_tf)
+        p = MhapParams(num_hashes=128, ordered_sketch_size=512, repeat_weight=rw)
+        _assert_sketch_parity(FastaData.from_strings(seqs[:6]), p, flt, oflt)
+        want = O.run_self(fa, H=128, S=512, nthreads=8, repeat_weight=rw, flt=oflt)
+        lines, _ = _self_lines(fa, p, flt)
+        assert lines == O.record_lines(want["records"]), (rw, no_tf)
+
+
+def test_index_vs_stream_mode():
+    """-s index -q queries (toSelf=false): brute-force expectation built from oracle primitives."""
+    base = mhap_amd.synth_reads(60, 2500, seed=91, error_rate=0.05)
+    index = base.subset(np.arange(0, 40))
+    index.ids[:] = np.arange(1, 41)
+    queries = base.subset(np.arange(30, 60))
+    queries.ids[:] = np.arange(41, 71)           # id offset = #index reads (MhapMain.java:462,527)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=400)
+    with MinHashSearch(p) as ms:
+        ms.add_data(index)
+        recs = ms.find_matches_stream(queries)
+    got = sorted(mhap_amd.records_to_lines(recs))
+    ent = []
+    for i in range(len(index)):
+        s = index.sequence(i)
+        for fwd, t in ((1, s), (0, O.rc(s))):
+            ent.append((int(index.ids[i]), fwd, len(s), O.minhash(t, 16, 64)[1], O.ordered(t, 12, 400)))
+    want = []
+    for qi in range(len(queries)):
+        s = queries.sequence(qi)
+        qmh = O.minhash(s, 16, 64)[1]
+        _, qo, qlen = O.ordered(s, 12, 400)
+        for mid, fwd, L, mh, (_, mo, mlen) in ent:
+            if int((qmh == mh).sum()) < 3:
+                continue
+            r = O.overlap(qo, qlen, mo, mlen)
+            if r["score"] >= 0.78:
+                b1, b2 = (r["b1"], r["b2"]) if fwd else (L - r["b2"] - 1, L - r["b1"] - 1)
+                want.append(O.format_record({"from_id": int(queries.ids[qi]), "to_id": mid, "score": r["score"], "raw": r["raw"],
+                                             "a1": r["a1"], "a2": r["a2"], "alen": len(s), "b1": b1, "b2": b2, "blen": L,
+                                             "to_rc": 0 if fwd else 1}))
+    assert len(want) > 20
+    assert got == sorted(want)
+
+
+def test_index_export_roundtrip_and_query_sharding():
+    """Sketch tables survive export -> add_sketches (the `.dat` path) and sharded query ranges add up."""
+    fa = mhap_amd.synth_reads(120, 3000, seed=55, error_rate=0.05)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=300)
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        full = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+        n = ms.size()
+        parts = []
+        for lo in range(0, n, 50):
+            parts += mhap_amd.records_to_lines(ms.find_matches(lo, 50))
+        assert sorted(parts) == full
+        tables = ms.export()
+    keep = tables["status"] == 0
+    sk = {k: v[keep] for k, v in tables.items() if k != "status"}
+    with MinHashSearch(p) as ms2:
+        ms2.add_sketches(sk)
+        again = sorted(mhap_amd.records_to_lines(ms2.find_matches()))
+    assert again == full and len(full) > 50
+
+
+def test_batching_and_chunking_do_not_change_results(monkeypatch):
+    fa = mhap_amd.synth_reads(300, 2000, seed=8, error_rate=0.05)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=300)
+    ref, _ = _self_lines(fa, p)
+    monkeypatch.setenv("MHAP_BATCH_BASES", "50000")
+    monkeypatch.setenv("MHAP_QUERY_CHUNK", "128")
+    small, _ = _self_lines(fa, p)
+    monkeypatch.setenv("MHAP_NO_TRIANGULAR", "1")
+    rect, _ = _self_lines(fa, p)
+    assert small == ref and rect == ref and len(ref) > 100
+
+
+def test_full_size_properties_config2_slice():
+    """Size-independent properties at BASELINE configs[1] read shape (10 kb, H=512, S=1536) on a slice of reads:
+    rc(rc(x)) sketches equal x's, every record obeys id/coordinate invariants, and a read vs its own copy is found."""
+    fa = mhap_amd.synth_reads(2000, 10000, seed=0x4D484150 ^ 2, error_rate=0.15)
+    p = MhapParams()
+    with MinHashSearch(p) as ms:
+        sk = ms.sketch(fa.subset(np.arange(8)))
+        rcfa = FastaData.from_strings([O.rc(fa.sequence(i)) for i in range(8)])
+        sk2 = ms.sketch(rcfa)
+        for i in range(8):   # strand symmetry: sketch(rc(x)).fwd == sketch(x).rc and vice versa
+            assert np.array_equal(sk["minhash"][2 * i + 1], sk2["minhash"][2 * i])
+            assert np.array_equal(sk["ordered"][2 * i], sk2["ordered"][2 * i + 1])
+        ms.add_data(fa)
+        recs = ms.find_matches()
+    assert len(recs) > 100
+    assert np.all(recs["to_id"] < recs["from_id"])                       # MinHashSearch.java:215-219 with minStore 0
+    assert np.all((recs["score"] >= 0.78) & (recs["a1"] >= 0) & (recs["a2"] <= 10000 - 11) & (recs["a1"] <= recs["a2"]))
+    assert np.all((recs["b1"] >= -1) & (recs["b2"] <= 10000) & (recs["alen"] == 10000) & (recs["blen"] == 10000))
+    pairs = set(zip(recs["from_id"].tolist(), recs["to_id"].tolist(), recs["to_rc"].tolist()))
+    assert len(pairs) == len(recs)                                       # one record per (query, entry)
+    # oracle cross-check on a 150-read prefix (every pair among them must agree exactly)
+    sub = fa.subset(np.arange(150))
+    want = O.record_lines(O.run_self(sub, nthreads=8)["records"])
+    m = (recs["from_id"] <= 150) & (recs["to_id"] <= 150)
+    assert sorted(mhap_amd.records_to_lines(recs[m])) == want
