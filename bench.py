@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import mhap_amd  # noqa: E402
 from mhap_amd import MhapParams, MinHashSearch  # noqa: E402
+from mhap_amd import distributed as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x max clock = 78.6e12 int lane-ops/s
@@ -69,12 +70,8 @@ def main():
     t_gen = time.time()
     fa = mhap_amd.synth_reads(n_total, L, seed=seed, error_rate=args.error_rate, shard=rank, nshards=world)
     n_local = len(fa)
-    n_pad = (n_total + world - 1) // world      # equal shard size for the all-gather (pad = zero-length reads)
-    if n_local < n_pad:
-        pad = n_pad - n_local
-        fa = mhap_amd.FastaData(fa.bases, np.concatenate([fa.offsets, np.zeros(pad, np.int64)]),
-                                np.concatenate([fa.lengths, np.zeros(pad, np.int32)]),
-                                np.concatenate([fa.ids, np.arange(n_total + 1, n_total + pad + 1, dtype=np.int64)]))
+    n_pad = mdist.shard_size(n_total, world)    # equal shard size for the all-gather (pad = zero-length reads)
+    fa = mdist.pad_shard(fa, n_total, world)
     t_gen = time.time() - t_gen
 
     ms = MinHashSearch(p)
@@ -84,12 +81,7 @@ def main():
         loc_mh = torch.zeros((2 * n_pad, H), dtype=torch.int32, device=dev)
         loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
         loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
-        all_mh = torch.empty((world, n_pad, 2, H), dtype=torch.int32, device=dev)
-        all_od = torch.empty((world, n_pad, 2, S * 2), dtype=torch.int32, device=dev)
-        all_mt = torch.empty((world, n_pad, 2, 4), dtype=torch.int32, device=dev)
-        # global read order r = j*world + rank  ->  entry 2r+s
-        gids = np.repeat(np.arange(1, n_pad * world + 1, dtype=np.int64), 2)
-        gfwd = np.tile(np.array([1, 0], dtype=np.uint8), n_pad * world)
+        gids, gfwd = mdist.global_entry_ids(n_total, world)
 
     def step():
         ms.clear()
@@ -98,12 +90,9 @@ def main():
             recs = ms.find_matches()
         else:
             ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-            dist.all_gather_into_tensor(all_mh.view(world, -1), loc_mh.view(1, -1))
-            dist.all_gather_into_tensor(all_od.view(world, -1), loc_od.view(1, -1))
-            dist.all_gather_into_tensor(all_mt.view(world, -1), loc_mt.view(1, -1))
-            g_mh = all_mh.permute(1, 0, 2, 3).contiguous()     # [j][rank][strand] = global read order
-            g_od = all_od.permute(1, 0, 2, 3).contiguous()
-            g_mt = all_mt.permute(1, 0, 2, 3).contiguous()
+            g_mh = mdist.gather_global_order(loc_mh, world, dist)    # RCCL all-gather + global read order
+            g_od = mdist.gather_global_order(loc_od, world, dist)
+            g_mt = mdist.gather_global_order(loc_mt, world, dist)
             torch.cuda.synchronize()
             ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
             recs = ms.find_matches_shard(rank, world)

@@ -1,0 +1,59 @@
+"""One-process-per-GPU plumbing for the sharded self-overlap.
+
+Reads are dealt round-robin: global read r (0-based FASTA order) lives on rank r % world at local slot r // world.
+Each rank sketches its shard into local tables; the tables are exchanged with ONE all-gather per table
+(RCCL over xGMI when the backend is "nccl"; gloo on CPU in the tests) and re-laid out in global read order so
+that entry 2r / 2r+1 is the forward / reverse-complement strand of read r — ids are then monotonic in entry
+order, which the candidate kernel's triangular tile skipping relies on.  Every rank then searches the queries
+whose read ordinal is congruent to its rank (mhap_find_matches_self_shard); no collective is needed after that,
+records are concatenated by the host (their order is unspecified in the reference too).
+"""
+import numpy as np
+import torch
+
+
+def shard_size(n_total, world):
+    """Equal shard size (reads per rank) — shards are padded with zero-length reads, which sketch to status 2."""
+    return (n_total + world - 1) // world
+
+
+def pad_shard(fasta, n_total, world):
+    """Pad a rank's FastaData (reads rank, rank+world, ...) to shard_size() with zero-length placeholder reads."""
+    from .api import FastaData
+    n_pad = shard_size(n_total, world)
+    pad = n_pad - len(fasta)
+    if pad <= 0:
+        return fasta
+    return FastaData(fasta.bases, np.concatenate([fasta.offsets, np.zeros(pad, np.int64)]),
+                     np.concatenate([fasta.lengths, np.zeros(pad, np.int32)]),
+                     np.concatenate([fasta.ids, np.zeros(pad, dtype=np.int64)]))
+
+
+def global_entry_ids(n_total, world):
+    """(ids, is_fwd) host arrays of the gathered index in global read order (padding reads get ids past n_total)."""
+    n_pad = shard_size(n_total, world)
+    ids = np.repeat(np.arange(1, n_pad * world + 1, dtype=np.int64), 2)
+    fwd = np.tile(np.array([1, 0], dtype=np.uint8), n_pad * world)
+    return ids, fwd
+
+
+def gather_global_order(local, world, dist=None):
+    """All-gather a per-rank table [2*n_pad, ...] and return it as [2*n_pad*world, ...] in global read order."""
+    if world == 1:
+        return local
+    n_pad = local.shape[0] // 2
+    tail = tuple(local.shape[1:])
+    gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(gathered.view(world, -1), local.contiguous().view(1, -1))
+    else:
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local.contiguous())
+        gathered = torch.stack(parts, 0)
+    g = gathered.view(world, n_pad, 2, -1).permute(1, 0, 2, 3).contiguous()    # [slot][rank][strand] = read slot*world+rank
+    return g.view((n_pad * world * 2,) + tail)
+
+
+def shard_query_reads(n_total, world, rank):
+    """0-based global read indices this rank searches (round-robin balances the triangular id rule)."""
+    return np.arange(rank, shard_size(n_total, world) * world, world, dtype=np.int64)

@@ -1,0 +1,69 @@
+"""N>1 path on CPU: two gloo processes deal reads round-robin, exchange their per-rank sketch tables with the same
+all-gather + global-order re-layout the GPU path uses (mhap_amd/distributed.py), and the result must equal the
+single-process table; the per-rank query shards must partition the reads."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_TOTAL, LEN, H, WORLD = 11, 400, 16, 2   # odd read count: exercises the padded shard
+
+
+def _oracle_rows(fa):
+    import oracle_lib as O
+    rows = np.zeros((2 * len(fa), H), dtype=np.int32)
+    for i in range(len(fa)):
+        if fa.lengths[i] == 0:
+            continue                                   # padding read: status 2, row stays zero
+        s = fa.sequence(i)
+        rows[2 * i] = O.minhash(s, 16, H)[1]
+        rows[2 * i + 1] = O.minhash(O.rc(s), 16, H)[1]
+    return rows
+
+
+def _worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import mhap_amd
+    from mhap_amd import distributed as md
+    shard = mhap_amd.synth_reads(N_TOTAL, LEN, seed=9, shard=rank, nshards=WORLD)
+    assert shard.ids.tolist() == [r + 1 for r in range(rank, N_TOTAL, WORLD)]
+    shard = md.pad_shard(shard, N_TOTAL, WORLD)
+    assert len(shard) == md.shard_size(N_TOTAL, WORLD)
+    local = torch.from_numpy(_oracle_rows(shard))
+    g = md.gather_global_order(local, WORLD, dist)
+    mine = md.shard_query_reads(N_TOTAL, WORLD, rank)
+    allq = [torch.zeros(len(mine), dtype=torch.int64) for _ in range(WORLD)]
+    dist.all_gather(allq, torch.from_numpy(mine))
+    if rank == 0:
+        torch.save({"table": g, "queries": torch.stack(allq)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_process(tmp_path):
+    import mhap_amd
+    from mhap_amd import distributed as md
+    out = str(tmp_path / "g.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
+    got = torch.load(out)
+    full = mhap_amd.synth_reads(N_TOTAL, LEN, seed=9)
+    want = _oracle_rows(full)
+    n_pad = md.shard_size(N_TOTAL, WORLD)
+    table = got["table"].numpy()
+    assert table.shape == (2 * n_pad * WORLD, H)
+    assert np.array_equal(table[:2 * N_TOTAL], want)          # global read order, fwd/rc interleaved
+    assert not table[2 * N_TOTAL:].any()                       # padding entries
+    ids, fwd = md.global_entry_ids(N_TOTAL, WORLD)
+    assert ids[:2 * N_TOTAL].tolist() == np.repeat(full.ids, 2).tolist() and fwd[:4].tolist() == [1, 0, 1, 0]
+    q = got["queries"].numpy()
+    assert sorted(q.ravel().tolist()) == list(range(n_pad * WORLD))   # query shards partition the reads
+    assert all((q[r] % WORLD == r).all() for r in range(WORLD))
