@@ -135,7 +135,7 @@ def main():
         K = max(args.steps, 1)
         kernel_ms_per_step = {kname: float(kms[i].item()) / K for i, kname in enumerate(mhap_amd.KERNEL_NAMES)}
         sketch_ms = sum(kernel_ms_per_step[x] for x in ("hash_kmers", "kmer_weight", "minhash", "ordered"))
-        search_ms = kernel_ms_per_step["candidate"] + kernel_ms_per_step["overlap"]
+        search_ms = sum(kernel_ms_per_step[x] for x in ("candidate", "overlap", "index_build", "index_query"))
         # dominant kernel roofline
         dom = max(kernel_ms_per_step, key=kernel_ms_per_step.get)
         launches = max(kt[dom]["launches"], 1)
@@ -144,7 +144,9 @@ def main():
         if dom == "candidate":
             alg_bytes = (n_total + 2 * n_total) * 4 * H / world * K / launches      # §8(d): every sketch row read once per pass
         elif dom == "overlap":
-            alg_bytes = st["candidates_compared"] / launches * 8 * S * 2
+            alg_bytes = st["candidates_compared"] * K / launches * 8 * S * 2
+        elif dom in ("index_build", "index_query"):
+            alg_bytes = (n_total + 2 * n_total) * 4 * H / world * K / launches
         else:
             alg_bytes = sketch_bytes_per_read(L, H, S, k2) * reads_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
@@ -157,8 +159,8 @@ def main():
         xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
         valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1), "lane_ops_per_step": 11,
                 "frac_of_int_valu_peak": round(xs_rate * 11 / VALU_LANE_OPS_PEAK, 4)}
-        if kernel_ms_per_step["candidate"] > 0:
-            valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / K / (kernel_ms_per_step["candidate"] / 1e3), 1)
+        if kernel_ms_per_step["candidate"] > 0 and st["slot_compares"] > 0:   # stats are per step (the index is cleared every step)
+            valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / (kernel_ms_per_step["candidate"] / 1e3), 1)
 
         out = {
             "metric": "overlaps/sec", "value": round(total_records / sec_per_step, 2), "unit": "overlaps/s",
@@ -172,7 +174,8 @@ def main():
             "sketches_per_sec_note": "strands / summed sketch-kernel time (rank max)",
             "overlaps_per_sec_search_only": round(total_records / (search_ms / 1e3), 1) if search_ms > 0 else None,
             "kernel_ms_per_step": {kk: round(v, 3) for kk, v in kernel_ms_per_step.items()},
-            "candidates_per_step": int(st["candidates_compared"] // K) if world == 1 else None,
+            "candidates_per_step": int(st["candidates_compared"]),
+            "index_elements_per_step": int(st["table_elements"]),
             "roofline": roofline, "valu": valu,
             "input_gen_s": round(t_gen, 2),
         }

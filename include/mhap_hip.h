@@ -68,7 +68,8 @@ typedef struct mhap_stats {
   int64_t queries_searched;       /* getNumberSequencesSearched()                */
   int64_t candidates_compared;    /* getNumberSequencesFullyCompared()           */
   int64_t matches_found;          /* getMatchesProcessed()                       */
-  int64_t slot_compares;          /* brute-force slot comparisons performed      */
+  int64_t slot_compares;          /* slot comparisons done by the brute-force (fallback) candidate kernel */
+  int64_t table_elements;         /* getNumberElementsProcessed(): inverted-index hits walked             */
 } mhap_stats;
 
 /* Per-kernel HIP-event timings accumulated on the handle's stream (for bench/roofline). */
@@ -76,9 +77,11 @@ typedef struct mhap_stats {
 #define MHAP_K_DEDUP 1     /* per-strand k-mer multiplicity (tf weight)          */
 #define MHAP_K_MINHASH 2   /* weighted xorshift MinHash                          */
 #define MHAP_K_ORDERED 3   /* bottom-S select + sort                             */
-#define MHAP_K_CANDIDATE 4 /* all-pairs slot-equality count                      */
+#define MHAP_K_CANDIDATE 4 /* brute-force all-pairs slot-equality count (fallback / MHAP_CANDIDATES=bruteforce) */
 #define MHAP_K_OVERLAP 5   /* second-stage getOverlapInfo                        */
-#define MHAP_K_COUNT 6
+#define MHAP_K_INDEX_BUILD 6 /* inverted index build (MinHashSearch.addSequence) */
+#define MHAP_K_INDEX_QUERY 7 /* inverted index lookups + per-query hit counting  */
+#define MHAP_K_COUNT 8
 typedef struct mhap_kernel_times {
   double ms[MHAP_K_COUNT];      /* summed kernel time, milliseconds */
   int64_t launches[MHAP_K_COUNT];

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "lib", "libmhaphip.so")
 _lib = None
 
-KERNEL_NAMES = ["hash_kmers", "kmer_weight", "minhash", "ordered", "candidate", "overlap"]
+KERNEL_NAMES = ["hash_kmers", "kmer_weight", "minhash", "ordered", "candidate", "overlap", "index_build", "index_query"]
 
 
 class MhapError(RuntimeError):
@@ -32,11 +32,11 @@ class _Params(C.Structure):
 
 class _Stats(C.Structure):
     _fields_ = [("strands_indexed", C.c_int64), ("queries_searched", C.c_int64), ("candidates_compared", C.c_int64),
-                ("matches_found", C.c_int64), ("slot_compares", C.c_int64)]
+                ("matches_found", C.c_int64), ("slot_compares", C.c_int64), ("table_elements", C.c_int64)]
 
 
 class _KTimes(C.Structure):
-    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6)]
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_int64 * 8)]
 
 
 class _Fasta(C.Structure):
@@ -425,7 +425,7 @@ class MinHashSearch:
     def kernel_times(self):
         t = _KTimes()
         self._chk(self._lib.mhap_get_kernel_times(self._h, C.byref(t)))
-        return {KERNEL_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(6)}
+        return {KERNEL_NAMES[i]: {"ms": t.ms[i], "launches": t.launches[i]} for i in range(len(KERNEL_NAMES))}
 
     def reset_kernel_times(self):
         self._chk(self._lib.mhap_reset_kernel_times(self._h))

@@ -5,14 +5,16 @@
 namespace mhap {
 
 constexpr int HASH_TILE = 1024;      // window starts per hash workgroup
-constexpr int WEIGHT_THREADS = 512;  // threads per k-mer-weight workgroup
+constexpr int WEIGHT_THREADS = 1024;
+constexpr int WEIGHT_MAXIT = 24;     // k-mers per thread on the LDS path (24 x 1024 = 24576 = 0.75 x 32768 table slots)  // threads per k-mer-weight workgroup
 constexpr int MH_U = 4;              // k-mers per lane per row in the MinHash hot loop
 constexpr int ORD_THREADS = 256;
 constexpr int ORD_BINS = 2048;
 constexpr int CAND_TQ = 128;         // queries per candidate tile
 constexpr int CAND_TM = 128;         // index entries per candidate tile
 constexpr int CAND_KS = 32;          // slots staged per LDS chunk
-constexpr int OVL_THREADS = 128;     // lanes per second-stage workgroup
+constexpr int OVL_THREADS = 128;
+constexpr int INV_CT = 4096;         // LDS hit-count table entries per query (inverted-index path)     // lanes per second-stage workgroup
 
 struct StrandInfo { int32_t valid; int32_t heavy; };
 
@@ -46,8 +48,9 @@ struct SearchParams {
 // ---- sketch_kernels.hip ----
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store, int64_t* keys,
                        int32_t* h32, int k, int k2);
-void launch_kmer_weights(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, uint32_t* wts,
-                         uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
+int weight_grid(int num_cus, int64_t nstrands, int max_len, int k);   // persistent workgroups = HBM slabs needed
+void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
+                         uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
                          double repeat_weight, StrandInfo* info);
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
@@ -65,6 +68,13 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
                        const int32_t* qlist, int nq, int ne, const int64_t* ids, const int64_t* qids, const int32_t* meta,
                        const int32_t* qmeta, const SearchParams& sp, const long long* rowstart, long long nblocks_tri, Candidate* cand,
                        unsigned long long* cand_count, unsigned long long cand_cap);
+// Inverted index (one open-addressing table of 2^k (value,entry+1) words per MinHash slot) + per-query lookup.
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H,
+                        unsigned long long* table, uint32_t cmask);
+void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_t cmask, const int32_t* qminhash, int64_t qrow_stride,
+                        const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
+                        const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
+                        int32_t* overflow, unsigned long long* overflow_count, unsigned long long* elements);
 // Second stage: one lane per candidate.
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,

@@ -106,7 +106,7 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, recs, ovl_scratch;
+  DevBuf qlist, rowstart, cand, recs, ovl_scratch, inv_table, inv_overflow;
   std::vector<DevRecord> h_recs;
   std::vector<mhap_record> out_recs;
 
@@ -261,10 +261,10 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     HIPCHK(h, h->h32.ensure((size_t)std::max<int64_t>(h2_elems, 4) * 4));
     HIPCHK(h, h->info.ensure((size_t)nstr * sizeof(StrandInfo)));
     HIPCHK(h, h->counters.ensure(256));
-    const int wblocks = (int)std::min<int64_t>(nstr, (int64_t)h->num_cus * 4);
+    const int wblocks = weight_grid(h->num_cus, nstr, max_len, k);
     int64_t slab_entries = 64;
-    while (slab_entries < 2LL * std::max(1, max_len - k + 1)) slab_entries <<= 1;
-    HIPCHK(h, h->slabs.ensure((size_t)wblocks * (size_t)slab_entries * 2 * 4));
+    while (3 * slab_entries < 4LL * std::max(1, max_len - k + 1)) slab_entries <<= 1;
+    HIPCHK(h, h->slabs.ensure((size_t)wblocks * (size_t)slab_entries * 4));
     HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
 
@@ -277,7 +277,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     launch_hash_kmers(h->stream, h->descs.as<ReadDesc>(), nstr, max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2);
     time_end(h);
     time_begin(h, MHAP_K_DEDUP);
-    launch_kmer_weights(h->stream, wblocks, h->descs.as<ReadDesc>(), nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
+    launch_kmer_weights(h->stream, h->num_cus, h->descs.as<ReadDesc>(), nstr, max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
                         h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>());
     time_end(h);
     time_begin(h, MHAP_K_MINHASH);
@@ -348,7 +348,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   sp.num_min_matches = h->P.num_min_matches; sp.min_store_length = h->P.min_store_length; sp.to_self = to_self ? 1 : 0;
   sp.max_shift = h->P.max_shift; sp.threshold = h->P.threshold;
   const int ne = (int)h->n_entries;
-  int64_t qchunk = 16384;
+  int64_t qchunk = 262144;   // queries per candidate/overlap launch pair (bounds the candidate buffer)
   if (const char* e = getenv("MHAP_QUERY_CHUNK")) { long long v = atoll(e); if (v >= CAND_TQ) qchunk = (v / CAND_TQ) * CAND_TQ; }
   HIPCHK(h, h->qlist.ensure(ql.size() * 4));
   HIPCHK(h, hipMemcpyAsync(h->qlist.p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice, h->stream));
@@ -360,13 +360,29 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const int64_t per_lane = 3LL * (2LL * S + 2);
   HIPCHK(h, h->ovl_scratch.ensure((size_t)lanes * (size_t)per_lane * 4));
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
+  // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
+  const char* cmode = getenv("MHAP_CANDIDATES");
+  const bool use_index = !(cmode && strcmp(cmode, "bruteforce") == 0);
+  uint32_t cmask = 0;
+  if (use_index) {
+    uint64_t cap = 1024;
+    while (cap < 2ull * (uint64_t)ne) cap <<= 1;
+    cmask = (uint32_t)(cap - 1);
+    const size_t bytes = (size_t)sp.H * (size_t)cap * 8;
+    HIPCHK(h, h->inv_table.ensure(bytes));
+    HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
+    time_begin(h, MHAP_K_INDEX_BUILD);
+    launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, sp.H, h->inv_table.as<unsigned long long>(), cmask);
+    time_end(h);
+    HIPCHK(h, hipGetLastError());
+  }
 
   for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
     const int nq = (int)std::min<int64_t>(qchunk, (int64_t)ql.size() - c0);
     const int ntq = (nq + CAND_TQ - 1) / CAND_TQ;
     const long long* d_rowstart = nullptr;
     long long nblocks_tri = 0;
-    if (triangular_ok) {
+    if (triangular_ok && !use_index) {
       std::vector<long long> rs((size_t)ntq + 1);
       long long acc = 0;
       for (int t = 0; t < ntq; t++) {
@@ -379,27 +395,57 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       HIPCHK(h, hipMemcpyAsync(h->rowstart.p, rs.data(), rs.size() * 8, hipMemcpyHostToDevice, h->stream));
       HIPCHK(h, hipStreamSynchronize(h->stream));  // rs is a stack vector
       d_rowstart = h->rowstart.as<long long>();
-      if (nblocks_tri == 0) continue;
+      if (nblocks_tri == 0) { h->stats.queries_searched += nq; continue; }
     }
     unsigned long long ncand = 0;
     for (;;) {
       HIPCHK(h, h->cand.ensure(cand_cap * sizeof(Candidate)));
       HIPCHK(h, hipMemsetAsync(ctr, 0, 64, h->stream));
-      time_begin(h, MHAP_K_CANDIDATE);
-      launch_candidates(h->stream, h->d_minhash, h->Hrow, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq, ne,
-                        h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, d_rowstart, nblocks_tri, h->cand.as<Candidate>(),
-                        ctr + 0, (unsigned long long)cand_cap);
-      time_end(h);
-      HIPCHK(h, hipGetLastError());
-      HIPCHK(h, hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
-      int rc = sync_stream(h);
-      if (rc != MHAP_OK) return rc;
+      if (use_index) {
+        HIPCHK(h, h->inv_overflow.ensure((size_t)nq * 4));
+        time_begin(h, MHAP_K_INDEX_QUERY);
+        launch_index_query(h->stream, h->inv_table.as<unsigned long long>(), cmask, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
+                           h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
+                           (unsigned long long)cand_cap, h->inv_overflow.as<int32_t>(), ctr + 3, ctr + 4);
+        time_end(h);
+        HIPCHK(h, hipGetLastError());
+        unsigned long long c5[5] = {0, 0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(c5, ctr, 40, hipMemcpyDeviceToHost, h->stream));
+        int rc = sync_stream(h);
+        if (rc != MHAP_OK) return rc;
+        ncand = c5[0];
+        const unsigned long long nover = c5[3];
+        if (ncand <= cand_cap && nover > 0) {
+          // queries whose hit set outgrew the LDS count table: exact brute-force count for just those
+          time_begin(h, MHAP_K_CANDIDATE);
+          launch_candidates(h->stream, h->d_minhash, h->Hrow, qs.d_minhash, qs.mh_stride, h->inv_overflow.as<int32_t>(), (int)nover, ne,
+                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, nullptr, 0, h->cand.as<Candidate>(), ctr + 0,
+                            (unsigned long long)cand_cap);
+          time_end(h);
+          HIPCHK(h, hipGetLastError());
+          HIPCHK(h, hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
+          rc = sync_stream(h);
+          if (rc != MHAP_OK) return rc;
+          if (ncand <= cand_cap) h->stats.slot_compares += (long long)((nover + CAND_TQ - 1) / CAND_TQ) * ntu * CAND_TQ * CAND_TM * sp.H;
+        }
+        if (ncand <= cand_cap) h->stats.table_elements += (int64_t)c5[4];
+      } else {
+        time_begin(h, MHAP_K_CANDIDATE);
+        launch_candidates(h->stream, h->d_minhash, h->Hrow, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq, ne,
+                          h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, d_rowstart, nblocks_tri, h->cand.as<Candidate>(),
+                          ctr + 0, (unsigned long long)cand_cap);
+        time_end(h);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
+        int rc = sync_stream(h);
+        if (rc != MHAP_OK) return rc;
+        if (ncand <= cand_cap) {
+          const long long tiles = d_rowstart ? nblocks_tri : (long long)ntq * ntu;
+          h->stats.slot_compares += tiles * (long long)CAND_TQ * CAND_TM * sp.H;
+        }
+      }
       if (ncand <= cand_cap) break;
       cand_cap = (size_t)ncand + (size_t)(ncand / 4) + 1024;   // overflow: grow and redo this chunk
-    }
-    {
-      const long long tiles = triangular_ok ? nblocks_tri : (long long)ntq * ntu;
-      h->stats.slot_compares += tiles * (long long)CAND_TQ * CAND_TM * sp.H;
     }
     h->stats.queries_searched += nq;
     if (ncand == 0) continue;
@@ -495,7 +541,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->recs, &h->ovl_scratch};
+                    &h->qlist, &h->rowstart, &h->cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;

@@ -14,6 +14,18 @@
 
 namespace mhap {
 
+// count += (a == b): exactly two VALU issues per slot pair (v_cmp_eq -> vcc, v_addc consumes vcc).  Left to the
+// compiler the compare lands in arbitrary SGPR pairs (v_cmp_e64 + v_cndmask + add) and spills SGPRs through
+// v_writelane/v_readlane inside the hot loop.
+#define CMP_ACC4(c, q, m)                                                                                   \
+  asm("v_cmp_eq_u32 vcc, %1, %5\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"                                    \
+      "v_cmp_eq_u32 vcc, %2, %6\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"                                    \
+      "v_cmp_eq_u32 vcc, %3, %7\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"                                    \
+      "v_cmp_eq_u32 vcc, %4, %8\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc"                                          \
+      : "+v"(c)                                                                                             \
+      : "v"((q).x), "v"((q).y), "v"((q).z), "v"((q).w), "v"((m).x), "v"((m).y), "v"((m).z), "v"((m).w)      \
+      : "vcc")
+
 constexpr int CAND_LD = CAND_KS + 4;  // padded LDS row (ints): 36 -> conflict-free ds_read_b128 across 16 rows
 
 __device__ inline bool pair_passes(const SearchParams& sp, int64_t qid, int64_t mid, int qlen, int mlen) {
@@ -24,7 +36,7 @@ __device__ inline bool pair_passes(const SearchParams& sp, int64_t qid, int64_t 
   return true;
 }
 
-__global__ __launch_bounds__(256) void candidate_kernel(const int32_t* __restrict__ minhash, int64_t row_stride,
+__global__ __launch_bounds__(256, 2) void candidate_kernel(const int32_t* __restrict__ minhash, int64_t row_stride,
                                                         const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                         const int32_t* __restrict__ qlist, int nq, int ne,
                                                         const int64_t* __restrict__ ids, const int64_t* __restrict__ qids,
@@ -67,14 +79,16 @@ __global__ __launch_bounds__(256) void candidate_kernel(const int32_t* __restric
 
   const int H = sp.H;
   const bool vec_ok = ((row_stride & 3) == 0) && ((qrow_stride & 3) == 0);
-  for (int s0 = 0; s0 < H; s0 += CAND_KS) {
-    // stage [128 x 32] slots of both tiles; 1024 int4 per tile -> 4 per thread
+  // Register-staged software pipeline: the global loads of chunk c+1 are issued before the compare phase of
+  // chunk c and land in LDS after it, so HBM/L2 latency hides under ~8k VALU cycles of compares.
+  int4 pq[4], pm[4];
+  auto fetch = [&](int s0) {
     const bool full = vec_ok && (s0 + CAND_KS <= H);
 #pragma unroll
     for (int rep = 0; rep < 4; rep++) {
       const int idx = tid + rep * 256;
       const int row = idx >> 3, c4 = (idx & 7) * 4;
-      int4 qv = make_int4(0, 0, 0, 0), mv = make_int4(1, 1, 1, 1);
+      int4 qv = make_int4(0, 0, 0, 0), mv = make_int4(1, 1, 1, 1);   // never-equal sentinels for absent rows/slots
       const int qe = qent[row];
       const int me = m0 + row;
       if (full) {
@@ -93,11 +107,21 @@ __global__ __launch_bounds__(256) void candidate_kernel(const int32_t* __restric
         qv = make_int4(qa[0], qa[1], qa[2], qa[3]);
         mv = make_int4(ma[0], ma[1], ma[2], ma[3]);
       }
-      *(int4*)&qs[row * CAND_LD + c4] = qv;
-      *(int4*)&ms[row * CAND_LD + c4] = mv;
+      pq[rep] = qv; pm[rep] = mv;
+    }
+  };
+  fetch(0);
+  for (int s0 = 0; s0 < H; s0 += CAND_KS) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+      const int idx = tid + rep * 256;
+      const int row = idx >> 3, c4 = (idx & 7) * 4;
+      *(int4*)&qs[row * CAND_LD + c4] = pq[rep];
+      *(int4*)&ms[row * CAND_LD + c4] = pm[rep];
     }
     __syncthreads();
-#pragma unroll 2
+    if (s0 + CAND_KS < H) fetch(s0 + CAND_KS);
+#pragma unroll 1
     for (int s4 = 0; s4 < CAND_KS; s4 += 4) {
       int4 qv[8], mv[8];
 #pragma unroll
@@ -108,31 +132,31 @@ __global__ __launch_bounds__(256) void candidate_kernel(const int32_t* __restric
       for (int i = 0; i < 8; i++)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          cnt[i][j] += (qv[i].x == mv[j].x) ? 1 : 0;
-          cnt[i][j] += (qv[i].y == mv[j].y) ? 1 : 0;
-          cnt[i][j] += (qv[i].z == mv[j].z) ? 1 : 0;
-          cnt[i][j] += (qv[i].w == mv[j].w) ? 1 : 0;
+          CMP_ACC4(cnt[i][j], qv[i], mv[j]);
         }
     }
     __syncthreads();
   }
-  // emit
+  // emit: flag the (rare) pairs that reach --num-min-matches, then handle them one at a time
+  unsigned long long hitmask = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (cnt[i][j] >= sp.num_min_matches) hitmask |= 1ULL << (i * 8 + j);                   // MinHashSearch.java:204
+  while (hitmask) {
+    const int bit = __ffsll((long long)hitmask) - 1;
+    hitmask &= hitmask - 1;
+    const int i = bit >> 3, j = bit & 7;
     const int qe = qent[i * 16 + tq];
-    if (qe < 0) continue;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      if (cnt[i][j] < sp.num_min_matches) continue;                                          // :204
-      const int me = m0 + j * 16 + tm;
-      if (me >= ne) continue;
-      const int32_t* qm = qmeta + (int64_t)qe * META_W;
-      const int32_t* mm = meta + (int64_t)me * META_W;
-      if (qm[3] != 0 || mm[3] != 0) continue;   // placeholder entries (skipped strands) are not in the index
-      if (!pair_passes(sp, qids[qe], ids[me], qm[2], mm[2])) continue;
-      const unsigned long long slot = atomicAdd(cand_count, 1ULL);
-      if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = me; }
-    }
+    const int me = m0 + j * 16 + tm;
+    if (qe < 0 || me >= ne) continue;
+    const int32_t* qm = qmeta + (int64_t)qe * META_W;
+    const int32_t* mm = meta + (int64_t)me * META_W;
+    if (qm[3] != 0 || mm[3] != 0) continue;   // placeholder entries (skipped strands) are not in the index
+    if (!pair_passes(sp, qids[qe], ids[me], qm[2], mm[2])) continue;
+    const unsigned long long slot = atomicAdd(cand_count, 1ULL);
+    if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = me; }
   }
 }
 
@@ -149,6 +173,113 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
   const long long nb8 = ((nblocks + 7) / 8) * 8;
   hipLaunchKernelGGL(candidate_kernel, dim3((unsigned)nb8), dim3(256), 0, st, minhash, row_stride, qminhash, qrow_stride, qlist, nq, ne,
                      ids, qids, meta, qmeta, sp, triangular, rowstart, ntq, nblocks, ntu, cand, cand_count, cand_cap);
+}
+
+// =============================================================================================
+// Inverted index on the GPU (the reference's own structure, J/impl/MinHashSearch.java:100-147,161-181):
+// one open-addressing table per MinHash slot holding (value, entry+1) words; entries with equal values sit in
+// one probe run.  A query does H probes and counts hits per stored entry in an LDS count table; the hit count
+// of a pair equals the number of equal slots, so the candidate set is identical to the brute-force count.
+// Work ~ N*H probes + hits instead of N*2N*H/2 compares.
+// =============================================================================================
+__device__ inline uint32_t inv_hash(uint32_t v) { return fmix32(v); }
+
+__global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta,
+                                                          int ne, int H, unsigned long long* __restrict__ table, uint32_t cmask) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)ne * H;
+  if (idx >= total) return;
+  const int e = (int)(idx / H), s = (int)(idx % H);
+  if (meta[(int64_t)e * META_W + 3] != 0) return;                       // skipped strands are not stored (addSequence never sees them)
+  const uint32_t v = (uint32_t)minhash[(int64_t)e * row_stride + s];
+  unsigned long long* T = table + (size_t)s * ((size_t)cmask + 1);
+  const unsigned long long word = ((unsigned long long)v << 32) | (unsigned long long)(uint32_t)(e + 1);
+  uint32_t pos = inv_hash(v) & cmask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&T[pos], 0ULL, word);
+    if (old == 0ULL) break;
+    pos = (pos + 1) & cmask;
+  }
+}
+
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H,
+                        unsigned long long* table, uint32_t cmask) {
+  const int64_t total = (int64_t)ne * H;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, minhash, row_stride, meta, ne, H, table, cmask);
+}
+
+// One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].  A query whose distinct-hit set outgrows the table is
+// appended to `overflow` (the caller re-runs those through candidate_kernel).
+__global__ __launch_bounds__(256) void index_query_kernel(const unsigned long long* __restrict__ table, uint32_t cmask,
+                                                          const int32_t* __restrict__ qminhash, int64_t qrow_stride,
+                                                          const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
+                                                          const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
+                                                          const int32_t* __restrict__ qmeta, SearchParams sp,
+                                                          Candidate* __restrict__ cand, unsigned long long* __restrict__ cand_count,
+                                                          unsigned long long cand_cap, int32_t* __restrict__ overflow,
+                                                          unsigned long long* __restrict__ overflow_count,
+                                                          unsigned long long* __restrict__ elements) {
+  __shared__ uint32_t keys[INV_CT];
+  __shared__ uint32_t cnts[INV_CT];
+  __shared__ uint32_t s_distinct, s_over;
+  const int qi = blockIdx.x;
+  if (qi >= nq) return;
+  const int qe = qlist[qi];
+  for (int j = threadIdx.x; j < INV_CT; j += 256) { keys[j] = 0; cnts[j] = 0; }
+  if (threadIdx.x == 0) { s_distinct = 0; s_over = 0; }
+  __syncthreads();
+  const int32_t* qm = qmeta + (int64_t)qe * META_W;
+  const int64_t qid = qids[qe];
+  const int qlen = qm[2];
+  unsigned long long mine = 0;
+  for (int s = threadIdx.x; s < sp.H; s += 256) {
+    const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
+    const unsigned long long* T = table + (size_t)s * ((size_t)cmask + 1);
+    uint32_t pos = inv_hash(v) & cmask;
+    for (;;) {
+      const unsigned long long w = T[pos];
+      if (w == 0ULL) break;
+      pos = (pos + 1) & cmask;
+      if ((uint32_t)(w >> 32) != v) continue;
+      mine++;                                                              // "table elements processed" (:173)
+      const int me = (int)(uint32_t)w - 1;
+      if (!pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) continue;   // id/length rules do not depend on the count
+      // count the hit
+      uint32_t slot = inv_hash((uint32_t)me) & (INV_CT - 1);
+      for (int tries = 0; tries < INV_CT; tries++) {
+        uint32_t k = *(volatile uint32_t*)&keys[slot];
+        if (k == 0) {
+          if (*(volatile uint32_t*)&s_distinct >= (INV_CT * 3) / 4) { s_over = 1; break; }
+          const uint32_t old = atomicCAS(&keys[slot], 0u, (uint32_t)me + 1u);
+          if (old == 0) { atomicAdd(&s_distinct, 1u); k = (uint32_t)me + 1u; } else k = old;
+        }
+        if (k == (uint32_t)me + 1u) { atomicAdd(&cnts[slot], 1u); break; }
+        slot = (slot + 1) & (INV_CT - 1);
+      }
+    }
+  }
+  if (mine) atomicAdd(elements, mine);
+  __syncthreads();
+  if (s_over) {
+    if (threadIdx.x == 0) { const unsigned long long o = atomicAdd(overflow_count, 1ULL); overflow[o] = qe; }
+    return;
+  }
+  for (int j = threadIdx.x; j < INV_CT; j += 256) {
+    const uint32_t k = keys[j];
+    if (k == 0 || (int)cnts[j] < sp.num_min_matches) continue;                               // MinHashSearch.java:204
+    const unsigned long long slot = atomicAdd(cand_count, 1ULL);
+    if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)k - 1; }
+  }
+}
+
+void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_t cmask, const int32_t* qminhash, int64_t qrow_stride,
+                        const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
+                        const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
+                        int32_t* overflow, unsigned long long* overflow_count, unsigned long long* elements) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(index_query_kernel, dim3((unsigned)nq), dim3(256), 0, st, table, cmask, qminhash, qrow_stride, qlist, nq, ids, qids,
+                     meta, qmeta, sp, cand, cand_count, cand_cap, overflow, overflow_count, elements);
 }
 
 // =============================================================================================

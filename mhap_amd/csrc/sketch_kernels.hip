@@ -71,9 +71,14 @@ void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, 
 }
 
 // =============================================================================================
-// K-mer multiplicity -> weight.  Persistent workgroups; each takes strands from an atomic counter
-// and owns a private open-addressing table slab in HBM (stays in L2/MALL): pos[TS] holds
-// (first position + 1) of the k-mer that owns the slot, cnt[TS] its multiplicity.
+// K-mer multiplicity -> weight (the tf part of MHAP's tf-idf MinHash, MinHashSketch.java:66-81,98-128).
+// Persistent workgroups pull strands from an atomic counter.  Each strand gets an open-addressing table of
+// "first position + 1" entries keyed by the 64-bit k-mer hash:
+//   * LDS path (nk <= 65534 and the table fits the launch's LDS budget): entry = fp16<<16 | (pos+1); the 16-bit
+//     fingerprint filters probes so the full 64-bit key is only gathered from HBM/L2 on a fingerprint match
+//     (true duplicate or 2^-16 collision).  ds_cmpst/ds_min atomics, no HBM traffic besides the key stream.
+//   * HBM path (long reads): entry = pos+1 in a per-workgroup slab (stays in L2/MALL), global atomics.
+// Multiplicities are accumulated directly in the output array: wts[first] += 1 per later occurrence.
 // Output wts[i] = weight of k-mer i if i is the first occurrence of its key, else 0.
 // =============================================================================================
 __device__ inline uint32_t ld_agent(const uint32_t* p) {
@@ -91,20 +96,158 @@ __device__ inline bool filter_lookup(const FilterTable& ft, int64_t key, double&
   }
 }
 
+constexpr uint32_t DUP_MARK = 0x80000000u;
+
+template <bool PACKED>
+__device__ inline uint32_t wt_encode(int64_t key, int i) {
+  return PACKED ? ((((uint32_t)((uint64_t)key >> 32)) << 16) | (uint32_t)(i + 1)) : (uint32_t)(i + 1);
+}
+template <bool PACKED>
+__device__ inline bool wt_maybe(uint32_t e, uint32_t mine) { return PACKED ? ((e ^ mine) >> 16) == 0 : true; }
+template <bool PACKED>
+__device__ inline int wt_pos(uint32_t e) { return (int)((PACKED ? (e & 0xFFFFu) : e) - 1u); }
+
+// One strand, whole workgroup.  tab: ts entries (LDS when PACKED, HBM slab otherwise), zeroed here.
+template <bool PACKED>
+__device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
+                                     unsigned int* s_heavy) {
+  const uint32_t mask = ts - 1;
+  for (uint32_t j = threadIdx.x; j < ts; j += WEIGHT_THREADS) tab[j] = 0;
+  if (!PACKED) __threadfence();
+  __syncthreads();
+  for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+    const int64_t key = kp[i];
+    const uint32_t mine = wt_encode<PACKED>(key, i);
+    uint32_t slot = (uint32_t)(uint64_t)key & mask;
+    for (;;) {
+      uint32_t e = PACKED ? *(volatile uint32_t*)&tab[slot] : ld_agent(&tab[slot]);
+      if (e == 0) {
+        const uint32_t old = atomicCAS(&tab[slot], 0u, mine);
+        if (old == 0) break;
+        e = old;
+      }
+      if (wt_maybe<PACKED>(e, mine) && kp[wt_pos<PACKED>(e)] == key) { atomicMin(&tab[slot], mine); break; }
+      slot = (slot + 1) & mask;
+    }
+  }
+  if (!PACKED) __threadfence();
+  __syncthreads();
+  // pass A: first occurrences get 1, later occurrences remember their first position
+  bool anydup = false;
+  for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+    const int64_t key = kp[i];
+    const uint32_t mine = wt_encode<PACKED>(key, i);
+    uint32_t slot = (uint32_t)(uint64_t)key & mask;
+    uint32_t w;
+    for (;;) {
+      const uint32_t e = PACKED ? *(volatile uint32_t*)&tab[slot] : ld_agent(&tab[slot]);
+      if (e == mine) { w = 1u; break; }
+      if (e != 0 && wt_maybe<PACKED>(e, mine)) {
+        const int p = wt_pos<PACKED>(e);
+        if (kp[p] == key) { w = DUP_MARK | (uint32_t)p; anydup = true; break; }
+      }
+      slot = (slot + 1) & mask;
+    }
+    wp[i] = w;
+  }
+  if (anydup) atomicOr(s_heavy, 1u);
+  __threadfence();
+  __syncthreads();
+  // pass B (only strands with duplicates): fold multiplicities into the first occurrence
+  if (*(volatile unsigned int*)s_heavy) {
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const uint32_t w = wp[i];
+      if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
+// LDS fast path: the whole strand's probe state lives in registers (one dword per k-mer: fp16<<16 | slot), keys are
+// fetched 8 at a time (one HBM latency per chunk instead of one per k-mer), inserts go straight to ds_cmpst (no
+// read-before-CAS), and the post-barrier pass is ONE ds_read per k-mer: the remembered slot holds the smallest
+// position of that key, so `entry == mine` <=> first occurrence.  Requires nk <= MAXIT*WEIGHT_THREADS, ts <= 32768.
+template <int MAXIT>
+__device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
+                                         unsigned int* s_heavy) {
+  const uint32_t mask = ts - 1;
+  for (uint32_t j = threadIdx.x * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  uint32_t st[MAXIT];
+#pragma unroll
+  for (int c = 0; c < MAXIT; c += 8) {
+    if (c * WEIGHT_THREADS < nk) {
+      int64_t key[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
+        key[u] = (i < nk) ? kp[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
+        st[c + u] = 0;
+        if (i < nk) {
+          const uint32_t fp = ((uint32_t)((uint64_t)key[u] >> 32)) << 16;
+          const uint32_t mine = fp | (uint32_t)(i + 1);
+          uint32_t slot = (uint32_t)(uint64_t)key[u] & mask;
+          for (;;) {
+            const uint32_t old = atomicCAS(&tab[slot], 0u, mine);
+            if (old == 0) break;
+            if (((old ^ mine) >> 16) == 0 && kp[(old & 0xFFFFu) - 1u] == key[u]) { atomicMin(&tab[slot], mine); break; }
+            slot = (slot + 1) & mask;
+          }
+          st[c + u] = fp | slot;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  bool anydup = false;
+#pragma unroll
+  for (int it = 0; it < MAXIT; it++) {
+    const int i = threadIdx.x + it * WEIGHT_THREADS;
+    if (i < nk) {
+      const uint32_t e = tab[st[it] & 0xFFFFu];
+      const uint32_t mine = (st[it] & 0xFFFF0000u) | (uint32_t)(i + 1);
+      uint32_t w = 1u;
+      if (e != mine) { w = DUP_MARK | ((e & 0xFFFFu) - 1u); anydup = true; }
+      wp[i] = w;
+    }
+  }
+  if (anydup) atomicOr(s_heavy, 1u);
+  __syncthreads();
+  if (*(volatile unsigned int*)s_heavy) {
+    __threadfence();
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const uint32_t w = wp[i];
+      if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(WEIGHT_THREADS) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                                      const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
-                                                                     uint32_t* __restrict__ slabs, int64_t slab_entries,
+                                                                     uint32_t* __restrict__ slabs, int64_t slab_entries, uint32_t lds_entries,
                                                                      unsigned long long* __restrict__ counter, int k,
                                                                      FilterTable ft, double repeat_weight,
                                                                      StrandInfo* __restrict__ info) {
-  __shared__ long long s_strand;
-  __shared__ unsigned int s_valid, s_heavy;
-  uint32_t* tpos = slabs + (size_t)blockIdx.x * (size_t)slab_entries * 2;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
+  uint32_t* svars = lds_tab + lds_entries;   // [0..1] strand index, [2] valid, [3] heavy
+  uint32_t* slab = slabs + (size_t)blockIdx.x * (size_t)slab_entries;
+  const bool reweigh = (repeat_weight < 0.0) || (ft.enabled && repeat_weight < 1.0);
   for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) { s_strand = (long long)atomicAdd(counter, 1ULL); s_valid = 0; s_heavy = 0; }
+    if (threadIdx.x == 0) {
+      const unsigned long long sx = atomicAdd(counter, 1ULL);
+      svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32); svars[2] = 0; svars[3] = 0;
+    }
     __syncthreads();
-    const int64_t strand = s_strand;
+    const int64_t strand = (int64_t)(((unsigned long long)svars[1] << 32) | svars[0]);
     if (strand >= nstrands) break;
     const ReadDesc rd = descs[strand >> 1];
     const int rcs = (int)(strand & 1);
@@ -116,72 +259,69 @@ __global__ __launch_bounds__(WEIGHT_THREADS) void kmer_weight_kernel(const ReadD
     const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
     uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
     uint32_t ts = 64;
-    while (ts < 2u * (uint32_t)nk) ts <<= 1;
-    const uint32_t mask = ts - 1;
-    uint32_t* tcnt = tpos + ts;
-    for (uint32_t j = threadIdx.x; j < 2 * ts; j += WEIGHT_THREADS) tpos[j] = 0;
-    __threadfence();
+    while (3ull * ts < 4ull * (uint32_t)nk) ts <<= 1;          // load factor <= 0.75
+    if (ts <= lds_entries && nk <= WEIGHT_MAXIT * WEIGHT_THREADS) weight_strand_lds<WEIGHT_MAXIT>(lds_tab, ts, kp, wp, nk, &svars[3]);
+    else weight_strand<false>(slab, ts, kp, wp, nk, &svars[3]);
     __syncthreads();
-    // insert
-    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
-      const int64_t key = kp[i];
-      uint32_t slot = (uint32_t)(uint64_t)key & mask;
-      for (;;) {
-        uint32_t e = ld_agent(&tpos[slot]);
-        if (e == 0) {
-          uint32_t old = atomicCAS(&tpos[slot], 0u, (uint32_t)i + 1u);
-          if (old == 0) { atomicAdd(&tcnt[slot], 1u); break; }
-          e = old;
-        }
-        if (kp[e - 1] == key) { atomicMin(&tpos[slot], (uint32_t)i + 1u); atomicAdd(&tcnt[slot], 1u); break; }
-        slot = (slot + 1) & mask;
-      }
-    }
-    __threadfence();
-    __syncthreads();
-    // finalize: weight of first occurrences
     unsigned int myvalid = 0, myheavy = 0;
-    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
-      const int64_t key = kp[i];
-      uint32_t slot = (uint32_t)(uint64_t)key & mask;
-      uint32_t e;
-      for (;;) {
-        e = ld_agent(&tpos[slot]);
-        if (e != 0 && kp[e - 1] == key) break;
-        slot = (slot + 1) & mask;
-      }
-      uint32_t w = 0;
-      if (e == (uint32_t)i + 1u) {
-        const int count = (int)ld_agent(&tcnt[slot]);
-        int weight = count;                                   // tf weight (MinHashSketch.java:98)
-        if (repeat_weight < 0.0) {                            // :101-107
-          weight = 1;
-          double v;
-          if (ft.size > 0 && filter_lookup(ft, key, v)) weight = 0;
-        } else if (ft.enabled && repeat_weight < 1.0) {       // :109-124
-          double idf = ft.range, v;
+    if (reweigh) {
+      // weights differ from plain multiplicity: v1.0 mode or tf-idf (MinHashSketch.java:101-124)
+      for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+        const int count = (int)ld_agent(&wp[i]);
+        if (count == 0) continue;
+        const int64_t key = kp[i];
+        int weight;
+        double v;
+        if (repeat_weight < 0.0) {
+          weight = (ft.size > 0 && filter_lookup(ft, key, v)) ? 0 : 1;
+        } else {
+          double idf = ft.range;
           if (ft.size > 0 && filter_lookup(ft, key, v)) idf = v;
-          double tf = ft.no_tf ? 1.0 : (double)count;
+          const double tf = ft.no_tf ? 1.0 : (double)count;
           weight = (int)java_round(tf * idf);
           if (weight < 1) weight = 1;
         }
-        if (weight > 0) { w = (uint32_t)weight; myvalid = 1; if (weight > 1) myheavy = 1; }
+        wp[i] = (uint32_t)weight;
+        if (weight > 0) myvalid = 1;
+        if (weight > 1) myheavy = 1;
       }
-      wp[i] = w;
-    }
-    if (myvalid) atomicOr(&s_valid, 1u);
-    if (myheavy) atomicOr(&s_heavy, 1u);
+      if (myvalid) atomicOr(&svars[2], 1u);
+      if (threadIdx.x == 0) svars[3] = 0;
+      __syncthreads();
+      if (myheavy) atomicOr(&svars[3], 1u);
+      __threadfence();
+      __syncthreads();
+    } else if (threadIdx.x == 0) svars[2] = 1;   // weight = multiplicity >= 1 for every distinct k-mer
     __syncthreads();
-    if (threadIdx.x == 0) { info[strand].valid = (int)s_valid; info[strand].heavy = (int)s_heavy; }
+    if (threadIdx.x == 0) { info[strand].valid = (int)svars[2]; info[strand].heavy = (int)svars[3]; }
   }
 }
 
-void launch_kmer_weights(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, uint32_t* wts,
-                         uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
+void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
+                         uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
                          double repeat_weight, StrandInfo* info) {
   if (nstrands <= 0) return;
-  hipLaunchKernelGGL(kmer_weight_kernel, dim3(nblocks), dim3(WEIGHT_THREADS), 0, st, descs, nstrands, keys, wts, slabs, slab_entries,
-                     counter, k, ft, repeat_weight, info);
+  uint32_t need = 64;
+  const uint32_t nkmax = (uint32_t)(max_len - k + 1 > 1 ? max_len - k + 1 : 1);
+  while (3ull * need < 4ull * nkmax) need <<= 1;
+  const uint32_t lds_entries = need > 32768u ? 32768u : need;           // <= 128 KiB of the CU's 160 KiB LDS
+  const size_t lds = (size_t)lds_entries * 4 + 16;
+  const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+  const int nblocks = weight_grid(num_cus, nstrands, max_len, k);
+  (void)per_cu;
+  hipLaunchKernelGGL(kmer_weight_kernel, dim3(nblocks), dim3(WEIGHT_THREADS), lds, st, descs, nstrands, keys, wts, slabs, slab_entries,
+                     lds_entries, counter, k, ft, repeat_weight, info);
+}
+
+// number of persistent workgroups (= HBM slabs the caller must provide)
+int weight_grid(int num_cus, int64_t nstrands, int max_len, int k) {
+  uint32_t need = 64;
+  const uint32_t nkmax = (uint32_t)(max_len - k + 1 > 1 ? max_len - k + 1 : 1);
+  while (3ull * need < 4ull * nkmax) need <<= 1;
+  const size_t lds = (size_t)(need > 32768u ? 32768u : need) * 4 + 16;
+  const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+  const int64_t g = (int64_t)num_cus * per_cu;
+  return (int)(nstrands < g ? nstrands : g);
 }
 
 // =============================================================================================
@@ -194,26 +334,33 @@ void launch_kmer_weights(hipStream_t st, int nblocks, const ReadDesc* descs, int
 // Ties (x equal, different k-mers; 2^-64) resolve to the earlier first-occurrence position, which
 // is the reference's insertion order.
 // =============================================================================================
-__device__ inline void minhash_update(volatile int64_t* best, volatile int32_t* bpos, int s, const int64_t* xv, const int* pv,
-                                      const bool* act, int n, int lane) {
+// Exact update of slot s from the wave's N candidate values per lane.  Wave-uniform control flow; the winner is
+// moved with v_readlane (SGPR lane index from the ballot), no LDS permutes.
+template <int N>
+__device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int s, const int64_t (&xv)[N], const int (&pv)[N],
+                                               const bool (&act)[N], int lane) {
   int64_t cur = best[s];
   int32_t curpos = bpos[s];
   bool changed = false;
-  for (int u = 0; u < n; u++) {
+#pragma unroll
+  for (int u = 0; u < N; u++) {
     const int64_t x = xv[u];
     const int p = pv[u];
     bool c = act[u] && (x < cur || (x == cur && p < curpos));
     unsigned long long m = __ballot(c);
     while (m) {
-      const int l = __ffsll((long long)m) - 1;
-      cur = __shfl(x, l);
-      curpos = __shfl(p, l);
+      const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(m));
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)x, l);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)x >> 32), l);
+      cur = (int64_t)(((uint64_t)hi << 32) | lo);
+      curpos = __builtin_amdgcn_readlane(p, l);
       changed = true;
       c = act[u] && (x < cur || (x == cur && p < curpos));
       m = __ballot(c);
     }
   }
   if (changed && lane == 0) { best[s] = cur; bpos[s] = curpos; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -226,8 +373,9 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t per_wave = (size_t)H * 12;
-  volatile int64_t* best = (volatile int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
-  volatile int32_t* bpos = (volatile int32_t*)(best + H);
+  int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
+  int32_t* bpos = (int32_t*)(best + H);
+  const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loop's threshold
   for (;;) {
     long long sidx = 0;
     if (lane == 0) sidx = (long long)atomicAdd(counter, 1ULL);
@@ -247,6 +395,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
     const uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
     for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass 1: weight == 1 k-mers, U per lane ----
@@ -264,8 +413,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         if (i < nk && wp[i] == 1u) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
       }
       if (!__any(anyact)) continue;
+      int32_t bh_next = besthi[1];
       for (int s = 0; s < H; s++) {
-        const int32_t bh = ((volatile int32_t*)best)[2 * s + 1];
+        const int32_t bh = bh_next;
+        bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];   // prefetch the next slot's threshold (uniform ds_read)
         bool hit = false;
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -276,7 +427,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           int64_t xs[U];
 #pragma unroll
           for (int u = 0; u < U; u++) xs[u] = (int64_t)x[u];
-          minhash_update(best, bpos, s, xs, pv, act, U, lane);
+          minhash_update<U>(best, bpos, s, xs, pv, act, lane);
         }
       }
     }
@@ -296,13 +447,13 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           for (uint32_t c = 0; c < wmax; c++) {
             if (heavy && c < wt) { x = xorshift_step(x); mn = (int64_t)x < mn ? (int64_t)x : mn; }
           }
-          const int32_t bh = ((volatile int32_t*)best)[2 * s + 1];
+          const int32_t bh = besthi[2 * s + 1];
           const bool hit = heavy && ((int32_t)(mn >> 32) <= bh);
           if (__any(hit)) {
             int64_t xs[1] = {mn};
             int pp[1] = {i};
             bool aa[1] = {heavy};
-            minhash_update(best, bpos, s, xs, pp, aa, 1, lane);
+            minhash_update<1>(best, bpos, s, xs, pp, aa, lane);
           }
         }
       }

@@ -223,12 +223,22 @@ bool minhash_sketch(const char* seq, int L, int k, int H, const Filter* filter, 
   if (n < 1) return false;                                            // :56-57
   std::vector<int64_t> keys = kmer_hashes64(seq, L, k, false);        // :63
   // insertion-ordered dedup with counts (Long2ObjectLinkedOpenHashMap)  :66-81
-  std::unordered_map<int64_t, int> where; where.reserve(keys.size() * 2);
+  // (flat open-addressing table instead of a node-based map: same insertion order and counts, but no per-k-mer
+  //  heap allocation, so the multithreaded CPU baseline is not throttled by the allocator)
   std::vector<int64_t> order; std::vector<int> cnt;
-  for (int64_t key : keys) {
-    auto it = where.find(key);
-    if (it == where.end()) { where.emplace(key, (int)order.size()); order.push_back(key); cnt.push_back(1); }
-    else cnt[it->second]++;
+  order.reserve(keys.size()); cnt.reserve(keys.size());
+  {
+    size_t ts = 64; while (ts < keys.size() * 2) ts <<= 1;
+    std::vector<int32_t> slot_of(ts, -1);
+    for (int64_t key : keys) {
+      size_t s = (size_t)fmix64((uint64_t)key) & (ts - 1);
+      for (;;) {
+        const int32_t e = slot_of[s];
+        if (e < 0) { slot_of[s] = (int32_t)order.size(); order.push_back(key); cnt.push_back(1); break; }
+        if (order[(size_t)e] == key) { cnt[(size_t)e]++; break; }
+        s = (s + 1) & (ts - 1);
+      }
+    }
   }
   if (order.empty()) return false;                                    // :84-85
   int outn = std::max(1, H);

@@ -249,3 +249,37 @@ def test_full_size_properties_config2_slice():
     want = O.record_lines(O.run_self(sub, nthreads=8)["records"])
     m = (recs["from_id"] <= 150) & (recs["to_id"] <= 150)
     assert sorted(mhap_amd.records_to_lines(recs[m])) == want
+
+
+def _sorted_records(recs):
+    names = ["from_id", "to_id", "to_rc", "score", "raw", "a1", "a2", "alen", "b1", "b2", "blen"]
+    a = np.zeros(len(recs), dtype=[(n, recs.dtype[n]) for n in names])
+    for n in names:
+        a[n] = recs[n]
+    return np.sort(a, order=names)
+
+
+def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
+    """Inverted-index candidates (default) == brute-force all-pairs candidates == oracle, including queries whose hit
+    set overflows the per-query LDS count table (3072 distinct entries) and falls back to the brute-force kernel."""
+    rnd = random.Random(41)
+    base = _rand_seq(rnd, 220)
+    seqs = [base] * 3300 + [_rand_seq(rnd, 220) for _ in range(20)]
+    fa = FastaData.from_strings(seqs)
+    p = MhapParams(num_hashes=16, ordered_sketch_size=32, min_olap_length=50)
+    want = O.run_self(fa, H=16, S=32, min_olap_length=50, nthreads=8, cap=1 << 23)
+    assert len(want["records"]) > 5_000_000
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        got = ms.find_matches()
+        st = ms.stats()
+    assert st["slot_compares"] > 0          # some queries took the fallback
+    assert np.array_equal(_sorted_records(got), _sorted_records(want["records"]))
+    small = mhap_amd.synth_reads(400, 2500, seed=12, error_rate=0.05)
+    p2 = MhapParams(num_hashes=96, ordered_sketch_size=300)
+    a, sa = _self_lines(small, p2)
+    monkeypatch.setenv("MHAP_CANDIDATES", "bruteforce")
+    b, sb = _self_lines(small, p2)
+    assert a == b and len(a) > 100
+    assert sa["table_elements"] > 0 and sa["slot_compares"] == 0 and sb["slot_compares"] > 0
+    assert sa["candidates_compared"] == sb["candidates_compared"]
