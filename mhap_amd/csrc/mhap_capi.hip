@@ -355,10 +355,11 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   HIPCHK(h, h->counters.ensure(256));
   unsigned long long* ctr = h->counters.as<unsigned long long>();
   size_t cand_cap = std::max<size_t>(h->cand.cap / sizeof(Candidate), (size_t)4 << 20);
-  const int oblocks = h->num_cus * 2;
-  const int64_t lanes = (int64_t)oblocks * OVL_THREADS;
+  // second stage: one lane per candidate; it is latency-bound, so put as many lanes in flight as the candidates allow
+  // (per-lane scratch = 3 int arrays of 2S+2 entries: 37 KB at S=1536; 16 workgroups/CU = 19 GB of the 288 GB HBM)
+  int64_t ovl_max_blocks = (int64_t)h->num_cus * 16;
+  if (const char* e = getenv("MHAP_OVERLAP_BLOCKS")) { long long v = atoll(e); if (v > 0) ovl_max_blocks = v; }
   const int64_t per_lane = 3LL * (2LL * S + 2);
-  HIPCHK(h, h->ovl_scratch.ensure((size_t)lanes * (size_t)per_lane * 4));
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
   // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
   const char* cmode = getenv("MHAP_CANDIDATES");
@@ -450,6 +451,8 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     h->stats.queries_searched += nq;
     if (ncand == 0) continue;
     HIPCHK(h, h->recs.ensure((size_t)ncand * sizeof(DevRecord)));
+    const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)ncand + OVL_THREADS - 1) / OVL_THREADS));
+    HIPCHK(h, h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS * (size_t)per_lane * 4));
     time_begin(h, MHAP_K_OVERLAP);
     launch_overlap(h->stream, oblocks, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                    qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
@@ -882,7 +885,8 @@ int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const
   const int maxrec = 2 * std::max(nA, nB) + 2;
   std::vector<int32_t> scratch((size_t)3 * (size_t)maxrec * (size_t)stride, 0);
   LaneScratch sc; sc.base = scratch.data(); sc.stride = stride; sc.maxrec = maxrec;
-  const LaneOverlap r = lane_overlap(A, nA, lenA, B, nB, lenB, max_shift, sc);
+  PlainView va{A, nA}, vb{B, nB};
+  const LaneOverlap r = lane_overlap(va, lenA, vb, lenB, max_shift, sc);
   out8[0] = r.empty; out8[1] = r.valid; out8[2] = r.a1; out8[3] = r.a2; out8[4] = r.b1; out8[5] = r.b2; out8[6] = r.inter; out8[7] = r.kk;
   return MHAP_OK;
 }

@@ -28,6 +28,16 @@ struct LaneScratch {
 
 struct ShiftStats { int32_t med, absmax; };
 
+// Read-only view of one ordered sketch: entry i = (hash, pos).  The algorithms below only ever move FORWARD through a
+// view between two reset() calls, which lets the device view keep one 64-byte line per lane in LDS and prefetch the
+// next line in registers (search_kernels.hip: CachedView).
+struct PlainView {
+  const int32_t* p;
+  int n;
+  __host__ __device__ inline void reset() {}
+  __host__ __device__ inline void get(int i, int& h, int& pos) { h = p[2 * i]; pos = p[2 * i + 1]; }
+};
+
 // Utils.quickSelect, verbatim control flow, on scratch array 2.
 __host__ __device__ inline int32_t lane_quickselect(const LaneScratch& sc, int k, int length) {
   if (length <= k) return INT32_MAX;
@@ -66,8 +76,9 @@ __host__ __device__ inline ShiftStats lane_stats(const LaneScratch& sc, int coun
 }
 
 // recordMatchingKmers (:397-516): returns the new record count (records in scratch arrays 0/1).
-__host__ __device__ inline int lane_merge(const LaneScratch& sc, const int32_t* __restrict__ A, int nA, const int32_t* __restrict__ B,
-                                          int nB, int len1, int len2, ShiftStats st) {
+template <class VA, class VB>
+__host__ __device__ inline int lane_merge(const LaneScratch& sc, VA& A, VB& B, int len1, int len2, ShiftStats st) {
+  const int nA = A.n, nB = B.n;
   const int med = st.med, absmax = st.absmax;
   const int t1 = -med - absmax, t2 = len2 - med + absmax, t3 = med - absmax, t4 = len1 + med + absmax;
   const int v1lo = 0 > t1 ? 0 : t1;            // valid1Lower :246-252
@@ -75,8 +86,11 @@ __host__ __device__ inline int lane_merge(const LaneScratch& sc, const int32_t* 
   const int v2lo = 0 > t3 ? 0 : t3;            // valid2Lower :262-268
   const int v2hi = len2 < t4 ? len2 : t4;      // valid2Upper :270-276
   int i1 = 0, i2 = 0, count = 0;
+  A.reset(); B.reset();
   while (i1 < nA && i2 < nB) {
-    const int h1 = A[2 * i1], p1 = A[2 * i1 + 1], h2 = B[2 * i2], p2 = B[2 * i2 + 1];
+    int h1, p1, h2, p2;
+    A.get(i1, h1, p1);
+    B.get(i2, h2, p2);
     if (h1 < h2 || p1 < v1lo || p1 >= v1hi) i1++;
     else if (h2 < h1 || p2 < v2lo || p2 >= v2hi) i2++;
     else {
@@ -87,26 +101,30 @@ __host__ __device__ inline int lane_merge(const LaneScratch& sc, const int32_t* 
       else {
         if (count < sc.maxrec) { sc.at(0, count) = p1; sc.at(1, count) = p2; }
         count++;
-        int i1Last = i1, i1Try = i1 + 1;
+        // last entry of the run with the same hash and an in-window position (:460-496); positions of the run ends
+        // are carried along so that the views are never read backwards
+        int i1Last = i1, i1Try = i1 + 1, p1Last = p1;
         if (i1Try < nA) {
-          int ht = A[2 * i1Try], pt = A[2 * i1Try + 1];
+          int ht, pt;
+          A.get(i1Try, ht, pt);
           while (ht == h1 && pt >= v1lo && pt < v1hi) {
-            i1Last = i1Try; i1Try++;
+            i1Last = i1Try; p1Last = pt; i1Try++;
             if (i1Try >= nA) break;
-            ht = A[2 * i1Try]; pt = A[2 * i1Try + 1];
+            A.get(i1Try, ht, pt);
           }
         }
-        int i2Last = i2, i2Try = i2 + 1;
+        int i2Last = i2, i2Try = i2 + 1, p2Last = p2;
         if (i2Try < nB) {
-          int ht = B[2 * i2Try], pt = B[2 * i2Try + 1];
+          int ht, pt;
+          B.get(i2Try, ht, pt);
           while (ht == h2 && pt >= v2lo && pt < v2hi) {
-            i2Last = i2Try; i2Try++;
+            i2Last = i2Try; p2Last = pt; i2Try++;
             if (i2Try >= nB) break;
-            ht = B[2 * i2Try]; pt = B[2 * i2Try + 1];
+            B.get(i2Try, ht, pt);
           }
         }
         if (i1 != i1Last || i2 != i2Last) {
-          if (count < sc.maxrec) { sc.at(0, count) = A[2 * i1Last + 1]; sc.at(1, count) = B[2 * i2Last + 1]; }
+          if (count < sc.maxrec) { sc.at(0, count) = p1Last; sc.at(1, count) = p2Last; }
           count++;
           i1 = i1Last + 1; i2 = i2Last + 1;
         } else { i1++; i2++; }
@@ -118,15 +136,16 @@ __host__ __device__ inline int lane_merge(const LaneScratch& sc, const int32_t* 
 
 __host__ __device__ inline int iabs32(int v) { return v < 0 ? -v : v; }
 
-__host__ __device__ inline LaneOverlap lane_overlap(const int32_t* __restrict__ A, int nA, int len1, const int32_t* __restrict__ B, int nB,
-                                                    int len2, double max_shift, const LaneScratch& sc) {
+template <class VA, class VB>
+__host__ __device__ inline LaneOverlap lane_overlap(VA& A, int len1, VB& B, int len2, double max_shift, const LaneScratch& sc) {
+  const int nA = A.n, nB = B.n;
   LaneOverlap r;
   r.empty = 1; r.valid = 0; r.a1 = r.a2 = r.b1 = r.b2 = 0; r.inter = 0; r.kk = 0;
   ShiftStats st = lane_stats(sc, 0, len1, len2, max_shift);
-  int count = lane_merge(sc, A, nA, B, nB, len1, len2, st);           // pass 1 (:600)
+  int count = lane_merge(sc, A, B, len1, len2, st);                   // pass 1 (:600)
   if (count <= 0) return r;
   st = lane_stats(sc, count, len1, len2, max_shift);
-  count = lane_merge(sc, A, nA, B, nB, len1, len2, st);               // pass 2 (:606)
+  count = lane_merge(sc, A, B, len1, len2, st);                       // pass 2 (:606)
   if (count <= 0) return r;
   // optimizeShifts (:156-189)
   st = lane_stats(sc, count, len1, len2, max_shift);
@@ -168,16 +187,20 @@ __host__ __device__ inline LaneOverlap lane_overlap(const int32_t* __restrict__ 
   int b2 = (int)java_round((double)nb2 / den); if (b2 > len2) b2 = len2;
   // computeKBottomSketchJaccard (:304-364) without materialising the filtered arrays
   int s1 = 0, s2 = 0;
-  for (int i = 0; i < nA; i++) { const int pos = A[2 * i + 1]; s1 += (pos >= a1 && pos <= a2) ? 1 : 0; }
-  for (int j = 0; j < nB; j++) { const int pos = B[2 * j + 1]; s2 += (pos >= b1 && pos <= b2) ? 1 : 0; }
+  A.reset(); B.reset();
+  for (int i = 0; i < nA; i++) { int h, pos; A.get(i, h, pos); s1 += (pos >= a1 && pos <= a2) ? 1 : 0; }
+  for (int j = 0; j < nB; j++) { int h, pos; B.get(j, h, pos); s2 += (pos >= b1 && pos <= b2) ? 1 : 0; }
   const int kk = s1 < s2 ? s1 : s2;
   int inter = 0;
   if (kk > 0) {
     int i = 0, j = 0, uni = 0;
+    A.reset(); B.reset();
     while (uni < kk) {
-      while (!(A[2 * i + 1] >= a1 && A[2 * i + 1] <= a2)) i++;
-      while (!(B[2 * j + 1] >= b1 && B[2 * j + 1] <= b2)) j++;
-      const int ha = A[2 * i], hb = B[2 * j];
+      int ha, pa, hb, pb;
+      A.get(i, ha, pa);
+      while (!(pa >= a1 && pa <= a2)) { i++; A.get(i, ha, pa); }
+      B.get(j, hb, pb);
+      while (!(pb >= b1 && pb <= b2)) { j++; B.get(j, hb, pb); }
       if (ha < hb) i++;
       else if (ha > hb) j++;
       else { inter++; i++; j++; }

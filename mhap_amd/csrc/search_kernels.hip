@@ -286,6 +286,35 @@ void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_
 // Second stage.  Persistent lanes: lane g handles candidates g, g+G, ...  Scratch (3 int arrays of
 // maxrec entries per lane) is interleaved across lanes so that lanes of a wave touch adjacent words.
 // =============================================================================================
+// Per-lane streaming view of one ordered-sketch row: the current 64-byte line (8 entries) sits in LDS
+// (lane-interleaved 8-byte words), the next line is already in flight into registers.  lane_overlap only walks
+// forward between reset()s, so one line + one prefetch hides the HBM/L2 latency of the otherwise dependent loads.
+struct CachedView {
+  const uint2* row;      // global row: entry i = (hash, pos)
+  int n;
+  uint2* lds;            // this lane's slot: entry e of the current line at lds[e * OVL_THREADS]
+  int cur, nxt;
+  uint2 r[8];
+  __device__ inline void init(const int32_t* p, int n_, uint2* lds_) { row = (const uint2*)p; n = n_; lds = lds_; cur = -1; nxt = -1; }
+  __device__ inline void reset() {}
+  __device__ inline void fetch(int line) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) r[e] = row[line * 8 + e];
+  }
+  __device__ inline void get(int i, int& h, int& pos) {
+    const int line = i >> 3;
+    if (line != cur) {
+      if (line != nxt) fetch(line);
+#pragma unroll
+      for (int e = 0; e < 8; e++) lds[e * OVL_THREADS] = r[e];
+      cur = line;
+      if ((line + 1) * 8 < n) { fetch(line + 1); nxt = line + 1; } else nxt = -1;
+    }
+    const uint2 v = lds[(i & 7) * OVL_THREADS];
+    h = (int)v.x; pos = (int)v.y;
+  }
+};
+
 __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                               unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                               int64_t ord_stride, const int32_t* __restrict__ meta,
@@ -295,6 +324,7 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
                                                               int64_t scratch_per_lane, DevRecord* __restrict__ recs,
                                                               unsigned long long* __restrict__ rec_count, unsigned long long rec_cap,
                                                               unsigned long long* __restrict__ compared) {
+  __shared__ uint2 lines[2][8 * OVL_THREADS];
   unsigned long long n = *cand_count;
   if (n > cand_cap) n = cand_cap;
   const int64_t G = (int64_t)gridDim.x * OVL_THREADS;
@@ -308,9 +338,10 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
     const Candidate cd = cand[c];
     const int32_t* qm = qmeta + (int64_t)cd.q * META_W;
     const int32_t* mm = meta + (int64_t)cd.m * META_W;
-    const int32_t* A = qordered + (int64_t)cd.q * qord_stride;
-    const int32_t* B = ordered + (int64_t)cd.m * ord_stride;
-    const LaneOverlap r = lane_overlap(A, qm[0], qm[1], B, mm[0], mm[1], sp.max_shift, sc);   // MinHashSearch.java:228
+    CachedView A, B;
+    A.init(qordered + (int64_t)cd.q * qord_stride, qm[0], &lines[0][threadIdx.x]);
+    B.init(ordered + (int64_t)cd.m * ord_stride, mm[0], &lines[1][threadIdx.x]);
+    const LaneOverlap r = lane_overlap(A, qm[1], B, mm[1], sp.max_shift, sc);   // MinHashSearch.java:228
     mine++;
     double score = 0.0;
     if (!r.empty) score = score_table[score_index(r.inter, r.kk)];

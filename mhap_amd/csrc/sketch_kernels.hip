@@ -8,6 +8,8 @@
 //                         in LDS, ballot-driven rare update path (J/sketch/MinHashSketch.java:130-154).
 //   ordered_kernel      : bottom-S (signed hash, pos) select + sort
 //                         (J/sketch/BottomOverlapSketch.java:525-559).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace mhap {
@@ -364,7 +366,33 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int U>
+// xorshift64 step on 32-bit halves: 10 full-rate VALU ops (2 v_alignbit, 3 shifts, 5 xors) instead of two
+// 64-bit shifts (half rate on the SIMD-32s) + 6 ops.
+__device__ __forceinline__ void xorshift_step32(uint32_t& lo, uint32_t& hi) {
+  uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 11);   // (x << 21).hi = hi<<21 | lo>>11
+  hi ^= t;
+  lo ^= lo << 21;
+  lo ^= hi >> 3;                                        // x >>> 35 only reaches the low dword
+  t = __builtin_amdgcn_alignbit(hi, lo, 28);            // (x << 4).hi = hi<<4 | lo>>28
+  hi ^= t;
+  lo ^= lo << 4;
+}
+
+// wave64 signed-min reduction on the VALU (DPP), result broadcast from lane 63.
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
+#define MHAP_DPP_MIN(ctrl, rmask) { const int32_t o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false); v = o < v ? o : v; }
+  MHAP_DPP_MIN(0xb1, 0xf)    // quad_perm [1,0,3,2]
+  MHAP_DPP_MIN(0x4e, 0xf)    // quad_perm [2,3,0,1]
+  MHAP_DPP_MIN(0x124, 0xf)   // row_ror:4
+  MHAP_DPP_MIN(0x128, 0xf)   // row_ror:8
+  MHAP_DPP_MIN(0x142, 0xa)   // row_bcast:15 -> rows 1,3
+  MHAP_DPP_MIN(0x143, 0xc)   // row_bcast:31 -> rows 2,3
+#undef MHAP_DPP_MIN
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// VAR bits: 1 = 32-bit-halves xorshift, 2 = first row seeded by a DPP wave arg-min, 4 = single-strict-winner update
+template <int U, int VAR>
 __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const StrandInfo* __restrict__ info, int k, int k2, int H,
@@ -399,8 +427,9 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass 1: weight == 1 k-mers, U per lane ----
+    bool seeded = false;
     for (int base = 0; base < nk; base += 64 * U) {
-      uint64_t x[U];
+      uint32_t xl[U], xh[U];
       int pv[U];
       bool act[U];
       bool anyact = false;
@@ -409,10 +438,32 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         const int i = base + u * 64 + lane;
         pv[u] = i;
         act[u] = false;
-        x[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
-        if (i < nk && wp[i] == 1u) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
+        xl[u] = 0; xh[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
+        if (i < nk && wp[i] == 1u) { act[u] = true; const uint64_t key = (uint64_t)kp[i]; xl[u] = (uint32_t)key; xh[u] = (uint32_t)(key >> 32); anyact = true; }
       }
       if (!__any(anyact)) continue;
+      if ((VAR & 2) && !seeded) {
+        // First populated row: every slot is still empty, so all lanes would "win".  Find the row's minimum with a
+        // VALU-only DPP reduction on the high dword and let only the lanes that hold it into the exact update.
+        seeded = true;
+        for (int s = 0; s < H; s++) {
+          int32_t m = INT32_MAX;
+#pragma unroll
+          for (int u = 0; u < U; u++) {
+            if (VAR & 1) xorshift_step32(xl[u], xh[u]);
+            else { uint64_t x = xorshift_step(((uint64_t)xh[u] << 32) | xl[u]); xl[u] = (uint32_t)x; xh[u] = (uint32_t)(x >> 32); }
+            const int32_t h = act[u] ? (int32_t)xh[u] : INT32_MAX;
+            m = h < m ? h : m;
+          }
+          const int32_t wmin = wave_min_i32(m);
+          int64_t xs[U];
+          bool a2[U];
+#pragma unroll
+          for (int u = 0; u < U; u++) { xs[u] = (int64_t)(((uint64_t)xh[u] << 32) | xl[u]); a2[u] = act[u] && ((int32_t)xh[u] == wmin); }
+          minhash_update<U>(best, bpos, s, xs, pv, a2, lane);
+        }
+        continue;
+      }
       int32_t bh_next = besthi[1];
       for (int s = 0; s < H; s++) {
         const int32_t bh = bh_next;
@@ -420,14 +471,43 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         bool hit = false;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          x[u] = xorshift_step(x[u]);
-          hit |= ((int32_t)(x[u] >> 32) <= bh);
+          if (VAR & 1) xorshift_step32(xl[u], xh[u]);
+          else { uint64_t x = xorshift_step(((uint64_t)xh[u] << 32) | xl[u]); xl[u] = (uint32_t)x; xh[u] = (uint32_t)(x >> 32); }
+          hit |= ((int32_t)xh[u] <= bh);
         }
         if (__any(hit)) {
-          int64_t xs[U];
+          bool done = false;
+          if (VAR & 4) {
+            // Usual case after the first rows: exactly one lane/k-mer undercuts the threshold, strictly in the high
+            // dword.  It is the new minimum; no LDS read-back, no compare chain.
+            unsigned long long mk[U];
+            int tot = 0;
 #pragma unroll
-          for (int u = 0; u < U; u++) xs[u] = (int64_t)x[u];
-          minhash_update<U>(best, bpos, s, xs, pv, act, lane);
+            for (int u = 0; u < U; u++) { mk[u] = __ballot(act[u] && ((int32_t)xh[u] <= bh)); tot += __popcll(mk[u]); }
+            if (tot == 0) done = true;   // only idle lanes tripped the compare
+            if (tot == 1) {
+#pragma unroll
+              for (int u = 0; u < U; u++) {
+                if (mk[u]) {
+                  const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mk[u]));
+                  const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)xl[u], l);
+                  const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)xh[u], l);
+                  if ((int32_t)wh < bh) {
+                    if (lane == 0) { best[s] = (int64_t)(((uint64_t)wh << 32) | wl); bpos[s] = base + u * 64 + l; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    done = true;
+                  }
+                }
+              }
+            }
+          }
+          if (!done) {
+            int64_t xs[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) xs[u] = (int64_t)(((uint64_t)xh[u] << 32) | xl[u]);
+            minhash_update<U>(best, bpos, s, xs, pv, act, lane);
+          }
         }
       }
     }
@@ -472,14 +552,36 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
   }
 }
 
-void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
-                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride) {
+// variant = U*16 + VAR (microbenchmark knob; 0 = tuned default)
+void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys,
+                            const uint32_t* wts, const StrandInfo* info, int k, int k2, int H, unsigned long long* counter,
+                            int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride) {
   if (nstrands <= 0) return;
   size_t per_wave = (((size_t)H * 12) + 15) & ~(size_t)15;
   size_t lds = per_wave * 4;
-  hipLaunchKernelGGL((minhash_kernel<MH_U>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter,
-                     out_rows, out_stride, out_status, status_stride);
+#define MHAP_MH_CASE(UU, VV)                                                                                                    \
+  case (UU) * 16 + (VV):                                                                                                        \
+    hipLaunchKernelGGL((minhash_kernel<UU, VV>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H, \
+                       counter, out_rows, out_stride, out_status, status_stride);                                               \
+    break;
+  if (variant == 0) variant = MH_U * 16 + MH_VAR;
+  switch (variant) {
+    MHAP_MH_CASE(4, 0) MHAP_MH_CASE(4, 1) MHAP_MH_CASE(4, 2) MHAP_MH_CASE(4, 4) MHAP_MH_CASE(4, 6) MHAP_MH_CASE(4, 7)
+    MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
+    default:
+      hipLaunchKernelGGL((minhash_kernel<MH_U, MH_VAR>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H,
+                         counter, out_rows, out_stride, out_status, status_stride);
+  }
+#undef MHAP_MH_CASE
+}
+
+void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
+                    int32_t* out_status, int64_t status_stride) {
+  static int variant = -1;
+  if (variant < 0) { const char* e = getenv("MHAP_MINHASH_VARIANT"); variant = e ? atoi(e) : 0; }
+  launch_minhash_variant(st, variant, nblocks, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows, out_stride, out_status,
+                         status_stride);
 }
 
 // =============================================================================================

@@ -1,0 +1,120 @@
+"""The native driver (mhap_amd/lib/mhap-hip) keeps MHAP's command line, record format and `.dat` files."""
+import json
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import mhap_amd
+from mhap_amd import FastaData, MhapParams, MinHashSearch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+CLI = os.path.join(ROOT, "mhap_amd", "lib", "mhap-hip")
+GFLAGS = ["-k", "16", "--num-hashes", "64", "--ordered-kmer-size", "12", "--ordered-sketch-size", "256", "--min-olap-length", "116"]
+
+
+def _run(args):
+    r = subprocess.run([CLI] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return sorted(l for l in r.stdout.split("\n") if l), r.stderr
+
+
+def test_cli_self_overlap_matches_golden():
+    g = json.load(open(os.path.join(GOLD, "small_reads.json")))
+    lines, err = _run(["-s", os.path.join(GOLD, "small_reads.fasta")] + GFLAGS)
+    assert lines == g["sorted_records"]
+    assert "Time (s) to read and hash from file:" in err and "Total matches found: %d" % len(lines) in err
+
+
+def test_cli_dat_roundtrip_and_format(tmp_path):
+    """-p writes MHAP's `.dat` (big-endian framing, Appendix B); -s x.dat reproduces the FASTA run."""
+    indir, outdir = tmp_path / "in", tmp_path / "out"
+    indir.mkdir(); outdir.mkdir()
+    fasta = indir / "small_reads.fasta"
+    fasta.write_bytes(open(os.path.join(GOLD, "small_reads.fasta"), "rb").read())
+    _run(["-p", str(indir), "-q", str(outdir)] + GFLAGS)
+    dat = outdir / "small_reads.dat"
+    blob = dat.read_bytes()
+    # first record: u8 isFwd, i32 size, payload = u8 isFwd, i64 id, UTF header, i32 seqlen, i32 H, H*i32, i32 n, i32 k2, i32 size, ...
+    is_fwd, size = struct.unpack(">bi", blob[:5])
+    pay = blob[5:5 + size]
+    f2, rid, hl = struct.unpack(">bqH", pay[:11])
+    hdr = pay[11:11 + hl].decode()
+    seqlen, H = struct.unpack(">ii", pay[11 + hl:19 + hl])
+    assert (is_fwd, f2, rid, hdr, H) == (1, 1, 1, "1", 64)
+    fa = FastaData.from_file(str(fasta))
+    assert seqlen == fa.lengths[0]
+    mh = struct.unpack(">64i", pay[19 + hl:19 + hl + 256])
+    assert list(mh) == O.minhash(fa.sequence(0), 16, 64)[1].tolist()
+    n, k2, osz = struct.unpack(">iii", pay[19 + hl + 256:19 + hl + 268])
+    assert (n, k2, osz) == (seqlen - 11, 12, 256)
+    g = json.load(open(os.path.join(GOLD, "small_reads.json")))
+    lines, _ = _run(["-s", str(dat)] + GFLAGS)
+    assert lines == g["sorted_records"]
+
+
+def test_cli_query_mode_and_full_ids(tmp_path):
+    base = mhap_amd.synth_reads(60, 2500, seed=91, error_rate=0.05)
+
+    def write(path, idx, prefix):
+        with open(path, "w") as fh:
+            for i in idx:
+                fh.write(f">{prefix}{i} extra,words\n{base.sequence(i)}\n")
+    sfile, qfile = tmp_path / "index.fasta", tmp_path / "query.fa"
+    write(sfile, range(0, 40), "s")
+    write(qfile, range(30, 60), "q")
+    flags = ["--num-hashes", "64", "--ordered-sketch-size", "400"]
+    lines, err = _run(["-s", str(sfile), "-q", str(qfile)] + flags)
+    index = FastaData.from_file(str(sfile))
+    queries = FastaData.from_file(str(qfile), id_offset=40)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=400)
+    with MinHashSearch(p) as ms:
+        ms.add_data(index)
+        want = mhap_amd.records_to_lines(ms.find_matches()) + mhap_amd.records_to_lines(ms.find_matches_stream(queries))
+    assert lines == sorted(want) and len(lines) > 30
+    noself, _ = _run(["-s", str(sfile), "-q", str(qfile), "--no-self"] + flags)
+    with MinHashSearch(p) as ms:
+        ms.add_data(index)
+        assert noself == sorted(mhap_amd.records_to_lines(ms.find_matches_stream(queries)))
+    full, _ = _run(["-s", str(sfile), "-q", str(qfile), "--store-full-id"] + flags)
+    hdr = {i + 1: f"s{i}" for i in range(40)}
+    hdr.update({41 + j: f"q{30 + j}" for j in range(30)})
+    expect = sorted(" ".join([hdr[int(l.split()[0])], hdr[int(l.split()[1])]] + l.split()[2:]) for l in lines)
+    assert full == expect
+
+
+def test_cli_filter_file_and_presets(tmp_path):
+    fa = mhap_amd.synth_reads(120, 3000, seed=31, error_rate=0.05)
+    fasta = tmp_path / "r.fasta"
+    with open(fasta, "w") as fh:
+        for i in range(len(fa)):
+            fh.write(f">r{i}\n{fa.sequence(i)}\n")
+    counts = {}
+    for i in range(len(fa)):
+        s = fa.sequence(i)
+        for j in range(len(s) - 15):
+            counts[s[j:j + 16]] = counts.get(s[j:j + 16], 0) + 1
+    total = sum(counts.values())
+    top = sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))[:300]
+    ffile = tmp_path / "kmers.txt"
+    with open(ffile, "w") as fh:
+        fh.write(f"{len(counts)} {len(top)}\n")
+        for kmer, c in top:
+            fh.write(f"{kmer}\t{c / total:.10f}\n")
+    flags = ["--num-hashes", "128", "--ordered-sketch-size", "512", "--filter-threshold", "1e-5"]
+    lines, err = _run(["-s", str(fasta), "-f", str(ffile)] + flags)
+    flt = mhap_amd.FrequencyCounts.from_file(str(ffile), filter_cutoff=1e-5, repeat_weight=0.9)
+    oflt = O.Filter(flt.hashes, flt.fractions, 1e-5, 0.9, 3.0, False)
+    want = O.record_lines(O.run_self(FastaData.from_file(str(fasta)), H=128, S=512, nthreads=8, flt=oflt)["records"])
+    assert lines == want and len(lines) > 50
+    assert "Read in k-mer filter for sizes: [16]" in err
+    fast, _ = _run(["-s", str(fasta), "--settings", "2"])          # fast preset: H 256, thr 0.80, S 1000, k2 14
+    wantf = O.record_lines(O.run_self(FastaData.from_file(str(fasta)), H=256, S=1000, k2=14, threshold=0.80, nthreads=8)["records"])
+    assert fast == wantf
+    bad = subprocess.run([CLI, "-s", str(fasta), "--threshold", "2"], capture_output=True, text=True)
+    assert bad.returncode == 1 and "0<=threshold<=1.0" in bad.stdout
