@@ -29,7 +29,7 @@ from mhap_amd import MhapParams, MinHashSearch  # noqa: E402
 from mhap_amd import distributed as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_LANE_OPS_PEAK = 256 * 4 * 32 * 2.4e9   # CUs x SIMDs x lanes/clk x max clock = 78.6e12 int lane-ops/s
+XORSHIFT_CEILING = 4.79e12     # measured: tools/valu_peak.hip (profiles/r01_valu_microbench.txt)
 
 
 def sketch_bytes_per_read(L, H, S, k2):
@@ -150,15 +150,18 @@ def main():
         else:
             alg_bytes = sketch_bytes_per_read(L, H, S, k2) * reads_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(dom + "_kernel", n_total, L, world)
         roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches)}
         # integer-VALU view of the MinHash kernel (the path is integer min-reduction work, not HBM-bound: SURVEY F12)
         steps_per_read = 2 * (L - k + 1) * H
         mh_s = kernel_ms_per_step["minhash"] / 1e3
         xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
-        valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1), "lane_ops_per_step": 11,
-                "frac_of_int_valu_peak": round(xs_rate * 11 / VALU_LANE_OPS_PEAK, 4)}
+        valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
+                "ceiling_steps_per_s": XORSHIFT_CEILING, "frac_of_ceiling": round(xs_rate / XORSHIFT_CEILING, 4),
+                "ceiling_note": "tools/valu_peak.hip on MI355X: a pure xorshift64 loop (4 chains/lane, 8 waves/SIMD) sustains "
+                                "4.79e12 steps/s = 14.7 full-rate VALU issue slots per step (64-bit shifts issue at quarter rate)"}
         if kernel_ms_per_step["candidate"] > 0 and st["slot_compares"] > 0:   # stats are per step (the index is cleared every step)
             valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / (kernel_ms_per_step["candidate"] / 1e3), 1)
 
@@ -186,6 +189,19 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel, n_total, L, world):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (tools/pmc_summary.py).  The counters
+    were collected on the default workload (100k x 10kb, 1 GPU); for any other shape the field stays null."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if not (os.path.exists(path) and n_total == 100000 and L == 10000 and world == 1):
+        return None, None
+    try:
+        d = json.load(open(path))["kernels"].get(kernel)
+        return (int(d["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic.json (" + d["fetch_rule"] + ")") if d else (None, None)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(args, L, H, S, k, k2):

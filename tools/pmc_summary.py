@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic per launch.
+
+  python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv \
+                              gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv > profiles/r01_pmc_traffic.json
+
+Units and gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB;
+FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streaming reads, so it is reported both raw and doubled
+(`fetch_bytes_x2`); WRITE_SIZE is uncalibrated and reported raw.  bench.py picks `hbm_bytes_per_launch` =
+fetch_bytes_x2 + write_bytes for kernels whose reads are wide coalesced streams, raw fetch otherwise (field `fetch_rule`).
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+WIDE_STREAM = {"candidate_kernel", "hash_kmers_kernel", "ordered_kernel", "index_build_kernel"}   # dwordx2/x4 coalesced row reads
+
+
+def short(name):
+    n = name.split("(")[0]
+    n = n.replace("void ", "").replace("mhap::", "")
+    return n.split("<")[0]
+
+
+def main():
+    acc = defaultdict(lambda: defaultdict(list))
+    for path in sys.argv[1:]:
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, cs in sorted(acc.items()):
+        if k.startswith("__amd") or "at::" in k:
+            continue
+        f = cs.get("FETCH_SIZE", [])
+        w = cs.get("WRITE_SIZE", [])
+        e = {"launches": max(len(f), len(w))}
+        if f:
+            e["fetch_bytes_raw"] = sum(f) / len(f) * 1024
+            e["fetch_bytes_x2"] = 2 * e["fetch_bytes_raw"]
+        if w:
+            e["write_bytes"] = sum(w) / len(w) * 1024
+        rule = "x2 (wide coalesced stream)" if k in WIDE_STREAM else "raw (narrow/gather accesses: uncalibrated)"
+        e["fetch_rule"] = rule
+        fb = e.get("fetch_bytes_x2" if k in WIDE_STREAM else "fetch_bytes_raw", 0.0)
+        e["hbm_bytes_per_launch"] = fb + e.get("write_bytes", 0.0)
+        out[k] = e
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 0, 100k x 10kb",
+               "kernels": out}, sys.stdout, indent=1)
+
+
+if __name__ == "__main__":
+    main()
