@@ -132,6 +132,26 @@ __host__ __device__ inline uint64_t xorshift_step(uint64_t x) {
   return x;
 }
 
+// In-place transpose of a 32x32 bit matrix held as 32 dwords: afterwards bit j of a[b] == bit b of the old a[j].
+// Five butterfly stages with compile-time indices (registers on the device).  Used to turn 32 k-mer keys per lane
+// into 64 bit-planes for the bit-sliced xorshift rows of minhash_kernel.
+__host__ __device__ inline void transpose32(uint32_t (&a)[32]) {
+#define MHAP_TR_STAGE(J, M)                                                    \
+  _Pragma("unroll") for (int k = 0; k < 32; k++) {                             \
+    if ((k & (J)) == 0) {                                                      \
+      const uint32_t t = ((a[k] >> (J)) ^ a[k + (J)]) & (M);                   \
+      a[k] ^= t << (J);                                                        \
+      a[k + (J)] ^= t;                                                         \
+    }                                                                          \
+  }
+  MHAP_TR_STAGE(16, 0x0000FFFFu)
+  MHAP_TR_STAGE(8, 0x00FF00FFu)
+  MHAP_TR_STAGE(4, 0x0F0F0F0Fu)
+  MHAP_TR_STAGE(2, 0x33333333u)
+  MHAP_TR_STAGE(1, 0x55555555u)
+#undef MHAP_TR_STAGE
+}
+
 // Java Math.round(double) for the tf-idf weight (J/sketch/MinHashSketch.java:120): ties toward +inf.
 __host__ __device__ inline int64_t java_round(double x) {
   if (x != x) return 0;

@@ -878,6 +878,16 @@ int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t 
   return MHAP_OK;
 }
 
+// in-place 32x32 bit-matrix transpose used by the bit-sliced MinHash rows (device_common.hpp: transpose32)
+int mhap_selftest_transpose32(uint32_t* a32) {
+  if (!a32) return MHAP_E_INVALID;
+  uint32_t a[32];
+  memcpy(a, a32, sizeof a);
+  transpose32(a);
+  memcpy(a32, a, sizeof a);
+  return MHAP_OK;
+}
+
 // out8 = {empty, valid, a1, a2, b1, b2, inter, k}
 int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const int32_t* B, int32_t nB, int32_t lenB, double max_shift,
                                int32_t stride, int32_t* out8) {

@@ -366,15 +366,15 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
   __builtin_amdgcn_wave_barrier();
 }
 
-// xorshift64 step on 32-bit halves: 10 full-rate VALU ops (2 v_alignbit, 3 shifts, 5 xors) instead of two
-// 64-bit shifts (half rate on the SIMD-32s) + 6 ops.
+// xorshift64 step on 32-bit halves, priced with tools/valu_ops.hip on MI355X: v_xor / v_lshrrev / v_bitop3 issue at
+// full rate, v_lshlrev_b32 / v_alignbit_b32 at half rate, v_lshlrev_b64 at quarter rate.  The compiler's 64-bit
+// lowering (2 x v_lshlrev_b64 + 6 ops) costs ~14.7 issue slots; this form costs 13:
+//   2 v_alignbit (funnel shifts) + 2 v_lshlrev + 1 v_lshrrev + 1 v_bitop3 (3-way xor) + 3 v_xor.
 __device__ __forceinline__ void xorshift_step32(uint32_t& lo, uint32_t& hi) {
-  uint32_t t = __builtin_amdgcn_alignbit(hi, lo, 11);   // (x << 21).hi = hi<<21 | lo>>11
-  hi ^= t;
-  lo ^= lo << 21;
-  lo ^= hi >> 3;                                        // x >>> 35 only reaches the low dword
-  t = __builtin_amdgcn_alignbit(hi, lo, 28);            // (x << 4).hi = hi<<4 | lo>>28
-  hi ^= t;
+  const uint32_t a = lo << 21;
+  hi ^= __builtin_amdgcn_alignbit(hi, lo, 11);             // (x << 21).hi = hi<<21 | lo>>11
+  lo = __builtin_amdgcn_bitop3_b32(lo, a, hi >> 3, 0x96);  // lo ^ lo<<21 ^ (x >>> 35)   (0x96 = a^b^c)
+  hi ^= __builtin_amdgcn_alignbit(hi, lo, 28);             // (x << 4).hi = hi<<4 | lo>>28
   lo ^= lo << 4;
 }
 
@@ -391,13 +391,75 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-// VAR bits: 1 = 32-bit-halves xorshift, 2 = first row seeded by a DPP wave arg-min, 4 = single-strict-winner update
+// ---- bit-sliced rows (VAR bit 8) ---------------------------------------------------------------------------------
+// 32 k-mers per lane are held as 64 bit-planes (P[b] bit j = bit b of k-mer j's chain value), so one xorshift64 step
+// of all 32 chains is 132 full-rate v_xor_b32 (the shifts become register renaming) = 4.1 issue slots per chain step
+// instead of ~14.7.  A slot's candidates are the chains whose value is negative with at least as many leading zero
+// magnitude bits as the slot's current minimum (a necessary condition for x <= min: 1 + z more VALU ops); the rare
+// candidates are pulled out of the planes with v_readlane + scalar bit ops and go through the exact 64-bit update.
+constexpr int BS_ZMAX = 24;
+
+__device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
+#pragma unroll
+  for (int b = 63; b >= 21; b--) P[b] ^= P[b - 21];   // x ^= x << 21
+#pragma unroll
+  for (int b = 0; b <= 28; b++) P[b] ^= P[b + 35];    // x ^= x >>> 35
+#pragma unroll
+  for (int b = 63; b >= 4; b--) P[b] ^= P[b - 4];     // x ^= x << 4
+}
+
+// nacc has a 0 bit for every chain that may undercut the slot minimum whose high dword is bhs
+__device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, int32_t bhs) {
+  if (bhs >= 0) return ~ACT;                     // no negative minimum yet: every active chain is a candidate
+  const uint32_t mag = (uint32_t)bhs & 0x7fffffffu;
+  int z = mag ? (__builtin_clz(mag) - 1) : 31;   // leading zero magnitude bits of the current minimum
+  if (z > BS_ZMAX) z = BS_ZMAX;
+  uint32_t nacc = ~P[63];                        // must be negative
+  // ... with planes 62 .. 63-z all zero.  z is wave-uniform: a straight chain of scalar compare+branch, one v_or each.
+  do {
+#define MHAP_BS_OR(K) if (z < K) break; nacc |= P[63 - K];
+    MHAP_BS_OR(1) MHAP_BS_OR(2) MHAP_BS_OR(3) MHAP_BS_OR(4) MHAP_BS_OR(5) MHAP_BS_OR(6) MHAP_BS_OR(7) MHAP_BS_OR(8)
+    MHAP_BS_OR(9) MHAP_BS_OR(10) MHAP_BS_OR(11) MHAP_BS_OR(12) MHAP_BS_OR(13) MHAP_BS_OR(14) MHAP_BS_OR(15) MHAP_BS_OR(16)
+    MHAP_BS_OR(17) MHAP_BS_OR(18) MHAP_BS_OR(19) MHAP_BS_OR(20) MHAP_BS_OR(21) MHAP_BS_OR(22) MHAP_BS_OR(23) MHAP_BS_OR(24)
+#undef MHAP_BS_OR
+  } while (0);
+  return nacc | ~ACT;
+}
+
+// exact update of slot s from the candidate chains (bits of `cand`); chain (lane l, bit j) is k-mer rb + j*64 + l
+__device__ __forceinline__ void bs_update(int64_t* best, int32_t* bpos, int s, const uint32_t (&P)[64], uint32_t cand, int rb, int lane) {
+  int64_t cur = best[s];
+  int32_t curpos = bpos[s];
+  bool changed = false;
+  unsigned long long bal = __ballot(cand != 0u);
+  while (bal) {
+    const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal));
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)cand, l);
+    const int j = __builtin_ctz(m);
+    uint32_t xlo = 0, xhi = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+      xlo |= ((((uint32_t)__builtin_amdgcn_readlane((int)P[b], l)) >> j) & 1u) << b;
+      xhi |= ((((uint32_t)__builtin_amdgcn_readlane((int)P[32 + b], l)) >> j) & 1u) << b;
+    }
+    const int64_t x = (int64_t)(((uint64_t)xhi << 32) | xlo);
+    const int pos = rb + j * 64 + l;
+    if (x < cur || (x == cur && pos < curpos)) { cur = x; curpos = pos; changed = true; }
+    if (lane == l) cand &= ~(1u << j);
+    bal = __ballot(cand != 0u);
+  }
+  if (changed && lane == 0) { best[s] = cur; bpos[s] = curpos; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// VAR bits: 8 = bit-sliced rows after the first BS_SEED k-mers, 1 = 32-bit-halves xorshift, 2 = first row seeded by a DPP wave arg-min, 4 = single-strict-winner update
 template <int U, int VAR>
 __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const StrandInfo* __restrict__ info, int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
-                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride) {
+                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride, int BS_SEED, int BS_MINREM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t per_wave = (size_t)H * 12;
@@ -429,6 +491,33 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     // ---- pass 1: weight == 1 k-mers, U per lane ----
     bool seeded = false;
     for (int base = 0; base < nk; base += 64 * U) {
+      if ((VAR & 8) && base >= BS_SEED) {
+        // ---- bit-sliced rows: 2048 chains per wave, 32 per lane ----
+        while (nk - base >= BS_MINREM) {
+          uint32_t P[64];
+          uint32_t ACT = 0;
+#pragma unroll
+          for (int j = 0; j < 32; j++) {
+            const int i = base + j * 64 + lane;
+            uint64_t key = 0;
+            if (i < nk && wp[i] == 1u) { key = (uint64_t)kp[i]; ACT |= 1u << j; }
+            P[j] = (uint32_t)key;
+            P[32 + j] = (uint32_t)(key >> 32);
+          }
+          transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
+          transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
+          int32_t bh_next = besthi[1];
+          for (int s = 0; s < H; s++) {
+            const int32_t bh = bh_next;
+            bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
+            bs_step(P);
+            const uint32_t nacc = bs_filter(P, ACT, __builtin_amdgcn_readfirstlane(bh));
+            if (!(VAR & 16) && __any(nacc != 0xFFFFFFFFu)) bs_update(best, bpos, s, P, ~nacc, base, lane);
+          }
+          base += 2048;
+        }
+        if (base >= nk) break;
+      }
       uint32_t xl[U], xh[U];
       int pv[U];
       bool act[U];
@@ -562,15 +651,17 @@ void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const Read
 #define MHAP_MH_CASE(UU, VV)                                                                                                    \
   case (UU) * 16 + (VV):                                                                                                        \
     hipLaunchKernelGGL((minhash_kernel<UU, VV>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H, \
-                       counter, out_rows, out_stride, out_status, status_stride);                                               \
+                       counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem);                            \
     break;
+  static int bs_seed = -1, bs_minrem = -1;   // k-mers handled per chain first / remaining k-mers needed for a bit-sliced row
+  if (bs_seed < 0) { const char* e = getenv("MHAP_BS_SEED"); bs_seed = e ? atoi(e) : 1024; e = getenv("MHAP_BS_MINREM"); bs_minrem = e ? atoi(e) : 1024; }
   if (variant == 0) variant = MH_U * 16 + MH_VAR;
   switch (variant) {
     MHAP_MH_CASE(4, 0) MHAP_MH_CASE(4, 1) MHAP_MH_CASE(4, 2) MHAP_MH_CASE(4, 4) MHAP_MH_CASE(4, 6) MHAP_MH_CASE(4, 7)
-    MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
+    MHAP_MH_CASE(4, 8) MHAP_MH_CASE(4, 12) MHAP_MH_CASE(4, 24) MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
     default:
       hipLaunchKernelGGL((minhash_kernel<MH_U, MH_VAR>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H,
-                         counter, out_rows, out_stride, out_status, status_stride);
+                         counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem);
   }
 #undef MHAP_MH_CASE
 }

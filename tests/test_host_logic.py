@@ -59,6 +59,17 @@ def test_kernel_hash_arithmetic_matches_oracle(k, k2):
     assert h32.tolist() == O.kmer_hashes32(seq, k2).tolist()
 
 
+def test_bit_transpose_used_by_bitsliced_minhash():
+    lib = mhap_amd.load_library()
+    rnd = np.random.default_rng(3)
+    a = rnd.integers(0, 2**32, size=32, dtype=np.uint64).astype(np.uint32)
+    b = a.copy()
+    assert lib.mhap_selftest_transpose32(api._ptr(b)) == 0
+    for r in range(32):
+        for c in range(32):
+            assert (int(b[r]) >> c) & 1 == (int(a[c]) >> r) & 1
+
+
 def test_filter_kmer_hash_is_canonical_when_rc():
     lib = mhap_amd.load_library()
     out = C.c_int64()

@@ -1,8 +1,11 @@
-for v in 64 65 66 68 70 71 128 134 135 39 102 103; do
-  MHAP_MINHASH_VARIANT=$v python bench.py --reads 20000 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+run() { python bench.py --reads 20000 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-print('variant',$v,'U',$v//16,'VAR',$v%16,'minhash_ms',d['kernel_ms_per_step']['minhash'],'records',d['records_per_step'],'step_ms',d['ms_per_step'])"
-done
-MHAP_MINHASH_VARIANT=71 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-MHAP_MINHASH_VARIANT=135 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+print('$1', 'minhash_ms',d['kernel_ms_per_step']['minhash'],'records',d['records_per_step'])"; }
+MHAP_MINHASH_VARIANT=64 run base_U4
+MHAP_MINHASH_VARIANT=65 run xs32_U4
+MHAP_MINHASH_VARIANT=71 run xs32_seed_single_U4
+MHAP_MINHASH_VARIANT=135 run xs32_seed_single_U8
+MHAP_MINHASH_VARIANT=103 run xs32_seed_single_U6
+MHAP_MINHASH_VARIANT=39 run xs32_seed_single_U2
+MHAP_MINHASH_VARIANT=65 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
