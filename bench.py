@@ -58,11 +58,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # MHAP_BENCH_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path without RCCL)
+    backend = os.environ.get("MHAP_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     n_total, L, H, S, k, k2 = args.reads, args.length, args.hashes, 1536, 16, 12
     p = MhapParams(kmer_size=k, num_hashes=H, ordered_kmer_size=k2, ordered_sketch_size=S, device=local_rank)
@@ -122,9 +128,10 @@ def main():
     st = ms.stats()
     kt = ms.kernel_times()
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot_rec = torch.tensor([nrec], dtype=torch.int64, device=dev)
-    kms = torch.tensor([kt[kname]["ms"] for kname in mhap_amd.KERNEL_NAMES], dtype=torch.float64, device=dev)
+    rdev = dev if backend == "nccl" else torch.device("cpu")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+    tot_rec = torch.tensor([nrec], dtype=torch.int64, device=rdev)
+    kms = torch.tensor([kt[kname]["ms"] for kname in mhap_amd.KERNEL_NAMES], dtype=torch.float64, device=rdev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_rec, op=dist.ReduceOp.SUM)

@@ -129,14 +129,14 @@ int fail(mhap_handle* h, int code, const std::string& msg) { h->err = msg; retur
                   std::string(#expr) + ": " + hipGetErrorString(_e));                                \
   } while (0)
 
-void time_begin(mhap_handle* h, int kind) {
+void time_begin(mhap_handle* h, int kind, hipStream_t st = nullptr) {
   TimedLaunch t; t.kind = kind;
   if (!h->free_events.empty()) { t.a = h->free_events.back().first; t.b = h->free_events.back().second; h->free_events.pop_back(); }
   else { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
-  (void)hipEventRecord(t.a, h->stream);
+  (void)hipEventRecord(t.a, st ? st : h->stream);
   h->pending.push_back(t);
 }
-void time_end(mhap_handle* h) { (void)hipEventRecord(h->pending.back().b, h->stream); }
+void time_end(mhap_handle* h, hipStream_t st = nullptr) { (void)hipEventRecord(h->pending.back().b, st ? st : h->stream); }
 
 // call after the stream is synchronised
 void time_collect(mhap_handle* h) {
@@ -230,69 +230,90 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
 }
 
 // Sketch the staged reads into device rows [0, 2*st_n) of the given tables (kernels only + tiny descriptor uploads).
+// Batches run back to back on the handle's stream.  (A two-stream variant that overlapped hash/weight/ordered of
+// batch b+1 with MinHash of batch b was measured at 358 -> 355..365 ms/step: the kernels compete for the same VALU
+// issue slots and LDS, so it was removed.)
 int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
   int64_t batch_bases = 256LL << 20;
   if (const char* e = getenv("MHAP_BATCH_BASES")) { long long v = atoll(e); if (v > 0) batch_bases = v; }
-  int64_t r0 = 0;
-  while (r0 < n) {
-    // ---- choose batch [r0, r1) ----
+  // ---- batch plan + worst-case scratch sizes (allocated once) ----
+  struct Batch { int64_t r0, r1, key_elems, h2_elems; int max_len; };
+  std::vector<Batch> plan;
+  int64_t max_key = 4, max_h2 = 4, max_nb = 1;
+  int max_len_all = 0;
+  for (int64_t r0 = 0; r0 < n;) {
     int64_t r1 = r0, tot = 0;
     while (r1 < n && (r1 == r0 || tot + h->st_descs[(size_t)r1].length <= batch_bases) && (r1 - r0) < (1 << 22)) { tot += h->st_descs[(size_t)r1].length; r1++; }
-    const int64_t nb = r1 - r0;
-    // ---- per-batch scratch layout ----
-    h->h_descs.assign(h->st_descs.begin() + r0, h->st_descs.begin() + r1);
+    Batch b{r0, r1, 0, 0, 0};
+    for (int64_t i = r0; i < r1; i++) {
+      const ReadDesc& d = h->st_descs[(size_t)i];
+      if (d.flags & MHAP_RD_SKIP) continue;
+      b.key_elems += 2 * align4(std::max(0, d.length - k + 1));
+      b.h2_elems += 2 * align4(std::max(0, d.length - k2 + 1));
+      b.max_len = std::max(b.max_len, d.length);
+    }
+    max_key = std::max(max_key, b.key_elems); max_h2 = std::max(max_h2, b.h2_elems); max_nb = std::max(max_nb, r1 - r0);
+    max_len_all = std::max(max_len_all, b.max_len);
+    plan.push_back(b);
+    r0 = r1;
+  }
+  HIPCHK(h, h->descs.ensure((size_t)max_nb * sizeof(ReadDesc)));
+  HIPCHK(h, h->keys.ensure((size_t)max_key * 8));
+  HIPCHK(h, h->wts.ensure((size_t)max_key * 4));
+  HIPCHK(h, h->h32.ensure((size_t)max_h2 * 4));
+  HIPCHK(h, h->info.ensure((size_t)(2 * max_nb) * sizeof(StrandInfo)));
+  HIPCHK(h, h->counters.ensure(256));
+  {
+    const int wb = weight_grid(h->num_cus, 2 * max_nb, max_len_all, k);
+    int64_t se = 64;
+    while (3 * se < 4LL * std::max(1, max_len_all - k + 1)) se <<= 1;
+    HIPCHK(h, h->slabs.ensure((size_t)wb * (size_t)se * 4));
+  }
+  for (const Batch& B : plan) {
+    const int64_t nb = B.r1 - B.r0, nstr = 2 * nb;
+    h->h_descs.resize((size_t)nb);
     int64_t key_elems = 0, h2_elems = 0;
-    int max_len = 0;
     for (int64_t i = 0; i < nb; i++) {
-      ReadDesc& d = h->h_descs[(size_t)i];
-      const int L = d.length;
-      const int64_t nk = align4(std::max(0, L - k + 1)), nk2 = align4(std::max(0, L - k2 + 1));
+      ReadDesc d = h->st_descs[(size_t)(B.r0 + i)];
+      const int64_t nk = align4(std::max(0, d.length - k + 1)), nk2 = align4(std::max(0, d.length - k2 + 1));
       d.key_off = key_elems; d.key_stride = (int32_t)nk;
       d.h2_off = h2_elems; d.h2_stride = (int32_t)nk2;
-      if (!(d.flags & MHAP_RD_SKIP)) { key_elems += 2 * nk; h2_elems += 2 * nk2; max_len = std::max(max_len, L); }
+      if (!(d.flags & MHAP_RD_SKIP)) { key_elems += 2 * nk; h2_elems += 2 * nk2; }
+      h->h_descs[(size_t)i] = d;
     }
-    const int64_t nstr = 2 * nb;
-    HIPCHK(h, h->descs.ensure((size_t)nb * sizeof(ReadDesc)));
-    HIPCHK(h, h->keys.ensure((size_t)std::max<int64_t>(key_elems, 4) * 8));
-    HIPCHK(h, h->wts.ensure((size_t)std::max<int64_t>(key_elems, 4) * 4));
-    HIPCHK(h, h->h32.ensure((size_t)std::max<int64_t>(h2_elems, 4) * 4));
-    HIPCHK(h, h->info.ensure((size_t)nstr * sizeof(StrandInfo)));
-    HIPCHK(h, h->counters.ensure(256));
-    const int wblocks = weight_grid(h->num_cus, nstr, max_len, k);
     int64_t slab_entries = 64;
-    while (3 * slab_entries < 4LL * std::max(1, max_len - k + 1)) slab_entries <<= 1;
-    HIPCHK(h, h->slabs.ensure((size_t)wblocks * (size_t)slab_entries * 4));
+    while (3 * slab_entries < 4LL * std::max(1, B.max_len - k + 1)) slab_entries <<= 1;
+    int32_t* mh_rows = d_minhash + (2 * B.r0) * mh_stride;
+    int32_t* ord_rows = d_ordered + (2 * B.r0) * ord_stride;
+    int32_t* meta_rows = d_meta + (2 * B.r0) * META_W;
+    unsigned long long* ctr = h->counters.as<unsigned long long>();
+    const ReadDesc* dd = h->descs.as<ReadDesc>();
     HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
-
-    int32_t* mh_rows = d_minhash + (2 * r0) * mh_stride;
-    int32_t* ord_rows = d_ordered + (2 * r0) * ord_stride;
-    int32_t* meta_rows = d_meta + (2 * r0) * META_W;
-    unsigned long long* ctr = h->counters.as<unsigned long long>();
-
     time_begin(h, MHAP_K_HASH);
-    launch_hash_kmers(h->stream, h->descs.as<ReadDesc>(), nstr, max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2);
+    launch_hash_kmers(h->stream, dd, nstr, B.max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2);
     time_end(h);
     time_begin(h, MHAP_K_DEDUP);
-    launch_kmer_weights(h->stream, h->num_cus, h->descs.as<ReadDesc>(), nstr, max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
-                        h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>());
+    launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->slabs.as<uint32_t>(),
+                        slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>());
     time_end(h);
     time_begin(h, MHAP_K_MINHASH);
-    const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * 8);
-    launch_minhash(h->stream, mblocks, h->descs.as<ReadDesc>(), nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(),
-                   k, k2, H, ctr + 1, mh_rows, mh_stride, meta_rows + 3, META_W);
+    int per_cu = 8;
+    if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
+    const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
+    launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(), k, k2, H, ctr + 1,
+                   mh_rows, mh_stride, meta_rows + 3, META_W);
     time_end(h);
     time_begin(h, MHAP_K_ORDERED);
-    launch_ordered(h->stream, h->descs.as<ReadDesc>(), nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
+    launch_ordered(h->stream, dd, nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
     time_end(h);
     launch_fix_status(h->stream, meta_rows, nb);
     HIPCHK(h, hipGetLastError());
     int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
-    r0 = r1;
   }
   return MHAP_OK;
 }

@@ -177,17 +177,18 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   for (uint32_t j = threadIdx.x * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   uint32_t st[MAXIT];
+  constexpr int CH = (MAXIT >= 24) ? 8 : 4;   // keys in flight per lane (register budget: two workgroups per CU need <= 64 VGPRs)
 #pragma unroll
-  for (int c = 0; c < MAXIT; c += 8) {
+  for (int c = 0; c < MAXIT; c += CH) {
     if (c * WEIGHT_THREADS < nk) {
-      int64_t key[8];
+      int64_t key[CH];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < CH; u++) {
         const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
         key[u] = (i < nk) ? kp[i] : 0;
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < CH; u++) {
         const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
         st[c + u] = 0;
         if (i < nk) {
@@ -232,7 +233,8 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   }
 }
 
-__global__ __launch_bounds__(WEIGHT_THREADS) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
+template <int MAXIT, int WAVES_PER_SIMD>
+__global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                                      const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
                                                                      uint32_t* __restrict__ slabs, int64_t slab_entries, uint32_t lds_entries,
                                                                      unsigned long long* __restrict__ counter, int k,
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(WEIGHT_THREADS) void kmer_weight_kernel(const ReadD
     uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
     uint32_t ts = 64;
     while (3ull * ts < 4ull * (uint32_t)nk) ts <<= 1;          // load factor <= 0.75
-    if (ts <= lds_entries && nk <= WEIGHT_MAXIT * WEIGHT_THREADS) weight_strand_lds<WEIGHT_MAXIT>(lds_tab, ts, kp, wp, nk, &svars[3]);
+    if (ts <= lds_entries && nk <= MAXIT * WEIGHT_THREADS) weight_strand_lds<MAXIT>(lds_tab, ts, kp, wp, nk, &svars[3]);
     else weight_strand<false>(slab, ts, kp, wp, nk, &svars[3]);
     __syncthreads();
     unsigned int myvalid = 0, myheavy = 0;
@@ -308,11 +310,13 @@ void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int
   while (3ull * need < 4ull * nkmax) need <<= 1;
   const uint32_t lds_entries = need > 32768u ? 32768u : need;           // <= 128 KiB of the CU's 160 KiB LDS
   const size_t lds = (size_t)lds_entries * 4 + 16;
-  const int per_cu = lds <= 72 * 1024 ? 2 : 1;
   const int nblocks = weight_grid(num_cus, nstrands, max_len, k);
-  (void)per_cu;
-  hipLaunchKernelGGL(kmer_weight_kernel, dim3(nblocks), dim3(WEIGHT_THREADS), lds, st, descs, nstrands, keys, wts, slabs, slab_entries,
-                     lds_entries, counter, k, ft, repeat_weight, info);
+  if (lds_entries <= 16384u)   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
+    hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8>), dim3(nblocks), dim3(WEIGHT_THREADS), lds, st, descs, nstrands, keys, wts, slabs,
+                       slab_entries, lds_entries, counter, k, ft, repeat_weight, info);
+  else
+    hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4>), dim3(nblocks), dim3(WEIGHT_THREADS), lds, st, descs, nstrands, keys, wts, slabs,
+                       slab_entries, lds_entries, counter, k, ft, repeat_weight, info);
 }
 
 // number of persistent workgroups (= HBM slabs the caller must provide)

@@ -43,13 +43,14 @@ def gather_global_order(local, world, dist=None):
         return local
     n_pad = local.shape[0] // 2
     tail = tuple(local.shape[1:])
-    gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    if local.is_cuda:
+    if local.is_cuda and dist.get_backend() == "nccl":      # RCCL over xGMI
+        gathered = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(gathered.view(world, -1), local.contiguous().view(1, -1))
-    else:
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local.contiguous())
-        gathered = torch.stack(parts, 0)
+    else:                                                    # gloo (CPU tests; functional multi-rank runs on one GPU)
+        src = local.contiguous().cpu()
+        parts = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(parts, src)
+        gathered = torch.stack(parts, 0).to(local.device)
     g = gathered.view(world, n_pad, 2, -1).permute(1, 0, 2, 3).contiguous()    # [slot][rank][strand] = read slot*world+rank
     return g.view((n_pad * world * 2,) + tail)
 

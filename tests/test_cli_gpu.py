@@ -118,3 +118,21 @@ def test_cli_filter_file_and_presets(tmp_path):
     assert fast == wantf
     bad = subprocess.run([CLI, "-s", str(fasta), "--threshold", "2"], capture_output=True, text=True)
     assert bad.returncode == 1 and "0<=threshold<=1.0" in bad.stdout
+
+
+def test_bench_two_ranks_on_one_gpu_matches_one_rank():
+    """Functional check of bench.py's N>1 path (round-robin shards, table gather in global read order, sharded
+    queries) with 2 gloo ranks sharing this GPU: the record count must equal the single-rank run's."""
+    import sys
+    args = ["--reads", "3000", "--length", "3000", "--steps", "1", "--warmup", "0", "--error-rate", "0.05", "--no-cpu-baseline"]
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().split("\n")[-1])
+    env = dict(os.environ, MHAP_BENCH_BACKEND="gloo")
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    r2 = json.loads([l for l in two.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert r2["n_gpus"] == 2 and r1["n_gpus"] == 1
+    assert r2["records_per_step"] == r1["records_per_step"] and r1["records_per_step"] > 1000
