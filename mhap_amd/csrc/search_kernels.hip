@@ -265,11 +265,31 @@ __global__ __launch_bounds__(256) void index_query_kernel(const unsigned long lo
     if (threadIdx.x == 0) { const unsigned long long o = atomicAdd(overflow_count, 1ULL); overflow[o] = qe; }
     return;
   }
-  for (int j = threadIdx.x; j < INV_CT; j += 256) {
-    const uint32_t k = keys[j];
-    if (k == 0 || (int)cnts[j] < sp.num_min_matches) continue;                               // MinHashSearch.java:204
-    const unsigned long long slot = atomicAdd(cand_count, 1ULL);
-    if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)k - 1; }
+  // emit this query's candidates as ONE contiguous block (one global atomic per query): the second stage then finds
+  // the lanes of a wave sharing the query's ordered-sketch row
+  uint32_t mymask = 0;   // bit t set -> table slot threadIdx.x + 256*t is a candidate
+  int mycount = 0;
+#pragma unroll
+  for (int t = 0; t < INV_CT / 256; t++) {
+    const int j = threadIdx.x + 256 * t;
+    if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) { mymask |= 1u << t; mycount++; }   // MinHashSearch.java:204
+  }
+  __syncthreads();            // s_distinct is dead from here on: reuse it as the block's emit counter
+  if (threadIdx.x == 0) s_distinct = 0;
+  __syncthreads();
+  uint32_t local = 0;
+  if (mycount) local = atomicAdd(&s_distinct, (uint32_t)mycount);
+  __syncthreads();
+  __shared__ unsigned long long s_base;
+  if (threadIdx.x == 0) s_base = s_distinct ? atomicAdd(cand_count, (unsigned long long)s_distinct) : 0ULL;
+  __syncthreads();
+  unsigned long long slot = s_base + local;
+#pragma unroll
+  for (int t = 0; t < INV_CT / 256; t++) {
+    if (mymask & (1u << t)) {
+      if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)keys[threadIdx.x + 256 * t] - 1; }
+      slot++;
+    }
   }
 }
 

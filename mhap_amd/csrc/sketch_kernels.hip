@@ -419,14 +419,21 @@ __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t 
   int z = mag ? (__builtin_clz(mag) - 1) : 31;   // leading zero magnitude bits of the current minimum
   if (z > BS_ZMAX) z = BS_ZMAX;
   uint32_t nacc = ~P[63];                        // must be negative
-  // ... with planes 62 .. 63-z all zero.  z is wave-uniform: a straight chain of scalar compare+branch, one v_or each.
-  do {
+  // ... with planes 62 .. 63-z all zero.  z is wave-uniform.  After the per-chain seed rows z >= 8 practically always:
+  // those eight planes are OR-ed straight-line, the remaining depth is a chain of scalar compare+branch, one v_or each.
 #define MHAP_BS_OR(K) if (z < K) break; nacc |= P[63 - K];
-    MHAP_BS_OR(1) MHAP_BS_OR(2) MHAP_BS_OR(3) MHAP_BS_OR(4) MHAP_BS_OR(5) MHAP_BS_OR(6) MHAP_BS_OR(7) MHAP_BS_OR(8)
-    MHAP_BS_OR(9) MHAP_BS_OR(10) MHAP_BS_OR(11) MHAP_BS_OR(12) MHAP_BS_OR(13) MHAP_BS_OR(14) MHAP_BS_OR(15) MHAP_BS_OR(16)
-    MHAP_BS_OR(17) MHAP_BS_OR(18) MHAP_BS_OR(19) MHAP_BS_OR(20) MHAP_BS_OR(21) MHAP_BS_OR(22) MHAP_BS_OR(23) MHAP_BS_OR(24)
+  if (z >= 8) {
+    nacc |= (P[62] | P[61]) | (P[60] | P[59]) | ((P[58] | P[57]) | (P[56] | P[55]));
+    do {
+      MHAP_BS_OR(9) MHAP_BS_OR(10) MHAP_BS_OR(11) MHAP_BS_OR(12) MHAP_BS_OR(13) MHAP_BS_OR(14) MHAP_BS_OR(15) MHAP_BS_OR(16)
+      MHAP_BS_OR(17) MHAP_BS_OR(18) MHAP_BS_OR(19) MHAP_BS_OR(20) MHAP_BS_OR(21) MHAP_BS_OR(22) MHAP_BS_OR(23) MHAP_BS_OR(24)
+    } while (0);
+  } else {
+    do {
+      MHAP_BS_OR(1) MHAP_BS_OR(2) MHAP_BS_OR(3) MHAP_BS_OR(4) MHAP_BS_OR(5) MHAP_BS_OR(6) MHAP_BS_OR(7)
+    } while (0);
+  }
 #undef MHAP_BS_OR
-  } while (0);
   return nacc | ~ACT;
 }
 
@@ -457,7 +464,99 @@ __device__ __forceinline__ void bs_update(int64_t* best, int32_t* bpos, int s, c
   __builtin_amdgcn_wave_barrier();
 }
 
-// VAR bits: 8 = bit-sliced rows after the first BS_SEED k-mers, 1 = 32-bit-halves xorshift, 2 = first row seeded by a DPP wave arg-min, 4 = single-strict-winner update
+// Deferred candidates (VAR bit 32): instead of pulling a candidate's 64-bit value out of the planes (64 v_readlane +
+// ~250 scalar ops, ~1600 issue cycles each), a trigger only appends (slot, lane, bit) to a wave-private LDS queue.
+// Slots are independent within a row, so the queue can be drained later: 64 candidates at a time, one per lane,
+// each lane re-walks its k-mer's chain from the key to its slot (entries arrive in slot order, so the lanes of a batch
+// run nearly the same number of steps) and the exact update is applied per distinct slot.
+constexpr int BS_QCAP = 768;
+
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, uint32_t* q, uint32_t* qn_p, int rb, const int64_t* __restrict__ kp,
+                                         int lane) {
+  const int qn = (int)__builtin_amdgcn_readfirstlane((int)*qn_p);
+  for (int b0 = 0; b0 < qn; b0 += 64) {
+    const bool valid = b0 + lane < qn;
+    const uint32_t e = valid ? q[b0 + lane] : 0u;
+    const int s = (int)(e >> 16);
+    const int l = (int)((e >> 5) & 63u), j = (int)(e & 31u);
+    const int pos = rb + j * 64 + l;
+    uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
+    int smax = valid ? s : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(smax, off); smax = o > smax ? o : smax; }
+    for (int t = 0; t <= smax; t++) {
+      const uint64_t nx = xorshift_step(x);
+      x = (t <= s) ? nx : x;
+    }
+    bool todo = valid;
+    unsigned long long bal = __ballot(todo);
+    while (bal) {
+      const int lf = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal));
+      const int s0 = __builtin_amdgcn_readlane(s, lf);
+      const bool mine = todo && (s == s0);
+      int64_t xs[1] = {(int64_t)x};
+      int pp[1] = {pos};
+      bool aa[1] = {mine};
+      minhash_update<1>(best, bpos, s0, xs, pp, aa, lane);
+      todo = todo && !mine;
+      bal = __ballot(todo);
+    }
+  }
+  if (lane == 0) *qn_p = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// First bit-sliced row of a strand (no slot minimum exists yet): bit-serial arg-min over the row's active chains.
+// Walking the planes from the sign bit down, the candidate set is narrowed to the chains that have the "smaller" bit
+// whenever at least one does (wave-uniform decision via ballot).  Distinct k-mers have distinct chain values (the
+// step is a bijection), so exactly one chain survives; it is the row's minimum for this slot.
+__device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t ACT) {
+  uint32_t cand = ACT & P[63];                 // negative values first (signed compare)
+  if (!__any(cand != 0u)) cand = ACT;
+  bool done = false;                           // wave-uniform; no `break`, so the loop unrolls and P stays in registers
+#pragma unroll
+  for (int b = 62; b >= 0; b--) {
+    if (!done) {
+      const uint32_t m = cand & ~P[b];
+      if (__any(m != 0u)) cand = m;
+      if (b <= 50) {                           // 2048 chains need >= 11 planes; test for a single survivor from here on
+        const unsigned long long bal = __ballot(cand != 0u);
+        if (__popcll(bal) == 1) {
+          const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cand, __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)));
+          done = (w & (w - 1u)) == 0u;
+        }
+      }
+    }
+  }
+  return cand;
+}
+
+// append this trigger's candidates (one LDS atomic per candidate, no capacity pre-check); if the queue fills up it is
+// drained and the rest of the trigger goes through the immediate plane extraction
+__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, uint32_t* qn_p, int s, const uint32_t (&P)[64],
+                                         uint32_t cand, int rb, const int64_t* __restrict__ kp, int lane) {
+  bool full = false;
+  while (cand && !full) {
+    const uint32_t idx = atomicAdd(qn_p, 1u);
+    if (idx < (uint32_t)BS_QCAP) {
+      const int j = __builtin_ctz(cand);
+      cand &= cand - 1u;
+      q[idx] = ((uint32_t)s << 16) | ((uint32_t)lane << 5) | (uint32_t)j;
+    } else full = true;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (__any(full)) {
+    if (lane == 0) *qn_p = (uint32_t)BS_QCAP;   // the counter overshot: clamp to the entries actually stored
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bs_flush(best, bpos, q, qn_p, rb, kp, lane);
+    bs_update(best, bpos, s, P, cand, rb, lane);
+  }
+}
+
+// VAR bits: 32 = deferred bit-sliced candidates, 8 = bit-sliced rows after the first BS_SEED k-mers, 1 = 32-bit-halves xorshift, 2 = first row seeded by a DPP wave arg-min, 4 = single-strict-winner update
 template <int U, int VAR>
 __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
@@ -466,9 +565,11 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride, int BS_SEED, int BS_MINREM) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const size_t per_wave = (size_t)H * 12;
+  const size_t per_wave = (size_t)H * 12 + ((VAR & 32) ? (size_t)(BS_QCAP + 4) * 4 : 0);
   int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
   int32_t* bpos = (int32_t*)(best + H);
+  uint32_t* bsq = (uint32_t*)(bpos + H) + 4;      // deferred-candidate queue (VAR & 32); bsq[-4] = fill count
+  uint32_t* bsqn = bsq - 4;
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loop's threshold
   for (;;) {
     long long sidx = 0;
@@ -489,11 +590,13 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
     const uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
     for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
+    if ((VAR & 32) && lane == 0) *bsqn = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass 1: weight == 1 k-mers, U per lane ----
     bool seeded = false;
+    uint32_t dbg_acc = 0;
     for (int base = 0; base < nk; base += 64 * U) {
       if ((VAR & 8) && base >= BS_SEED) {
         // ---- bit-sliced rows: 2048 chains per wave, 32 per lane ----
@@ -515,9 +618,18 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
             const int32_t bh = bh_next;
             bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
             bs_step(P);
+            if ((VAR & 32) && base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
+              if (__any(ACT != 0u)) bs_defer(best, bpos, bsq, bsqn, s, P, bs_argmin(P, ACT), base, kp, lane);
+              continue;
+            }
             const uint32_t nacc = bs_filter(P, ACT, __builtin_amdgcn_readfirstlane(bh));
-            if (!(VAR & 16) && __any(nacc != 0xFFFFFFFFu)) bs_update(best, bpos, s, P, ~nacc, base, lane);
+            if (VAR & 16) dbg_acc ^= nacc;   // timing experiment: main loop only, keep the planes alive
+            if (!(VAR & 16) && __any(nacc != 0xFFFFFFFFu)) {
+              if (VAR & 32) bs_defer(best, bpos, bsq, bsqn, s, P, ~nacc, base, kp, lane);
+              else bs_update(best, bpos, s, P, ~nacc, base, lane);
+            }
           }
+          if (VAR & 32) bs_flush(best, bpos, bsq, bsqn, base, kp, lane);
           base += 2048;
         }
         if (base >= nk) break;
@@ -642,29 +754,34 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
       orow[s] = v;
     }
     if (lane == 0) out_status[sidx * status_stride] = 0;
+    if ((VAR & 16) && dbg_acc == 0x12345u) orow[0] = 1;
   }
 }
 
-// variant = U*16 + VAR (microbenchmark knob; 0 = tuned default)
+// variant = U*64 + VAR (experiment knob MHAP_MINHASH_VARIANT; 0 = tuned default)
 void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys,
                             const uint32_t* wts, const StrandInfo* info, int k, int k2, int H, unsigned long long* counter,
                             int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride) {
   if (nstrands <= 0) return;
-  size_t per_wave = (((size_t)H * 12) + 15) & ~(size_t)15;
-  size_t lds = per_wave * 4;
+  if (variant == 0) variant = MH_U * 64 + MH_VAR;
+  size_t per_wave = (((size_t)H * 12 + (((variant % 64) & 32) ? (size_t)(BS_QCAP + 4) * 4 : 0)) + 15) & ~(size_t)15;
+  int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
+  while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
+  const size_t lds = per_wave * waves;
+  const dim3 block(64 * waves);
+  nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
 #define MHAP_MH_CASE(UU, VV)                                                                                                    \
-  case (UU) * 16 + (VV):                                                                                                        \
-    hipLaunchKernelGGL((minhash_kernel<UU, VV>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H, \
+  case (UU) * 64 + (VV):                                                                                                        \
+    hipLaunchKernelGGL((minhash_kernel<UU, VV>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, \
                        counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem);                            \
     break;
   static int bs_seed = -1, bs_minrem = -1;   // k-mers handled per chain first / remaining k-mers needed for a bit-sliced row
-  if (bs_seed < 0) { const char* e = getenv("MHAP_BS_SEED"); bs_seed = e ? atoi(e) : 1024; e = getenv("MHAP_BS_MINREM"); bs_minrem = e ? atoi(e) : 1024; }
-  if (variant == 0) variant = MH_U * 16 + MH_VAR;
+  if (bs_seed < 0) { const char* e = getenv("MHAP_BS_SEED"); bs_seed = e ? atoi(e) : 0; e = getenv("MHAP_BS_MINREM"); bs_minrem = e ? atoi(e) : 512; }
   switch (variant) {
     MHAP_MH_CASE(4, 0) MHAP_MH_CASE(4, 1) MHAP_MH_CASE(4, 2) MHAP_MH_CASE(4, 4) MHAP_MH_CASE(4, 6) MHAP_MH_CASE(4, 7)
-    MHAP_MH_CASE(4, 8) MHAP_MH_CASE(4, 12) MHAP_MH_CASE(4, 24) MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
+    MHAP_MH_CASE(4, 8) MHAP_MH_CASE(4, 24) MHAP_MH_CASE(4, 40) MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
     default:
-      hipLaunchKernelGGL((minhash_kernel<MH_U, MH_VAR>), dim3(nblocks), dim3(256), lds, st, descs, nstrands, keys, wts, info, k, k2, H,
+      hipLaunchKernelGGL((minhash_kernel<MH_U, MH_VAR>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H,
                          counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem);
   }
 #undef MHAP_MH_CASE

@@ -283,3 +283,12 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     assert a == b and len(a) > 100
     assert sa["table_elements"] > 0 and sa["slot_compares"] == 0 and sb["slot_compares"] > 0
     assert sa["candidates_compared"] == sb["candidates_compared"]
+
+
+def test_minhash_large_num_hashes_and_short_strands():
+    """--num-hashes large enough that one wave's slot table fills most of the LDS (fewer waves per workgroup), plus
+    strands on both sides of the 512-k-mer switch between per-chain rows and bit-sliced rows."""
+    rnd = random.Random(77)
+    fa = FastaData.from_strings([_rand_seq(rnd, n) for n in (150, 520, 527, 528, 600, 2100, 2200, 4200, 9000)])
+    _assert_sketch_parity(fa, MhapParams(num_hashes=4000, ordered_sketch_size=64, min_olap_length=100))
+    _assert_sketch_parity(fa, MhapParams(num_hashes=8192, ordered_sketch_size=64, min_olap_length=100))
