@@ -215,6 +215,7 @@ int mhap_hash_kmer(const char* kmer, int32_t len, int32_t do_rc, int64_t* out);
  * product path; lets a GPU-less container check the hash and second-stage lane logic) --------------------- */
 int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t k2, int64_t* out64, int32_t* out32);
 int mhap_selftest_transpose32(uint32_t* a32);
+int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out);
 /* out8 = {empty, valid(rawScore), a1, a2, b1, b2, inter, k} */
 int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const int32_t* B, int32_t nB, int32_t lenB,
                                double max_shift, int32_t stride, int32_t* out8);

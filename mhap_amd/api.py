@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "mhap_get_stats", "mhap_get_kernel_times", "mhap_reset_kernel_times", "mhap_set_stream", "mhap_synchronize",
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
-    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32",
+    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump",
 ]
 
 

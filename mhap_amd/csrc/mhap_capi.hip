@@ -81,7 +81,7 @@ struct mhap_handle {
   // filter
   DevBuf f_keys, f_vals;
   FilterTable ft{};
-  DevBuf score_tbl;
+  DevBuf score_tbl, jump_tbl;
 
   // index (owned or external)
   bool external = false;
@@ -305,7 +305,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
     launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(), k, k2, H, ctr + 1,
-                   mh_rows, mh_stride, meta_rows + 3, META_W);
+                   mh_rows, mh_stride, meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>());
     time_end(h);
     time_begin(h, MHAP_K_ORDERED);
     launch_ordered(h->stream, dd, nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
@@ -553,6 +553,14 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   h->ft = FilterTable{nullptr, nullptr, 0, 0, 0, 0, 3.0};
   int rc = build_score_table(h);
   if (rc != MHAP_OK) { seterr(h->err); mhap_destroy(h); return rc; }
+  {   // xorshift jump-ahead tables for slots up to H (MinHash kernel's deferred-candidate drain)
+    const int na = (P.num_hashes + 1) / 64 + 1;
+    std::vector<uint64_t> jt((size_t)na * 2048);
+    build_xorshift_jump_tables(na, jt.data());
+    if (h->jump_tbl.ensure(jt.size() * 8) != hipSuccess || hipMemcpy(h->jump_tbl.p, jt.data(), jt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
+    }
+  }
   *out = h;
   return MHAP_OK;
 }
@@ -563,7 +571,7 @@ void mhap_destroy(mhap_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
+  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
@@ -896,6 +904,25 @@ int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t 
   memcpy(W.data(), seq, (size_t)len);
   if (out64) for (int p = 0; p + k <= len; p++) out64[p] = (k == 16) ? (int64_t)murmur128_h1_chars<16>(W.data(), p, k) : (int64_t)murmur128_h1_chars<0>(W.data(), p, k);
   if (out32) for (int p = 0; p + k2 <= len; p++) out32[p] = (k2 == 12) ? (int32_t)murmur32_chars<12>(W.data(), p, k2) : (int32_t)murmur32_chars<0>(W.data(), p, k2);
+  return MHAP_OK;
+}
+
+// chain value after `nsteps` xorshift64 steps computed the way the MinHash kernel's candidate drain does it
+// (GF(2) byte tables for the multiple of 64, single steps for the rest)
+int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out) {
+  if (!out || nsteps < 0 || nsteps > (1 << 20)) return MHAP_E_INVALID;
+  const int a = nsteps >> 6, r = nsteps & 63;
+  uint64_t x = key;
+  if (a > 0) {
+    std::vector<uint64_t> jt((size_t)a * 2048);
+    build_xorshift_jump_tables(a, jt.data());
+    const uint64_t* T = jt.data() + (size_t)(a - 1) * 2048;
+    uint64_t y = 0;
+    for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+    x = y;
+  }
+  for (int t = 0; t < r; t++) x = xorshift_step(x);
+  *out = x;
   return MHAP_OK;
 }
 

@@ -233,6 +233,70 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   }
 }
 
+// Long reads (more k-mers than the LDS table or the per-lane register state can hold): the k-mers are split by the top
+// bits of their hash into `npart` partitions and each partition gets its own pass through the LDS table (equal keys
+// always share a partition).  Entry = fingerprint << posbits | (pos+1).  Returns false (wave-uniformly) if a partition
+// ever fills the table (pathological skew); the caller then falls back to the HBM-slab path.
+__device__ inline bool weight_strand_lds_part(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
+                                              int npart_log2, int posbits, unsigned int* s_heavy, unsigned int* s_fill) {
+  const uint32_t mask = ts - 1, posmask = (posbits >= 32) ? 0xFFFFFFFFu : ((1u << posbits) - 1u);
+  const uint32_t limit = ts - ts / 8;
+  bool anydup = false;
+  for (int part = 0; part < (1 << npart_log2); part++) {
+    for (uint32_t j = threadIdx.x * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) *s_fill = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const int64_t key = kp[i];
+      if (npart_log2 && (int)((uint64_t)key >> (64 - npart_log2)) != part) continue;
+      const uint32_t fp = (posbits >= 32) ? 0u : (((uint32_t)((uint64_t)key >> 32)) << posbits);
+      const uint32_t mine = fp | (uint32_t)(i + 1);
+      uint32_t slot = (uint32_t)(uint64_t)key & mask;
+      for (uint32_t tries = 0; tries < ts; tries++) {
+        const uint32_t old = atomicCAS(&tab[slot], 0u, mine);
+        if (old == 0) { atomicAdd(s_fill, 1u); break; }
+        if (((old ^ mine) & ~posmask) == 0 && kp[(old & posmask) - 1u] == key) { atomicMin(&tab[slot], mine); break; }
+        if (*(volatile unsigned int*)s_fill >= limit) break;    // table (nearly) full: give up, see below
+        slot = (slot + 1) & mask;
+      }
+    }
+    __syncthreads();
+    if (*(volatile unsigned int*)s_fill >= limit) return false;
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const int64_t key = kp[i];
+      if (npart_log2 && (int)((uint64_t)key >> (64 - npart_log2)) != part) continue;
+      const uint32_t fp = (posbits >= 32) ? 0u : (((uint32_t)((uint64_t)key >> 32)) << posbits);
+      const uint32_t mine = fp | (uint32_t)(i + 1);
+      uint32_t slot = (uint32_t)(uint64_t)key & mask;
+      uint32_t w;
+      for (;;) {
+        const uint32_t e = tab[slot];
+        if (e == mine) { w = 1u; break; }
+        if (e != 0 && ((e ^ mine) & ~posmask) == 0) {
+          const uint32_t p = (e & posmask) - 1u;
+          if (kp[p] == key) { w = DUP_MARK | p; anydup = true; break; }
+        }
+        slot = (slot + 1) & mask;
+      }
+      wp[i] = w;
+    }
+    __syncthreads();
+  }
+  if (anydup) atomicOr(s_heavy, 1u);
+  __syncthreads();
+  if (*(volatile unsigned int*)s_heavy) {
+    __threadfence();
+    __syncthreads();
+    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+      const uint32_t w = wp[i];
+      if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  return true;
+}
+
 template <int MAXIT, int WAVES_PER_SIMD>
 __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                                      const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
@@ -265,7 +329,20 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
     uint32_t ts = 64;
     while (3ull * ts < 4ull * (uint32_t)nk) ts <<= 1;          // load factor <= 0.75
     if (ts <= lds_entries && nk <= MAXIT * WEIGHT_THREADS) weight_strand_lds<MAXIT>(lds_tab, ts, kp, wp, nk, &svars[3]);
-    else weight_strand<false>(slab, ts, kp, wp, nk, &svars[3]);
+    else {
+      // long read: hash-partitioned passes through the LDS table; HBM slab only if a partition overflows it
+      int plog = 0;
+      while (plog < 10 && 3ull * lds_entries < (4ull * (uint32_t)nk * 5 / 4) >> plog) plog++;   // 25 % head-room for uneven partitions
+      int posbits = 1;
+      while (posbits < 32 && (1ull << posbits) <= (unsigned long long)nk) posbits++;
+      if (!weight_strand_lds_part(lds_tab, lds_entries, kp, wp, nk, plog, posbits, &svars[3], &svars[2])) {
+        __syncthreads();
+        if (threadIdx.x == 0) svars[3] = 0;
+        __syncthreads();
+        weight_strand<false>(slab, ts, kp, wp, nk, &svars[3]);
+      }
+      if (threadIdx.x == 0) svars[2] = 0;
+    }
     __syncthreads();
     unsigned int myvalid = 0, myheavy = 0;
     if (reweigh) {
@@ -471,9 +548,11 @@ __device__ __forceinline__ void bs_update(int64_t* best, int32_t* bpos, int s, c
 // run nearly the same number of steps) and the exact update is applied per distinct slot.
 constexpr int BS_QCAP = 768;
 
-__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, uint32_t* q, uint32_t* qn_p, int rb, const int64_t* __restrict__ kp,
-                                         int lane) {
-  const int qn = (int)__builtin_amdgcn_readfirstlane((int)*qn_p);
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
+                                         const uint64_t* __restrict__ jump, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
+  __builtin_amdgcn_wave_barrier();
+  const int qn = qn_ref;
   for (int b0 = 0; b0 < qn; b0 += 64) {
     const bool valid = b0 + lane < qn;
     const uint32_t e = valid ? q[b0 + lane] : 0u;
@@ -481,30 +560,34 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, uint32_t*
     const int l = (int)((e >> 5) & 63u), j = (int)(e & 31u);
     const int pos = rb + j * 64 + l;
     uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
-    int smax = valid ? s : 0;
+    // chain value at slot s = (s+1) steps from the key: jump 64*a steps with the GF(2) byte tables, walk the rest
+    const int nsteps = s + 1, a = nsteps >> 6;
+    int r = valid ? (nsteps & 63) : 0;
+    if (valid && a > 0) {
+      const uint64_t* T = jump + (size_t)(a - 1) * 2048;
+      uint64_t y = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(smax, off); smax = o > smax ? o : smax; }
-    for (int t = 0; t <= smax; t++) {
+      for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+      x = y;
+    }
+    int rmax = r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
+    for (int t = 0; t < rmax; t++) {
       const uint64_t nx = xorshift_step(x);
-      x = (t <= s) ? nx : x;
+      x = (t < r) ? nx : x;
     }
-    bool todo = valid;
-    unsigned long long bal = __ballot(todo);
-    while (bal) {
-      const int lf = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal));
-      const int s0 = __builtin_amdgcn_readlane(s, lf);
-      const bool mine = todo && (s == s0);
-      int64_t xs[1] = {(int64_t)x};
-      int pp[1] = {pos};
-      bool aa[1] = {mine};
-      minhash_update<1>(best, bpos, s0, xs, pp, aa, lane);
-      todo = todo && !mine;
-      bal = __ballot(todo);
-    }
+    // exact update, all lanes at once: ds_min_rtn_i64 lowers the slot minimum; the lane whose value is the slot's
+    // final minimum and that strictly undercut what it saw owns the slot (chain values of distinct k-mers are distinct)
+    long long old = INT64_MAX;
+    if (valid) old = atomicMin((long long*)&best[s], (long long)x);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  if (lane == 0) *qn_p = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  qn_ref = 0;
 }
 
 // First bit-sliced row of a strand (no slot minimum exists yet): bit-serial arg-min over the row's active chains.
@@ -532,27 +615,23 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
   return cand;
 }
 
-// append this trigger's candidates (one LDS atomic per candidate, no capacity pre-check); if the queue fills up it is
-// drained and the rest of the trigger goes through the immediate plane extraction
-__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, uint32_t* qn_p, int s, const uint32_t (&P)[64],
-                                         uint32_t cand, int rb, const int64_t* __restrict__ kp, int lane) {
-  bool full = false;
-  while (cand && !full) {
-    const uint32_t idx = atomicAdd(qn_p, 1u);
-    if (idx < (uint32_t)BS_QCAP) {
+// append this trigger's candidates.  The fill count lives in a wave-uniform register: queue slots are handed out with
+// ballot + mbcnt (no LDS atomic, no read-back), one candidate per lane per round; the queue is drained whenever the
+// next round might not fit.
+__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, int& qn, int s, uint32_t cand, int rb,
+                                         const int64_t* __restrict__ kp, const uint64_t* __restrict__ jump, int lane) {
+  unsigned long long m = __ballot(cand != 0u);
+  while (m) {
+    const int c = __popcll(m);
+    if (qn + c > BS_QCAP) bs_flush(best, bpos, q, qn, rb, kp, jump, lane);   // a round adds at most 64 entries: always fits afterwards
+    if (cand) {
+      const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       const int j = __builtin_ctz(cand);
       cand &= cand - 1u;
       q[idx] = ((uint32_t)s << 16) | ((uint32_t)lane << 5) | (uint32_t)j;
-    } else full = true;
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (__any(full)) {
-    if (lane == 0) *qn_p = (uint32_t)BS_QCAP;   // the counter overshot: clamp to the entries actually stored
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    bs_flush(best, bpos, q, qn_p, rb, kp, lane);
-    bs_update(best, bpos, s, P, cand, rb, lane);
+    }
+    qn += c;
+    m = __ballot(cand != 0u);
   }
 }
 
@@ -562,14 +641,14 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const StrandInfo* __restrict__ info, int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
-                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride, int BS_SEED, int BS_MINREM) {
+                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride, int BS_SEED, int BS_MINREM,
+                                                      const uint64_t* __restrict__ jump) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const size_t per_wave = (size_t)H * 12 + ((VAR & 32) ? (size_t)(BS_QCAP + 4) * 4 : 0);
   int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
   int32_t* bpos = (int32_t*)(best + H);
-  uint32_t* bsq = (uint32_t*)(bpos + H) + 4;      // deferred-candidate queue (VAR & 32); bsq[-4] = fill count
-  uint32_t* bsqn = bsq - 4;
+  uint32_t* bsq = (uint32_t*)(bpos + H);          // deferred-candidate queue (VAR & 32), BS_QCAP entries
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loop's threshold
   for (;;) {
     long long sidx = 0;
@@ -590,12 +669,12 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
     const uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
     for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
-    if ((VAR & 32) && lane == 0) *bsqn = 0u;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     // ---- pass 1: weight == 1 k-mers, U per lane ----
     bool seeded = false;
+    int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
     uint32_t dbg_acc = 0;
     for (int base = 0; base < nk; base += 64 * U) {
       if ((VAR & 8) && base >= BS_SEED) {
@@ -610,6 +689,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
             if (i < nk && wp[i] == 1u) { key = (uint64_t)kp[i]; ACT |= 1u << j; }
             P[j] = (uint32_t)key;
             P[32 + j] = (uint32_t)(key >> 32);
+            if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 loads in flight at a time: keeps the register peak at the planes
           }
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
@@ -619,17 +699,17 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
             bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
             bs_step(P);
             if ((VAR & 32) && base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
-              if (__any(ACT != 0u)) bs_defer(best, bpos, bsq, bsqn, s, P, bs_argmin(P, ACT), base, kp, lane);
+              if (__any(ACT != 0u)) bs_defer(best, bpos, bsq, bsqn, s, bs_argmin(P, ACT), base, kp, jump, lane);
               continue;
             }
             const uint32_t nacc = bs_filter(P, ACT, __builtin_amdgcn_readfirstlane(bh));
             if (VAR & 16) dbg_acc ^= nacc;   // timing experiment: main loop only, keep the planes alive
             if (!(VAR & 16) && __any(nacc != 0xFFFFFFFFu)) {
-              if (VAR & 32) bs_defer(best, bpos, bsq, bsqn, s, P, ~nacc, base, kp, lane);
+              if (VAR & 32) bs_defer(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane);
               else bs_update(best, bpos, s, P, ~nacc, base, lane);
             }
           }
-          if (VAR & 32) bs_flush(best, bpos, bsq, bsqn, base, kp, lane);
+          if (VAR & 32) bs_flush(best, bpos, bsq, bsqn, base, kp, jump, lane);
           base += 2048;
         }
         if (base >= nk) break;
@@ -758,10 +838,27 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
   }
 }
 
+// Jump-ahead tables for the xorshift64 chain: the step is linear over GF(2), so M^(64a) x is the XOR of eight byte-indexed
+// table entries.  out[(a-1)*2048 + i*256 + v] = M^(64a) applied to (v << 8i), a = 1..na.
+void build_xorshift_jump_tables(int na, uint64_t* out) {
+  uint64_t col[64], nxt[64];
+  auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
+  for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < 64; t++) x = xorshift_step(x); col[j] = x; }   // M^64
+  uint64_t base[64];
+  for (int j = 0; j < 64; j++) base[j] = col[j];
+  for (int a = 1; a <= na; a++) {
+    uint64_t* T = out + (size_t)(a - 1) * 2048;
+    for (int i = 0; i < 8; i++)
+      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(col, (uint64_t)v << (8 * i));
+    for (int j = 0; j < 64; j++) nxt[j] = apply(base, col[j]);   // M^(64(a+1)) = M^64 o M^(64a)
+    for (int j = 0; j < 64; j++) col[j] = nxt[j];
+  }
+}
+
 // variant = U*64 + VAR (experiment knob MHAP_MINHASH_VARIANT; 0 = tuned default)
 void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys,
                             const uint32_t* wts, const StrandInfo* info, int k, int k2, int H, unsigned long long* counter,
-                            int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride) {
+                            int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride, const uint64_t* jump) {
   if (nstrands <= 0) return;
   if (variant == 0) variant = MH_U * 64 + MH_VAR;
   size_t per_wave = (((size_t)H * 12 + (((variant % 64) & 32) ? (size_t)(BS_QCAP + 4) * 4 : 0)) + 15) & ~(size_t)15;
@@ -773,7 +870,7 @@ void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const Read
 #define MHAP_MH_CASE(UU, VV)                                                                                                    \
   case (UU) * 64 + (VV):                                                                                                        \
     hipLaunchKernelGGL((minhash_kernel<UU, VV>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, \
-                       counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem);                            \
+                       counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem, jump);                      \
     break;
   static int bs_seed = -1, bs_minrem = -1;   // k-mers handled per chain first / remaining k-mers needed for a bit-sliced row
   if (bs_seed < 0) { const char* e = getenv("MHAP_BS_SEED"); bs_seed = e ? atoi(e) : 0; e = getenv("MHAP_BS_MINREM"); bs_minrem = e ? atoi(e) : 512; }
@@ -782,18 +879,18 @@ void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const Read
     MHAP_MH_CASE(4, 8) MHAP_MH_CASE(4, 24) MHAP_MH_CASE(4, 40) MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
     default:
       hipLaunchKernelGGL((minhash_kernel<MH_U, MH_VAR>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H,
-                         counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem);
+                         counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem, jump);
   }
 #undef MHAP_MH_CASE
 }
 
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride) {
+                    int32_t* out_status, int64_t status_stride, const uint64_t* jump) {
   static int variant = -1;
   if (variant < 0) { const char* e = getenv("MHAP_MINHASH_VARIANT"); variant = e ? atoi(e) : 0; }
   launch_minhash_variant(st, variant, nblocks, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows, out_stride, out_status,
-                         status_stride);
+                         status_stride, jump);
 }
 
 // =============================================================================================

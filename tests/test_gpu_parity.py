@@ -292,3 +292,12 @@ def test_minhash_large_num_hashes_and_short_strands():
     fa = FastaData.from_strings([_rand_seq(rnd, n) for n in (150, 520, 527, 528, 600, 2100, 2200, 4200, 9000)])
     _assert_sketch_parity(fa, MhapParams(num_hashes=4000, ordered_sketch_size=64, min_olap_length=100))
     _assert_sketch_parity(fa, MhapParams(num_hashes=8192, ordered_sketch_size=64, min_olap_length=100))
+
+
+def test_long_reads_partitioned_kmer_weights():
+    """Reads with more k-mers than the LDS weight table holds (24 576): hash-partitioned passes; >65 534: wider positions."""
+    rnd = random.Random(123)
+    a = _rand_seq(rnd, 40000)
+    seqs = [_rand_seq(rnd, 26000), _rand_seq(rnd, 70000), _rand_seq(rnd, 131500), a + a[:15000] + a[5000:9000], "ACGTTGCAAT" * 3000]
+    fa = FastaData.from_strings(seqs)
+    _assert_sketch_parity(fa, MhapParams(num_hashes=32, ordered_sketch_size=128))

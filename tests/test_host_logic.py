@@ -70,6 +70,26 @@ def test_bit_transpose_used_by_bitsliced_minhash():
             assert (int(b[r]) >> c) & 1 == (int(a[c]) >> r) & 1
 
 
+def test_xorshift_jump_tables_match_stepping():
+    lib = mhap_amd.load_library()
+    M = (1 << 64) - 1
+
+    def step(x):
+        x ^= (x << 21) & M
+        x ^= x >> 35
+        x ^= (x << 4) & M
+        return x
+    rnd = random.Random(5)
+    out = C.c_uint64()
+    for n in (0, 1, 63, 64, 65, 128, 300, 511, 512, 513, 1000):
+        key = rnd.getrandbits(64)
+        x = key
+        for _ in range(n):
+            x = step(x)
+        assert lib.mhap_selftest_xorshift_jump(C.c_uint64(key), C.c_int32(n), C.byref(out)) == 0
+        assert out.value == x, n
+
+
 def test_filter_kmer_hash_is_canonical_when_rc():
     lib = mhap_amd.load_library()
     out = C.c_int64()
