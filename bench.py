@@ -29,7 +29,9 @@ from mhap_amd import MhapParams, MinHashSearch  # noqa: E402
 from mhap_amd import distributed as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-XORSHIFT_CEILING = 4.79e12     # measured: tools/valu_peak.hip (profiles/r01_valu_microbench.txt)
+# MinHash instruction ceilings measured on MI355X (profiles/r01_valu_microbench.txt):
+XORSHIFT_CEILING_PER_CHAIN = 4.79e12   # tools/valu_peak.hip: one chain per lane-register pair (2 v_lshlrev_b64 + 6 ops per step)
+XORSHIFT_CEILING_BITSLICED = 1.23e13   # bit-sliced stepping + filter only (MHAP_MINHASH_VARIANT=280: 16.6 ms for 2.04e11 steps)
 
 
 def sketch_bytes_per_read(L, H, S, k2):
@@ -168,9 +170,11 @@ def main():
         mh_s = kernel_ms_per_step["minhash"] / 1e3
         xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
         valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
-                "ceiling_steps_per_s": XORSHIFT_CEILING, "frac_of_ceiling": round(xs_rate / XORSHIFT_CEILING, 4),
-                "ceiling_note": "tools/valu_peak.hip on MI355X: a pure xorshift64 loop (4 chains/lane, 8 waves/SIMD) sustains "
-                                "4.79e12 steps/s = 14.7 full-rate VALU issue slots per step (64-bit shifts issue at quarter rate)"}
+                "ceiling_steps_per_s": XORSHIFT_CEILING_BITSLICED, "frac_of_ceiling": round(xs_rate / XORSHIFT_CEILING_BITSLICED, 4),
+                "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes, 132 v_xor per 32 chain steps): stepping + "
+                                "candidate filter alone sustain 1.23e13 steps/s on MI355X; the per-chain formulation (2 v_lshlrev_b64 "
+                                "+ 6 ops per step) tops out at 4.79e12 steps/s (tools/valu_peak.hip)",
+                "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4)}
         if kernel_ms_per_step["candidate"] > 0 and st["slot_compares"] > 0:   # stats are per step (the index is cleared every step)
             valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / (kernel_ms_per_step["candidate"] / 1e3), 1)
 
