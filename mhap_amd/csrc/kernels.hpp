@@ -7,8 +7,7 @@ namespace mhap {
 constexpr int HASH_TILE = 1024;      // window starts per hash workgroup
 constexpr int WEIGHT_THREADS = 1024;
 constexpr int WEIGHT_MAXIT = 24;     // k-mers per thread on the LDS path (24 x 1024 = 24576 = 0.75 x 32768 table slots)  // threads per k-mer-weight workgroup
-constexpr int MH_U = 4;              // k-mers per lane per row in the MinHash hot loop
-constexpr int MH_VAR = 40;           // default minhash_kernel variant: bit-sliced rows (8) with deferred candidates (32)
+constexpr int MH_U = 4;              // k-mers per lane in the MinHash kernel's per-chain rows
 constexpr int ORD_THREADS = 256;
 constexpr int ORD_BINS = 2048;
 constexpr int CAND_TQ = 128;         // queries per candidate tile

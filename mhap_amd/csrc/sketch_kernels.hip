@@ -4,11 +4,12 @@
 //                         (J/sketch/HashUtils.java:213-258), both strands, chars staged in LDS.
 //   kmer_weight_kernel  : per-strand k-mer multiplicity / tf-idf weight, first-occurrence flag
 //                         (J/sketch/MinHashSketch.java:66-81,98-128).
-//   minhash_kernel      : weighted xorshift MinHash, one wavefront per strand, per-slot threshold
-//                         in LDS, ballot-driven rare update path (J/sketch/MinHashSketch.java:130-154).
+//   minhash_kernel      : weighted xorshift MinHash, one wavefront per strand, bit-sliced chains with a
+//                         deferred candidate queue (J/sketch/MinHashSketch.java:130-154).
 //   ordered_kernel      : bottom-S (signed hash, pos) select + sort
 //                         (J/sketch/BottomOverlapSketch.java:525-559).
 #include <cstdlib>
+#include <cstring>
 
 #include "kernels.hpp"
 
@@ -408,15 +409,19 @@ int weight_grid(int num_cus, int64_t nstrands, int max_len, int k) {
 }
 
 // =============================================================================================
-// Weighted MinHash.  One wavefront per strand (strands pulled from an atomic counter), 4 waves per
-// workgroup.  Each lane owns MH_U k-mers per row and walks their xorshift chains through all H
-// slots; the per-slot running minimum lives in LDS (best[s], bpos[s]) and is wave-private.  The hot
-// loop only compares the high dword of x against the slot's current minimum (uniform LDS read);
-// a ballot sends the wave into the exact 64-bit update path, which becomes rare after the first
-// rows (expected ~ln(#rows) updates per slot).
-// Ties (x equal, different k-mers; 2^-64) resolve to the earlier first-occurrence position, which
+// Weighted MinHash (J/sketch/MinHashSketch.java:130-154).  One wavefront per strand (strands pulled from an atomic
+// counter); the per-slot running minimum (best[s], bpos[s] = first position of the winning k-mer) is wave-private in
+// LDS.  Ties (equal chain values of different k-mers; 2^-64) resolve to the earlier first-occurrence position, which
 // is the reference's insertion order.
+//
+// Two row formats walk the xorshift chains of the weight-1 k-mers through all H slots:
+//   * bit-sliced rows (default, strands with >= BS_MINREM k-mers left): 32 chains per lane as 64 bit-planes;
+//   * per-chain rows (strand tails, MHAP_MINHASH=perchain): MH_U chains per lane in 64-bit registers, the hot loop
+//     compares the high dword with the slot threshold (uniform ds_read, prefetched; v_min3 over the chains) and a
+//     ballot sends the wave into the exact update.
+// k-mers with weight > 1 (repeats, tf-idf) take a per-lane w-steps-per-slot pass afterwards.
 // =============================================================================================
+
 // Exact update of slot s from the wave's N candidate values per lane.  Wave-uniform control flow; the winner is
 // moved with v_readlane (SGPR lane index from the ballot), no LDS permutes.
 template <int N>
@@ -447,38 +452,14 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
   __builtin_amdgcn_wave_barrier();
 }
 
-// xorshift64 step on 32-bit halves, priced with tools/valu_ops.hip on MI355X: v_xor / v_lshrrev / v_bitop3 issue at
-// full rate, v_lshlrev_b32 / v_alignbit_b32 at half rate, v_lshlrev_b64 at quarter rate.  The compiler's 64-bit
-// lowering (2 x v_lshlrev_b64 + 6 ops) costs ~14.7 issue slots; this form costs 13:
-//   2 v_alignbit (funnel shifts) + 2 v_lshlrev + 1 v_lshrrev + 1 v_bitop3 (3-way xor) + 3 v_xor.
-__device__ __forceinline__ void xorshift_step32(uint32_t& lo, uint32_t& hi) {
-  const uint32_t a = lo << 21;
-  hi ^= __builtin_amdgcn_alignbit(hi, lo, 11);             // (x << 21).hi = hi<<21 | lo>>11
-  lo = __builtin_amdgcn_bitop3_b32(lo, a, hi >> 3, 0x96);  // lo ^ lo<<21 ^ (x >>> 35)   (0x96 = a^b^c)
-  hi ^= __builtin_amdgcn_alignbit(hi, lo, 28);             // (x << 4).hi = hi<<4 | lo>>28
-  lo ^= lo << 4;
-}
-
-// wave64 signed-min reduction on the VALU (DPP), result broadcast from lane 63.
-__device__ __forceinline__ int32_t wave_min_i32(int32_t v) {
-#define MHAP_DPP_MIN(ctrl, rmask) { const int32_t o = __builtin_amdgcn_update_dpp(v, v, ctrl, rmask, 0xf, false); v = o < v ? o : v; }
-  MHAP_DPP_MIN(0xb1, 0xf)    // quad_perm [1,0,3,2]
-  MHAP_DPP_MIN(0x4e, 0xf)    // quad_perm [2,3,0,1]
-  MHAP_DPP_MIN(0x124, 0xf)   // row_ror:4
-  MHAP_DPP_MIN(0x128, 0xf)   // row_ror:8
-  MHAP_DPP_MIN(0x142, 0xa)   // row_bcast:15 -> rows 1,3
-  MHAP_DPP_MIN(0x143, 0xc)   // row_bcast:31 -> rows 2,3
-#undef MHAP_DPP_MIN
-  return __builtin_amdgcn_readlane(v, 63);
-}
-
-// ---- bit-sliced rows (VAR bit 8) ---------------------------------------------------------------------------------
+// ---- bit-sliced rows ---------------------------------------------------------------------------------------------
 // 32 k-mers per lane are held as 64 bit-planes (P[b] bit j = bit b of k-mer j's chain value), so one xorshift64 step
 // of all 32 chains is 132 full-rate v_xor_b32 (the shifts become register renaming) = 4.1 issue slots per chain step
-// instead of ~14.7.  A slot's candidates are the chains whose value is negative with at least as many leading zero
-// magnitude bits as the slot's current minimum (a necessary condition for x <= min: 1 + z more VALU ops); the rare
-// candidates are pulled out of the planes with v_readlane + scalar bit ops and go through the exact 64-bit update.
+// instead of ~10 (2 v_lshlrev_b64 + 6 ops).  A slot's candidates are the chains whose value is negative with at least
+// as many leading zero magnitude bits as the slot's current minimum (necessary for x <= min: 1 + z more VALU ops).
+constexpr int BS_MINREM = 512;   // remaining k-mers needed to start another 2048-chain bit-sliced row
 constexpr int BS_ZMAX = 24;
+constexpr int BS_QCAP = 768;     // deferred-candidate queue entries per wave (LDS)
 
 __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 #pragma unroll
@@ -489,15 +470,15 @@ __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
   for (int b = 63; b >= 4; b--) P[b] ^= P[b - 4];     // x ^= x << 4
 }
 
-// nacc has a 0 bit for every chain that may undercut the slot minimum whose high dword is bhs
+// returns a mask with a 0 bit for every chain that may undercut the slot minimum whose high dword is bhs
 __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, int32_t bhs) {
   if (bhs >= 0) return ~ACT;                     // no negative minimum yet: every active chain is a candidate
   const uint32_t mag = (uint32_t)bhs & 0x7fffffffu;
   int z = mag ? (__builtin_clz(mag) - 1) : 31;   // leading zero magnitude bits of the current minimum
   if (z > BS_ZMAX) z = BS_ZMAX;
   uint32_t nacc = ~P[63];                        // must be negative
-  // ... with planes 62 .. 63-z all zero.  z is wave-uniform.  After the per-chain seed rows z >= 8 practically always:
-  // those eight planes are OR-ed straight-line, the remaining depth is a chain of scalar compare+branch, one v_or each.
+  // ... with planes 62 .. 63-z all zero.  z is wave-uniform.  After the first row z >= 8 practically always: those eight
+  // planes are OR-ed straight-line, the remaining depth is a chain of scalar compare+branch, one v_or each.
 #define MHAP_BS_OR(K) if (z < K) break; nacc |= P[63 - K];
   if (z >= 8) {
     nacc |= (P[62] | P[61]) | (P[60] | P[59]) | ((P[58] | P[57]) | (P[56] | P[55]));
@@ -512,82 +493,6 @@ __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t 
   }
 #undef MHAP_BS_OR
   return nacc | ~ACT;
-}
-
-// exact update of slot s from the candidate chains (bits of `cand`); chain (lane l, bit j) is k-mer rb + j*64 + l
-__device__ __forceinline__ void bs_update(int64_t* best, int32_t* bpos, int s, const uint32_t (&P)[64], uint32_t cand, int rb, int lane) {
-  int64_t cur = best[s];
-  int32_t curpos = bpos[s];
-  bool changed = false;
-  unsigned long long bal = __ballot(cand != 0u);
-  while (bal) {
-    const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal));
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)cand, l);
-    const int j = __builtin_ctz(m);
-    uint32_t xlo = 0, xhi = 0;
-#pragma unroll
-    for (int b = 0; b < 32; b++) {
-      xlo |= ((((uint32_t)__builtin_amdgcn_readlane((int)P[b], l)) >> j) & 1u) << b;
-      xhi |= ((((uint32_t)__builtin_amdgcn_readlane((int)P[32 + b], l)) >> j) & 1u) << b;
-    }
-    const int64_t x = (int64_t)(((uint64_t)xhi << 32) | xlo);
-    const int pos = rb + j * 64 + l;
-    if (x < cur || (x == cur && pos < curpos)) { cur = x; curpos = pos; changed = true; }
-    if (lane == l) cand &= ~(1u << j);
-    bal = __ballot(cand != 0u);
-  }
-  if (changed && lane == 0) { best[s] = cur; bpos[s] = curpos; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// Deferred candidates (VAR bit 32): instead of pulling a candidate's 64-bit value out of the planes (64 v_readlane +
-// ~250 scalar ops, ~1600 issue cycles each), a trigger only appends (slot, lane, bit) to a wave-private LDS queue.
-// Slots are independent within a row, so the queue can be drained later: 64 candidates at a time, one per lane,
-// each lane re-walks its k-mer's chain from the key to its slot (entries arrive in slot order, so the lanes of a batch
-// run nearly the same number of steps) and the exact update is applied per distinct slot.
-constexpr int BS_QCAP = 768;
-
-__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
-                                         const uint64_t* __restrict__ jump, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
-  __builtin_amdgcn_wave_barrier();
-  const int qn = qn_ref;
-  for (int b0 = 0; b0 < qn; b0 += 64) {
-    const bool valid = b0 + lane < qn;
-    const uint32_t e = valid ? q[b0 + lane] : 0u;
-    const int s = (int)(e >> 16);
-    const int l = (int)((e >> 5) & 63u), j = (int)(e & 31u);
-    const int pos = rb + j * 64 + l;
-    uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
-    // chain value at slot s = (s+1) steps from the key: jump 64*a steps with the GF(2) byte tables, walk the rest
-    const int nsteps = s + 1, a = nsteps >> 6;
-    int r = valid ? (nsteps & 63) : 0;
-    if (valid && a > 0) {
-      const uint64_t* T = jump + (size_t)(a - 1) * 2048;
-      uint64_t y = 0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
-      x = y;
-    }
-    int rmax = r;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
-    for (int t = 0; t < rmax; t++) {
-      const uint64_t nx = xorshift_step(x);
-      x = (t < r) ? nx : x;
-    }
-    // exact update, all lanes at once: ds_min_rtn_i64 lowers the slot minimum; the lane whose value is the slot's
-    // final minimum and that strictly undercut what it saw owns the slot (chain values of distinct k-mers are distinct)
-    long long old = INT64_MAX;
-    if (valid) old = atomicMin((long long*)&best[s], (long long)x);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  qn_ref = 0;
 }
 
 // First bit-sliced row of a strand (no slot minimum exists yet): bit-serial arg-min over the row's active chains.
@@ -615,6 +520,54 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
   return cand;
 }
 
+// Deferred candidates: pulling a candidate's 64-bit value out of the planes would cost 64 v_readlane + ~250 scalar ops
+// (~1600 issue cycles).  Instead a trigger only appends (slot, lane, bit) to a wave-private LDS queue; slots are
+// independent within a row, so the queue can be drained later, 64 candidates at a time, one per lane: each lane
+// re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 64 steps + <= 63 single steps;
+// entries arrive in slot order, so the lanes of a batch walk about the same number of steps), then ds_min_rtn_i64
+// lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
+                                         const uint64_t* __restrict__ jump, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
+  __builtin_amdgcn_wave_barrier();
+  const int qn = qn_ref;
+  for (int b0 = 0; b0 < qn; b0 += 64) {
+    const bool valid = b0 + lane < qn;
+    const uint32_t e = valid ? q[b0 + lane] : 0u;
+    const int s = (int)(e >> 16);
+    const int l = (int)((e >> 5) & 63u), j = (int)(e & 31u);
+    const int pos = rb + j * 64 + l;
+    uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
+    // chain value at slot s = (s+1) steps from the key
+    const int nsteps = s + 1, a = nsteps >> 6;
+    int r = valid ? (nsteps & 63) : 0;
+    if (valid && a > 0) {
+      const uint64_t* T = jump + (size_t)(a - 1) * 2048;
+      uint64_t y = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+      x = y;
+    }
+    int rmax = r;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
+    for (int t = 0; t < rmax; t++) {
+      const uint64_t nx = xorshift_step(x);
+      x = (t < r) ? nx : x;
+    }
+    // exact update, all lanes at once: the lane whose value is the slot's final minimum and that strictly undercut
+    // what it saw owns the slot (chain values of distinct k-mers are distinct)
+    long long old = INT64_MAX;
+    if (valid) old = atomicMin((long long*)&best[s], (long long)x);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  qn_ref = 0;
+}
+
 // append this trigger's candidates.  The fill count lives in a wave-uniform register: queue slots are handed out with
 // ballot + mbcnt (no LDS atomic, no read-back), one candidate per lane per round; the queue is drained whenever the
 // next round might not fit.
@@ -635,21 +588,20 @@ __device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t*
   }
 }
 
-// VAR bits: 32 = deferred bit-sliced candidates, 8 = bit-sliced rows after the first BS_SEED k-mers, 1 = 32-bit-halves xorshift, 2 = first row seeded by a DPP wave arg-min, 4 = single-strict-winner update
-template <int U, int VAR>
+template <int U, bool BITSLICED>
 __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const StrandInfo* __restrict__ info, int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
-                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride, int BS_SEED, int BS_MINREM,
+                                                      int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
                                                       const uint64_t* __restrict__ jump) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const size_t per_wave = (size_t)H * 12 + ((VAR & 32) ? (size_t)(BS_QCAP + 4) * 4 : 0);
+  const size_t per_wave = (size_t)H * 12 + (BITSLICED ? (size_t)BS_QCAP * 4 : 0);
   int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
   int32_t* bpos = (int32_t*)(best + H);
-  uint32_t* bsq = (uint32_t*)(bpos + H);          // deferred-candidate queue (VAR & 32), BS_QCAP entries
-  const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loop's threshold
+  uint32_t* bsq = (uint32_t*)(bpos + H);          // deferred-candidate queue (bit-sliced rows)
+  const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
   for (;;) {
     long long sidx = 0;
     if (lane == 0) sidx = (long long)atomicAdd(counter, 1ULL);
@@ -672,12 +624,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    // ---- pass 1: weight == 1 k-mers, U per lane ----
-    bool seeded = false;
+    // ---- pass 1: weight == 1 k-mers ----
     int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
-    uint32_t dbg_acc = 0;
     for (int base = 0; base < nk; base += 64 * U) {
-      if ((VAR & 8) && base >= BS_SEED) {
+      if (BITSLICED && base == 0) {
         // ---- bit-sliced rows: 2048 chains per wave, 32 per lane ----
         while (nk - base >= BS_MINREM) {
           uint32_t P[64];
@@ -689,7 +639,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
             if (i < nk && wp[i] == 1u) { key = (uint64_t)kp[i]; ACT |= 1u << j; }
             P[j] = (uint32_t)key;
             P[32 + j] = (uint32_t)(key >> 32);
-            if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 loads in flight at a time: keeps the register peak at the planes
+            if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 loads in flight at a time
           }
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
@@ -698,23 +648,20 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
             const int32_t bh = bh_next;
             bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
             bs_step(P);
-            if ((VAR & 32) && base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
+            if (base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
               if (__any(ACT != 0u)) bs_defer(best, bpos, bsq, bsqn, s, bs_argmin(P, ACT), base, kp, jump, lane);
               continue;
             }
             const uint32_t nacc = bs_filter(P, ACT, __builtin_amdgcn_readfirstlane(bh));
-            if (VAR & 16) dbg_acc ^= nacc;   // timing experiment: main loop only, keep the planes alive
-            if (!(VAR & 16) && __any(nacc != 0xFFFFFFFFu)) {
-              if (VAR & 32) bs_defer(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane);
-              else bs_update(best, bpos, s, P, ~nacc, base, lane);
-            }
+            if (__any(nacc != 0xFFFFFFFFu)) bs_defer(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane);
           }
-          if (VAR & 32) bs_flush(best, bpos, bsq, bsqn, base, kp, jump, lane);
+          bs_flush(best, bpos, bsq, bsqn, base, kp, jump, lane);
           base += 2048;
         }
         if (base >= nk) break;
       }
-      uint32_t xl[U], xh[U];
+      // ---- per-chain row: U k-mers per lane ----
+      uint64_t x[U];
       int pv[U];
       bool act[U];
       bool anyact = false;
@@ -723,32 +670,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         const int i = base + u * 64 + lane;
         pv[u] = i;
         act[u] = false;
-        xl[u] = 0; xh[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
-        if (i < nk && wp[i] == 1u) { act[u] = true; const uint64_t key = (uint64_t)kp[i]; xl[u] = (uint32_t)key; xh[u] = (uint32_t)(key >> 32); anyact = true; }
+        x[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
+        if (i < nk && wp[i] == 1u) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
       }
       if (!__any(anyact)) continue;
-      if ((VAR & 2) && !seeded) {
-        // First populated row: every slot is still empty, so all lanes would "win".  Find the row's minimum with a
-        // VALU-only DPP reduction on the high dword and let only the lanes that hold it into the exact update.
-        seeded = true;
-        for (int s = 0; s < H; s++) {
-          int32_t m = INT32_MAX;
-#pragma unroll
-          for (int u = 0; u < U; u++) {
-            if (VAR & 1) xorshift_step32(xl[u], xh[u]);
-            else { uint64_t x = xorshift_step(((uint64_t)xh[u] << 32) | xl[u]); xl[u] = (uint32_t)x; xh[u] = (uint32_t)(x >> 32); }
-            const int32_t h = act[u] ? (int32_t)xh[u] : INT32_MAX;
-            m = h < m ? h : m;
-          }
-          const int32_t wmin = wave_min_i32(m);
-          int64_t xs[U];
-          bool a2[U];
-#pragma unroll
-          for (int u = 0; u < U; u++) { xs[u] = (int64_t)(((uint64_t)xh[u] << 32) | xl[u]); a2[u] = act[u] && ((int32_t)xh[u] == wmin); }
-          minhash_update<U>(best, bpos, s, xs, pv, a2, lane);
-        }
-        continue;
-      }
       int32_t bh_next = besthi[1];
       for (int s = 0; s < H; s++) {
         const int32_t bh = bh_next;
@@ -756,43 +681,14 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         bool hit = false;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          if (VAR & 1) xorshift_step32(xl[u], xh[u]);
-          else { uint64_t x = xorshift_step(((uint64_t)xh[u] << 32) | xl[u]); xl[u] = (uint32_t)x; xh[u] = (uint32_t)(x >> 32); }
-          hit |= ((int32_t)xh[u] <= bh);
+          x[u] = xorshift_step(x[u]);
+          hit |= ((int32_t)(x[u] >> 32) <= bh);
         }
         if (__any(hit)) {
-          bool done = false;
-          if (VAR & 4) {
-            // Usual case after the first rows: exactly one lane/k-mer undercuts the threshold, strictly in the high
-            // dword.  It is the new minimum; no LDS read-back, no compare chain.
-            unsigned long long mk[U];
-            int tot = 0;
+          int64_t xs[U];
 #pragma unroll
-            for (int u = 0; u < U; u++) { mk[u] = __ballot(act[u] && ((int32_t)xh[u] <= bh)); tot += __popcll(mk[u]); }
-            if (tot == 0) done = true;   // only idle lanes tripped the compare
-            if (tot == 1) {
-#pragma unroll
-              for (int u = 0; u < U; u++) {
-                if (mk[u]) {
-                  const int l = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mk[u]));
-                  const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)xl[u], l);
-                  const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)xh[u], l);
-                  if ((int32_t)wh < bh) {
-                    if (lane == 0) { best[s] = (int64_t)(((uint64_t)wh << 32) | wl); bpos[s] = base + u * 64 + l; }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    done = true;
-                  }
-                }
-              }
-            }
-          }
-          if (!done) {
-            int64_t xs[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) xs[u] = (int64_t)(((uint64_t)xh[u] << 32) | xl[u]);
-            minhash_update<U>(best, bpos, s, xs, pv, act, lane);
-          }
+          for (int u = 0; u < U; u++) xs[u] = (int64_t)x[u];
+          minhash_update<U>(best, bpos, s, xs, pv, act, lane);
         }
       }
     }
@@ -834,7 +730,6 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
       orow[s] = v;
     }
     if (lane == 0) out_status[sidx * status_stride] = 0;
-    if ((VAR & 16) && dbg_acc == 0x12345u) orow[0] = 1;
   }
 }
 
@@ -855,43 +750,27 @@ void build_xorshift_jump_tables(int na, uint64_t* out) {
   }
 }
 
-// variant = U*64 + VAR (experiment knob MHAP_MINHASH_VARIANT; 0 = tuned default)
-void launch_minhash_variant(hipStream_t st, int variant, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys,
-                            const uint32_t* wts, const StrandInfo* info, int k, int k2, int H, unsigned long long* counter,
-                            int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride, const uint64_t* jump) {
+// MHAP_MINHASH=perchain selects the kernel without bit-sliced rows (A/B measurements)
+void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
+                    int32_t* out_status, int64_t status_stride, const uint64_t* jump) {
   if (nstrands <= 0) return;
-  if (variant == 0) variant = MH_U * 64 + MH_VAR;
-  size_t per_wave = (((size_t)H * 12 + (((variant % 64) & 32) ? (size_t)(BS_QCAP + 4) * 4 : 0)) + 15) & ~(size_t)15;
+  static int perchain = -1;
+  if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
+  size_t per_wave = (((size_t)H * 12 + (perchain ? 0 : (size_t)BS_QCAP * 4)) + 15) & ~(size_t)15;
   int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
   while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
   const size_t lds = per_wave * waves;
   const dim3 block(64 * waves);
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
-#define MHAP_MH_CASE(UU, VV)                                                                                                    \
-  case (UU) * 64 + (VV):                                                                                                        \
-    hipLaunchKernelGGL((minhash_kernel<UU, VV>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, \
-                       counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem, jump);                      \
-    break;
-  static int bs_seed = -1, bs_minrem = -1;   // k-mers handled per chain first / remaining k-mers needed for a bit-sliced row
-  if (bs_seed < 0) { const char* e = getenv("MHAP_BS_SEED"); bs_seed = e ? atoi(e) : 0; e = getenv("MHAP_BS_MINREM"); bs_minrem = e ? atoi(e) : 512; }
-  switch (variant) {
-    MHAP_MH_CASE(4, 0) MHAP_MH_CASE(4, 1) MHAP_MH_CASE(4, 2) MHAP_MH_CASE(4, 4) MHAP_MH_CASE(4, 6) MHAP_MH_CASE(4, 7)
-    MHAP_MH_CASE(4, 8) MHAP_MH_CASE(4, 24) MHAP_MH_CASE(4, 40) MHAP_MH_CASE(8, 0) MHAP_MH_CASE(8, 7) MHAP_MH_CASE(8, 6) MHAP_MH_CASE(2, 7) MHAP_MH_CASE(6, 7) MHAP_MH_CASE(6, 6)
-    default:
-      hipLaunchKernelGGL((minhash_kernel<MH_U, MH_VAR>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H,
-                         counter, out_rows, out_stride, out_status, status_stride, bs_seed, bs_minrem, jump);
-  }
-#undef MHAP_MH_CASE
+  if (perchain)
+    hipLaunchKernelGGL((minhash_kernel<MH_U, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
+                       out_stride, out_status, status_stride, jump);
+  else
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
+                       out_stride, out_status, status_stride, jump);
 }
 
-void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
-                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride, const uint64_t* jump) {
-  static int variant = -1;
-  if (variant < 0) { const char* e = getenv("MHAP_MINHASH_VARIANT"); variant = e ? atoi(e) : 0; }
-  launch_minhash_variant(st, variant, nblocks, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows, out_stride, out_status,
-                         status_stride, jump);
-}
 
 // =============================================================================================
 // Ordered bottom-S sketch.  One workgroup per strand.  Composite key = (hash ^ 0x80000000) << 32 | pos

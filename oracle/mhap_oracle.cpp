@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <malloc.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -577,6 +578,10 @@ int64_t orc_run_self(const char* bases, const int64_t* offsets, const int32_t* l
                      orc_record* out, int64_t cap, double* timings, int64_t* stats,
                      int32_t* out_minhash /* optional: 2*nreads*max(1,H), kept strands only in order */,
                      int32_t* out_status /* optional per strand 2*nreads: 0 ok,1 zero-ngrams,2 skipped short */) {
+  // keep the per-strand work buffers (80-130 KB each) in the malloc arenas: with the default 128 KB mmap threshold every
+  // strand pays mmap/munmap + page faults, which serialises a many-core baseline in the kernel
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
   auto t0 = std::chrono::steady_clock::now();
   if (nthreads < 1) nthreads = 1;
   std::vector<Entry> all((size_t)nreads * 2);
