@@ -176,6 +176,13 @@ int mhap_find_matches_self_shard(mhap_handle* h, int64_t shard, int64_t nshards,
 int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths,
                             const int64_t* ids, int64_t n, mhap_record_sink sink, void* user);
 
+/* Index-vs-stream with PRECOMPUTED query sketches (a `.dat` file given to -q: only its forward entries are
+ * queries, J/impl/SequenceSketchStreamer.java:291-303 with fwdOnly=true): `m` query entries as host arrays laid out
+ * like mhap_index_add_sketches; toSelf=false. */
+int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t* seq_length, const int32_t* minhash,
+                               const int32_t* ordered, const int32_t* ordered_size, const int32_t* ordered_seqlen, int64_t m,
+                               mhap_record_sink sink, void* user);
+
 int mhap_get_stats(mhap_handle* h, mhap_stats* out);
 int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out);
 int mhap_reset_kernel_times(mhap_handle* h);

@@ -57,7 +57,7 @@ EXPORTED_SYMBOLS = [
     "mhap_get_stats", "mhap_get_kernel_times", "mhap_reset_kernel_times", "mhap_set_stream", "mhap_synchronize",
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
-    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump",
+    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_find_matches_sketches",
 ]
 
 
@@ -415,6 +415,14 @@ class MinHashSearch:
         return self._collect(lambda cb: self._lib.mhap_find_matches_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets),
                                                                           _ptr(fasta.lengths), _ptr(fasta.ids),
                                                                           C.c_int64(len(fasta)), cb, None))
+
+    def find_matches_sketches(self, sk):
+        """-q x.dat: precomputed (forward) query sketches against the index, toSelf=false."""
+        a = {k: np.ascontiguousarray(v) for k, v in sk.items()}
+        ids = a["ids"].astype(np.int64); sl = a["seq_length"].astype(np.int32); mh = a["minhash"].astype(np.int32)
+        od = a["ordered"].astype(np.int32); osz = a["ordered_size"].astype(np.int32); osl = a["ordered_seqlen"].astype(np.int32)
+        return self._collect(lambda cb: self._lib.mhap_find_matches_sketches(self._h, _ptr(ids), _ptr(sl), _ptr(mh), _ptr(od), _ptr(osz),
+                                                                            _ptr(osl), C.c_int64(len(ids)), cb, None))
 
     # -- counters -------------------------------------------------------------------------------
     def stats(self):

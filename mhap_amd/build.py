@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     hipcc = _hipcc()
     if force or _stale(LIB, deps):
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wno-pass-failed", *srcs, "-o", LIB]
+               "-Wno-pass-failed", *srcs, "-o", LIB, "-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True, cwd=CSRC)

@@ -1,5 +1,8 @@
 // host_util.cpp — host-side helpers of libmhaphip.so that need no GPU: the reference's IO conventions
 // (FASTA ingest, overlap-record text format) and the deterministic synthetic read generator.
+#include <dlfcn.h>
+#include <zlib.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -87,11 +90,38 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
   auto seterr = [&](const std::string& m) { if (err && errcap) snprintf(err, errcap, "%s", m.c_str()); };
   if (!path || !out) { seterr("null argument"); return MHAP_E_INVALID; }
   memset(out, 0, sizeof *out);
-  FILE* f = fopen(path, "rb");
-  if (!f) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
+  // Utils.getFile (J/utils/Utils.java:228-266): *bz2 -> bzip2, *gz -> gzip, otherwise the name must carry a FASTA suffix
+  const std::string name(path);
+  auto ends = [&](const char* suf) { const size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
   std::string data;
-  {
-    char buf[1 << 16];
+  char buf[1 << 16];
+  if (ends("bz2")) {
+    // libbz2 ships without headers in this image: bind the three stdio-style entry points at run time
+    void* lib = dlopen("libbz2.so.1.0", RTLD_NOW);
+    if (!lib) lib = dlopen("libbz2.so.1", RTLD_NOW);
+    typedef void* (*open_t)(const char*, const char*); typedef int (*read_t)(void*, void*, int); typedef void (*close_t)(void*);
+    open_t bzopen = lib ? (open_t)dlsym(lib, "BZ2_bzopen") : nullptr;
+    read_t bzread = lib ? (read_t)dlsym(lib, "BZ2_bzread") : nullptr;
+    close_t bzclose = lib ? (close_t)dlsym(lib, "BZ2_bzclose") : nullptr;
+    if (!bzopen || !bzread || !bzclose) { seterr("bzip2 input needs libbz2.so.1.0"); return MHAP_E_INVALID; }
+    void* bf = bzopen(path, "rb");
+    if (!bf) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
+    int got;
+    while ((got = bzread(bf, buf, (int)sizeof buf)) > 0) data.append(buf, (size_t)got);
+    bzclose(bf);
+  } else if (ends("gz")) {
+    gzFile gf = gzopen(path, "rb");
+    if (!gf) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
+    int got;
+    while ((got = gzread(gf, buf, (unsigned)sizeof buf)) > 0) data.append(buf, (size_t)got);
+    gzclose(gf);
+  } else {
+    static const char* suffixes[] = {"fna", "contigs", "contig", "final", "fasta", "fa"};   // FastaData.java:50
+    bool ok = false;
+    for (const char* suf : suffixes) ok = ok || ends(suf);
+    if (!ok) { seterr(std::string("Unknown file format of file ") + path + "."); return MHAP_E_INVALID; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
     size_t got;
     while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
     fclose(f);

@@ -860,6 +860,34 @@ int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* of
   return search_core(h, qs, ql, false, false, sink, user);
 }
 
+int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t* seq_length, const int32_t* minhash, const int32_t* ordered,
+                               const int32_t* ordered_size, const int32_t* ordered_seqlen, int64_t m, mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  if (m <= 0) return MHAP_OK;
+  if (!ids || !seq_length || !minhash || !ordered || !ordered_size || !ordered_seqlen) return fail(h, MHAP_E_INVALID, "null argument");
+  (void)hipSetDevice(h->device);
+  const int S = h->P.ordered_sketch_size;
+  std::vector<int32_t> meta((size_t)m * META_W);
+  std::vector<int32_t> ql((size_t)m);
+  for (int64_t e = 0; e < m; e++) {
+    if (ordered_size[e] < 0 || ordered_size[e] > S) return fail(h, MHAP_E_INVALID, "ordered sketch larger than --ordered-sketch-size");
+    meta[(size_t)e * META_W + 0] = ordered_size[e]; meta[(size_t)e * META_W + 1] = ordered_seqlen[e];
+    meta[(size_t)e * META_W + 2] = seq_length[e]; meta[(size_t)e * META_W + 3] = 0;
+    ql[(size_t)e] = (int32_t)e;
+  }
+  HIPCHK(h, h->q_minhash.ensure((size_t)m * h->Hrow * 4));
+  HIPCHK(h, h->q_ordered.ensure((size_t)m * S * 8));
+  HIPCHK(h, h->q_meta.ensure((size_t)m * META_W * 4));
+  HIPCHK(h, h->q_ids.ensure((size_t)m * 8));
+  HIPCHK(h, hipMemcpy(h->q_minhash.p, minhash, (size_t)m * h->Hrow * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->q_ordered.p, ordered, (size_t)m * S * 8, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->q_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
+  QuerySide qs{h->q_minhash.as<int32_t>(), h->Hrow, h->q_ordered.as<int32_t>(), 2LL * S, h->q_meta.as<int32_t>(), h->q_ids.as<int64_t>(), ids,
+               seq_length};
+  return search_core(h, qs, ql, false, false, sink, user);
+}
+
 int mhap_get_stats(mhap_handle* h, mhap_stats* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->stats; return MHAP_OK; }
 int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->ktimes; return MHAP_OK; }
 int mhap_reset_kernel_times(mhap_handle* h) { if (!h) return MHAP_E_INVALID; h->ktimes = mhap_kernel_times{}; return MHAP_OK; }

@@ -354,7 +354,19 @@ int main(int argc, char** argv) {
       t = now();
       fprintf(stderr, "Opened fasta file %s.\n", cf.c_str());
       int64_t nq = 0;
-      if (ends_with(cf, ".dat")) die("-q with .dat query files is not supported yet by mhap-hip (use FASTA queries)");
+      if (ends_with(cf, ".dat")) {   // precomputed query sketches: forward entries only (SequenceSketchStreamer.java:291-303)
+        DatEntries d;
+        read_dat(cf, seq_processed, P.num_hashes, P.ordered_sketch_size, true, d);
+        if (g_headers.full) for (size_t i = 0; i < d.ids.size(); i++) g_headers.byid[d.ids[i]] = d.hdr[i];
+        if (!d.ids.empty())
+          chk(h, mhap_find_matches_sketches(h, d.ids.data(), d.seqlen.data(), d.mh.data(), d.ord.data(), d.osz.data(), d.olen.data(),
+                                            (int64_t)d.ids.size(), sink_cb, &sink));
+        sink_flush(sink);
+        seq_processed += (int64_t)d.ids.size();
+        fprintf(stderr, "Processed %lld to sequences.\n", (long long)d.ids.size());
+        fprintf(stderr, "Time (s) to score, hash to-file, and output: %g\n", now() - t);
+        continue;
+      }
       mhap_fasta fa;
       if (mhap_fasta_read(cf.c_str(), seq_processed, &fa, err, sizeof err) != MHAP_OK) die(err);   // id offset = reads so far (MhapMain.java:527)
       if (g_headers.full) collect_headers(cf, seq_processed);

@@ -81,6 +81,13 @@ def test_cli_query_mode_and_full_ids(tmp_path):
     with MinHashSearch(p) as ms:
         ms.add_data(index)
         assert noself == sorted(mhap_amd.records_to_lines(ms.find_matches_stream(queries)))
+    # the same queries as a precomputed .dat (-p), then -q queries.dat: forward entries only, same records
+    qdir, ddir = tmp_path / "qfa", tmp_path / "qdat"
+    qdir.mkdir(); ddir.mkdir()
+    (qdir / "query.fa").write_bytes(qfile.read_bytes())
+    _run(["-p", str(qdir), "-q", str(ddir)] + flags)
+    viadat, _ = _run(["-s", str(sfile), "-q", str(ddir / "query.dat"), "--no-self"] + flags)
+    assert viadat == noself
     full, _ = _run(["-s", str(sfile), "-q", str(qfile), "--store-full-id"] + flags)
     hdr = {i + 1: f"s{i}" for i in range(40)}
     hdr.update({41 + j: f"q{30 + j}" for j in range(30)})

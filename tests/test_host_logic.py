@@ -170,6 +170,17 @@ def test_fasta_reader_follows_fastadata(tmp_path):
     bad.write_bytes(b"ACGT\n>r\nAC\n")
     with pytest.raises(mhap_amd.MhapError):
         mhap_amd.FastaData.from_file(str(bad))
+    # Utils.getFile: *gz / *bz2 are decompressed, anything else needs a FASTA suffix (FastaData.java:50)
+    import bz2
+    import gzip
+    raw = p.read_bytes()
+    gz, bz, txt = tmp_path / "x.fasta.gz", tmp_path / "y.fa.bz2", tmp_path / "z.txt"
+    gz.write_bytes(gzip.compress(raw)); bz.write_bytes(bz2.compress(raw)); txt.write_bytes(raw)
+    for q in (gz, bz):
+        f2 = mhap_amd.FastaData.from_file(str(q))
+        assert [f2.sequence(i) for i in range(3)] == ["ACGTACGN", "TTTTGG", "A"]
+    with pytest.raises(mhap_amd.MhapError):
+        mhap_amd.FastaData.from_file(str(txt))
     g = mhap_amd.FastaData.from_file(os.path.join(ROOT, "tests", "golden", "small_reads.fasta"))
     assert len(g) == 30 and g.sequence(7) == g.sequence(7).upper()
 
