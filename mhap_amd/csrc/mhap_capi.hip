@@ -554,7 +554,7 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   int rc = build_score_table(h);
   if (rc != MHAP_OK) { seterr(h->err); mhap_destroy(h); return rc; }
   {   // xorshift jump-ahead tables for slots up to H (MinHash kernel's deferred-candidate drain)
-    const int na = (P.num_hashes + 1) / 64 + 1;
+    const int na = ((P.num_hashes + 1) >> XS_JUMP_LOG2) + 1;
     std::vector<uint64_t> jt((size_t)na * 2048);
     build_xorshift_jump_tables(na, jt.data());
     if (h->jump_tbl.ensure(jt.size() * 8) != hipSuccess || hipMemcpy(h->jump_tbl.p, jt.data(), jt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
@@ -938,8 +938,8 @@ int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t 
 // chain value after `nsteps` xorshift64 steps computed the way the MinHash kernel's candidate drain does it
 // (GF(2) byte tables for the multiple of 64, single steps for the rest)
 int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out) {
-  if (!out || nsteps < 0 || nsteps > (1 << 20)) return MHAP_E_INVALID;
-  const int a = nsteps >> 6, r = nsteps & 63;
+  if (!out || nsteps < 0 || nsteps > (1 << 16)) return MHAP_E_INVALID;
+  const int a = nsteps >> XS_JUMP_LOG2, r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
   uint64_t x = key;
   if (a > 0) {
     std::vector<uint64_t> jt((size_t)a * 2048);

@@ -495,27 +495,19 @@ __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t 
   return nacc | ~ACT;
 }
 
-// First bit-sliced row of a strand (no slot minimum exists yet): bit-serial arg-min over the row's active chains.
+// First bit-sliced row of a strand (no slot minimum exists yet): bit-serial narrowing towards the row's arg-min.
 // Walking the planes from the sign bit down, the candidate set is narrowed to the chains that have the "smaller" bit
-// whenever at least one does (wave-uniform decision via ballot).  Distinct k-mers have distinct chain values (the
-// step is a bijection), so exactly one chain survives; it is the row's minimum for this slot.
+// whenever at least one does (wave-uniform decision).  The row's minimum always survives; after BS_ARGMIN_PLANES planes
+// about 2048 / 2^BS_ARGMIN_PLANES other chains still share its prefix, and the deferred exact update sorts those out,
+// so the walk stops there instead of testing for a single survivor.
+constexpr int BS_ARGMIN_PLANES = 14;
 __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t ACT) {
   uint32_t cand = ACT & P[63];                 // negative values first (signed compare)
   if (!__any(cand != 0u)) cand = ACT;
-  bool done = false;                           // wave-uniform; no `break`, so the loop unrolls and P stays in registers
 #pragma unroll
-  for (int b = 62; b >= 0; b--) {
-    if (!done) {
-      const uint32_t m = cand & ~P[b];
-      if (__any(m != 0u)) cand = m;
-      if (b <= 50) {                           // 2048 chains need >= 11 planes; test for a single survivor from here on
-        const unsigned long long bal = __ballot(cand != 0u);
-        if (__popcll(bal) == 1) {
-          const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cand, __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)));
-          done = (w & (w - 1u)) == 0u;
-        }
-      }
-    }
+  for (int b = 62; b > 62 - BS_ARGMIN_PLANES; b--) {
+    const uint32_t m = cand & ~P[b];
+    if (__any(m != 0u)) cand = m;
   }
   return cand;
 }
@@ -526,8 +518,11 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
 // re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 64 steps + <= 63 single steps;
 // entries arrive in slot order, so the lanes of a batch walk about the same number of steps), then ds_min_rtn_i64
 // lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
+#define MHAP_TICK() (PROF ? (unsigned long long)clock64() : 0ULL)
+template <bool PROF = false>
 __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
-                                         const uint64_t* __restrict__ jump, int lane) {
+                                         const uint64_t* __restrict__ jump, int lane, unsigned long long* tf = nullptr) {
+  const unsigned long long t0 = MHAP_TICK();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
   __builtin_amdgcn_wave_barrier();
   const int qn = qn_ref;
@@ -539,8 +534,8 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
     const int pos = rb + j * 64 + l;
     uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
     // chain value at slot s = (s+1) steps from the key
-    const int nsteps = s + 1, a = nsteps >> 6;
-    int r = valid ? (nsteps & 63) : 0;
+    const int nsteps = s + 1, a = nsteps >> XS_JUMP_LOG2;
+    int r = valid ? (nsteps & ((1 << XS_JUMP_LOG2) - 1)) : 0;
     if (valid && a > 0) {
       const uint64_t* T = jump + (size_t)(a - 1) * 2048;
       uint64_t y = 0;
@@ -566,17 +561,19 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
     __builtin_amdgcn_wave_barrier();
   }
   qn_ref = 0;
+  if (PROF) { tf[0] += MHAP_TICK() - t0; tf[1] += (unsigned long long)((qn + 63) >> 6); }
 }
 
 // append this trigger's candidates.  The fill count lives in a wave-uniform register: queue slots are handed out with
 // ballot + mbcnt (no LDS atomic, no read-back), one candidate per lane per round; the queue is drained whenever the
 // next round might not fit.
+template <bool PROF = false>
 __device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, int& qn, int s, uint32_t cand, int rb,
-                                         const int64_t* __restrict__ kp, const uint64_t* __restrict__ jump, int lane) {
+                                         const int64_t* __restrict__ kp, const uint64_t* __restrict__ jump, int lane, unsigned long long* tf = nullptr) {
   unsigned long long m = __ballot(cand != 0u);
   while (m) {
     const int c = __popcll(m);
-    if (qn + c > BS_QCAP) bs_flush(best, bpos, q, qn, rb, kp, jump, lane);   // a round adds at most 64 entries: always fits afterwards
+    if (qn + c > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, kp, jump, lane, tf);   // a round adds at most 64 entries: always fits afterwards
     if (cand) {
       const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
       const int j = __builtin_ctz(cand);
@@ -588,15 +585,18 @@ __device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t*
   }
 }
 
-template <int U, bool BITSLICED>
+template <int U, bool BITSLICED, bool PROF = false>
 __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const StrandInfo* __restrict__ info, int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
-                                                      const uint64_t* __restrict__ jump) {
+                                                      const uint64_t* __restrict__ jump, unsigned long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // PROF: wave-clock attribution {strand total, row-0 total, row-0 argmin, row-0 defer, later-row defer, key load+transpose,
+  // flush (nested in the defers / row ends), flush batches, strands}
+  unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tf[2] = {0, 0}, nst = 0;
   const size_t per_wave = (size_t)H * 12 + (BITSLICED ? (size_t)BS_QCAP * 4 : 0);
   int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
   int32_t* bpos = (int32_t*)(best + H);
@@ -624,6 +624,8 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
+    const unsigned long long ts0 = MHAP_TICK();
+    nst++;
     // ---- pass 1: weight == 1 k-mers ----
     int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
     for (int base = 0; base < nk; base += 64 * U) {
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         while (nk - base >= BS_MINREM) {
           uint32_t P[64];
           uint32_t ACT = 0;
+          const unsigned long long tr0 = MHAP_TICK();
 #pragma unroll
           for (int j = 0; j < 32; j++) {
             const int i = base + j * 64 + lane;
@@ -643,19 +646,31 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           }
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
+          if (PROF) tp[5] += MHAP_TICK() - tr0;
           int32_t bh_next = besthi[1];
           for (int s = 0; s < H; s++) {
             const int32_t bh = bh_next;
             bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
             bs_step(P);
             if (base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
-              if (__any(ACT != 0u)) bs_defer(best, bpos, bsq, bsqn, s, bs_argmin(P, ACT), base, kp, jump, lane);
+              if (__any(ACT != 0u)) {
+                const unsigned long long ta = MHAP_TICK();
+                const uint32_t cand = bs_argmin(P, ACT);
+                const unsigned long long tb = MHAP_TICK();
+                bs_defer<PROF>(best, bpos, bsq, bsqn, s, cand, base, kp, jump, lane, tf);
+                if (PROF) { tp[2] += tb - ta; tp[3] += MHAP_TICK() - tb; }
+              }
               continue;
             }
             const uint32_t nacc = bs_filter(P, ACT, __builtin_amdgcn_readfirstlane(bh));
-            if (__any(nacc != 0xFFFFFFFFu)) bs_defer(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane);
+            if (__any(nacc != 0xFFFFFFFFu)) {
+              const unsigned long long ta = MHAP_TICK();
+              bs_defer<PROF>(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane, tf);
+              if (PROF) tp[4] += MHAP_TICK() - ta;
+            }
           }
-          bs_flush(best, bpos, bsq, bsqn, base, kp, jump, lane);
+          bs_flush<PROF>(best, bpos, bsq, bsqn, base, kp, jump, lane, tf);
+          if (PROF && base == 0) tp[1] += MHAP_TICK() - tr0;
           base += 2048;
         }
         if (base >= nk) break;
@@ -730,22 +745,27 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
       orow[s] = v;
     }
     if (lane == 0) out_status[sidx * status_stride] = 0;
+    if (PROF) tp[0] += MHAP_TICK() - ts0;
+  }
+  if (PROF && lane == 0) {
+    for (int i = 0; i < 6; i++) atomicAdd(&prof[i], tp[i]);
+    atomicAdd(&prof[6], tf[0]); atomicAdd(&prof[7], tf[1]); atomicAdd(&prof[8], nst);
   }
 }
 
-// Jump-ahead tables for the xorshift64 chain: the step is linear over GF(2), so M^(64a) x is the XOR of eight byte-indexed
-// table entries.  out[(a-1)*2048 + i*256 + v] = M^(64a) applied to (v << 8i), a = 1..na.
+// Jump-ahead tables for the xorshift64 chain: the step is linear over GF(2), so M^(g a) x (g = 2^XS_JUMP_LOG2) is the XOR of
+// eight byte-indexed table entries.  out[(a-1)*2048 + i*256 + v] = M^(g a) applied to (v << 8i), a = 1..na.
 void build_xorshift_jump_tables(int na, uint64_t* out) {
   uint64_t col[64], nxt[64];
   auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
-  for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < 64; t++) x = xorshift_step(x); col[j] = x; }   // M^64
+  for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < (1 << XS_JUMP_LOG2); t++) x = xorshift_step(x); col[j] = x; }   // M^g
   uint64_t base[64];
   for (int j = 0; j < 64; j++) base[j] = col[j];
   for (int a = 1; a <= na; a++) {
     uint64_t* T = out + (size_t)(a - 1) * 2048;
     for (int i = 0; i < 8; i++)
       for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(col, (uint64_t)v << (8 * i));
-    for (int j = 0; j < 64; j++) nxt[j] = apply(base, col[j]);   // M^(64(a+1)) = M^64 o M^(64a)
+    for (int j = 0; j < 64; j++) nxt[j] = apply(base, col[j]);   // M^(g(a+1)) = M^g o M^(g a)
     for (int j = 0; j < 64; j++) col[j] = nxt[j];
   }
 }
@@ -763,6 +783,24 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
   const size_t lds = per_wave * waves;
   const dim3 block(64 * waves);
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
+  static int profmode = -1;
+  if (profmode < 0) { const char* e = getenv("MHAP_MINHASH_PROF"); profmode = (e && atoi(e)) ? 1 : 0; }
+  if (profmode && !perchain) {   // wave-clock attribution of the bit-sliced kernel (diagnostics; printed per launch)
+    static unsigned long long* dprof = nullptr;
+    if (!dprof) (void)hipMalloc(&dprof, 16 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
+                       out_stride, out_status, status_stride, jump, dprof);
+    unsigned long long hp[16];
+    (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
+    (void)hipStreamSynchronize(st);
+    const double tot = (double)hp[0];
+    fprintf(stderr, "[minhash prof] strands %llu  wave-clocks/strand %.0f  row0 %.1f%% (argmin %.1f%%, defer %.1f%%)  later defers %.1f%%  load+transpose %.1f%%  "
+                    "flush %.1f%% (%.1f batches/strand, %.0f clocks/batch)\n",
+            hp[8], tot / (double)hp[8], 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot,
+            100.0 * hp[6] / tot, (double)hp[7] / (double)hp[8], hp[7] ? (double)hp[6] / (double)hp[7] : 0.0);
+    return;
+  }
   if (perchain)
     hipLaunchKernelGGL((minhash_kernel<MH_U, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
                        out_stride, out_status, status_stride, jump);
