@@ -459,7 +459,7 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
 // as many leading zero magnitude bits as the slot's current minimum (necessary for x <= min: 1 + z more VALU ops).
 constexpr int BS_MINREM = 512;   // remaining k-mers needed to start another 2048-chain bit-sliced row
 constexpr int BS_ZMAX = 24;
-constexpr int BS_QCAP = 768;     // deferred-candidate queue entries per wave (LDS)
+constexpr int BS_QCAP = 512;     // deferred-candidate queue entries per wave (LDS, 8 bytes each)
 
 __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 #pragma unroll
@@ -513,76 +513,75 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
 }
 
 // Deferred candidates: pulling a candidate's 64-bit value out of the planes would cost 64 v_readlane + ~250 scalar ops
-// (~1600 issue cycles).  Instead a trigger only appends (slot, lane, bit) to a wave-private LDS queue; slots are
-// independent within a row, so the queue can be drained later, 64 candidates at a time, one per lane: each lane
-// re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 64 steps + <= 63 single steps;
-// entries arrive in slot order, so the lanes of a batch walk about the same number of steps), then ds_min_rtn_i64
-// lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
+// (~1600 issue cycles).  Instead a trigger only appends (slot, lane, candidate bit mask) to a wave-private LDS queue;
+// slots are independent within a row, so the queue can be drained later, 64 entries at a time, one per lane: each lane
+// re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 16 steps + <= 15 single steps),
+// then ds_min_rtn_i64 lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
+// An entry's mask nearly always has a single bit; the drain loops while any lane has bits left.
 #define MHAP_TICK() (PROF ? (unsigned long long)clock64() : 0ULL)
 template <bool PROF = false>
-__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint64_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
                                          const uint64_t* __restrict__ jump, int lane, unsigned long long* tf = nullptr) {
   const unsigned long long t0 = MHAP_TICK();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
   __builtin_amdgcn_wave_barrier();
   const int qn = qn_ref;
   for (int b0 = 0; b0 < qn; b0 += 64) {
-    const bool valid = b0 + lane < qn;
-    const uint32_t e = valid ? q[b0 + lane] : 0u;
-    const int s = (int)(e >> 16);
-    const int l = (int)((e >> 5) & 63u), j = (int)(e & 31u);
-    const int pos = rb + j * 64 + l;
-    uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
+    const uint64_t e = (b0 + lane < qn) ? q[b0 + lane] : 0ULL;
+    uint32_t mask = (uint32_t)e;
+    const int s = (int)(e >> 38), l = (int)((e >> 32) & 63u);
     // chain value at slot s = (s+1) steps from the key
-    const int nsteps = s + 1, a = nsteps >> XS_JUMP_LOG2;
-    int r = valid ? (nsteps & ((1 << XS_JUMP_LOG2) - 1)) : 0;
-    if (valid && a > 0) {
-      const uint64_t* T = jump + (size_t)(a - 1) * 2048;
-      uint64_t y = 0;
+    const int nsteps = s + 1, a = nsteps >> XS_JUMP_LOG2, r0 = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+    while (__any(mask != 0u)) {
+      const bool valid = mask != 0u;
+      const int j = valid ? __builtin_ctz(mask) : 0;
+      mask &= mask - 1u;
+      const int pos = rb + j * 64 + l;
+      uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
+      const int r = valid ? r0 : 0;
+      if (valid && a > 0) {
+        const uint64_t* T = jump + (size_t)(a - 1) * 2048;
+        uint64_t y = 0;
 #pragma unroll
-      for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
-      x = y;
-    }
-    int rmax = r;
+        for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+        x = y;
+      }
+      int rmax = r;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
-    for (int t = 0; t < rmax; t++) {
-      const uint64_t nx = xorshift_step(x);
-      x = (t < r) ? nx : x;
+      for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
+      for (int t = 0; t < rmax; t++) {
+        const uint64_t nx = xorshift_step(x);
+        x = (t < r) ? nx : x;
+      }
+      // exact update, all lanes at once: the lane whose value is the slot's final minimum and that strictly undercut
+      // what it saw owns the slot (chain values of distinct k-mers are distinct)
+      long long old = INT64_MAX;
+      if (valid) old = atomicMin((long long*)&best[s], (long long)x);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    // exact update, all lanes at once: the lane whose value is the slot's final minimum and that strictly undercut
-    // what it saw owns the slot (chain values of distinct k-mers are distinct)
-    long long old = INT64_MAX;
-    if (valid) old = atomicMin((long long*)&best[s], (long long)x);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
   qn_ref = 0;
   if (PROF) { tf[0] += MHAP_TICK() - t0; tf[1] += (unsigned long long)((qn + 63) >> 6); }
 }
 
-// append this trigger's candidates.  The fill count lives in a wave-uniform register: queue slots are handed out with
-// ballot + mbcnt (no LDS atomic, no read-back), one candidate per lane per round; the queue is drained whenever the
-// next round might not fit.
+// append this trigger's candidates: one entry per lane that has any.  The fill count lives in a wave-uniform register
+// and queue slots are handed out with ballot + mbcnt (no LDS atomic, no read-back); the queue is drained whenever the
+// next trigger might not fit.
 template <bool PROF = false>
-__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, int& qn, int s, uint32_t cand, int rb,
+__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint64_t* q, int& qn, int s, uint32_t cand, int rb,
                                          const int64_t* __restrict__ kp, const uint64_t* __restrict__ jump, int lane, unsigned long long* tf = nullptr) {
-  unsigned long long m = __ballot(cand != 0u);
-  while (m) {
-    const int c = __popcll(m);
-    if (qn + c > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, kp, jump, lane, tf);   // a round adds at most 64 entries: always fits afterwards
-    if (cand) {
-      const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      const int j = __builtin_ctz(cand);
-      cand &= cand - 1u;
-      q[idx] = ((uint32_t)s << 16) | ((uint32_t)lane << 5) | (uint32_t)j;
-    }
-    qn += c;
-    m = __ballot(cand != 0u);
+  const unsigned long long m = __ballot(cand != 0u);
+  const int c = __popcll(m);
+  if (qn + c > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, kp, jump, lane, tf);   // at most 64 entries per trigger: fits afterwards
+  if (cand) {
+    const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    q[idx] = ((uint64_t)(((uint32_t)s << 6) | (uint32_t)lane) << 32) | cand;
   }
+  qn += c;
 }
 
 template <int U, bool BITSLICED, bool PROF = false>
@@ -597,10 +596,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
   // PROF: wave-clock attribution {strand total, row-0 total, row-0 argmin, row-0 defer, later-row defer, key load+transpose,
   // flush (nested in the defers / row ends), flush batches, strands}
   unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tf[2] = {0, 0}, nst = 0;
-  const size_t per_wave = (size_t)H * 12 + (BITSLICED ? (size_t)BS_QCAP * 4 : 0);
+  const size_t per_wave = (size_t)H * 12 + 8 + (BITSLICED ? (size_t)BS_QCAP * 8 : 0);
   int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
   int32_t* bpos = (int32_t*)(best + H);
-  uint32_t* bsq = (uint32_t*)(bpos + H);          // deferred-candidate queue (bit-sliced rows)
+  uint64_t* bsq = (uint64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15) + (((size_t)H * 12 + 7) & ~(size_t)7));   // deferred-candidate queue
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
   for (;;) {
     long long sidx = 0;
@@ -777,7 +776,7 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
   if (nstrands <= 0) return;
   static int perchain = -1;
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
-  size_t per_wave = (((size_t)H * 12 + (perchain ? 0 : (size_t)BS_QCAP * 4)) + 15) & ~(size_t)15;
+  size_t per_wave = (((size_t)H * 12 + 8 + (perchain ? 0 : (size_t)BS_QCAP * 8)) + 15) & ~(size_t)15;
   int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
   while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
   const size_t lds = per_wave * waves;
