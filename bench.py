@@ -192,6 +192,7 @@ def main():
             "kernel_ms_per_step": {kk: round(v, 3) for kk, v in kernel_ms_per_step.items()},
             "candidates_per_step": int(st["candidates_compared"]),
             "index_elements_per_step": int(st["table_elements"]),
+            "overlap_slow_pairs_per_step": int(st["slow_pairs"]),
             "roofline": roofline, "valu": valu,
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),

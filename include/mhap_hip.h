@@ -70,6 +70,7 @@ typedef struct mhap_stats {
   int64_t matches_found;          /* getMatchesProcessed()                       */
   int64_t slot_compares;          /* slot comparisons done by the brute-force (fallback) candidate kernel */
   int64_t table_elements;         /* getNumberElementsProcessed(): inverted-index hits walked             */
+  int64_t slow_pairs;             /* candidates the wave-per-pair second stage handed to the per-lane merge */
 } mhap_stats;
 
 /* Per-kernel HIP-event timings accumulated on the handle's stream (for bench/roofline). */

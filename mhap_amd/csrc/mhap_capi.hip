@@ -106,7 +106,7 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, recs, ovl_scratch, inv_table, inv_overflow;
+  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_overflow;
   std::vector<DevRecord> h_recs;
   std::vector<mhap_record> out_recs;
 
@@ -381,6 +381,8 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   int64_t ovl_max_blocks = (int64_t)h->num_cus * 16;
   if (const char* e = getenv("MHAP_OVERLAP_BLOCKS")) { long long v = atoll(e); if (v > 0) ovl_max_blocks = v; }
   const int64_t per_lane = 3LL * (2LL * S + 2);
+  const char* omode = getenv("MHAP_OVERLAP");
+  const bool lane_only = omode && strcmp(omode, "lane") == 0;
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
   // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
   const char* cmode = getenv("MHAP_CANDIDATES");
@@ -472,14 +474,37 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     h->stats.queries_searched += nq;
     if (ncand == 0) continue;
     HIPCHK(h, h->recs.ensure((size_t)ncand * sizeof(DevRecord)));
-    const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)ncand + OVL_THREADS - 1) / OVL_THREADS));
-    HIPCHK(h, h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS * (size_t)per_lane * 4));
-    time_begin(h, MHAP_K_OVERLAP);
-    launch_overlap(h->stream, oblocks, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
-                   qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
-                   h->recs.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2);
-    time_end(h);
-    HIPCHK(h, hipGetLastError());
+    // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
+    // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
+    const bool use_join = !lane_only && S <= OJ_MAX_S && overlap_join_lds_bytes(S) <= 64 * 1024;
+    unsigned long long nslow = use_join ? 0 : ncand;
+    if (use_join) {
+      HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
+      const int chunk = 8;
+      const int64_t want = ((int64_t)ncand + 4LL * chunk - 1) / (4LL * chunk);
+      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * 4, want));
+      time_begin(h, MHAP_K_OVERLAP);
+      launch_overlap_join(h->stream, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
+                          qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,
+                          (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5);
+      time_end(h);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(&nslow, ctr + 5, 8, hipMemcpyDeviceToHost, h->stream));
+      int rcj = sync_stream(h);
+      if (rcj != MHAP_OK) return rcj;
+      h->stats.slow_pairs += (int64_t)nslow;
+    }
+    if (nslow > 0) {
+      const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)nslow + OVL_THREADS - 1) / OVL_THREADS));
+      HIPCHK(h, h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS * (size_t)per_lane * 4));
+      time_begin(h, MHAP_K_OVERLAP);
+      launch_overlap(h->stream, oblocks, use_join ? h->slow_cand.as<Candidate>() : h->cand.as<Candidate>(), use_join ? ctr + 5 : ctr + 0,
+                     use_join ? (unsigned long long)ncand : (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
+                     qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
+                     h->recs.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2);
+      time_end(h);
+      HIPCHK(h, hipGetLastError());
+    }
     unsigned long long counts[3] = {0, 0, 0};
     HIPCHK(h, hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
     int rc = sync_stream(h);

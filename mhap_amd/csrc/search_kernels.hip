@@ -8,7 +8,8 @@
 //                      `>= numMinMatches` cut and the same id/length filters (:200-225) yields the identical
 //                      candidate set.  Integer VALU work (v_cmp_eq + v_addc per slot pair), tiles staged
 //                      through LDS, 8x8 register micro-tile per lane, triangular tile skipping in self mode.
-//   overlap_kernel   : BottomOverlapSketch.getOverlapInfo per candidate, one lane each (overlap_lane.hpp).
+//   overlap_join_kernel : BottomOverlapSketch.getOverlapInfo per candidate, one wavefront each, from the equal-hash join.
+//   overlap_kernel   : the same per candidate, one lane each, literal merge (overlap_lane.hpp): pairs the join path hands back.
 #include "kernels.hpp"
 #include "overlap_lane.hpp"
 
@@ -375,6 +376,472 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
     }
   }
   if (mine) atomicAdd(compared, mine);
+}
+
+// =============================================================================================
+// Second stage, one WAVEFRONT per candidate pair (default path).
+//
+// Both ordered sketches are sorted by (hash, pos), and everything getOverlapInfo does with them is a function of the
+// equal-hash JOIN of the two lists: recordMatchingKmers (both passes) keeps the joined k-mers whose positions pass the
+// pass's windows, and the bottom-k Jaccard walk counts the joined k-mers inside [a1,a2]x[b1,b2] whose rank in the
+// merged union is below k.  So the wave computes the join once — the query's hashes sit in LDS, every lane binary-
+// searches the hash of one entry of the other sketch (coalesced 8-byte loads) — and the rest is a handful of wave-wide
+// filters, one rank selection (the median shift = Utils.quickSelect's k-th order statistic) and min/max reductions over
+// the few joined k-mers.  Per pair that is ~n log n lane steps instead of the ~4n divergent merge steps per LANE of
+// overlap_kernel.
+//
+// A joined hash that is unique inside both sketches contributes at most one record per pass, independent of all other
+// hashes (the two-pointer merge has no run there), and record ORDER only matters to optimizeShifts, which merges
+// neighbouring records of one query position, i.e. of one hash.  A hash that is duplicated in either sketch forms a
+// "group": the merge's run logic (:460-496), optimizeShifts and the one-to-one pairing of the Jaccard walk are replayed
+// literally on the group's few entries (oj_group_merge etc., wave-uniform), and its records join the others.  Pairs
+// beyond the caps below (joined k-mers, groups, group length) are appended to `slow` for overlap_kernel's literal merge.
+// =============================================================================================
+constexpr int OJ_WAVES = 4;
+constexpr int OJ_JCAP = 256;           // joined k-mers + group records kept per pair
+constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
+constexpr int OJ_GCAP = 8;             // duplicated-hash groups per pair
+constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
+constexpr int OJ_LDS_EXTRA = 4 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN);   // ints per wave besides the query hashes
+
+__device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ int oj_wave_min(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o < v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ int oj_wave_max(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(v, off); v = o > v ? o : v; }
+  return v;
+}
+__device__ __forceinline__ void oj_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// MatchData.performUpdate (:191-215) given the median shift of the current records (have = any records)
+__device__ __forceinline__ ShiftStats oj_shift_stats(bool have, int med, int len1, int len2, double max_shift) {
+  ShiftStats st;
+  if (have) {
+    st.med = med;
+    const int left = 0 > -med ? 0 : -med;
+    const int right = len1 < len2 - med ? len1 : len2 - med;
+    int ov = right - left; if (ov < 10) ov = 10;
+    const int mx = len1 > len2 ? len1 : len2;
+    const int lim = (int)((double)ov * max_shift);
+    st.absmax = mx < lim ? mx : lim;
+  } else {
+    st.med = 0;
+    st.absmax = (len1 > len2 ? len1 : len2) + 1;
+  }
+  return st;
+}
+
+struct OjWindows { int v1lo, v1hi, v2lo, v2hi, med, absmax; };
+__device__ __forceinline__ OjWindows oj_windows(ShiftStats st, int len1, int len2) {   // MatchData :246-276
+  const int med = st.med, absmax = st.absmax;
+  const int t1 = -med - absmax, t2 = len2 - med + absmax, t3 = med - absmax, t4 = len1 + med + absmax;
+  OjWindows w;
+  w.v1lo = 0 > t1 ? 0 : t1; w.v1hi = len1 < t2 ? len1 : t2;
+  w.v2lo = 0 > t3 ? 0 : t3; w.v2hi = len2 < t4 ? len2 : t4;
+  w.med = med; w.absmax = absmax;
+  return w;
+}
+
+// recordMatchingKmers restricted to one hash value that is duplicated in at least one sketch: pa[0..m) / pb[0..n) are the
+// positions of ALL entries with that hash (ascending), and the loop below is the reference's, run on just those entries
+// (entries of other hashes end a run exactly like the end of these arrays does).  Wave-uniform: every lane walks the same
+// few LDS words; lane 0 stores the records.  Returns the number of records written to o1/o2.
+__device__ __forceinline__ int oj_group_merge(const int32_t* pa, int m, const int32_t* pb, int n, const OjWindows& w, int32_t* o1, int32_t* o2,
+                                              int lane) {
+  int i1 = 0, i2 = 0, cnt = 0;
+  while (i1 < m && i2 < n) {
+    const int p1 = pa[i1], p2 = pb[i2];
+    if (p1 < w.v1lo || p1 >= w.v1hi) { i1++; continue; }
+    if (p2 < w.v2lo || p2 >= w.v2hi) { i2++; continue; }
+    const int diff = (p2 - p1) - w.med;
+    if (diff > w.absmax) { i1++; continue; }
+    if (diff < -w.absmax) { i2++; continue; }
+    if (lane == 0) { o1[cnt] = p1; o2[cnt] = p2; }
+    cnt++;
+    int i1Last = i1, p1Last = p1;
+    for (int t = i1 + 1; t < m; t++) {
+      const int pt = pa[t];
+      if (!(pt >= w.v1lo && pt < w.v1hi)) break;
+      i1Last = t; p1Last = pt;
+    }
+    int i2Last = i2, p2Last = p2;
+    for (int t = i2 + 1; t < n; t++) {
+      const int pt = pb[t];
+      if (!(pt >= w.v2lo && pt < w.v2hi)) break;
+      i2Last = t; p2Last = pt;
+    }
+    if (i1 != i1Last || i2 != i2Last) {
+      if (lane == 0) { o1[cnt] = p1Last; o2[cnt] = p2Last; }
+      cnt++;
+      i1 = i1Last + 1; i2 = i2Last + 1;
+    } else { i1++; i2++; }
+  }
+  return cnt;
+}
+
+// One recordMatchingKmers pass over the join.  Entries [0, nj) are the unique-hash joined k-mers (kept if they pass the
+// pass's windows), the groups' records are appended behind them at [nj, nj + nx).  Bit r of the result = entry r*64+lane is a
+// record of this pass; count = number of records.
+__device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, int ng, int32_t* gi, const int32_t* gpa, const int32_t* gpb,
+                                           int len1, int len2, ShiftStats st, int lane, int& count, int& nx_out) {
+  const OjWindows w = oj_windows(st, len1, len2);
+  int nx = 0;
+  for (int g = 0; g < ng; g++) {
+    const int k = oj_group_merge(gpa + g * OJ_GLEN, gi[g * 6 + 2], gpb + g * OJ_GLEN, gi[g * 6 + 3], w, jp1 + nj + nx, jp2 + nj + nx, lane);
+    if (lane == 0) { gi[g * 6 + 4] = nj + nx; gi[g * 6 + 5] = k; }
+    nx += k;
+  }
+  if (ng) oj_lds_sync();
+  uint32_t fl = 0;
+  int cnt = 0;
+#pragma unroll
+  for (int r = 0; r < OJ_R; r++) {
+    if (r * 64 < nj + nx) {
+      const int t = r * 64 + lane;
+      bool ok = false;
+      if (t < nj) {
+        const int p1 = jp1[t], p2 = jp2[t];
+        const int diff = (p2 - p1) - w.med;
+        ok = p1 >= w.v1lo && p1 < w.v1hi && p2 >= w.v2lo && p2 < w.v2hi && !(diff > w.absmax) && !(diff < -w.absmax);
+      } else if (t < nj + nx) ok = true;
+      fl |= (ok ? 1u : 0u) << r;
+      cnt += __popcll(__ballot(ok));
+    }
+  }
+  count = cnt;
+  nx_out = nx;
+  return fl;
+}
+
+// k-th smallest (k = count / 2) of the records' shifts = Utils.quickSelect(shifts, count / 2, count)
+__device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t* jp2, int32_t* sh, uint32_t fl, int ntot, int count, int lane) {
+  int myv[OJ_R], myidx[OJ_R], less[OJ_R];
+  int base = 0;
+#pragma unroll
+  for (int r = 0; r < OJ_R; r++) {
+    myv[r] = 0; myidx[r] = 0; less[r] = 0;
+    if (r * 64 < ntot) {
+      const bool ok = (fl >> r) & 1u;
+      const unsigned long long bal = __ballot(ok);
+      if (ok) {
+        const int t = r * 64 + lane;
+        myv[r] = jp2[t] - jp1[t];
+        myidx[r] = base + oj_mbcnt(bal);
+        sh[myidx[r]] = myv[r];
+      }
+      base += __popcll(bal);
+    }
+  }
+  oj_lds_sync();
+  for (int u = 0; u < count; u++) {
+    const int v = sh[u];   // same address in every lane: LDS broadcast
+#pragma unroll
+    for (int r = 0; r < OJ_R; r++)
+      if (r * 64 < ntot) less[r] += (v < myv[r] || (v == myv[r] && u < myidx[r])) ? 1 : 0;
+  }
+  const int k = count / 2;
+  int med = 0;
+#pragma unroll
+  for (int r = 0; r < OJ_R; r++) {
+    if (r * 64 < ntot) {
+      const unsigned long long bal = __ballot(((fl >> r) & 1u) && less[r] == k);
+      if (bal) med = __builtin_amdgcn_readlane(myv[r], __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)));
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return med;
+}
+
+__global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
+                                                                     unsigned long long cand_cap, const int32_t* __restrict__ ordered,
+                                                                     int64_t ord_stride, const int32_t* __restrict__ meta,
+                                                                     const int32_t* __restrict__ qordered, int64_t qord_stride,
+                                                                     const int32_t* __restrict__ qmeta, SearchParams sp,
+                                                                     const double* __restrict__ score_table, DevRecord* __restrict__ recs,
+                                                                     unsigned long long* __restrict__ rec_count, unsigned long long rec_cap,
+                                                                     unsigned long long* __restrict__ compared, Candidate* __restrict__ slow,
+                                                                     unsigned long long* __restrict__ slow_count, int chunk) {
+  extern __shared__ int32_t oj_lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int32_t* ah = oj_lds + (size_t)wv * ((size_t)sp.S + OJ_LDS_EXTRA);   // the query sketch's hashes
+  int32_t* jp1 = ah + sp.S;                                            // join: position in the query / in the other sketch,
+  int32_t* jp2 = jp1 + OJ_JCAP;
+  uint32_t* jij = (uint32_t*)(jp2 + OJ_JCAP);                          // ... entry indices (i | j << 16)
+  int32_t* sh = (int32_t*)(jij + OJ_JCAP);                             // shifts of the current records (median selection)
+  int32_t* gi = sh + OJ_JCAP;                                          // groups: {first i, first j, m, n, first record, records}
+  int32_t* gpa = gi + OJ_GCAP * 6;                                     // ... positions of the group's entries in the query
+  int32_t* gpb = gpa + OJ_GCAP * OJ_GLEN;                              // ... and in the other sketch
+  unsigned long long n = *cand_count;
+  if (n > cand_cap) n = cand_cap;
+  const unsigned long long W = (unsigned long long)gridDim.x * OJ_WAVES, w = (unsigned long long)blockIdx.x * OJ_WAVES + wv;
+  int curq = -1, nA = 0, len1 = 0;
+  const int32_t* qrow = nullptr;
+  unsigned long long mine = 0;
+  for (unsigned long long c0 = w * (unsigned long long)chunk; c0 < n; c0 += W * (unsigned long long)chunk) {
+    const unsigned long long c1 = c0 + (unsigned long long)chunk < n ? c0 + (unsigned long long)chunk : n;
+    for (unsigned long long c = c0; c < c1; c++) {
+      const Candidate cd = cand[c];
+      if (cd.q != curq) {   // candidates of one query are contiguous: its hashes are staged once per run
+        curq = cd.q;
+        const int32_t* qm = qmeta + (int64_t)cd.q * META_W;
+        nA = qm[0]; len1 = qm[1];
+        qrow = qordered + (int64_t)cd.q * qord_stride;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nA; i += 64) ah[i] = qrow[2 * i];
+        oj_lds_sync();
+      }
+      const int32_t* mm = meta + (int64_t)cd.m * META_W;
+      const int nB = mm[0], len2 = mm[1];
+      const uint2* brow = (const uint2*)(ordered + (int64_t)cd.m * ord_stride);
+      // ---- join ----
+      int nj = 0, ng = 0;
+      bool bad = false;
+      if (nA > 0 && nB > 0) {
+        const int steps = 32 - __builtin_clz((unsigned)nA);
+        int carry = 0;   // hash of the last entry of the previous 64-entry block (run detection across blocks)
+        for (int j0 = 0; j0 < nB; j0 += 64) {
+          const int j = j0 + lane;
+          const bool valid = j < nB;
+          uint2 e = make_uint2(0u, 0u);
+          if (valid) e = brow[j];
+          const int hb = (int)e.x;
+          int lo = 0, hi = valid ? nA : 0;
+          for (int it = 0; it < steps; it++) {
+            const int mid = (lo + hi) >> 1;
+            const int v = ah[mid < nA ? mid : nA - 1];
+            const bool act = lo < hi;
+            const bool lt = v < hb;
+            lo = (act && lt) ? mid + 1 : lo;
+            hi = (act && !lt) ? mid : hi;
+          }
+          const bool found = valid && lo < nA && ah[lo] == hb;
+          int hprev = __shfl_up(hb, 1);
+          if (lane == 0) hprev = carry;
+          carry = __builtin_amdgcn_readlane(hb, 63);
+          // the first entry of a run of equal hashes in the other sketch speaks for the run
+          const bool leader = found && !(j > 0 && hprev == hb);
+          bool grp = false;
+          if (leader) grp = (lo + 1 < nA && ah[lo + 1] == hb) || (j + 1 < nB && (int)brow[j + 1].x == hb);
+          const bool reg = leader && !grp;
+          const unsigned long long balr = __ballot(reg), balg = __ballot(grp);
+          if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) { bad = true; break; }
+          if (reg) {
+            const int idx = nj + oj_mbcnt(balr);
+            jp2[idx] = (int)e.y;
+            jij[idx] = (uint32_t)lo | ((uint32_t)j << 16);
+          }
+          if (grp) {
+            const int idx = ng + oj_mbcnt(balg);
+            gi[idx * 6 + 0] = lo; gi[idx * 6 + 1] = j;
+          }
+          nj += __popcll(balr);
+          ng += __popcll(balg);
+        }
+      }
+      oj_lds_sync();
+      int gtot = 0;
+      for (int g = 0; g < ng && !bad; g++) {   // collect the groups' entries: lanes 0..8 the query's, lanes 16..24 the other sketch's
+        const int lo = gi[g * 6 + 0], j = gi[g * 6 + 1];
+        const int h = ah[lo];
+        const int x = lane & 15;
+        const bool a_ok = lane <= OJ_GLEN && lo + x < nA && ah[lo + x] == h;
+        const bool b_ok = lane >= 16 && lane <= 16 + OJ_GLEN && j + x < nB && (int)brow[j + x].x == h;
+        const int m = __popcll(__ballot(a_ok)), nn = __popcll(__ballot(b_ok));
+        if (m > OJ_GLEN || nn > OJ_GLEN) { bad = true; break; }
+        if (a_ok) gpa[g * OJ_GLEN + x] = qrow[2 * (lo + x) + 1];
+        if (b_ok) gpb[g * OJ_GLEN + x] = (int)brow[j + x].y;
+        if (lane == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; }
+        gtot += m + nn;
+      }
+      if (nj + gtot > OJ_JCAP) bad = true;
+      if (bad) {
+        if (lane == 0) { const unsigned long long slot = atomicAdd(slow_count, 1ULL); slow[slot] = cd; }
+        continue;
+      }
+      mine++;
+      // OverlapInfo.EMPTY (score 0, all zero) unless the pair gets through every stage below
+      double score = 0.0;
+      int valid = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
+      do {
+        if (nj == 0 && ng == 0) break;
+        for (int t = lane; t < nj; t += 64) jp1[t] = qrow[2 * (int)(jij[t] & 0xffffu) + 1];
+        oj_lds_sync();
+        // ---- recordMatchingKmers twice (:600-606), median shift after each ----
+        int count = 0, nx = 0;
+        ShiftStats st = oj_shift_stats(false, 0, len1, len2, sp.max_shift);
+        uint32_t fl = oj_pass(jp1, jp2, nj, ng, gi, gpa, gpb, len1, len2, st, lane, count, nx);
+        if (count <= 0) break;
+        st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
+        fl = oj_pass(jp1, jp2, nj, ng, gi, gpa, gpb, len1, len2, st, lane, count, nx);
+        if (count <= 0) break;
+        st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
+        // optimizeShifts (:156-189): neighbouring records of one query position exist only inside a group
+        int removed = 0;
+        for (int g = 0; g < ng; g++) {
+          const int start = gi[g * 6 + 4], k = gi[g * 6 + 5];
+          int red = -1;
+          for (int x = 0; x < k; x++) {
+            const int t = start + x;
+            const int p1 = jp1[t], p2 = jp2[t];
+            int drop = -1;
+            if (red >= 0 && jp1[red] == p1) {
+              const int sr = jp2[red] - jp1[red];
+              if (iabs32(sr - st.med) > iabs32((p2 - p1) - st.med)) { drop = red; red = t; } else drop = t;
+            } else red = t;
+            if (drop >= 0) { removed++; if ((drop & 63) == lane) fl &= ~(1u << (drop >> 6)); }
+          }
+        }
+        if (removed) {
+          count -= removed;
+          st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
+        }
+        // computeEdges (:90-137)
+        int le1 = INT32_MAX, le2 = INT32_MAX, re1 = INT32_MIN, re2 = INT32_MIN, nvalid = 0;
+#pragma unroll
+        for (int r = 0; r < OJ_R; r++) {
+          if (r * 64 < nj + nx) {
+            bool ok = (fl >> r) & 1u;
+            if (ok) {
+              const int t = r * 64 + lane;
+              const int p1 = jp1[t], p2 = jp2[t];
+              ok = !(iabs32((p2 - p1) - st.med) > st.absmax);
+              if (ok) {
+                le1 = p1 < le1 ? p1 : le1; le2 = p2 < le2 ? p2 : le2;
+                re1 = p1 > re1 ? p1 : re1; re2 = p2 > re2 ? p2 : re2;
+              }
+            }
+            nvalid += __popcll(__ballot(ok));
+          }
+        }
+        if (nvalid < 3) break;
+        le1 = oj_wave_min(le1); le2 = oj_wave_min(le2); re1 = oj_wave_max(re1); re2 = oj_wave_max(re2);
+        const double den = (double)(nvalid - 1);
+        const int32_t na1 = (int32_t)((uint32_t)nvalid * (uint32_t)le1 - (uint32_t)re1);   // int products wrap like Java's (:131-134)
+        const int32_t na2 = (int32_t)((uint32_t)nvalid * (uint32_t)re1 - (uint32_t)le1);
+        const int32_t nb1 = (int32_t)((uint32_t)nvalid * (uint32_t)le2 - (uint32_t)re2);
+        const int32_t nb2 = (int32_t)((uint32_t)nvalid * (uint32_t)re2 - (uint32_t)le2);
+        a1 = (int)java_round((double)na1 / den); if (a1 < 0) a1 = 0;
+        a2 = (int)java_round((double)na2 / den); if (a2 > len1) a2 = len1;
+        b1 = (int)java_round((double)nb1 / den); if (b1 < 0) b1 = 0;
+        b2 = (int)java_round((double)nb2 / den); if (b2 > len2) b2 = len2;
+        valid = nvalid;
+        // ---- computeKBottomSketchJaccard (:304-364): in-window counts, and for every joined k-mer (and every group's first
+        // entries) its rank among the in-window entries of either sketch: prefix counts over 64-entry blocks, the lane that
+        // holds entry i of the block hands the rank to the lane that holds the joined k-mer ----
+        int iA[OJ_R], jB[OJ_R], rA[OJ_R], rB[OJ_R];
+#pragma unroll
+        for (int r = 0; r < OJ_R; r++) {
+          const int t = r * 64 + lane;
+          const uint32_t ij = t < nj ? jij[t] : 0xffffffffu;
+          iA[r] = (int)(ij & 0xffffu); jB[r] = (int)(ij >> 16); rA[r] = 0; rB[r] = 0;
+        }
+        // lane g < ng speaks for group g
+        int giA = 0xffff, gjB = 0xffff, grA = 0, grB = 0, gmin = 0;
+        if (lane < ng) {
+          giA = gi[lane * 6 + 0]; gjB = gi[lane * 6 + 1];
+          int ca = 0, cb = 0;
+          for (int x = 0; x < gi[lane * 6 + 2]; x++) { const int p = gpa[lane * OJ_GLEN + x]; ca += (p >= a1 && p <= a2) ? 1 : 0; }
+          for (int x = 0; x < gi[lane * 6 + 3]; x++) { const int p = gpb[lane * OJ_GLEN + x]; cb += (p >= b1 && p <= b2) ? 1 : 0; }
+          gmin = ca < cb ? ca : cb;   // equal hashes pair up one to one in the union walk
+        }
+        const int jrounds = (nj + 63) >> 6;
+        int s1 = 0, s2 = 0;
+        for (int i0 = 0; i0 < nA; i0 += 64) {
+          const int i = i0 + lane;
+          const int pos = i < nA ? qrow[2 * i + 1] : INT32_MIN;
+          const bool in = i < nA && pos >= a1 && pos <= a2;
+          const unsigned long long bal = __ballot(in);
+          const int rank = s1 + oj_mbcnt(bal);
+#pragma unroll
+          for (int r = 0; r < OJ_R; r++) {
+            if (r < jrounds) {
+              const int v = __shfl(rank, iA[r] & 63);
+              if ((iA[r] & ~63) == i0) rA[r] = v;
+            }
+          }
+          if (ng) { const int v = __shfl(rank, giA & 63); if ((giA & ~63) == i0) grA = v; }
+          s1 += __popcll(bal);
+        }
+        for (int j0 = 0; j0 < nB; j0 += 64) {
+          const int j = j0 + lane;
+          const int pos = j < nB ? (int)brow[j].y : INT32_MIN;
+          const bool in = j < nB && pos >= b1 && pos <= b2;
+          const unsigned long long bal = __ballot(in);
+          const int rank = s2 + oj_mbcnt(bal);
+#pragma unroll
+          for (int r = 0; r < OJ_R; r++) {
+            if (r < jrounds) {
+              const int v = __shfl(rank, jB[r] & 63);
+              if ((jB[r] & ~63) == j0) rB[r] = v;
+            }
+          }
+          if (ng) { const int v = __shfl(rank, gjB & 63); if ((gjB & ~63) == j0) grB = v; }
+          s2 += __popcll(bal);
+        }
+        const int kk = s1 < s2 ? s1 : s2;
+        // a joined k-mer counts if its index in the merged union (in-window entries of both, joined ones once) is below k:
+        // index = rank in the query + rank in the other sketch - joined in-window k-mers ahead of it
+        int inter = 0, before = 0;
+        bool both[OJ_R];
+#pragma unroll
+        for (int r = 0; r < OJ_R; r++) {
+          both[r] = false;
+          if (r < jrounds) {
+            const int t = r * 64 + lane;
+            if (t < nj) { const int p1 = jp1[t], p2 = jp2[t]; both[r] = p1 >= a1 && p1 <= a2 && p2 >= b1 && p2 <= b2; }
+            const unsigned long long bal = __ballot(both[r]);
+            int m = before + oj_mbcnt(bal);
+            for (int g = 0; g < ng; g++)   // pairs of the groups ahead of it
+              m += (__builtin_amdgcn_readlane(giA, g) < iA[r]) ? __builtin_amdgcn_readlane(gmin, g) : 0;
+            inter += __popcll(__ballot(both[r] && rA[r] + rB[r] - m < kk));
+            before += __popcll(bal);
+          }
+        }
+        int gacc = 0;   // pairs of the groups ahead of group g
+        for (int g = 0; g < ng; g++) {
+          const int glo = __builtin_amdgcn_readlane(giA, g), gm = __builtin_amdgcn_readlane(gmin, g);
+          int ahead = gacc;
+#pragma unroll
+          for (int r = 0; r < OJ_R; r++)
+            if (r < jrounds) ahead += __popcll(__ballot(both[r] && iA[r] < glo));
+          const int base = __builtin_amdgcn_readlane(grA, g) + __builtin_amdgcn_readlane(grB, g) - ahead;
+          int take = kk - base;                    // the group's pairs sit at union indices base, base+1, ...
+          take = take < 0 ? 0 : (take > gm ? gm : take);
+          inter += take;
+          gacc += gm;
+        }
+        score = score_table[score_index(inter, kk)];
+      } while (0);
+      if (score >= sp.threshold && lane == 0) {                                                  // MinHashSearch.java:229
+        const unsigned long long slot = atomicAdd(rec_count, 1ULL);
+        if (slot < rec_cap) {
+          DevRecord d;
+          d.q = cd.q; d.m = cd.m; d.score = score; d.raw = valid; d.a1 = a1; d.a2 = a2; d.b1 = b1; d.b2 = b2; d.pad = 0;
+          recs[slot] = d;
+        }
+      }
+    }
+  }
+  if (mine && lane == 0) atomicAdd(compared, mine);
+}
+
+size_t overlap_join_lds_bytes(int S) { return (size_t)OJ_WAVES * ((size_t)S + OJ_LDS_EXTRA) * 4; }
+
+void launch_overlap_join(hipStream_t st, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
+                         const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
+                         const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs, unsigned long long* rec_count,
+                         unsigned long long rec_cap, unsigned long long* compared, Candidate* slow, unsigned long long* slow_count) {
+  hipLaunchKernelGGL(overlap_join_kernel, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S), st, cand, cand_count, cand_cap, ordered,
+                     ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk);
 }
 
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
