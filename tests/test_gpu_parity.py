@@ -301,3 +301,54 @@ def test_long_reads_partitioned_kmer_weights():
     seqs = [_rand_seq(rnd, 26000), _rand_seq(rnd, 70000), _rand_seq(rnd, 131500), a + a[:15000] + a[5000:9000], "ACGTTGCAAT" * 3000]
     fa = FastaData.from_strings(seqs)
     _assert_sketch_parity(fa, MhapParams(num_hashes=32, ordered_sketch_size=128))
+
+
+def _mutate(rnd, s, rate):
+    out = []
+    for ch in s:
+        r = rnd.random()
+        if r < rate / 3:
+            continue                               # deletion
+        if r < 2 * rate / 3:
+            out.append(rnd.choice("ACGT"))         # substitution
+            continue
+        out.append(ch)
+        if r < rate:
+            out.append(rnd.choice("ACGT"))         # insertion
+    return "".join(out)
+
+
+def test_overlap_join_groups_and_lane_fallback(monkeypatch):
+    """Second stage on repeat-rich reads: sketches with duplicated ordered-k-mer hashes (replayed as groups by the
+    wave-per-pair kernel), near-identical reads (more joined k-mers than it keeps) and low-complexity reads (groups longer
+    than it keeps) that go to the per-lane merge.  Default path == MHAP_OVERLAP=lane == oracle."""
+    rnd = random.Random(2024)
+    unit = _rand_seq(rnd, 30)
+    parts = []
+    for _ in range(40):                               # interspersed repeats of one unit, lightly diverged, with unique spacers
+        parts.append(_mutate(rnd, unit, 0.01))
+        parts.append(_rand_seq(rnd, rnd.randrange(400, 900)))
+    genome = "".join(parts)
+    seqs = []
+    for _ in range(260):
+        L = rnd.randrange(1500, 3500)
+        o = rnd.randrange(0, len(genome) - L)
+        s = _mutate(rnd, genome[o:o + L], rnd.choice([0.03, 0.05, 0.07]))
+        seqs.append(O.rc(s) if rnd.random() < 0.5 else s)
+    seqs += [genome[1000:4000]] * 3                   # identical reads: every ordered k-mer joins
+    seqs += [("ACGTTGCA" * 300)[i:i + 2200] for i in range(4)] + ["ACGGT" * 500, "A" * 1800, "A" * 2100]
+    fa = FastaData.from_strings(seqs)
+    for kw in (dict(), dict(num_min_matches=1, threshold=0.0, max_shift=0.4)):
+        p = MhapParams(num_hashes=128, ordered_sketch_size=600, **kw)
+        want = O.run_self(fa, H=128, S=600, nthreads=8, num_min_matches=p.num_min_matches, threshold=p.threshold, max_shift=p.max_shift)
+        monkeypatch.delenv("MHAP_OVERLAP", raising=False)
+        a, sa = _self_lines(fa, p)
+        monkeypatch.setenv("MHAP_OVERLAP", "lane")
+        b, sb = _self_lines(fa, p)
+        monkeypatch.delenv("MHAP_OVERLAP", raising=False)
+        assert a == O.record_lines(want["records"]), kw
+        assert b == a
+        assert 0 < sa["slow_pairs"] < sa["candidates_compared"], sa
+        assert sb["slow_pairs"] == 0 and sb["candidates_compared"] == sa["candidates_compared"]
+        print("slow pairs", sa["slow_pairs"], "of", sa["candidates_compared"])
+        assert len(a) > 1000
