@@ -402,7 +402,8 @@ constexpr int OJ_JCAP = 256;           // joined k-mers + group records kept per
 constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
 constexpr int OJ_GCAP = 8;             // duplicated-hash groups per pair
 constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
-constexpr int OJ_LDS_EXTRA = 4 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN);   // ints per wave besides the query hashes
+constexpr int OJ_U = 4;                // 64-entry blocks of the other sketch in flight per wave
+constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN);   // ints per wave besides the query hashes
 
 __device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -576,8 +577,8 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
   int32_t* jp1 = ah + sp.S;                                            // join: position in the query / in the other sketch,
   int32_t* jp2 = jp1 + OJ_JCAP;
   uint32_t* jij = (uint32_t*)(jp2 + OJ_JCAP);                          // ... entry indices (i | j << 16)
-  int32_t* sh = (int32_t*)(jij + OJ_JCAP);                             // shifts of the current records (median selection)
-  int32_t* gi = sh + OJ_JCAP;                                          // groups: {first i, first j, m, n, first record, records}
+  int32_t* sh = (int32_t*)jij;                                         // (later) shifts of the current records, median selection
+  int32_t* gi = (int32_t*)(jij + OJ_JCAP);                                        // groups: {first i, first j, m, n, first record, records}
   int32_t* gpa = gi + OJ_GCAP * 6;                                     // ... positions of the group's entries in the query
   int32_t* gpb = gpa + OJ_GCAP * OJ_GLEN;                              // ... and in the other sketch
   unsigned long long n = *cand_count;
@@ -608,43 +609,61 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
       if (nA > 0 && nB > 0) {
         const int steps = 32 - __builtin_clz((unsigned)nA);
         int carry = 0;   // hash of the last entry of the previous 64-entry block (run detection across blocks)
-        for (int j0 = 0; j0 < nB; j0 += 64) {
-          const int j = j0 + lane;
-          const bool valid = j < nB;
-          uint2 e = make_uint2(0u, 0u);
-          if (valid) e = brow[j];
-          const int hb = (int)e.x;
-          int lo = 0, hi = valid ? nA : 0;
+        for (int j0 = 0; j0 < nB && !bad; j0 += 64 * OJ_U) {
+          // OJ_U blocks of 64 entries at a time: their loads and their binary searches (dependent LDS reads) overlap
+          uint2 e[OJ_U];
+          int lo[OJ_U], hi[OJ_U];
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) {
+            const int j = j0 + u * 64 + lane;
+            e[u] = make_uint2(0u, 0u);
+            if (j < nB) e[u] = brow[j];
+            lo[u] = 0; hi[u] = j < nB ? nA : 0;
+          }
           for (int it = 0; it < steps; it++) {
-            const int mid = (lo + hi) >> 1;
-            const int v = ah[mid < nA ? mid : nA - 1];
-            const bool act = lo < hi;
-            const bool lt = v < hb;
-            lo = (act && lt) ? mid + 1 : lo;
-            hi = (act && !lt) ? mid : hi;
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              const int mid = (lo[u] + hi[u]) >> 1;
+              const int v = ah[mid < nA ? mid : nA - 1];
+              const bool act = lo[u] < hi[u];
+              const bool lt = v < (int)e[u].x;
+              lo[u] = (act && lt) ? mid + 1 : lo[u];
+              hi[u] = (act && !lt) ? mid : hi[u];
+            }
           }
-          const bool found = valid && lo < nA && ah[lo] == hb;
-          int hprev = __shfl_up(hb, 1);
-          if (lane == 0) hprev = carry;
-          carry = __builtin_amdgcn_readlane(hb, 63);
-          // the first entry of a run of equal hashes in the other sketch speaks for the run
-          const bool leader = found && !(j > 0 && hprev == hb);
-          bool grp = false;
-          if (leader) grp = (lo + 1 < nA && ah[lo + 1] == hb) || (j + 1 < nB && (int)brow[j + 1].x == hb);
-          const bool reg = leader && !grp;
-          const unsigned long long balr = __ballot(reg), balg = __ballot(grp);
-          if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) { bad = true; break; }
-          if (reg) {
-            const int idx = nj + oj_mbcnt(balr);
-            jp2[idx] = (int)e.y;
-            jij[idx] = (uint32_t)lo | ((uint32_t)j << 16);
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) {
+            if (!bad && j0 + u * 64 < nB) {
+              const int j = j0 + u * 64 + lane;
+              const int hb = (int)e[u].x;
+              const bool found = j < nB && lo[u] < nA && ah[lo[u]] == hb;
+              int hprev = __shfl_up(hb, 1);
+              if (lane == 0) hprev = carry;
+              carry = __builtin_amdgcn_readlane(hb, 63);
+              // the first entry of a run of equal hashes in the other sketch speaks for the run
+              const bool leader = found && !(j > 0 && hprev == hb);
+              int hnext = __shfl_down(hb, 1);
+              if (lane == 63 && leader && j + 1 < nB) hnext = (int)brow[j + 1].x;
+              bool grp = false;
+              if (leader) grp = (lo[u] + 1 < nA && ah[lo[u] + 1] == hb) || (j + 1 < nB && hnext == hb);
+              const bool reg = leader && !grp;
+              const unsigned long long balr = __ballot(reg), balg = __ballot(grp);
+              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) bad = true;
+              else {
+                if (reg) {
+                  const int idx = nj + oj_mbcnt(balr);
+                  jp2[idx] = (int)e[u].y;
+                  jij[idx] = (uint32_t)lo[u] | ((uint32_t)j << 16);
+                }
+                if (grp) {
+                  const int idx = ng + oj_mbcnt(balg);
+                  gi[idx * 6 + 0] = lo[u]; gi[idx * 6 + 1] = j;
+                }
+                nj += __popcll(balr);
+                ng += __popcll(balg);
+              }
+            }
           }
-          if (grp) {
-            const int idx = ng + oj_mbcnt(balg);
-            gi[idx * 6 + 0] = lo; gi[idx * 6 + 1] = j;
-          }
-          nj += __popcll(balr);
-          ng += __popcll(balg);
         }
       }
       oj_lds_sync();
@@ -673,7 +692,14 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
       int valid = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
       do {
         if (nj == 0 && ng == 0) break;
-        for (int t = lane; t < nj; t += 64) jp1[t] = qrow[2 * (int)(jij[t] & 0xffffu) + 1];
+        int iA[OJ_R], jB[OJ_R];   // the joined k-mers' entry indices move to registers, their LDS words become `sh`
+#pragma unroll
+        for (int r = 0; r < OJ_R; r++) {
+          const int t = r * 64 + lane;
+          const uint32_t ij = t < nj ? jij[t] : 0xffffffffu;
+          iA[r] = (int)(ij & 0xffffu); jB[r] = (int)(ij >> 16);
+          if (t < nj) jp1[t] = qrow[2 * iA[r] + 1];
+        }
         oj_lds_sync();
         // ---- recordMatchingKmers twice (:600-606), median shift after each ----
         int count = 0, nx = 0;
@@ -737,13 +763,9 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
         // ---- computeKBottomSketchJaccard (:304-364): in-window counts, and for every joined k-mer (and every group's first
         // entries) its rank among the in-window entries of either sketch: prefix counts over 64-entry blocks, the lane that
         // holds entry i of the block hands the rank to the lane that holds the joined k-mer ----
-        int iA[OJ_R], jB[OJ_R], rA[OJ_R], rB[OJ_R];
+        int rA[OJ_R], rB[OJ_R];
 #pragma unroll
-        for (int r = 0; r < OJ_R; r++) {
-          const int t = r * 64 + lane;
-          const uint32_t ij = t < nj ? jij[t] : 0xffffffffu;
-          iA[r] = (int)(ij & 0xffffu); jB[r] = (int)(ij >> 16); rA[r] = 0; rB[r] = 0;
-        }
+        for (int r = 0; r < OJ_R; r++) { rA[r] = 0; rB[r] = 0; }
         // lane g < ng speaks for group g
         int giA = 0xffff, gjB = 0xffff, grA = 0, grB = 0, gmin = 0;
         if (lane < ng) {
@@ -755,37 +777,51 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
         }
         const int jrounds = (nj + 63) >> 6;
         int s1 = 0, s2 = 0;
-        for (int i0 = 0; i0 < nA; i0 += 64) {
-          const int i = i0 + lane;
-          const int pos = i < nA ? qrow[2 * i + 1] : INT32_MIN;
-          const bool in = i < nA && pos >= a1 && pos <= a2;
-          const unsigned long long bal = __ballot(in);
-          const int rank = s1 + oj_mbcnt(bal);
+        for (int ib = 0; ib < nA; ib += 64 * OJ_U) {
+          int posv[OJ_U];
 #pragma unroll
-          for (int r = 0; r < OJ_R; r++) {
-            if (r < jrounds) {
-              const int v = __shfl(rank, iA[r] & 63);
-              if ((iA[r] & ~63) == i0) rA[r] = v;
+          for (int u = 0; u < OJ_U; u++) { const int i = ib + u * 64 + lane; posv[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN; }
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) {
+            const int i0 = ib + u * 64;
+            if (i0 < nA) {
+              const bool in = i0 + lane < nA && posv[u] >= a1 && posv[u] <= a2;
+              const unsigned long long bal = __ballot(in);
+              const int rank = s1 + oj_mbcnt(bal);
+#pragma unroll
+              for (int r = 0; r < OJ_R; r++) {
+                if (r < jrounds) {
+                  const int v = __shfl(rank, iA[r] & 63);
+                  if ((iA[r] & ~63) == i0) rA[r] = v;
+                }
+              }
+              if (ng) { const int v = __shfl(rank, giA & 63); if ((giA & ~63) == i0) grA = v; }
+              s1 += __popcll(bal);
             }
           }
-          if (ng) { const int v = __shfl(rank, giA & 63); if ((giA & ~63) == i0) grA = v; }
-          s1 += __popcll(bal);
         }
-        for (int j0 = 0; j0 < nB; j0 += 64) {
-          const int j = j0 + lane;
-          const int pos = j < nB ? (int)brow[j].y : INT32_MIN;
-          const bool in = j < nB && pos >= b1 && pos <= b2;
-          const unsigned long long bal = __ballot(in);
-          const int rank = s2 + oj_mbcnt(bal);
+        for (int jb = 0; jb < nB; jb += 64 * OJ_U) {
+          int posv[OJ_U];
 #pragma unroll
-          for (int r = 0; r < OJ_R; r++) {
-            if (r < jrounds) {
-              const int v = __shfl(rank, jB[r] & 63);
-              if ((jB[r] & ~63) == j0) rB[r] = v;
+          for (int u = 0; u < OJ_U; u++) { const int j = jb + u * 64 + lane; posv[u] = j < nB ? (int)brow[j].y : INT32_MIN; }
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) {
+            const int j0 = jb + u * 64;
+            if (j0 < nB) {
+              const bool in = j0 + lane < nB && posv[u] >= b1 && posv[u] <= b2;
+              const unsigned long long bal = __ballot(in);
+              const int rank = s2 + oj_mbcnt(bal);
+#pragma unroll
+              for (int r = 0; r < OJ_R; r++) {
+                if (r < jrounds) {
+                  const int v = __shfl(rank, jB[r] & 63);
+                  if ((jB[r] & ~63) == j0) rB[r] = v;
+                }
+              }
+              if (ng) { const int v = __shfl(rank, gjB & 63); if ((gjB & ~63) == j0) grB = v; }
+              s2 += __popcll(bal);
             }
           }
-          if (ng) { const int v = __shfl(rank, gjB & 63); if ((gjB & ~63) == j0) grB = v; }
-          s2 += __popcll(bal);
         }
         const int kk = s1 < s2 ? s1 : s2;
         // a joined k-mer counts if its index in the merged union (in-window entries of both, joined ones once) is below k:
