@@ -590,80 +590,92 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
   for (unsigned long long c0 = w * (unsigned long long)chunk; c0 < n; c0 += W * (unsigned long long)chunk) {
     const unsigned long long c1 = c0 + (unsigned long long)chunk < n ? c0 + (unsigned long long)chunk : n;
     for (unsigned long long c = c0; c < c1; c++) {
-      const Candidate cd = cand[c];
+      Candidate cd = cand[c];   // wave-uniform values are pinned to SGPRs: loop bounds and branches below become scalar
+      cd.q = __builtin_amdgcn_readfirstlane(cd.q); cd.m = __builtin_amdgcn_readfirstlane(cd.m);
       if (cd.q != curq) {   // candidates of one query are contiguous: its hashes are staged once per run
         curq = cd.q;
         const int32_t* qm = qmeta + (int64_t)cd.q * META_W;
-        nA = qm[0]; len1 = qm[1];
+        nA = __builtin_amdgcn_readfirstlane(qm[0]); len1 = __builtin_amdgcn_readfirstlane(qm[1]);
         qrow = qordered + (int64_t)cd.q * qord_stride;
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < nA; i += 64) ah[i] = qrow[2 * i];
         oj_lds_sync();
       }
       const int32_t* mm = meta + (int64_t)cd.m * META_W;
-      const int nB = mm[0], len2 = mm[1];
+      const int nB = __builtin_amdgcn_readfirstlane(mm[0]), len2 = __builtin_amdgcn_readfirstlane(mm[1]);
       const uint2* brow = (const uint2*)(ordered + (int64_t)cd.m * ord_stride);
       // ---- join ----
       int nj = 0, ng = 0;
       bool bad = false;
       if (nA > 0 && nB > 0) {
-        const int steps = 32 - __builtin_clz((unsigned)nA);
-        int carry = 0;   // hash of the last entry of the previous 64-entry block (run detection across blocks)
+        const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
+        int carry = 0;   // hash of the last entry of the previous OJ_U blocks (run detection across blocks)
+        uint2 en[OJ_U];
+#pragma unroll
+        for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = make_uint2(0u, 0u); if (j < nB) en[u] = brow[j]; }
         for (int j0 = 0; j0 < nB && !bad; j0 += 64 * OJ_U) {
-          // OJ_U blocks of 64 entries at a time: their loads and their binary searches (dependent LDS reads) overlap
+          // OJ_U blocks of 64 entries at a time: their binary searches (dependent LDS reads) overlap each other and the loads
+          // of the next OJ_U blocks
           uint2 e[OJ_U];
-          int lo[OJ_U], hi[OJ_U];
+          int l[OJ_U];
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) {
+            e[u] = en[u];
+            const int jn = j0 + (u + OJ_U) * 64 + lane;
+            en[u] = make_uint2(0u, 0u);
+            if (jn < nB) en[u] = brow[jn];
+          }
+          // lower bound of every hash among the query's: l = last index whose hash is smaller (-1: none).  Fixed probe
+          // sequence for a sorted array of any length (first probe splits [0,nA) into two overlapping halves of p2 entries)
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) l[u] = (ah[p2 - 1] < (int)e[u].x) ? nA - p2 : -1;
+          for (int q = p2 >> 1; q > 0; q >>= 1) {
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) l[u] = (ah[l[u] + q] < (int)e[u].x) ? l[u] + q : l[u];
+          }
+          bool found[OJ_U];
+          bool anyf = false;
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
             const int j = j0 + u * 64 + lane;
-            e[u] = make_uint2(0u, 0u);
-            if (j < nB) e[u] = brow[j];
-            lo[u] = 0; hi[u] = j < nB ? nA : 0;
+            l[u] += 1;
+            found[u] = j < nB && l[u] < nA && ah[l[u] < nA ? l[u] : 0] == (int)e[u].x;
+            anyf |= found[u];
           }
-          for (int it = 0; it < steps; it++) {
+          if (__any(anyf)) {
 #pragma unroll
             for (int u = 0; u < OJ_U; u++) {
-              const int mid = (lo[u] + hi[u]) >> 1;
-              const int v = ah[mid < nA ? mid : nA - 1];
-              const bool act = lo[u] < hi[u];
-              const bool lt = v < (int)e[u].x;
-              lo[u] = (act && lt) ? mid + 1 : lo[u];
-              hi[u] = (act && !lt) ? mid : hi[u];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < OJ_U; u++) {
-            if (!bad && j0 + u * 64 < nB) {
-              const int j = j0 + u * 64 + lane;
-              const int hb = (int)e[u].x;
-              const bool found = j < nB && lo[u] < nA && ah[lo[u]] == hb;
-              int hprev = __shfl_up(hb, 1);
-              if (lane == 0) hprev = carry;
-              carry = __builtin_amdgcn_readlane(hb, 63);
-              // the first entry of a run of equal hashes in the other sketch speaks for the run
-              const bool leader = found && !(j > 0 && hprev == hb);
-              int hnext = __shfl_down(hb, 1);
-              if (lane == 63 && leader && j + 1 < nB) hnext = (int)brow[j + 1].x;
-              bool grp = false;
-              if (leader) grp = (lo[u] + 1 < nA && ah[lo[u] + 1] == hb) || (j + 1 < nB && hnext == hb);
-              const bool reg = leader && !grp;
-              const unsigned long long balr = __ballot(reg), balg = __ballot(grp);
-              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) bad = true;
-              else {
-                if (reg) {
-                  const int idx = nj + oj_mbcnt(balr);
-                  jp2[idx] = (int)e[u].y;
-                  jij[idx] = (uint32_t)lo[u] | ((uint32_t)j << 16);
+              if (!bad && __any(found[u])) {
+                const int j = j0 + u * 64 + lane;
+                const int hb = (int)e[u].x;
+                int hprev = __shfl_up(hb, 1);
+                if (lane == 0) hprev = u ? __builtin_amdgcn_readlane((int)e[u ? u - 1 : 0].x, 63) : carry;
+                // the first entry of a run of equal hashes in the other sketch speaks for the run
+                const bool leader = found[u] && !(j > 0 && hprev == hb);
+                int hnext = __shfl_down(hb, 1);
+                if (lane == 63 && leader && j + 1 < nB) hnext = (int)brow[j + 1].x;
+                bool grp = false;
+                if (leader) grp = (l[u] + 1 < nA && ah[l[u] + 1] == hb) || (j + 1 < nB && hnext == hb);
+                const bool reg = leader && !grp;
+                const unsigned long long balr = __ballot(reg), balg = __ballot(grp);
+                if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) bad = true;
+                else {
+                  if (reg) {
+                    const int idx = nj + oj_mbcnt(balr);
+                    jp2[idx] = (int)e[u].y;
+                    jij[idx] = (uint32_t)l[u] | ((uint32_t)j << 16);
+                  }
+                  if (grp) {
+                    const int idx = ng + oj_mbcnt(balg);
+                    gi[idx * 6 + 0] = l[u]; gi[idx * 6 + 1] = j;
+                  }
+                  nj += __popcll(balr);
+                  ng += __popcll(balg);
                 }
-                if (grp) {
-                  const int idx = ng + oj_mbcnt(balg);
-                  gi[idx * 6 + 0] = lo[u]; gi[idx * 6 + 1] = j;
-                }
-                nj += __popcll(balr);
-                ng += __popcll(balg);
               }
             }
           }
+          carry = __builtin_amdgcn_readlane((int)e[OJ_U - 1].x, 63);
         }
       }
       oj_lds_sync();
@@ -777,10 +789,21 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
         }
         const int jrounds = (nj + 63) >> 6;
         int s1 = 0, s2 = 0;
+        int pan[OJ_U], pbn[OJ_U];   // next OJ_U blocks of positions of either sketch, in flight while the current ones are ranked
+#pragma unroll
+        for (int u = 0; u < OJ_U; u++) {
+          const int i = u * 64 + lane;
+          pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
+          pbn[u] = i < nB ? (int)brow[i].y : INT32_MIN;
+        }
         for (int ib = 0; ib < nA; ib += 64 * OJ_U) {
           int posv[OJ_U];
 #pragma unroll
-          for (int u = 0; u < OJ_U; u++) { const int i = ib + u * 64 + lane; posv[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN; }
+          for (int u = 0; u < OJ_U; u++) {
+            posv[u] = pan[u];
+            const int i = ib + (u + OJ_U) * 64 + lane;
+            pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
+          }
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
             const int i0 = ib + u * 64;
@@ -803,7 +826,11 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
         for (int jb = 0; jb < nB; jb += 64 * OJ_U) {
           int posv[OJ_U];
 #pragma unroll
-          for (int u = 0; u < OJ_U; u++) { const int j = jb + u * 64 + lane; posv[u] = j < nB ? (int)brow[j].y : INT32_MIN; }
+          for (int u = 0; u < OJ_U; u++) {
+            posv[u] = pbn[u];
+            const int j = jb + (u + OJ_U) * 64 + lane;
+            pbn[u] = j < nB ? (int)brow[j].y : INT32_MIN;
+          }
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
             const int j0 = jb + u * 64;
