@@ -461,13 +461,26 @@ constexpr int BS_MINREM = 512;   // remaining k-mers needed to start another 204
 constexpr int BS_ZMAX = 24;
 constexpr int BS_QCAP = 512;     // deferred-candidate queue entries per wave (LDS, 8 bytes each)
 
+// One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
+//   C[b] = A[b] ^ A[b-4]                      b = 33..63
+//   C[b] = A[b] ^ A[b-4] ^ A[b+31]            b = 29..32
+//   C[b] = A[b] ^ A[b-4] ^ C[b+35]            b =  4..28   (A[b+35] ^ A[b+31] is C[b+35])
+//   C[b] = A[b] ^ A[b+35]                     b =  0..3
+// = 43 + 64 = 107 full-rate ops (v_xor_b32 / three-input v_bitop3_b32) instead of the 132 two-input xors of the three
+// shifts done one after the other.
+__device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 #pragma unroll
-  for (int b = 63; b >= 21; b--) P[b] ^= P[b - 21];   // x ^= x << 21
+  for (int b = 63; b >= 21; b--) P[b] ^= P[b - 21];                       // A
+  uint32_t t[4], u[4];
 #pragma unroll
-  for (int b = 0; b <= 28; b++) P[b] ^= P[b + 35];    // x ^= x >>> 35
+  for (int k = 0; k < 4; k++) { t[k] = bs_xor3(P[29 + k], P[25 + k], P[60 + k]); u[k] = P[k] ^ P[k + 35]; }
 #pragma unroll
-  for (int b = 63; b >= 4; b--) P[b] ^= P[b - 4];     // x ^= x << 4
+  for (int b = 63; b >= 33; b--) P[b] ^= P[b - 4];
+#pragma unroll
+  for (int b = 28; b >= 4; b--) P[b] = bs_xor3(P[b], P[b - 4], P[b + 35]);
+#pragma unroll
+  for (int k = 0; k < 4; k++) { P[29 + k] = t[k]; P[k] = u[k]; }
 }
 
 // returns a mask with a 0 bit for every chain that may undercut the slot minimum whose high dword is bhs
