@@ -459,7 +459,7 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
 // as many leading zero magnitude bits as the slot's current minimum (necessary for x <= min: 1 + z more VALU ops).
 constexpr int BS_MINREM = 512;   // remaining k-mers needed to start another 2048-chain bit-sliced row
 constexpr int BS_ZMAX = 24;
-constexpr int BS_QCAP = 512;     // deferred-candidate queue entries per wave (LDS, 8 bytes each)
+constexpr int BS_QCAP = 448;     // deferred-candidate queue entries per wave (LDS, 8 bytes each; 4 workgroups per CU fit at H = 512)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
 //   C[b] = A[b] ^ A[b-4]                      b = 33..63
