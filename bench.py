@@ -31,7 +31,9 @@ from mhap_amd import distributed as mdist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # MinHash instruction ceilings measured on MI355X (profiles/r01_valu_microbench.txt):
 XORSHIFT_CEILING_PER_CHAIN = 4.79e12   # tools/valu_peak.hip: one chain per lane-register pair (2 v_lshlrev_b64 + 6 ops per step)
-XORSHIFT_CEILING_BITSLICED = 1.23e13   # bit-sliced stepping + filter only (MHAP_MINHASH_VARIANT=280: 16.6 ms for 2.04e11 steps)
+VALU_FULL_RATE = 6.5e13               # lane-ops/s of a full-rate 32-bit VALU op chip-wide (v_fma_f32 / v_xor_b32, tools/valu_ops.hip)
+BITSLICED_OPS_PER_32_STEPS = 107 + 15  # 43 v_xor + 64 v_xor/v_bitop3 per step of 32 chains + ~15 ops of candidate filter
+XORSHIFT_CEILING_BITSLICED = 32 * VALU_FULL_RATE / BITSLICED_OPS_PER_32_STEPS   # 1.70e13 steps/s
 
 
 def sketch_bytes_per_read(L, H, S, k2):
@@ -171,9 +173,10 @@ def main():
         xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
         valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
                 "ceiling_steps_per_s": XORSHIFT_CEILING_BITSLICED, "frac_of_ceiling": round(xs_rate / XORSHIFT_CEILING_BITSLICED, 4),
-                "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes, 132 v_xor per 32 chain steps): stepping + "
-                                "candidate filter alone sustain 1.23e13 steps/s on MI355X; the per-chain formulation (2 v_lshlrev_b64 "
-                                "+ 6 ops per step) tops out at 4.79e12 steps/s (tools/valu_peak.hip)",
+                "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes): one step of 32 chains is 107 full-rate ops "
+                                "(43 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32) + ~15 ops of candidate filter; ceiling = 32 x 6.5e13 "
+                                "lane-ops/s / 122 with every issue slot used.  The per-chain formulation (2 v_lshlrev_b64 + 6 ops "
+                                "per step) tops out at 4.79e12 steps/s (tools/valu_peak.hip)",
                 "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4)}
         if kernel_ms_per_step["candidate"] > 0 and st["slot_compares"] > 0:   # stats are per step (the index is cleared every step)
             valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / (kernel_ms_per_step["candidate"] / 1e3), 1)

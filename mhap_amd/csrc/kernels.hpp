@@ -47,7 +47,9 @@ struct SearchParams {
 
 // ---- sketch_kernels.hip ----
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store, int64_t* keys,
-                       int32_t* h32, int k, int k2);
+                       int32_t* h32, int k, int k2, const uint64_t* luts);
+// block-mix tables of the k = 16 / k2 = 12 fast path (768 words: murmur3_x64_128 k1 mix, k2 mix, murmur3_x86_32 pair)
+void build_kmer_hash_luts(uint64_t* out);
 int weight_grid(int num_cus, int64_t nstrands, int max_len, int k);   // persistent workgroups = HBM slabs needed
 void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
                          uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,

@@ -81,7 +81,7 @@ struct mhap_handle {
   // filter
   DevBuf f_keys, f_vals;
   FilterTable ft{};
-  DevBuf score_tbl, jump_tbl;
+  DevBuf score_tbl, jump_tbl, hash_luts;
 
   // index (owned or external)
   bool external = false;
@@ -294,7 +294,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
     time_begin(h, MHAP_K_HASH);
-    launch_hash_kmers(h->stream, dd, nstr, B.max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2);
+    launch_hash_kmers(h->stream, dd, nstr, B.max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2, h->hash_luts.as<uint64_t>());
     time_end(h);
     time_begin(h, MHAP_K_DEDUP);
     launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->slabs.as<uint32_t>(),
@@ -586,6 +586,13 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
       seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
   }
+  {   // block-mix tables of the k-mer hash kernel's k = 16 / k2 = 12 path
+    std::vector<uint64_t> lt(768);
+    build_kmer_hash_luts(lt.data());
+    if (h->hash_luts.ensure(lt.size() * 8) != hipSuccess || hipMemcpy(h->hash_luts.p, lt.data(), lt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      seterr("cannot allocate hash tables"); mhap_destroy(h); return MHAP_E_HIP;
+    }
+  }
   *out = h;
   return MHAP_OK;
 }
@@ -596,7 +603,7 @@ void mhap_destroy(mhap_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
+  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();

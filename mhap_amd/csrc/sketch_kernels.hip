@@ -20,10 +20,56 @@ namespace mhap {
 // window starts of one strand; the chars it needs are decoded once into LDS (packed 2-bit or raw
 // bytes -> ASCII, reverse-complemented on the fly for odd strands).
 // =============================================================================================
+// Fast path for k = 16, k2 = 12 on 2-bit packed strands (reads of pure ACGT): murmur3 mixes every 8-byte block
+// (4 UTF-16 chars) on its own before folding it into the state, so the mixed value of a block is a function of 8 bits of
+// base codes.  Three host-built 256-entry tables (k1-type and k2-type mixes of murmur3_x64_128, the two 4-byte mixes of
+// murmur3_x86_32) replace 8 of the 12 64-bit multiplies and all 12 block multiplies of the 32-bit hash by 7 ds_read_b64.
+constexpr int HASH_SEG = 4096;            // window starts per workgroup on the table path (4 tiles of the generic path's grid)
+constexpr int HASH_LUT_WORDS = 3 * 256;   // uint64 words: [0,256) k1 mix, [256,512) k2 mix, [512,768) murmur32 {lo: chars 0-1, hi: chars 2-3}
+
+void build_kmer_hash_luts(uint64_t* out) {
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  const uint32_t d1 = 0xcc9e2d51U, d2 = 0x1b873593U;
+  const char* acgt = "ACGT";
+  for (int idx = 0; idx < 256; idx++) {
+    uint64_t block = 0;
+    for (int c = 0; c < 4; c++) block |= (uint64_t)(uint8_t)acgt[(idx >> (2 * c)) & 3] << (16 * c);   // UTF-16LE, high bytes 0
+    uint64_t k1 = block * c1; k1 = rotl64(k1, 31); k1 *= c2;
+    uint64_t k2 = block * c2; k2 = rotl64(k2, 33); k2 *= c1;
+    uint32_t a = (uint32_t)block, b = (uint32_t)(block >> 32);
+    a *= d1; a = rotl32(a, 15); a *= d2;
+    b *= d1; b = rotl32(b, 15); b *= d2;
+    out[idx] = k1; out[256 + idx] = k2; out[512 + idx] = (uint64_t)a | ((uint64_t)b << 32);
+  }
+}
+
+// Base codes of strand positions i0 .. i0+15 of a packed read (A=0 C=1 G=2 T=3, position i0+b in bits 2b), i0 a multiple
+// of 16.  Forward strand: a 32-bit window of the packed bytes; reverse complement: the window that ends at base L-1-i0,
+// 2-bit groups reversed, complemented (3 - code = ~code).  Bases outside the read come back as arbitrary codes (callers
+// never hash a window that touches them); the loads stay inside the read's bytes.
+__device__ __forceinline__ uint32_t strand_codes16(const uint8_t* __restrict__ pk, int L, int rcs, int i0) {
+  const int f0 = rcs ? (L - 16 - i0) : i0;          // lowest forward base of the window (may be negative / beyond L)
+  const int q0 = f0 >> 2, nbytes = (L + 3) >> 2;
+  uint64_t w = 0;
+#pragma unroll
+  for (int b = 0; b < 5; b++) {
+    const int q = q0 + b;
+    if (q >= 0 && q < nbytes) w |= (uint64_t)pk[q] << (8 * b);
+  }
+  uint32_t x = (uint32_t)(w >> (2 * (f0 & 3)));
+  if (rcs) {
+    x = __builtin_bswap32(x);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ~x;
+  }
+  return x;
+}
+
 template <int KT, int K2T>
 __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restrict__ descs, const uint8_t* __restrict__ store,
                                                          int64_t* __restrict__ keys, int32_t* __restrict__ h32, int k_rt,
-                                                         int k2_rt) {
+                                                         int k2_rt, const uint64_t* __restrict__ luts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_chars[];
   const int k = KT > 0 ? KT : k_rt, k2 = K2T > 0 ? K2T : k2_rt;
   const int strand = blockIdx.x;
@@ -33,6 +79,50 @@ __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restr
   const int L = rd.length;
   const int nk = L - k + 1, nk2 = L - k2 + 1;
   const int nmax = nk > nk2 ? nk : nk2;
+  int64_t* kout = keys + rd.key_off + (rcs ? rd.key_stride : 0);
+  int32_t* hout = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
+  if (KT == 16 && K2T == 12 && !(rd.flags & MHAP_RD_RAW)) {
+    // ---- table path: LDS = three tables + the segment's base codes, 16 per dword ----
+    const int t0 = blockIdx.y * HASH_SEG;          // this workgroup's segment of window starts
+    if (t0 >= nmax) return;
+    uint64_t* lut = (uint64_t*)lds_chars;
+    uint32_t* codes = lds_chars + 2 * HASH_LUT_WORDS;
+    for (int i = threadIdx.x; i < HASH_LUT_WORDS; i += 256) lut[i] = luts[i];
+    const int ncw = (HASH_SEG + 15 + 15) / 16 + 1;
+    for (int wj = threadIdx.x; wj < ncw; wj += 256) codes[wj] = strand_codes16(store + rd.base_off, L, rcs, t0 + 16 * wj);
+    __syncthreads();
+    {
+      for (int pp = threadIdx.x; pp < HASH_SEG; pp += 256) {
+        const int p = t0 + pp;
+        if (p >= nmax) break;
+        const uint32_t cw = __builtin_amdgcn_alignbit(codes[(pp >> 4) + 1], codes[pp >> 4], (uint32_t)(2 * (pp & 15)));   // 16 bases from p on
+        const uint32_t i0 = cw & 255u, i1 = (cw >> 8) & 255u, i2 = (cw >> 16) & 255u, i3 = cw >> 24;
+        if (p < nk) {
+          uint64_t h1 = 0, h2 = 0;
+          h1 ^= lut[i0];       h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+          h2 ^= lut[256 + i1]; h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+          h1 ^= lut[i2];       h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+          h2 ^= lut[256 + i3]; h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+          h1 ^= 32ULL; h2 ^= 32ULL;
+          h1 += h2; h2 += h1;
+          h1 = fmix64(h1); h2 = fmix64(h2);
+          kout[p] = (int64_t)(h1 + h2);
+        }
+        if (p < nk2) {
+          uint32_t h = 0;
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const uint64_t kk = lut[512 + ((cw >> (8 * q)) & 255u)];
+            h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+            h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+          }
+          h ^= 24u;
+          hout[p] = (int32_t)fmix32(h);
+        }
+      }
+    }
+    return;
+  }
   const int t0 = blockIdx.y * HASH_TILE;
   if (t0 >= nmax) return;
   const int halo = (k > k2 ? k : k2) - 1;
@@ -49,8 +139,6 @@ __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restr
     lds_chars[wj] = d;
   }
   __syncthreads();
-  int64_t* kout = keys + rd.key_off + (rcs ? rd.key_stride : 0);
-  int32_t* hout = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
   for (int pp = threadIdx.x; pp < HASH_TILE; pp += 256) {
     const int p = t0 + pp;
     if (p < nk) kout[p] = (int64_t)murmur128_h1_chars<KT>(lds_chars, pp, k);
@@ -59,7 +147,7 @@ __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restr
 }
 
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store,
-                       int64_t* keys, int32_t* h32, int k, int k2) {
+                       int64_t* keys, int32_t* h32, int k, int k2, const uint64_t* luts) {
   if (nstrands <= 0) return;
   int kmin = k < k2 ? k : k2;
   int nmax = max_len - kmin + 1;
@@ -67,10 +155,14 @@ void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, 
   dim3 grid((unsigned)nstrands, (unsigned)((nmax + HASH_TILE - 1) / HASH_TILE));
   int halo = (k > k2 ? k : k2) - 1;
   size_t lds = (size_t)(((HASH_TILE + halo + 3) / 4 + 2) * 4);
-  if (k == 16 && k2 == 12)
-    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2);
-  else
-    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2);
+  if (k == 16 && k2 == 12) {
+    const size_t lut_lds = (size_t)HASH_LUT_WORDS * 8 + (size_t)((HASH_SEG + 30) / 16 + 2) * 4;
+    if (lut_lds > lds) lds = lut_lds;
+    // packed strands: the workgroups with blockIdx.y < ceil(windows / HASH_SEG) hash one segment each, the others exit
+    // (raw-byte strands of the same launch take the generic path tile by tile, so the grid keeps all tiles)
+    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts);
+  } else
+    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts);
 }
 
 // =============================================================================================
