@@ -47,13 +47,14 @@ struct SearchParams {
 
 // ---- sketch_kernels.hip ----
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store, int64_t* keys,
-                       int32_t* h32, int k, int k2, const uint64_t* luts);
+                       int32_t* h32, int k, int k2, const uint64_t* luts, int only_raw);
 // block-mix tables of the k = 16 / k2 = 12 fast path (768 words: murmur3_x64_128 k1 mix, k2 mix, murmur3_x86_32 pair)
 void build_kmer_hash_luts(uint64_t* out);
 int weight_grid(int num_cus, int64_t nstrands, int max_len, int k);   // persistent workgroups = HBM slabs needed
-void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
+bool kmer_weights_can_fuse(int max_len, int k, int k2);   // hashing of packed strands inside the weight kernel (k = 16, k2 = 12, LDS path)
+void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, int64_t* keys,
                          uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
-                         double repeat_weight, StrandInfo* info);
+                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts);
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
                     int32_t* out_status, int64_t status_stride, const uint64_t* jump);

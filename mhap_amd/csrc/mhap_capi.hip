@@ -276,8 +276,10 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     const int64_t nb = B.r1 - B.r0, nstr = 2 * nb;
     h->h_descs.resize((size_t)nb);
     int64_t key_elems = 0, h2_elems = 0;
+    bool any_raw = false;
     for (int64_t i = 0; i < nb; i++) {
       ReadDesc d = h->st_descs[(size_t)(B.r0 + i)];
+      if ((d.flags & MHAP_RD_RAW) && !(d.flags & MHAP_RD_SKIP)) any_raw = true;
       const int64_t nk = align4(std::max(0, d.length - k + 1)), nk2 = align4(std::max(0, d.length - k2 + 1));
       d.key_off = key_elems; d.key_stride = (int32_t)nk;
       d.h2_off = h2_elems; d.h2_stride = (int32_t)nk2;
@@ -293,12 +295,21 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     const ReadDesc* dd = h->descs.as<ReadDesc>();
     HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
-    time_begin(h, MHAP_K_HASH);
-    launch_hash_kmers(h->stream, dd, nstr, B.max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2, h->hash_luts.as<uint64_t>());
-    time_end(h);
+    // k = 16 / k2 = 12 and every strand on the LDS path: packed strands are hashed inside the weight kernel, the hash kernel
+    // only runs for raw-byte strands (MHAP_FUSED_HASH=0: always the separate hash kernel)
+    const char* fenv = getenv("MHAP_FUSED_HASH");
+    const bool fuse_ok = !(fenv && atoi(fenv) == 0);
+    const bool fused = fuse_ok && kmer_weights_can_fuse(B.max_len, k, k2);
+    if (!fused || any_raw) {
+      time_begin(h, MHAP_K_HASH);
+      launch_hash_kmers(h->stream, dd, nstr, B.max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2,
+                        h->hash_luts.as<uint64_t>(), fused ? 1 : 0);
+      time_end(h);
+    }
     time_begin(h, MHAP_K_DEDUP);
     launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->slabs.as<uint32_t>(),
-                        slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>());
+                        slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused, h->store.as<uint8_t>(),
+                        h->h32.as<int32_t>(), h->hash_luts.as<uint64_t>());
     time_end(h);
     time_begin(h, MHAP_K_MINHASH);
     int per_cu = 8;

@@ -66,16 +66,45 @@ __device__ __forceinline__ uint32_t strand_codes16(const uint8_t* __restrict__ p
   return x;
 }
 
+// 16 base codes from strand position p on, out of a code stream held 16 per dword
+__device__ __forceinline__ uint32_t codes_at(const uint32_t* codes, int p) {
+  return __builtin_amdgcn_alignbit(codes[(p >> 4) + 1], codes[p >> 4], (uint32_t)(2 * (p & 15)));
+}
+// murmur3_x64_128(seed 0).h1 of the 16-mer / murmur3_x86_32(seed 0) of the 12-mer that start the 16 codes cw
+__device__ __forceinline__ uint64_t lut_key16(const uint64_t* lut, uint32_t cw) {
+  uint64_t h1 = 0, h2 = 0;
+  h1 ^= lut[cw & 255u];                 h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+  h2 ^= lut[256 + ((cw >> 8) & 255u)];  h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  h1 ^= lut[(cw >> 16) & 255u];         h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+  h2 ^= lut[256 + (cw >> 24)];          h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  h1 ^= 32ULL; h2 ^= 32ULL;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  return h1 + h2;
+}
+__device__ __forceinline__ uint32_t lut_hash12(const uint64_t* lut, uint32_t cw) {
+  uint32_t h = 0;
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const uint64_t kk = lut[512 + ((cw >> (8 * q)) & 255u)];
+    h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+    h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+  }
+  h ^= 24u;
+  return fmix32(h);
+}
+
 template <int KT, int K2T>
 __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restrict__ descs, const uint8_t* __restrict__ store,
                                                          int64_t* __restrict__ keys, int32_t* __restrict__ h32, int k_rt,
-                                                         int k2_rt, const uint64_t* __restrict__ luts) {
+                                                         int k2_rt, const uint64_t* __restrict__ luts, int only_raw) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_chars[];
   const int k = KT > 0 ? KT : k_rt, k2 = K2T > 0 ? K2T : k2_rt;
   const int strand = blockIdx.x;
   const ReadDesc rd = descs[strand >> 1];
   const int rcs = strand & 1;
   if (strand_skipped(rd, rcs)) return;
+  if (only_raw && !(rd.flags & MHAP_RD_RAW)) return;   // packed strands are hashed inside kmer_weight_kernel<.., true>
   const int L = rd.length;
   const int nk = L - k + 1, nk2 = L - k2 + 1;
   const int nmax = nk > nk2 ? nk : nk2;
@@ -95,30 +124,9 @@ __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restr
       for (int pp = threadIdx.x; pp < HASH_SEG; pp += 256) {
         const int p = t0 + pp;
         if (p >= nmax) break;
-        const uint32_t cw = __builtin_amdgcn_alignbit(codes[(pp >> 4) + 1], codes[pp >> 4], (uint32_t)(2 * (pp & 15)));   // 16 bases from p on
-        const uint32_t i0 = cw & 255u, i1 = (cw >> 8) & 255u, i2 = (cw >> 16) & 255u, i3 = cw >> 24;
-        if (p < nk) {
-          uint64_t h1 = 0, h2 = 0;
-          h1 ^= lut[i0];       h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-          h2 ^= lut[256 + i1]; h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-          h1 ^= lut[i2];       h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-          h2 ^= lut[256 + i3]; h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-          h1 ^= 32ULL; h2 ^= 32ULL;
-          h1 += h2; h2 += h1;
-          h1 = fmix64(h1); h2 = fmix64(h2);
-          kout[p] = (int64_t)(h1 + h2);
-        }
-        if (p < nk2) {
-          uint32_t h = 0;
-#pragma unroll
-          for (int q = 0; q < 3; q++) {
-            const uint64_t kk = lut[512 + ((cw >> (8 * q)) & 255u)];
-            h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
-            h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
-          }
-          h ^= 24u;
-          hout[p] = (int32_t)fmix32(h);
-        }
+        const uint32_t cw = codes_at(codes, pp);
+        if (p < nk) kout[p] = (int64_t)lut_key16(lut, cw);
+        if (p < nk2) hout[p] = (int32_t)lut_hash12(lut, cw);
       }
     }
     return;
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restr
 }
 
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store,
-                       int64_t* keys, int32_t* h32, int k, int k2, const uint64_t* luts) {
+                       int64_t* keys, int32_t* h32, int k, int k2, const uint64_t* luts, int only_raw) {
   if (nstrands <= 0) return;
   int kmin = k < k2 ? k : k2;
   int nmax = max_len - kmin + 1;
@@ -160,9 +168,9 @@ void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, 
     if (lut_lds > lds) lds = lut_lds;
     // packed strands: the workgroups with blockIdx.y < ceil(windows / HASH_SEG) hash one segment each, the others exit
     // (raw-byte strands of the same launch take the generic path tile by tile, so the grid keeps all tiles)
-    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts);
+    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts, only_raw);
   } else
-    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts);
+    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts, only_raw);
 }
 
 // =============================================================================================
@@ -263,22 +271,33 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
 // fetched 8 at a time (one HBM latency per chunk instead of one per k-mer), inserts go straight to ds_cmpst (no
 // read-before-CAS), and the post-barrier pass is ONE ds_read per k-mer: the remembered slot holds the smallest
 // position of that key, so `entry == mine` <=> first occurrence.  Requires nk <= MAXIT*WEIGHT_THREADS, ts <= 32768.
-template <int MAXIT>
+// FUSED (k = 16, k2 = 12, packed strand): the keys are not loaded but hashed here from the strand's base codes in LDS
+// (fz.codes, block-mix tables fz.lut) and written out together with the 32-bit hashes of the ordered sketch, so the
+// separate hash kernel and the 8 B/k-mer key read-back (with its exposed load latency) disappear for such strands.
+struct FusedHash { const uint64_t* lut; const uint32_t* codes; int64_t* kout; int32_t* hout; int nk2; bool on; };
+template <int MAXIT, bool FUSED>
 __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
-                                         unsigned int* s_heavy) {
+                                         unsigned int* s_heavy, const FusedHash& fz) {
   const uint32_t mask = ts - 1;
   for (uint32_t j = threadIdx.x * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   uint32_t st[MAXIT];
-  constexpr int CH = (MAXIT >= 24) ? 8 : 4;   // keys in flight per lane (register budget: two workgroups per CU need <= 64 VGPRs)
+  constexpr int CH = FUSED ? 2 : ((MAXIT >= 24) ? 8 : 4);   // keys in flight per lane (register budget: two workgroups per CU need <= 64 VGPRs)
 #pragma unroll
   for (int c = 0; c < MAXIT; c += CH) {
-    if (c * WEIGHT_THREADS < nk) {
+    if (c * WEIGHT_THREADS < ((FUSED && fz.on) ? fz.nk2 : nk)) {
       int64_t key[CH];
 #pragma unroll
       for (int u = 0; u < CH; u++) {
         const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
-        key[u] = (i < nk) ? kp[i] : 0;
+        if (FUSED && fz.on) {
+          key[u] = 0;
+          if (i < fz.nk2) {
+            const uint32_t cw = codes_at(fz.codes, i);
+            if (i < nk) { key[u] = (int64_t)lut_key16(fz.lut, cw); fz.kout[i] = key[u]; }
+            fz.hout[i] = (int32_t)lut_hash12(fz.lut, cw);
+          }
+        } else key[u] = (i < nk) ? kp[i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < CH; u++) {
@@ -291,7 +310,11 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
           for (;;) {
             const uint32_t old = atomicCAS(&tab[slot], 0u, mine);
             if (old == 0) break;
-            if (((old ^ mine) >> 16) == 0 && kp[(old & 0xFFFFu) - 1u] == key[u]) { atomicMin(&tab[slot], mine); break; }
+            if (((old ^ mine) >> 16) == 0) {   // fingerprint match: compare the full keys (re-hashed when the keys are not in memory yet)
+              const int op = (int)((old & 0xFFFFu) - 1u);
+              const int64_t okey = (FUSED && fz.on) ? (int64_t)lut_key16(fz.lut, codes_at(fz.codes, op)) : kp[op];
+              if (okey == key[u]) { atomicMin(&tab[slot], mine); break; }
+            }
             slot = (slot + 1) & mask;
           }
           st[c + u] = fp | slot;
@@ -299,6 +322,8 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
       }
     }
   }
+  if (FUSED && fz.on)   // the last k2-mers of a strand that fills all MAXIT rounds
+    for (int i = threadIdx.x + MAXIT * WEIGHT_THREADS; i < fz.nk2; i += WEIGHT_THREADS) fz.hout[i] = (int32_t)lut_hash12(fz.lut, codes_at(fz.codes, i));
   __syncthreads();
   bool anydup = false;
 #pragma unroll
@@ -390,15 +415,19 @@ __device__ inline bool weight_strand_lds_part(uint32_t* tab, uint32_t ts, const 
   return true;
 }
 
-template <int MAXIT, int WAVES_PER_SIMD>
+template <int MAXIT, int WAVES_PER_SIMD, bool FUSED>
 __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
-                                                                     const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
+                                                                     int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
                                                                      uint32_t* __restrict__ slabs, int64_t slab_entries, uint32_t lds_entries,
                                                                      unsigned long long* __restrict__ counter, int k,
                                                                      FilterTable ft, double repeat_weight,
-                                                                     StrandInfo* __restrict__ info) {
+                                                                     StrandInfo* __restrict__ info, const uint8_t* __restrict__ store,
+                                                                     int32_t* __restrict__ h32, const uint64_t* __restrict__ luts) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
   uint32_t* svars = lds_tab + lds_entries;   // [0..1] strand index, [2] valid, [3] heavy
+  uint64_t* lut = (uint64_t*)(svars + 4);                       // FUSED: block-mix tables, then the strand's base codes
+  uint32_t* codes = (uint32_t*)(lut + HASH_LUT_WORDS);
+  if (FUSED) for (int i = threadIdx.x; i < HASH_LUT_WORDS; i += WEIGHT_THREADS) lut[i] = luts[i];
   uint32_t* slab = slabs + (size_t)blockIdx.x * (size_t)slab_entries;
   const bool reweigh = (repeat_weight < 0.0) || (ft.enabled && repeat_weight < 1.0);
   for (;;) {
@@ -421,8 +450,19 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
     uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
     uint32_t ts = 64;
     while (3ull * ts < 4ull * (uint32_t)nk) ts <<= 1;          // load factor <= 0.75
-    if (ts <= lds_entries && nk <= MAXIT * WEIGHT_THREADS) weight_strand_lds<MAXIT>(lds_tab, ts, kp, wp, nk, &svars[3]);
-    else {
+    FusedHash fz;
+    fz.lut = lut; fz.codes = codes; fz.on = false; fz.nk2 = rd.length - 12 + 1;
+    fz.kout = keys + rd.key_off + (rcs ? rd.key_stride : 0);
+    fz.hout = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
+    if (ts <= lds_entries && nk <= MAXIT * WEIGHT_THREADS) {
+      if (FUSED && !(rd.flags & MHAP_RD_RAW)) {
+        fz.on = true;
+        const int ncw = (rd.length + 15) / 16 + 2;
+        for (int wj = threadIdx.x; wj < ncw; wj += WEIGHT_THREADS) codes[wj] = strand_codes16(store + rd.base_off, rd.length, rcs, 16 * wj);
+        // (the table-zeroing barrier inside weight_strand_lds orders these stores before the first hash)
+      }
+      weight_strand_lds<MAXIT, FUSED>(lds_tab, ts, kp, wp, nk, &svars[3], fz);
+    } else {
       // long read: hash-partitioned passes through the LDS table; HBM slab only if a partition overflows it
       int plog = 0;
       while (plog < 10 && 3ull * lds_entries < (4ull * (uint32_t)nk * 5 / 4) >> plog) plog++;   // 25 % head-room for uneven partitions
@@ -471,22 +511,37 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
   }
 }
 
-void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
+// fused = the caller guarantees k = 16, k2 = 12 and that every strand of the launch takes the LDS path; packed strands are then
+// hashed here (raw-byte strands must have been hashed by hash_kmers_kernel before).
+bool kmer_weights_can_fuse(int max_len, int k, int k2) { return k == 16 && k2 == 12 && max_len - k + 1 <= WEIGHT_MAXIT * WEIGHT_THREADS; }
+
+void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, int64_t* keys,
                          uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
-                         double repeat_weight, StrandInfo* info) {
+                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts) {
   if (nstrands <= 0) return;
   uint32_t need = 64;
   const uint32_t nkmax = (uint32_t)(max_len - k + 1 > 1 ? max_len - k + 1 : 1);
   while (3ull * need < 4ull * nkmax) need <<= 1;
   const uint32_t lds_entries = need > 32768u ? 32768u : need;           // <= 128 KiB of the CU's 160 KiB LDS
-  const size_t lds = (size_t)lds_entries * 4 + 16;
+  size_t lds = (size_t)lds_entries * 4 + 16;
+  if (fused) lds += (size_t)HASH_LUT_WORDS * 8 + (size_t)((max_len + 15) / 16 + 4) * 4;   // block-mix tables + base codes of one strand
   const int nblocks = weight_grid(num_cus, nstrands, max_len, k);
-  if (lds_entries <= 16384u)   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
-    hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8>), dim3(nblocks), dim3(WEIGHT_THREADS), lds, st, descs, nstrands, keys, wts, slabs,
-                       slab_entries, lds_entries, counter, k, ft, repeat_weight, info);
-  else
-    hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4>), dim3(nblocks), dim3(WEIGHT_THREADS), lds, st, descs, nstrands, keys, wts, slabs,
-                       slab_entries, lds_entries, counter, k, ft, repeat_weight, info);
+  const dim3 g(nblocks), b(WEIGHT_THREADS);
+  if (lds_entries <= 16384u) {   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
+    if (fused)
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, true>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, h32, luts);
+    else
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, false>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, h32, luts);
+  } else {
+    if (fused)
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, true>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, h32, luts);
+    else
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, false>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, h32, luts);
+  }
 }
 
 // number of persistent workgroups (= HBM slabs the caller must provide)

@@ -352,3 +352,22 @@ def test_overlap_join_groups_and_lane_fallback(monkeypatch):
         assert sb["slow_pairs"] == 0 and sb["candidates_compared"] == sa["candidates_compared"]
         print("slow pairs", sa["slow_pairs"], "of", sa["candidates_compared"])
         assert len(a) > 1000
+
+
+def test_fused_and_separate_kmer_hashing_agree(monkeypatch):
+    """k=16/k2=12 packed strands are hashed inside the weight kernel (block-mix tables); raw-byte strands of the same batch
+    and MHAP_FUSED_HASH=0 use hash_kmers_kernel.  All three give the oracle's sketches."""
+    rnd = random.Random(99)
+    seqs = [_rand_seq(rnd, rnd.randrange(20, 9000)) for _ in range(60)]
+    seqs += [_rand_seq(rnd, 4000, "ACGTN"), _rand_seq(rnd, 12303), _rand_seq(rnd, 12304), _rand_seq(rnd, 16), _rand_seq(rnd, 27),
+             "ACGT" * 1000, _rand_seq(rnd, 2500).lower()]
+    fa = FastaData.from_strings(seqs)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=256, min_olap_length=0)
+    _assert_sketch_parity(fa, p)
+    with MinHashSearch(p) as ms:
+        a = ms.sketch(fa)
+    monkeypatch.setenv("MHAP_FUSED_HASH", "0")
+    with MinHashSearch(p) as ms:
+        b = ms.sketch(fa)
+    for key in ("minhash", "ordered", "ordered_size", "status"):
+        assert np.array_equal(a[key], b[key]), key
