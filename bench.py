@@ -167,6 +167,13 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches)}
+        # measured HBM rate of every kernel (PMC bytes per launch x launches / its summed time): which ones are memory-side
+        hbm_by_kernel = {}
+        for kname in mhap_amd.KERNEL_NAMES:
+            tb, _ = pmc_traffic(("overlap_join" if kname == "overlap" else kname) + "_kernel", n_total, L, world)
+            if tb and kt[kname]["ms"] > 0:
+                hbm_by_kernel[kname] = {"GB_per_step": round(tb * kt[kname]["launches"] / K / 1e9, 2),
+                                        "GB_per_s": round(tb * kt[kname]["launches"] / (kt[kname]["ms"] / 1e3) / 1e9, 1)}
         # integer-VALU view of the MinHash kernel (the path is integer min-reduction work, not HBM-bound: SURVEY F12)
         steps_per_read = 2 * (L - k + 1) * H
         mh_s = kernel_ms_per_step["minhash"] / 1e3
@@ -196,6 +203,7 @@ def main():
             "candidates_per_step": int(st["candidates_compared"]),
             "index_elements_per_step": int(st["table_elements"]),
             "overlap_slow_pairs_per_step": int(st["slow_pairs"]),
+            "hbm_traffic_by_kernel": hbm_by_kernel,
             "roofline": roofline, "valu": valu,
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),
