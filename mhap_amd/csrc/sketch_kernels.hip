@@ -975,6 +975,7 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
 // radix select (11/11/10 bits of hash, then 11/11/10 bits of pos) narrows the S smallest keys down to
 // at most CAP candidates, which are then bitonic-sorted in LDS.
 // =============================================================================================
+constexpr uint32_t ORD_BUCKET_MAX = 32;   // keys per first-level bin the bucket path sorts by insertion
 __device__ inline uint64_t okey(int32_t h, int pos) { return ((uint64_t)((uint32_t)h ^ 0x80000000u) << 32) | (uint32_t)pos; }
 
 __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
@@ -986,6 +987,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint32_t* part = hist + ORD_BINS;                       // ORD_THREADS partial sums
   uint32_t* svars = part + ORD_THREADS;                   // 4 scalars (kept in the dynamic region: 16-B aligned base)
   uint64_t* buf = (uint64_t*)(svars + 4);                 // cap keys
+  uint16_t* bstart = (uint16_t*)(buf + cap);              // bucket path: first buffer slot of every first-level bin
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
   const int64_t strand = blockIdx.x;
   if (strand >= nstrands) return;
@@ -1003,6 +1005,9 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   if (K <= 0) return;
 
   uint64_t bound = ~0ULL;  // select all keys <= bound
+  bool buckets = false;    // the first-level histogram already is a bucket sort (see below)
+  uint32_t bk_bin = 0, bk_total = 0;
+  if (threadIdx.x == 0) s_fill = 0;
   if (n > cap) {
     const int shifts[6] = {53, 42, 32, 21, 10, 0};
     const int widths[6] = {11, 11, 10, 11, 11, 10};
@@ -1024,16 +1029,16 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       const int per = ORD_BINS / ORD_THREADS;
       uint32_t loc = 0;
       for (int j = 0; j < per; j++) loc += hist[threadIdx.x * per + j];
-      part[threadIdx.x] = loc;
-      __syncthreads();
-      // exclusive scan of part[] (Hillis-Steele, ORD_THREADS elements)
-      for (int off = 1; off < ORD_THREADS; off <<= 1) {
-        uint32_t v = (threadIdx.x >= (unsigned)off) ? part[threadIdx.x - off] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+      // inclusive scan of the per-thread sums: shuffles inside a wavefront, the wavefront totals through LDS
+      uint32_t incl = loc;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if ((threadIdx.x & 63) >= (unsigned)off) incl += v;
       }
-      const uint32_t incl = part[threadIdx.x];
+      if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      for (unsigned w = 0; w < (threadIdx.x >> 6); w++) incl += part[w];
       const uint32_t excl = incl - loc;
       if (target >= excl && target < incl) {
         uint32_t run = excl;
@@ -1050,11 +1055,57 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       prefix |= (uint64_t)bin << sh;
       prefmask |= (uint64_t)(nb - 1) << sh;
       bound = prefix | (sh > 0 ? ((1ULL << sh) - 1) : 0ULL);
-      if (below + bincnt <= (uint32_t)cap) break;   // candidates (<= bound) fit the sort buffer
+      if (below + bincnt <= (uint32_t)cap) {   // candidates (<= bound) fit the sort buffer
+        if (lv == 0) {
+          // Hashes are close to uniform, so the 2048 first-level bins hold a handful of keys each: give every bin up to the
+          // cut its own slice of the buffer (exclusive prefix of the counts) and sort inside the bins only — O(n) instead
+          // of the bitonic network.  Skewed inputs (a bin with more than ORD_BUCKET_MAX keys) keep the network.
+          uint32_t run = excl, mx = 0;
+          for (int j = 0; j < per; j++) {
+            const uint32_t b = threadIdx.x * per + j, c = hist[b];
+            if (b <= bin) { bstart[b] = (uint16_t)run; mx = c > mx ? c : mx; }
+            run += c;
+          }
+          if (mx > ORD_BUCKET_MAX) atomicMax(&s_fill, mx);
+          __syncthreads();
+          buckets = s_fill == 0;
+          bk_bin = bin; bk_total = below + bincnt;
+          __syncthreads();
+          if (threadIdx.x == 0) s_fill = 0;
+        }
+        break;
+      }
     }
   }
+  if (buckets) {
+    for (uint32_t b = threadIdx.x; b <= bk_bin; b += ORD_THREADS) hist[b] = 0;   // becomes the bins' fill counters
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
+      const uint64_t key = okey(hp[i], i);
+      const uint32_t b = (uint32_t)(key >> 53);
+      if (b <= bk_bin) buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b <= bk_bin; b += ORD_THREADS) {   // insertion sort inside a bin (a handful of keys)
+      const uint32_t s0 = bstart[b], c = hist[b];
+      for (uint32_t a = 1; a < c; a++) {
+        const uint64_t key = buf[s0 + a];
+        int q = (int)a - 1;
+        while (q >= 0 && buf[s0 + q] > key) { buf[s0 + q + 1] = buf[s0 + q]; q--; }
+        buf[s0 + q + 1] = key;
+      }
+    }
+    __syncthreads();
+    (void)bk_total;
+    int32_t* orow = out_rows + strand * out_stride;
+    for (int j = threadIdx.x; j < K; j += ORD_THREADS) {
+      const uint64_t key = buf[j];
+      orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+      orow[2 * j + 1] = (int32_t)(uint32_t)key;
+    }
+    return;
+  }
   // compact candidates into LDS, pad, sort
-  if (threadIdx.x == 0) s_fill = 0;
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
     const uint64_t key = okey(hp[i], i);
@@ -1086,7 +1137,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   }
 }
 
-size_t ordered_lds_bytes(int cap) { return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8; }
+size_t ordered_lds_bytes(int cap) { return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)ORD_BINS * 2; }
 
 // A read whose forward sketch throws ZeroNGramsFoundException is dropped entirely
 // (J/impl/SequenceSketchStreamer.java:123-156,235-238): propagate the forward status to the rc entry.
