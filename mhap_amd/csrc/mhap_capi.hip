@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <string>
@@ -12,6 +13,8 @@
 #include <vector>
 
 #include "../../include/mhap_hip.h"
+static double hp_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+#define HPROF(tag) do { if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[host] %-28s %.3f ms\n", tag, hp_now()); } while (0)
 #include "kernels.hpp"
 #include "overlap_lane.hpp"
 
@@ -45,9 +48,9 @@ struct TimedLaunch { hipEvent_t a, b; int kind; };
 
 inline int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 
-void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t)>& fn) {
+void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int64_t)>& fn, int64_t grain = 16384) {
   if (n <= 0) return;
-  nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n));
+  nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(nthreads, n / grain + 1));   // spawning a thread costs more than `grain` cheap items
   if (nthreads == 1) { fn(0, n); return; }
   std::vector<std::thread> th;
   int64_t chunk = (n + nthreads - 1) / nthreads;
@@ -168,7 +171,7 @@ int build_score_table(mhap_handle* h) {
         double d = -1.0 / (double)k2 * std::log(2.0 * j / (1.0 + j));
         tbl[(size_t)score_index((int)it, (int)kk)] = std::exp(-d);
       }
-  });
+  }, 8);
   HIPCHK(h, h->score_tbl.ensure((size_t)n * 8));
   HIPCHK(h, hipMemcpy(h->score_tbl.p, tbl.data(), (size_t)n * 8, hipMemcpyHostToDevice));
   return MHAP_OK;
@@ -195,7 +198,7 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
       for (int j = 0; j < L; j++) if (code_of(s[j]) < 0) { raw = 1; break; }
       israw[(size_t)i] = raw;
     }
-  });
+  }, 64);
   int64_t store_bytes = 0;
   for (int64_t i = 0; i < n; i++) {
     ReadDesc& d = h->st_descs[(size_t)i];
@@ -220,7 +223,7 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
       else
         for (int j = 0; j < d.length; j++) dst[j >> 2] |= (uint8_t)(code_of(s[j]) << (2 * (j & 3)));
     }
-  });
+  }, 64);
   HIPCHK(h, h->store.ensure(h->h_store.size()));
   HIPCHK(h, hipMemcpyAsync(h->store.p, h->h_store.data(), h->h_store.size(), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -406,6 +409,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     const size_t bytes = (size_t)sp.H * (size_t)cap * 8;
     HIPCHK(h, h->inv_table.ensure(bytes));
     HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
+    HPROF("index build launch");
     time_begin(h, MHAP_K_INDEX_BUILD);
     launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, sp.H, h->inv_table.as<unsigned long long>(), cmask);
     time_end(h);
@@ -520,6 +524,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     HIPCHK(h, hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
     int rc = sync_stream(h);
     if (rc != MHAP_OK) return rc;
+    HPROF("overlap done");
     const unsigned long long nrec = counts[1];
     h->stats.candidates_compared += (int64_t)counts[2];
     if (nrec == 0) continue;
@@ -540,6 +545,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         r.pad = 0;
       }
     });
+    HPROF("records converted");
     h->stats.matches_found += (int64_t)nrec;
     if (sink) { if (sink(h->out_recs.data(), (int64_t)nrec, user) != 0) return fail(h, MHAP_E_STATE, "record sink aborted the search"); }
   }
@@ -680,13 +686,17 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
 
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
+  HPROF("finish_add begin");
   h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
   for (int64_t i = 0; i < n; i++) {
     h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
     h->fwd[(size_t)(first + 2 * i)] = 1; h->fwd[(size_t)(first + 2 * i + 1)] = 0;
   }
+  HPROF("ids built");
   HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)(2 * n) * 8, hipMemcpyHostToDevice));
+  HPROF("ids h2d");
   int rc = mirror_meta(h, h->d_meta, first, 2 * n);
+  HPROF("meta mirrored");
   if (rc != MHAP_OK) return rc;
   h->n_entries = first + 2 * n;
   h->stats.strands_indexed = 0;
@@ -843,6 +853,7 @@ int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_
 }
 
 static int self_search(mhap_handle* h, int64_t q_first, int64_t q_count, int64_t shard, int64_t nshards, mhap_record_sink sink, void* user) {
+  HPROF("self_search begin");
   (void)hipSetDevice(h->device);
   if (q_first < 0 || q_first > h->n_entries) return fail(h, MHAP_E_INVALID, "query range outside the index");
   if (nshards < 1 || shard < 0 || shard >= nshards) return fail(h, MHAP_E_INVALID, "bad shard");
@@ -860,7 +871,10 @@ static int self_search(mhap_handle* h, int64_t q_first, int64_t q_count, int64_t
   // tile skipping needs: ids sorted with entry order, every entry "long" (minStore == 0 -> only m.id < q.id survives)
   const bool tri = mono && h->P.min_store_length == 0 && !getenv("MHAP_NO_TRIANGULAR");
   QuerySide qs{h->d_minhash, h->Hrow, h->d_ordered, 2LL * h->P.ordered_sketch_size, h->d_meta, h->d_ids.as<int64_t>(), h->ids.data(), h->seqlen.data()};
-  return search_core(h, qs, ql, true, tri, sink, user);
+  HPROF("search_core begin");
+  const int rcs = search_core(h, qs, ql, true, tri, sink, user);
+  HPROF("search_core end");
+  return rcs;
 }
 
 int mhap_find_matches_self(mhap_handle* h, int64_t q_first, int64_t q_count, mhap_record_sink sink, void* user) {
