@@ -14,6 +14,7 @@ all-gathered with RCCL over xGMI; every rank searches its round-robin query shar
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -131,17 +132,28 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ms.stats()
     kt = ms.kernel_times()
+    # output fingerprint of the last step (outside the timed region): SHA-256 of the sorted record lines on one GPU, and an
+    # order- and shard-independent checksum (sum of the first 8 digest bytes of every line, mod 2^64) that is comparable across N
+    lines = sorted(mhap_amd.records_to_lines(recs))
+    sha = hashlib.sha256("\n".join(lines).encode()).hexdigest() if world == 1 else None
+    csum = 0
+    for ln in lines:
+        csum = (csum + int.from_bytes(hashlib.sha256(ln.encode()).digest()[:8], "little")) & ((1 << 64) - 1)
 
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     tot_rec = torch.tensor([nrec], dtype=torch.int64, device=rdev)
+    csum_t = torch.tensor([csum & 0xFFFF, (csum >> 16) & 0xFFFF, (csum >> 32) & 0xFFFF, csum >> 48], dtype=torch.int64, device=rdev)   # 16-bit limbs
     kms = torch.tensor([kt[kname]["ms"] for kname in mhap_amd.KERNEL_NAMES], dtype=torch.float64, device=rdev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_rec, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+        dist.all_reduce(csum_t, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     total_records = int(tot_rec.item())
+    limbs = [int(v) for v in csum_t.tolist()]
+    records_checksum = (limbs[0] + (limbs[1] << 16) + (limbs[2] << 32) + (limbs[3] << 48)) & ((1 << 64) - 1)
     sec_per_step = elapsed / max(args.steps, 1)
 
     if rank == 0:
@@ -203,6 +215,7 @@ def main():
             "candidates_per_step": int(st["candidates_compared"]),
             "index_elements_per_step": int(st["table_elements"]),
             "overlap_slow_pairs_per_step": int(st["slow_pairs"]),
+            "records_sha256_sorted_lines": sha, "records_checksum": "%016x" % records_checksum,
             "hbm_traffic_by_kernel": hbm_by_kernel,
             "roofline": roofline, "valu": valu,
             "input_gen_s": round(t_gen, 2),

@@ -129,7 +129,7 @@ def test_cli_filter_file_and_presets(tmp_path):
 
 def test_bench_two_ranks_on_one_gpu_matches_one_rank():
     """Functional check of bench.py's N>1 path (round-robin shards, table gather in global read order, sharded
-    queries) with 2 gloo ranks sharing this GPU: the record count must equal the single-rank run's."""
+    queries) with 2 gloo ranks sharing this GPU: record count and record checksum must equal the single-rank run's."""
     import sys
     args = ["--reads", "3000", "--length", "3000", "--steps", "1", "--warmup", "0", "--error-rate", "0.05", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900)
@@ -143,3 +143,5 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank():
     r2 = json.loads([l for l in two.stdout.strip().split("\n") if l.startswith("{")][-1])
     assert r2["n_gpus"] == 2 and r1["n_gpus"] == 1
     assert r2["records_per_step"] == r1["records_per_step"] and r1["records_per_step"] > 1000
+    # order- and shard-independent fingerprint of the record lines: the sharded run emits exactly the single-rank records
+    assert r2["records_checksum"] == r1["records_checksum"] and r1["records_sha256_sorted_lines"]
