@@ -16,7 +16,7 @@ constexpr int CAND_KS = 32;          // slots staged per LDS chunk
 constexpr int OVL_THREADS = 128;
 constexpr int INV_CT = 4096;         // LDS hit-count table entries per query (inverted-index path)     // lanes per second-stage workgroup
 
-struct StrandInfo { int32_t valid; int32_t heavy; };
+struct StrandInfo { int32_t valid; int32_t heavy; };   // heavy: 1 = some weight > 1, 2 = all weights 1 and wts[] not written
 
 // Host-built FrequencyCounts table (open addressing; vals[slot]==0.0 marks empty; vals = scaledIdf).
 struct FilterTable {

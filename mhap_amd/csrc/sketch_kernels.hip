@@ -277,7 +277,7 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
 struct FusedHash { const uint64_t* lut; const uint32_t* codes; int64_t* kout; int32_t* hout; int nk2; bool on; };
 template <int MAXIT, bool FUSED>
 __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
-                                         unsigned int* s_heavy, const FusedHash& fz) {
+                                         unsigned int* s_heavy, const FusedHash& fz, bool may_skip) {
   const uint32_t mask = ts - 1;
   for (uint32_t j = threadIdx.x * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
   __syncthreads();
@@ -325,6 +325,8 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   if (FUSED && fz.on)   // the last k2-mers of a strand that fills all MAXIT rounds
     for (int i = threadIdx.x + MAXIT * WEIGHT_THREADS; i < fz.nk2; i += WEIGHT_THREADS) fz.hout[i] = (int32_t)lut_hash12(fz.lut, codes_at(fz.codes, i));
   __syncthreads();
+  // a strand without a repeated k-mer (nearly all of them) has weight 1 everywhere: when the caller allows it, that is
+  // reported through *s_heavy = 2 and the weight array is not written at all (the MinHash kernel then does not read it)
   bool anydup = false;
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
@@ -334,11 +336,27 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
       const uint32_t mine = (st[it] & 0xFFFF0000u) | (uint32_t)(i + 1);
       uint32_t w = 1u;
       if (e != mine) { w = DUP_MARK | ((e & 0xFFFFu) - 1u); anydup = true; }
-      wp[i] = w;
+      if (!may_skip) wp[i] = w;
     }
   }
   if (anydup) atomicOr(s_heavy, 1u);
   __syncthreads();
+  if (may_skip) {
+    if (*(volatile unsigned int*)s_heavy == 0u) {
+      __syncthreads();
+      if (threadIdx.x == 0) *s_heavy = 2u;
+      return;
+    }
+#pragma unroll
+    for (int it = 0; it < MAXIT; it++) {
+      const int i = threadIdx.x + it * WEIGHT_THREADS;
+      if (i < nk) {
+        const uint32_t e = tab[st[it] & 0xFFFFu];
+        const uint32_t mine = (st[it] & 0xFFFF0000u) | (uint32_t)(i + 1);
+        wp[i] = (e != mine) ? (DUP_MARK | ((e & 0xFFFFu) - 1u)) : 1u;
+      }
+    }
+  }
   if (*(volatile unsigned int*)s_heavy) {
     __threadfence();
     __syncthreads();
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
         for (int wj = threadIdx.x; wj < ncw; wj += WEIGHT_THREADS) codes[wj] = strand_codes16(store + rd.base_off, rd.length, rcs, 16 * wj);
         // (the table-zeroing barrier inside weight_strand_lds orders these stores before the first hash)
       }
-      weight_strand_lds<MAXIT, FUSED>(lds_tab, ts, kp, wp, nk, &svars[3], fz);
+      weight_strand_lds<MAXIT, FUSED>(lds_tab, ts, kp, wp, nk, &svars[3], fz, !reweigh);
     } else {
       // long read: hash-partitioned passes through the LDS table; HBM slab only if a partition overflows it
       int plog = 0;
@@ -779,6 +797,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     }
     const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
     const uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
+    const bool uni = si.heavy == 2;   // every k-mer has weight 1 and the weight array was not written (kmer_weight_kernel)
     for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -798,7 +817,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           for (int j = 0; j < 32; j++) {
             const int i = base + j * 64 + lane;
             uint64_t key = 0;
-            if (i < nk && wp[i] == 1u) { key = (uint64_t)kp[i]; ACT |= 1u << j; }
+            if (i < nk && (uni || wp[i] == 1u)) { key = (uint64_t)kp[i]; ACT |= 1u << j; }
             P[j] = (uint32_t)key;
             P[32 + j] = (uint32_t)(key >> 32);
             if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 loads in flight at a time
@@ -845,7 +864,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
         pv[u] = i;
         act[u] = false;
         x[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
-        if (i < nk && wp[i] == 1u) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
+        if (i < nk && (uni || wp[i] == 1u)) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
       }
       if (!__any(anyact)) continue;
       int32_t bh_next = besthi[1];
@@ -867,7 +886,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
       }
     }
     // ---- pass 2: k-mers with weight > 1 (repeats / tf-idf), one per lane, w steps per slot ----
-    if (si.heavy) {
+    if (si.heavy == 1) {
       for (int base = 0; base < nk; base += 64) {
         const int i = base + lane;
         uint32_t wt = (i < nk) ? wp[i] : 0u;
