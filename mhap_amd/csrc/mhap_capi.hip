@@ -99,7 +99,8 @@ struct mhap_handle {
 
   // sketch scratch
   DevBuf store, descs, keys, wts, h32, info, slabs, counters;
-  std::vector<uint8_t> h_store;
+  uint8_t* pin_store = nullptr;   // pinned host staging buffer of stage_reads
+  size_t pin_cap = 0;
   std::vector<ReadDesc> h_descs;
   std::vector<ReadDesc> st_descs;   // staged reads (base_off/length/flags); packed bases resident in `store`
   std::vector<int64_t> st_ids;
@@ -185,6 +186,11 @@ inline int code_of(char c) {
 // Staging: pack reads (2 bits/base; raw bytes for reads with non-ACGT chars) and upload them once.
 // After staging the packed reads are resident in HBM; sketch_staged() only launches kernels.
 // ------------------------------------------------------------------------------------------------
+// 2-bit code of an upper-case base without a table: (c >> 1) & 3 maps A,C,G,T to 0,1,3,2; x ^ (x >> 1) turns that into
+// 0,1,2,3.  A char is a base iff the code maps back to it.  Both loops below are branch-free so that they vectorise.
+static inline uint32_t base_code(uint8_t c) { const uint32_t x = (c >> 1) & 3u; return x ^ (x >> 1); }
+static inline bool is_base(uint8_t c) { return ((0x54474341u >> (8 * base_code(c))) & 0xFFu) == c; }
+
 int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, bool fwd_only) {
   const int nthreads = host_threads();
   h->st_descs.resize((size_t)n);
@@ -192,13 +198,13 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
   std::vector<uint8_t> israw((size_t)n);
   parallel_for(n, nthreads, [&](int64_t lo, int64_t hi) {
     for (int64_t i = lo; i < hi; i++) {
-      const char* s = bases + offsets[i];
+      const uint8_t* s = (const uint8_t*)bases + offsets[i];
       const int L = lengths[i];
-      uint8_t raw = 0;
-      for (int j = 0; j < L; j++) if (code_of(s[j]) < 0) { raw = 1; break; }
-      israw[(size_t)i] = raw;
+      uint32_t bad = 0;
+      for (int j = 0; j < L; j++) bad |= is_base(s[j]) ? 0u : 1u;
+      israw[(size_t)i] = (uint8_t)bad;
     }
-  }, 64);
+  }, 256);
   int64_t store_bytes = 0;
   for (int64_t i = 0; i < n; i++) {
     ReadDesc& d = h->st_descs[(size_t)i];
@@ -212,23 +218,42 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
     d.key_off = d.h2_off = 0; d.key_stride = d.h2_stride = 0;
     if (!(d.flags & MHAP_RD_SKIP)) store_bytes += (d.flags & MHAP_RD_RAW) ? align4(L) : align4((L + 3) / 4);
   }
-  h->h_store.assign((size_t)std::max<int64_t>(store_bytes, 4), 0);
+  // pinned staging buffer (kept across calls): no zero-fill pass, and the upload runs at PCIe speed
+  const size_t need = (size_t)std::max<int64_t>(store_bytes, 4);
+  if (h->pin_cap < need) {
+    if (h->pin_store) (void)hipHostFree(h->pin_store);
+    h->pin_store = nullptr; h->pin_cap = 0;
+    HIPCHK(h, hipHostMalloc((void**)&h->pin_store, need + need / 8, hipHostMallocDefault));
+    h->pin_cap = need + need / 8;
+  }
+  uint8_t* hs = h->pin_store;
   parallel_for(n, nthreads, [&](int64_t lo, int64_t hi) {
     for (int64_t i = lo; i < hi; i++) {
       const ReadDesc& d = h->st_descs[(size_t)i];
       if (d.flags & MHAP_RD_SKIP) continue;
-      const char* s = bases + offsets[i];
-      uint8_t* dst = h->h_store.data() + d.base_off;
-      if (d.flags & MHAP_RD_RAW) memcpy(dst, s, (size_t)d.length);
-      else
-        for (int j = 0; j < d.length; j++) dst[j >> 2] |= (uint8_t)(code_of(s[j]) << (2 * (j & 3)));
+      const uint8_t* s = (const uint8_t*)bases + offsets[i];
+      uint8_t* dst = hs + d.base_off;
+      const int L = d.length;
+      if (d.flags & MHAP_RD_RAW) {
+        memcpy(dst, s, (size_t)L);
+        for (int j = L; j < (int)align4(L); j++) dst[j] = 0;
+      } else {
+        const int full = L >> 2;
+        for (int q = 0; q < full; q++)
+          dst[q] = (uint8_t)(base_code(s[4 * q]) | (base_code(s[4 * q + 1]) << 2) | (base_code(s[4 * q + 2]) << 4) | (base_code(s[4 * q + 3]) << 6));
+        const int nb = (int)align4((L + 3) / 4);
+        for (int q = full; q < nb; q++) {
+          uint32_t v = 0;
+          for (int j = 4 * q; j < L && j < 4 * q + 4; j++) v |= base_code(s[j]) << (2 * (j & 3));
+          dst[q] = (uint8_t)v;
+        }
+      }
     }
-  }, 64);
-  HIPCHK(h, h->store.ensure(h->h_store.size()));
-  HIPCHK(h, hipMemcpyAsync(h->store.p, h->h_store.data(), h->h_store.size(), hipMemcpyHostToDevice, h->stream));
+  }, 256);
+  HIPCHK(h, h->store.ensure(need));
+  HIPCHK(h, hipMemcpyAsync(h->store.p, hs, need, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  h->st_bytes = (int64_t)h->h_store.size();
-  std::vector<uint8_t>().swap(h->h_store);
+  h->st_bytes = (int64_t)need;
   return MHAP_OK;
 }
 
@@ -622,8 +647,9 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
+  if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
