@@ -429,7 +429,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   uint32_t cmask = 0;
   if (use_index) {
     uint64_t cap = 1024;
-    while (cap < 2ull * (uint64_t)ne) cap <<= 1;
+    while (cap < 4ull * (uint64_t)ne) cap <<= 1;   // load factor <= 0.25: short probe chains (a wave walks the longest chain of its 64 lanes)
     cmask = (uint32_t)(cap - 1);
     const size_t bytes = (size_t)sp.H * (size_t)cap * 8;
     HIPCHK(h, h->inv_table.ensure(bytes));
