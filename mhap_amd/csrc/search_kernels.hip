@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256) void index_query_kernel(const unsigned long lo
       if ((uint32_t)(w >> 32) != v) continue;
       mine++;                                                              // "table elements processed" (:173)
       const int me = (int)(uint32_t)w - 1;
-      if (!pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) continue;   // id/length rules do not depend on the count
-      // count the hit
+      // count the hit (the id/length rules do not depend on the count: they are applied to the few entries that reach
+      // numMinMatches, below, so that the probe loop's only global load is the table word)
       uint32_t slot = inv_hash((uint32_t)me) & (INV_CT - 1);
       for (int tries = 0; tries < INV_CT; tries++) {
         uint32_t k = *(volatile uint32_t*)&keys[slot];
@@ -276,7 +276,10 @@ __global__ __launch_bounds__(256) void index_query_kernel(const unsigned long lo
 #pragma unroll
   for (int t = 0; t < INV_CT / 256; t++) {
     const int j = threadIdx.x + 256 * t;
-    if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) { mymask |= 1u << t; mycount++; }   // MinHashSearch.java:204
+    if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) {                                    // MinHashSearch.java:204
+      const int me = (int)keys[j] - 1;
+      if (pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1u << t; mycount++; }   // :200-225
+    }
   }
   __syncthreads();            // s_distinct is dead from here on: reuse it as the block's emit counter
   if (threadIdx.x == 0) s_distinct = 0;
