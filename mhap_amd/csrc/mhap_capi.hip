@@ -265,7 +265,8 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
-  int64_t batch_bases = 256LL << 20;
+  int64_t batch_bases = 1LL << 30;   // bases per launch group: 32 B of scratch per base (keys, weights, 32-bit hashes of both strands) = 32 GB of the 288 GB;
+                                     // fewer, larger launches = fewer drain tails of the persistent MinHash waves (a strand takes ~2 ms)
   if (const char* e = getenv("MHAP_BATCH_BASES")) { long long v = atoll(e); if (v > 0) batch_bases = v; }
   // ---- batch plan + worst-case scratch sizes (allocated once) ----
   struct Batch { int64_t r0, r1, key_elems, h2_elems; int max_len; };
