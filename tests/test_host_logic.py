@@ -196,3 +196,78 @@ def test_synthetic_reads_are_deterministic_and_overlap():
     d = mhap_amd.synth_reads(50, 2000, seed=123, error_rate=0.05)
     res = O.run_self(d, H=128, S=512, nthreads=4)
     assert len(res["records"]) > 50
+
+
+def _join_overlap(A, lenA, B, lenB, max_shift=0.2):
+    """numpy restatement of what overlap_join_kernel computes for a pair whose joined hashes are unique in both sketches:
+    everything getOverlapInfo derives from the two sorted sketches is a function of their equal-hash join."""
+    hA, pA, hB, pB = A[:, 0], A[:, 1], B[:, 0], B[:, 1]
+    common, ia, ib = np.intersect1d(hA, hB, return_indices=True)        # sorted by (signed) hash = merge order
+    if any((hA == h).sum() > 1 or (hB == h).sum() > 1 for h in common):
+        return None                                                      # duplicated joined hash: the kernel replays the merge
+    p1, p2 = pA[ia].astype(np.int64), pB[ib].astype(np.int64)
+
+    def stats(shifts):
+        if len(shifts) == 0:
+            return 0, max(lenA, lenB) + 1
+        med = int(np.sort(shifts)[len(shifts) // 2])                      # Utils.quickSelect(k = n / 2)
+        ov = max(min(lenA, lenB - med) - max(0, -med), 10)
+        return med, min(max(lenA, lenB), int(ov * max_shift))
+
+    def one_pass(med, absmax):
+        v1lo, v1hi = max(0, -med - absmax), min(lenA, lenB - med + absmax)
+        v2lo, v2hi = max(0, med - absmax), min(lenB, lenA + med + absmax)
+        d = (p2 - p1) - med
+        return (p1 >= v1lo) & (p1 < v1hi) & (p2 >= v2lo) & (p2 < v2hi) & (d <= absmax) & (d >= -absmax)
+
+    empty = dict(empty=1)
+    keep = one_pass(*stats(np.zeros(0)))
+    if not keep.any():
+        return empty
+    keep = one_pass(*stats((p2 - p1)[keep]))
+    if not keep.any():
+        return empty
+    med, absmax = stats((p2 - p1)[keep])
+    ok = keep & (np.abs((p2 - p1) - med) <= absmax)
+    valid = int(ok.sum())
+    if valid < 3:
+        return empty
+    le1, re1, le2, re2 = p1[ok].min(), p1[ok].max(), p2[ok].min(), p2[ok].max()
+    den = float(valid - 1)
+    a1 = max(0, O.java_round((valid * le1 - re1) / den)); a2 = min(lenA, O.java_round((valid * re1 - le1) / den))
+    b1 = max(0, O.java_round((valid * le2 - re2) / den)); b2 = min(lenB, O.java_round((valid * re2 - le2) / den))
+    inA, inB = (pA >= a1) & (pA <= a2), (pB >= b1) & (pB <= b2)
+    kk = int(min(inA.sum(), inB.sum()))
+    rA, rB = np.cumsum(inA) - inA, np.cumsum(inB) - inB                  # in-window entries ahead of each entry
+    both = inA[ia] & inB[ib]
+    ahead = np.cumsum(both) - both
+    inter = int((both & (rA[ia] + rB[ib] - ahead < kk)).sum())
+    return dict(empty=0, raw=valid, a1=int(a1), a2=int(a2), b1=int(b1), b2=int(b2), inter=inter, k=kk)
+
+
+def test_join_formulation_of_the_second_stage_matches_the_literal_merge():
+    """The wave-per-pair kernel's formulation (equal-hash join + filters + rank arithmetic), restated in numpy, against the
+    oracle's literal getOverlapInfo on overlapping synthetic reads."""
+    fa = mhap_amd.synth_reads(60, 4000, seed=5, error_rate=0.08)
+    sk = []
+    for i in range(len(fa)):
+        s = fa.sequence(i)
+        for strand in (s, O.rc(s)):
+            rc_, od, _ = O.ordered(strand, 12, 400)
+            sk.append((od, len(strand)))
+    checked = nonempty = 0
+    for i in range(0, len(sk), 2):
+        for j in range(len(sk)):
+            if j // 2 == i // 2:
+                continue
+            got = _join_overlap(sk[i][0], sk[i][1], sk[j][0], sk[j][1])
+            if got is None:
+                continue
+            want = O.overlap(sk[i][0], sk[i][1], sk[j][0], sk[j][1])
+            checked += 1
+            if want["empty"]:
+                assert got["empty"] == 1
+                continue
+            nonempty += 1
+            assert got == {k: (int(want[k]) if k != "empty" else 0) for k in got}, (i, j, got, want)
+    assert checked > 5000 and nonempty > 100
