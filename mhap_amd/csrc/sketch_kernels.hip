@@ -1038,9 +1038,16 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       const uint32_t nb = 1u << widths[lv];
       for (uint32_t j = threadIdx.x; j < ORD_BINS; j += ORD_THREADS) hist[j] = 0;
       __syncthreads();
-      for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
-        const uint64_t key = okey(hp[i], i);
-        if ((key & prefmask) == prefix) atomicAdd(&hist[(uint32_t)(key >> sh) & (nb - 1)], 1u);
+      for (int i0 = threadIdx.x; i0 < n; i0 += 8 * ORD_THREADS) {   // eight loads in flight per lane
+        int32_t hv[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hp[i] : 0; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int i = i0 + u * ORD_THREADS;
+          const uint64_t key = okey(hv[u], i);
+          if (i < n && (key & prefmask) == prefix) atomicAdd(&hist[(uint32_t)(key >> sh) & (nb - 1)], 1u);
+        }
       }
       __syncthreads();
       // find the bin holding rank (K-1-below) among keys matching the prefix
@@ -1099,10 +1106,17 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   if (buckets) {
     for (uint32_t b = threadIdx.x; b <= bk_bin; b += ORD_THREADS) hist[b] = 0;   // becomes the bins' fill counters
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
-      const uint64_t key = okey(hp[i], i);
-      const uint32_t b = (uint32_t)(key >> 53);
-      if (b <= bk_bin) buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
+    for (int i0 = threadIdx.x; i0 < n; i0 += 8 * ORD_THREADS) {
+      int32_t hv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hp[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * ORD_THREADS;
+        const uint64_t key = okey(hv[u], i);
+        const uint32_t b = (uint32_t)(key >> 53);
+        if (i < n && b <= bk_bin) buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
+      }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b <= bk_bin; b += ORD_THREADS) {   // insertion sort inside a bin (a handful of keys)
