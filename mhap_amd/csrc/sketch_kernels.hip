@@ -1006,7 +1006,8 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint32_t* part = hist + ORD_BINS;                       // ORD_THREADS partial sums
   uint32_t* svars = part + ORD_THREADS;                   // 4 scalars (kept in the dynamic region: 16-B aligned base)
   uint64_t* buf = (uint64_t*)(svars + 4);                 // cap keys
-  uint16_t* bstart = (uint16_t*)(buf + cap);              // bucket path: first buffer slot of every first-level bin
+  uint16_t* bstart = (uint16_t*)(buf + cap);              // bucket path: first buffer slot of every first-level bin (+1 end marker)
+  uint32_t* stage = (uint32_t*)(bstart + ORD_BINS + 2);   // one-pass path: positions of the keys below the guessed cut
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
   const int64_t strand = blockIdx.x;
   if (strand >= nstrands) return;
@@ -1022,6 +1023,97 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   const int K = S < n ? S : n;   // BottomOverlapSketch.java:548
   if (threadIdx.x == 0) { meta[0] = K; meta[1] = n; meta[2] = rd.length; }
   if (K <= 0) return;
+
+  // ---- one-pass path.  murmur3 hashes are uniform, so the K-th smallest key is close to the K/n quantile of the hash range:
+  // one pass keeps the positions of the keys below a cut placed a few standard deviations above that quantile (and their
+  // first-level histogram); if the guess holds (at least K and at most cap keys kept, no crowded bin) the kept keys are
+  // bucket-sorted straight away, everything else about the strand's other ~85 % of keys is never looked at again.  If
+  // it does not hold (skewed hashes, e.g. low-complexity sequence) the exact multi-level selection below runs instead.
+  if (n > cap) {
+    const double quant = (double)K / (double)n * 1.15 + 0.005;
+    const uint32_t cut_u = quant >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(quant * 4294967296.0);   // on (hash ^ 0x80000000) = unsigned rank order
+    const uint32_t cutbin = cut_u >> 21;
+    for (uint32_t j = threadIdx.x; j < ORD_BINS; j += ORD_THREADS) hist[j] = 0;
+    if (threadIdx.x == 0) { s_fill = 0; s_cnt = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int i0 = threadIdx.x; i0 - (int)threadIdx.x < n; i0 += 8 * ORD_THREADS) {   // wave-uniform trip count: ballots inside
+      int32_t hv[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hp[i] : 0; }
+      unsigned long long bal[8];
+      uint32_t total = 0;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * ORD_THREADS;
+        bal[u] = __ballot(i < n && ((uint32_t)hv[u] ^ 0x80000000u) < cut_u);
+        total += (uint32_t)__popcll(bal[u]);
+      }
+      if (total) {   // one queue reservation per wavefront and group of eight
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_fill, total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if ((bal[u] >> lane) & 1ULL) {
+            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
+            if (idx < (uint32_t)cap) stage[idx] = (uint32_t)(i0 + u * ORD_THREADS);
+            atomicAdd(&hist[((uint32_t)hv[u] ^ 0x80000000u) >> 21], 1u);
+          }
+          base += (uint32_t)__popcll(bal[u]);
+        }
+      }
+    }
+    __syncthreads();
+    const uint32_t m = s_fill;
+    bool ok = m >= (uint32_t)K && m <= (uint32_t)cap;
+    if (ok) {
+      // exclusive prefix over the bins up to the cut: per-lane sums, shuffle scan inside a wavefront, wavefront totals through LDS
+      const int per = ORD_BINS / ORD_THREADS;
+      uint32_t loc = 0, mx = 0;
+      for (int j = 0; j < per; j++) { const uint32_t c = hist[threadIdx.x * per + j]; loc += c; mx = c > mx ? c : mx; }
+      uint32_t incl = loc;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+      if (lane == 63) part[threadIdx.x >> 6] = incl;
+      if (mx > ORD_BUCKET_MAX) atomicMax(&s_cnt, mx);
+      __syncthreads();
+      for (unsigned w = 0; w < (threadIdx.x >> 6); w++) incl += part[w];
+      uint32_t run = incl - loc;
+      for (int j = 0; j < per; j++) { const uint32_t b = threadIdx.x * per + j; bstart[b] = (uint16_t)run; run += hist[b]; }
+      ok = s_cnt == 0;
+      __syncthreads();
+    }
+    if (ok) {
+      for (uint32_t b = threadIdx.x; b <= cutbin; b += ORD_THREADS) hist[b] = 0;   // becomes the bins' fill counters
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < m; t += ORD_THREADS) {
+        const int i = (int)stage[t];
+        const uint64_t key = okey(hp[i], i);
+        const uint32_t b = (uint32_t)(key >> 53);
+        buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
+      }
+      __syncthreads();
+      for (uint32_t b = threadIdx.x; b <= cutbin; b += ORD_THREADS) {   // insertion sort inside a bin (a handful of keys)
+        const uint32_t s0 = bstart[b], c = hist[b];
+        for (uint32_t a = 1; a < c; a++) {
+          const uint64_t key = buf[s0 + a];
+          int q = (int)a - 1;
+          while (q >= 0 && buf[s0 + q] > key) { buf[s0 + q + 1] = buf[s0 + q]; q--; }
+          buf[s0 + q + 1] = key;
+        }
+      }
+      __syncthreads();
+      int32_t* orow = out_rows + strand * out_stride;
+      for (int j = threadIdx.x; j < K; j += ORD_THREADS) {
+        const uint64_t key = buf[j];
+        orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
+        orow[2 * j + 1] = (int32_t)(uint32_t)key;
+      }
+      return;
+    }
+    __syncthreads();
+  }
 
   uint64_t bound = ~0ULL;  // select all keys <= bound
   bool buckets = false;    // the first-level histogram already is a bucket sort (see below)
@@ -1170,7 +1262,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   }
 }
 
-size_t ordered_lds_bytes(int cap) { return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)ORD_BINS * 2; }
+size_t ordered_lds_bytes(int cap) { return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)cap * 4; }
 
 // A read whose forward sketch throws ZeroNGramsFoundException is dropped entirely
 // (J/impl/SequenceSketchStreamer.java:123-156,235-238): propagate the forward status to the rc entry.
