@@ -1029,8 +1029,11 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   // first-level histogram); if the guess holds (at least K and at most cap keys kept, no crowded bin) the kept keys are
   // bucket-sorted straight away, everything else about the strand's other ~85 % of keys is never looked at again.  If
   // it does not hold (skewed hashes, e.g. low-complexity sequence) the exact multi-level selection below runs instead.
-  if (n > cap) {
-    const double quant = (double)K / (double)n * 1.15 + 0.005;
+  // The number of keys below a cut is binomial, sigma < sqrt(expected): aim at K + 7 sigma, but stay 5 sigma under cap.
+  const double ksig = sqrt((double)K), csig = sqrt((double)cap);
+  const double target = fmin((double)K + 7.0 * ksig, (double)cap - 5.0 * csig);
+  if (n > cap && target >= (double)K + 3.0 * ksig) {
+    const double quant = target / (double)n;
     const uint32_t cut_u = quant >= 1.0 ? 0xFFFFFFFFu : (uint32_t)(quant * 4294967296.0);   // on (hash ^ 0x80000000) = unsigned rank order
     const uint32_t cutbin = cut_u >> 21;
     for (uint32_t j = threadIdx.x; j < ORD_BINS; j += ORD_THREADS) hist[j] = 0;
