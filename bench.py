@@ -90,7 +90,8 @@ def main():
     ms.stage(fa)                                  # 2-bit pack on the host + H2D: packed reads now resident in HBM
     t_stage = time.perf_counter() - t_stage
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = world > 1 or bool(os.environ.get("MHAP_BENCH_FORCE_DIST"))   # 1 rank through the N>1 code path (RCCL on one GPU)
+    if force_dist:
         loc_mh = torch.zeros((2 * n_pad, H), dtype=torch.int32, device=dev)
         loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
         loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
@@ -98,7 +99,7 @@ def main():
 
     def step():
         ms.clear()
-        if world == 1:
+        if not force_dist:
             ms.add_staged()
             recs = ms.find_matches()
         else:
