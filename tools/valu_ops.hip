@@ -33,6 +33,8 @@ DEFK(k_bitop3, "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
 DEFK(k_shl, "v_lshlrev_b32 %0, 21, %1")
 DEFK(k_shr, "v_lshrrev_b32 %0, 11, %1")
 DEFK(k_or, "v_or_b32 %0, %0, %1")
+DEFK(k_mullo, "v_mul_lo_u32 %0, %0, %1")
+DEFK(k_mulhi, "v_mul_hi_u32 %0, %0, %1")
 DEFK(k_sdwa, "v_xor_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1")
 #define DEFK64(NAME, ASM)                                                                \
   __global__ __launch_bounds__(256) void NAME(uint32_t* out, int iters) {                 \
@@ -46,6 +48,17 @@ DEFK(k_sdwa, "v_xor_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0
     _Pragma("unroll") for (int j = 0; j < 8; j++) s ^= a[j];                              \
     out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);              \
   }
+__global__ __launch_bounds__(256) void k_mad64(uint32_t* out, int iters) {
+  uint64_t a[8]; uint32_t b[8];
+  _Pragma("unroll") for (int j = 0; j < 8; j++) { a[j] = (threadIdx.x * 2654435761ull + j) * 0x9E3779B97F4A7C15ull; b[j] = threadIdx.x * 40503u + j; }
+  for (int i = 0; i < iters; i++) {
+    _Pragma("unroll") for (int r = 0; r < 8; r++)
+    _Pragma("unroll") for (int j = 0; j < 8; j++) asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(a[j]) : "v"(b[j]), "v"(b[(j + 1) & 7]) : "vcc");
+  }
+  uint64_t s = 0;
+  _Pragma("unroll") for (int j = 0; j < 8; j++) s ^= a[j];
+  out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
 DEFK64(k_shl64, "v_lshlrev_b64 %0, 21, %1")
 DEFK64(k_shr64, "v_lshrrev_b64 %0, 21, %1")
 DEFK64(k_ashr64, "v_ashrrev_i64 %0, 21, %1")
@@ -64,5 +77,6 @@ int main() {
   run("v_perm_b32", k_perm); run("v_bfi_b32", k_bfi); run("v_and_or_b32", k_andor); run("v_xad_u32", k_xad); run("v_or3_b32", k_or3);
   run("v_add3_u32", k_add3); run("v_mul_u32_u24", k_mul24); run("v_alignbit_b32", k_alignbit); run("v_fma_f32", k_fma);
   run("v_min3_i32", k_min3); run("v_lshlrev_b64", k_shl64); run("v_lshrrev_b64", k_shr64); run("v_ashrrev_i64", k_ashr64); run("v_bitop3_b32", k_bitop3); run("v_lshlrev_b32", k_shl); run("v_lshrrev_b32", k_shr); run("v_or_b32", k_or); run("v_cndmask_b32", k_cndmask); run("v_xor_sdwa", k_sdwa);
+  run("v_mul_lo_u32", k_mullo); run("v_mul_hi_u32", k_mulhi); run("v_mad_u64_u32", k_mad64);
   return 0;
 }
