@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
       double score = 0.0;
       int valid = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
       do {
-        if (nj == 0 && ng == 0) break;
+        if (ng == 0 && nj < 3) break;   // computeEdges needs three valid records (:126): fewer joined k-mers can only end EMPTY
         int iA[OJ_R], jB[OJ_R];   // the joined k-mers' entry indices move to registers, their LDS words become `sh`
 #pragma unroll
         for (int r = 0; r < OJ_R; r++) {
