@@ -75,7 +75,7 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
                        const int32_t* qmeta, const SearchParams& sp, const long long* rowstart, long long nblocks_tri, Candidate* cand,
                        unsigned long long* cand_count, unsigned long long cand_cap);
 // Inverted index (one open-addressing table of 2^k (value,entry+1) words per MinHash slot) + per-query lookup.
-void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H,
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H,
                         unsigned long long* table, uint32_t cmask);
 void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_t cmask, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,

@@ -77,6 +77,11 @@ struct mhap_handle {
   int num_cus = 256;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  hipStream_t side_stream = nullptr;      // eager inverted-index build next to the ordered-sketch kernel
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // inverted index state: the table in inv_table covers entries [0, inv_ne) with mask inv_cmask when inv_ready
+  bool inv_ready = false; int64_t inv_ne = 0; uint32_t inv_cmask = 0;
+  bool eager = false; int64_t eager_first = 0; uint32_t eager_cmask = 0;   // set by mhap_index_add_staged around sketch_staged
   std::string err;
   int Hrow = 1;      // minhash row stride (ints)
   int ord_cap = 0;   // ordered-kernel sort capacity
@@ -261,6 +266,12 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
 // Batches run back to back on the handle's stream.  (A two-stream variant that overlapped hash/weight/ordered of
 // batch b+1 with MinHash of batch b was measured at 358 -> 355..365 ms/step: the kernels compete for the same VALU
 // issue slots and LDS, so it was removed.)
+static uint64_t inv_capacity(int64_t ne) {
+  uint64_t cap = 1024;
+  while (cap < 4ull * (uint64_t)ne) cap <<= 1;   // load factor <= 0.25: short probe chains (a wave walks the longest chain of its 64 lanes)
+  return cap;
+}
+
 int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
@@ -347,10 +358,21 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(), k, k2, H, ctr + 1,
                    mh_rows, mh_stride, meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>());
     time_end(h);
+    launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
+    if (h->eager) {
+      // the postings of this launch group go into the inverted index on a second stream while the ordered-sketch kernel runs
+      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+      HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+      time_begin(h, MHAP_K_INDEX_BUILD, h->side_stream);
+      launch_index_build(h->side_stream, d_minhash - h->eager_first * mh_stride, mh_stride, d_meta - h->eager_first * META_W,
+                         (int)(h->eager_first + 2 * B.r0), (int)nstr, H, h->inv_table.as<unsigned long long>(), h->eager_cmask);
+      time_end(h, h->side_stream);
+      HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
+    }
     time_begin(h, MHAP_K_ORDERED);
     launch_ordered(h->stream, dd, nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
     time_end(h);
-    launch_fix_status(h->stream, meta_rows, nb);
+    if (h->eager) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     HIPCHK(h, hipGetLastError());
     int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
@@ -429,17 +451,19 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const bool use_index = !(cmode && strcmp(cmode, "bruteforce") == 0);
   uint32_t cmask = 0;
   if (use_index) {
-    uint64_t cap = 1024;
-    while (cap < 4ull * (uint64_t)ne) cap <<= 1;   // load factor <= 0.25: short probe chains (a wave walks the longest chain of its 64 lanes)
+    const uint64_t cap = inv_capacity(ne);
     cmask = (uint32_t)(cap - 1);
-    const size_t bytes = (size_t)sp.H * (size_t)cap * 8;
-    HIPCHK(h, h->inv_table.ensure(bytes));
-    HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
-    HPROF("index build launch");
-    time_begin(h, MHAP_K_INDEX_BUILD);
-    launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, sp.H, h->inv_table.as<unsigned long long>(), cmask);
-    time_end(h);
-    HIPCHK(h, hipGetLastError());
+    if (!(h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask)) {   // not built yet for these entries
+      const size_t bytes = (size_t)sp.H * (size_t)cap * 8;
+      HIPCHK(h, h->inv_table.ensure(bytes));
+      HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
+      HPROF("index build launch");
+      time_begin(h, MHAP_K_INDEX_BUILD);
+      launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, sp.H, h->inv_table.as<unsigned long long>(), cmask);
+      time_end(h);
+      HIPCHK(h, hipGetLastError());
+      h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
+    }
   }
 
   for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
@@ -615,6 +639,8 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = std::max(1, prop.multiProcessorCount);
   if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { seterr(hipGetErrorString(e)); delete h; return MHAP_E_HIP; }
   h->stream = h->own_stream;
+  if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { seterr("cannot create the side stream"); mhap_destroy(h); return MHAP_E_HIP; }
   h->Hrow = std::max(1, P.num_hashes);
   int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
   h->ord_cap = cap;
@@ -651,6 +677,9 @@ void mhap_destroy(mhap_handle* h) {
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
@@ -714,6 +743,7 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   HPROF("finish_add begin");
+  h->inv_ready = false;   // the entry set changes (mhap_index_add_staged re-validates an eagerly built table afterwards)
   h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
   for (int64_t i = 0; i < n; i++) {
     h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
@@ -750,9 +780,24 @@ int mhap_index_add_staged(mhap_handle* h) {
   if (rc != MHAP_OK) return rc;
   const int64_t first = h->n_entries;
   const int S = h->P.ordered_sketch_size;
+  // a fresh index is filled while its reads are being sketched: the inverted-index inserts of a launch group run on a
+  // second stream next to the group's ordered-sketch kernel (an index that grows by a later add is rebuilt at search time)
+  h->inv_ready = false;
+  const char* cmode = getenv("MHAP_CANDIDATES");
+  if (first == 0 && !(cmode && strcmp(cmode, "bruteforce") == 0) && !getenv("MHAP_NO_EAGER_INDEX")) {
+    const uint64_t cap = inv_capacity(2 * n);
+    const size_t bytes = (size_t)h->P.num_hashes * (size_t)cap * 8;
+    HIPCHK(h, h->inv_table.ensure(bytes));
+    HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->side_stream));
+    h->eager = true; h->eager_first = first; h->eager_cmask = (uint32_t)(cap - 1);
+  }
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
+  const bool built = h->eager && rc == MHAP_OK;
+  h->eager = false;
   if (rc != MHAP_OK) return rc;
-  return finish_add(h, first, h->st_ids.data(), n);
+  rc = finish_add(h, first, h->st_ids.data(), n);
+  if (rc == MHAP_OK && built) { h->inv_ready = true; h->inv_ne = h->n_entries; h->inv_cmask = h->eager_cmask; }
+  return rc;
 }
 
 int mhap_sketch_staged_device(mhap_handle* h, void* d_minhash, void* d_ordered, void* d_meta) {
@@ -810,7 +855,7 @@ int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* i
   HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)m * 8, hipMemcpyHostToDevice));
   rc = mirror_meta(h, h->d_meta, first, m);
   if (rc != MHAP_OK) return rc;
-  h->n_entries = first + m;
+  h->n_entries = first + m; h->inv_ready = false;
   h->stats.strands_indexed += m;
   return MHAP_OK;
 }
@@ -845,7 +890,7 @@ int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids
 
 int mhap_index_clear(mhap_handle* h) {
   if (!h) return MHAP_E_INVALID;
-  h->n_entries = 0; h->external = false;
+  h->n_entries = 0; h->external = false; h->inv_ready = false;
   h->ids.clear(); h->fwd.clear(); h->seqlen.clear(); h->status.clear();
   h->d_minhash = h->own_minhash.as<int32_t>(); h->d_ordered = h->own_ordered.as<int32_t>(); h->d_meta = h->own_meta.as<int32_t>();
   h->stats = mhap_stats{};
@@ -874,7 +919,7 @@ int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_
   HIPCHK(h, h->d_ids.ensure((size_t)std::max<int64_t>(m, 1) * 8));
   if (m > 0) HIPCHK(h, hipMemcpy(h->d_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
   if (m > 0) { int rc = mirror_meta(h, h->d_meta, 0, m); if (rc != MHAP_OK) return rc; }
-  h->n_entries = m;
+  h->n_entries = m; h->inv_ready = false;
   for (int64_t e = 0; e < m; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
   return MHAP_OK;
 }

@@ -186,14 +186,14 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 __device__ inline uint32_t inv_hash(uint32_t v) { return fmix32(v); }
 
 __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta,
-                                                          int ne, int H, unsigned long long* __restrict__ table, uint32_t cmask) {
+                                                          int e0, int ne, int H, unsigned long long* __restrict__ table, uint32_t cmask) {
   // slot-group-major order: a workgroup inserts 32 entries x 8 slots, and consecutive workgroups walk the entries of one
   // group of 8 slots, so only those 8 tables (32 MB at C2) are written at a time — they stay in the memory-side cache
   // instead of every CAS going to a random line of the whole 2.1 GB
   const int tiles = (ne + 31) / 32;
   const int g = (int)(blockIdx.x / (unsigned)tiles), tile = (int)(blockIdx.x % (unsigned)tiles);
-  const int e = tile * 32 + (int)(threadIdx.x >> 3), s = g * 8 + (int)(threadIdx.x & 7);
-  if (e >= ne || s >= H) return;
+  const int e = e0 + tile * 32 + (int)(threadIdx.x >> 3), s = g * 8 + (int)(threadIdx.x & 7);   // entries [e0, e0 + ne) of the tables
+  if (e >= e0 + ne || s >= H) return;
   if (meta[(int64_t)e * META_W + 3] != 0) return;                       // skipped strands are not stored (addSequence never sees them)
   const uint32_t v = (uint32_t)minhash[(int64_t)e * row_stride + s];
   unsigned long long* T = table + (size_t)s * ((size_t)cmask + 1);
@@ -206,11 +206,11 @@ __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restr
   }
 }
 
-void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H,
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H,
                         unsigned long long* table, uint32_t cmask) {
   const int64_t total = (int64_t)ne * H;
   if (total <= 0) return;
-  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)(((ne + 31) / 32) * ((H + 7) / 8))), dim3(256), 0, st, minhash, row_stride, meta, ne, H, table, cmask);
+  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)(((ne + 31) / 32) * ((H + 7) / 8))), dim3(256), 0, st, minhash, row_stride, meta, e0, ne, H, table, cmask);
 }
 
 // One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].  A query whose distinct-hit set outgrows the table is
