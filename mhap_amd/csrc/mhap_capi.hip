@@ -121,6 +121,7 @@ struct mhap_handle {
 
   // timing
   std::vector<TimedLaunch> pending;
+  std::vector<TimedLaunch> pending_side;   // launches on side_stream: collected once the main stream has joined it
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
   mhap_kernel_times ktimes{};
   mhap_stats stats{};
@@ -367,12 +368,12 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       launch_index_build(h->side_stream, d_minhash - h->eager_first * mh_stride, mh_stride, d_meta - h->eager_first * META_W,
                          (int)(h->eager_first + 2 * B.r0), (int)nstr, H, h->inv_table.as<unsigned long long>(), h->eager_cmask);
       time_end(h, h->side_stream);
+      h->pending_side.push_back(h->pending.back()); h->pending.pop_back();
       HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
     }
     time_begin(h, MHAP_K_ORDERED);
     launch_ordered(h->stream, dd, nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
     time_end(h);
-    if (h->eager) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
     HIPCHK(h, hipGetLastError());
     int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
@@ -793,10 +794,18 @@ int mhap_index_add_staged(mhap_handle* h) {
   }
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
   const bool built = h->eager && rc == MHAP_OK;
+  if (h->eager && rc != MHAP_OK) { (void)hipStreamSynchronize(h->side_stream); for (auto& t : h->pending_side) h->free_events.emplace_back(t.a, t.b); h->pending_side.clear(); }
   h->eager = false;
   if (rc != MHAP_OK) return rc;
   rc = finish_add(h, first, h->st_ids.data(), n);
-  if (rc == MHAP_OK && built) { h->inv_ready = true; h->inv_ne = h->n_entries; h->inv_cmask = h->eager_cmask; }
+  if (built) {   // join the second stream (its last inserts overlapped the host work above)
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    for (auto& t : h->pending_side) h->pending.push_back(t);
+    h->pending_side.clear();
+    const int rs = sync_stream(h);
+    if (rs != MHAP_OK) return rs;
+    if (rc == MHAP_OK) { h->inv_ready = true; h->inv_ne = h->n_entries; h->inv_cmask = h->eager_cmask; }
+  }
   return rc;
 }
 
