@@ -54,10 +54,11 @@ int weight_grid(int num_cus, int64_t nstrands, int max_len, int k);   // persist
 bool kmer_weights_can_fuse(int max_len, int k, int k2);   // hashing of packed strands inside the weight kernel (k = 16, k2 = 12, LDS path)
 void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, int64_t* keys,
                          uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
-                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts);
+                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts,
+                         const int32_t* order);   // order: read indices longest first (or null)
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride, const uint64_t* jump);
+                    int32_t* out_status, int64_t status_stride, const uint64_t* jump, const int32_t* order);
 // GF(2) jump-ahead tables of the xorshift64 step: na tables of 8x256 words (M^(g a), a = 1..na, g = 2^XS_JUMP_LOG2)
 constexpr int XS_JUMP_LOG2 = 4;
 void build_xorshift_jump_tables(int na, uint64_t* out);

@@ -103,7 +103,8 @@ struct mhap_handle {
   std::vector<uint8_t> status;   // per entry status (host mirror)
 
   // sketch scratch
-  DevBuf store, descs, keys, wts, h32, info, slabs, counters;
+  DevBuf store, descs, keys, wts, h32, info, slabs, counters, order;
+  std::vector<int32_t> h_order;
   uint8_t* pin_store = nullptr;   // pinned host staging buffer of stage_reads
   size_t pin_cap = 0;
   std::vector<ReadDesc> h_descs;
@@ -318,14 +319,31 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     h->h_descs.resize((size_t)nb);
     int64_t key_elems = 0, h2_elems = 0;
     bool any_raw = false;
+    int min_len_b = INT32_MAX;
     for (int64_t i = 0; i < nb; i++) {
       ReadDesc d = h->st_descs[(size_t)(B.r0 + i)];
+      if (!(d.flags & MHAP_RD_SKIP)) min_len_b = std::min(min_len_b, d.length);
       if ((d.flags & MHAP_RD_RAW) && !(d.flags & MHAP_RD_SKIP)) any_raw = true;
       const int64_t nk = align4(std::max(0, d.length - k + 1)), nk2 = align4(std::max(0, d.length - k2 + 1));
       d.key_off = key_elems; d.key_stride = (int32_t)nk;
       d.h2_off = h2_elems; d.h2_stride = (int32_t)nk2;
       if (!(d.flags & MHAP_RD_SKIP)) { key_elems += 2 * nk; h2_elems += 2 * nk2; }
       h->h_descs[(size_t)i] = d;
+    }
+    // reads of clearly different lengths: hand them out longest first (counting sort on length / 128), so that the persistent
+    // workgroups do not end on a long read while the rest of the GPU idles
+    const int32_t* d_order = nullptr;
+    if (min_len_b * 5 < B.max_len * 4 && nb > 1 && !getenv("MHAP_NO_LENGTH_ORDER")) {
+      const int nbk = B.max_len / 128 + 2;
+      std::vector<int64_t> start((size_t)nbk + 1, 0);
+      for (int64_t i = 0; i < nb; i++) start[(size_t)(nbk - 1 - h->h_descs[(size_t)i].length / 128)]++;
+      int64_t acc = 0;
+      for (int b = 0; b <= nbk; b++) { const int64_t c = start[(size_t)b]; start[(size_t)b] = acc; acc += c; }
+      h->h_order.resize((size_t)nb);
+      for (int64_t i = 0; i < nb; i++) h->h_order[(size_t)start[(size_t)(nbk - 1 - h->h_descs[(size_t)i].length / 128)]++] = (int32_t)i;
+      HIPCHK(h, h->order.ensure((size_t)nb * 4));
+      HIPCHK(h, hipMemcpyAsync(h->order.p, h->h_order.data(), (size_t)nb * 4, hipMemcpyHostToDevice, h->stream));
+      d_order = h->order.as<int32_t>();
     }
     int64_t slab_entries = 64;
     while (3 * slab_entries < 4LL * std::max(1, B.max_len - k + 1)) slab_entries <<= 1;
@@ -350,14 +368,14 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     time_begin(h, MHAP_K_DEDUP);
     launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->slabs.as<uint32_t>(),
                         slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused, h->store.as<uint8_t>(),
-                        h->h32.as<int32_t>(), h->hash_luts.as<uint64_t>());
+                        h->h32.as<int32_t>(), h->hash_luts.as<uint64_t>(), d_order);
     time_end(h);
     time_begin(h, MHAP_K_MINHASH);
     int per_cu = 8;
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
     launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(), k, k2, H, ctr + 1,
-                   mh_rows, mh_stride, meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>());
+                   mh_rows, mh_stride, meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), d_order);
     time_end(h);
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
     if (h->eager) {
@@ -674,7 +692,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
-                    &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
+                    &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);

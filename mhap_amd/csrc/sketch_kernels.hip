@@ -440,7 +440,8 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
                                                                      unsigned long long* __restrict__ counter, int k,
                                                                      FilterTable ft, double repeat_weight,
                                                                      StrandInfo* __restrict__ info, const uint8_t* __restrict__ store,
-                                                                     int32_t* __restrict__ h32, const uint64_t* __restrict__ luts) {
+                                                                     int32_t* __restrict__ h32, const uint64_t* __restrict__ luts,
+                                                                     const int32_t* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
   uint32_t* svars = lds_tab + lds_entries;   // [0..1] strand index, [2] valid, [3] heavy
   uint64_t* lut = (uint64_t*)(svars + 4);                       // FUSED: block-mix tables, then the strand's base codes
@@ -455,8 +456,9 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
       svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32); svars[2] = 0; svars[3] = 0;
     }
     __syncthreads();
-    const int64_t strand = (int64_t)(((unsigned long long)svars[1] << 32) | svars[0]);
+    int64_t strand = (int64_t)(((unsigned long long)svars[1] << 32) | svars[0]);
     if (strand >= nstrands) break;
+    if (order) strand = 2LL * order[strand >> 1] + (strand & 1);   // longest reads first
     const ReadDesc rd = descs[strand >> 1];
     const int rcs = (int)(strand & 1);
     const int nk = rd.length - k + 1;
@@ -535,7 +537,8 @@ bool kmer_weights_can_fuse(int max_len, int k, int k2) { return k == 16 && k2 ==
 
 void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, int64_t* keys,
                          uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
-                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts) {
+                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts,
+                         const int32_t* order) {
   if (nstrands <= 0) return;
   uint32_t need = 64;
   const uint32_t nkmax = (uint32_t)(max_len - k + 1 > 1 ? max_len - k + 1 : 1);
@@ -548,17 +551,17 @@ void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int
   if (lds_entries <= 16384u) {   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
     if (fused)
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, true>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts);
+                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
     else
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, false>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts);
+                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
   } else {
     if (fused)
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, true>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts);
+                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
     else
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, false>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts);
+                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
   }
 }
 
@@ -768,7 +771,8 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
                                                       const StrandInfo* __restrict__ info, int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
-                                                      const uint64_t* __restrict__ jump, unsigned long long* __restrict__ prof = nullptr) {
+                                                      const uint64_t* __restrict__ jump, const int32_t* __restrict__ order,
+                                                      unsigned long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   // PROF: wave-clock attribution {strand total, row-0 total, row-0 argmin, row-0 defer, later-row defer, key load+transpose,
@@ -784,6 +788,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     if (lane == 0) sidx = (long long)atomicAdd(counter, 1ULL);
     sidx = __shfl(sidx, 0);
     if (sidx >= nstrands) break;
+    if (order) sidx = 2LL * order[sidx >> 1] + (sidx & 1);   // longest reads first: short drain tail when read lengths vary
     const ReadDesc rd = descs[sidx >> 1];
     const int rcs = (int)(sidx & 1);
     const int nk = rd.length - k + 1;
@@ -951,7 +956,7 @@ void build_xorshift_jump_tables(int na, uint64_t* out) {
 // MHAP_MINHASH=perchain selects the kernel without bit-sliced rows (A/B measurements)
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride, const uint64_t* jump) {
+                    int32_t* out_status, int64_t status_stride, const uint64_t* jump, const int32_t* order) {
   if (nstrands <= 0) return;
   static int perchain = -1;
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
@@ -968,7 +973,7 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
     if (!dprof) (void)hipMalloc(&dprof, 16 * sizeof(unsigned long long));
     (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
     hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
-                       out_stride, out_status, status_stride, jump, dprof);
+                       out_stride, out_status, status_stride, jump, order, dprof);
     unsigned long long hp[16];
     (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
@@ -981,10 +986,10 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
   }
   if (perchain)
     hipLaunchKernelGGL((minhash_kernel<MH_U, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
-                       out_stride, out_status, status_stride, jump);
+                       out_stride, out_status, status_stride, jump, order);
   else
     hipLaunchKernelGGL((minhash_kernel<MH_U, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
-                       out_stride, out_status, status_stride, jump);
+                       out_stride, out_status, status_stride, jump, order);
 }
 
 
