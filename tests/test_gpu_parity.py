@@ -371,3 +371,28 @@ def test_fused_and_separate_kmer_hashing_agree(monkeypatch):
         b = ms.sketch(fa)
     for key in ("minhash", "ordered", "ordered_size", "status"):
         assert np.array_equal(a[key], b[key]), key
+
+
+def test_index_table_reuse_and_incremental_adds():
+    """The inverted index of a fresh add is built while its reads are sketched and reused by later searches; an index that
+    grows by a second add is rebuilt at search time.  Both give the one-shot result."""
+    fa = mhap_amd.synth_reads(900, 2500, seed=31, error_rate=0.06)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=400)
+    want, _ = _self_lines(fa, p)
+    assert len(want) > 500
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        a = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+        b = sorted(mhap_amd.records_to_lines(ms.find_matches()))          # second search: table reused
+        kt = ms.kernel_times()
+    assert a == want and b == want
+    assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 2
+    half = len(fa) // 2
+    f1 = FastaData.from_strings([fa.sequence(i) for i in range(half)])
+    f2 = FastaData.from_strings([fa.sequence(i) for i in range(half, len(fa))], id_offset=half)
+    with MinHashSearch(p) as ms:
+        ms.add_data(f1)
+        first = sorted(mhap_amd.records_to_lines(ms.find_matches()))      # uses the eagerly built table of the first half
+        ms.add_data(f2)
+        c = sorted(mhap_amd.records_to_lines(ms.find_matches()))          # entry set changed: rebuilt
+    assert c == want and 0 < len(first) < len(want)
