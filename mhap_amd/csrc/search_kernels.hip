@@ -215,7 +215,9 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 
 // One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].  A query whose distinct-hit set outgrows the table is
 // appended to `overflow` (the caller re-runs those through candidate_kernel).
-__global__ __launch_bounds__(256) void index_query_kernel(const unsigned long long* __restrict__ table, uint32_t cmask,
+constexpr int IQ_THREADS = 128;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
+                                  // CU by LDS either way: more probe chains in flight per CU only thrash the memory side)
+__global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(const unsigned long long* __restrict__ table, uint32_t cmask,
                                                           const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
@@ -230,14 +232,14 @@ __global__ __launch_bounds__(256) void index_query_kernel(const unsigned long lo
   const int qi = blockIdx.x;
   if (qi >= nq) return;
   const int qe = qlist[qi];
-  for (int j = threadIdx.x; j < INV_CT; j += 256) { keys[j] = 0; cnts[j] = 0; }
+  for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) { keys[j] = 0; cnts[j] = 0; }
   if (threadIdx.x == 0) { s_distinct = 0; s_over = 0; }
   __syncthreads();
   const int32_t* qm = qmeta + (int64_t)qe * META_W;
   const int64_t qid = qids[qe];
   const int qlen = qm[2];
   unsigned long long mine = 0;
-  for (int s = threadIdx.x; s < sp.H; s += 256) {
+  for (int s = threadIdx.x; s < sp.H; s += IQ_THREADS) {
     const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
     const unsigned long long* T = table + (size_t)s * ((size_t)cmask + 1);
     uint32_t pos = inv_hash(v) & cmask;
@@ -271,11 +273,11 @@ __global__ __launch_bounds__(256) void index_query_kernel(const unsigned long lo
   }
   // emit this query's candidates as ONE contiguous block (one global atomic per query): the second stage then finds
   // the lanes of a wave sharing the query's ordered-sketch row
-  uint32_t mymask = 0;   // bit t set -> table slot threadIdx.x + 256*t is a candidate
+  uint32_t mymask = 0;   // bit t set -> table slot threadIdx.x + IQ_THREADS*t is a candidate
   int mycount = 0;
 #pragma unroll
-  for (int t = 0; t < INV_CT / 256; t++) {
-    const int j = threadIdx.x + 256 * t;
+  for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
+    const int j = threadIdx.x + IQ_THREADS * t;
     if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) {                                    // MinHashSearch.java:204
       const int me = (int)keys[j] - 1;
       if (pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1u << t; mycount++; }   // :200-225
@@ -292,9 +294,9 @@ __global__ __launch_bounds__(256) void index_query_kernel(const unsigned long lo
   __syncthreads();
   unsigned long long slot = s_base + local;
 #pragma unroll
-  for (int t = 0; t < INV_CT / 256; t++) {
+  for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
     if (mymask & (1u << t)) {
-      if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)keys[threadIdx.x + 256 * t] - 1; }
+      if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)keys[threadIdx.x + IQ_THREADS * t] - 1; }
       slot++;
     }
   }
@@ -305,7 +307,7 @@ void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
                         int32_t* overflow, unsigned long long* overflow_count, unsigned long long* elements) {
   if (nq <= 0) return;
-  hipLaunchKernelGGL(index_query_kernel, dim3((unsigned)nq), dim3(256), 0, st, table, cmask, qminhash, qrow_stride, qlist, nq, ids, qids,
+  hipLaunchKernelGGL(index_query_kernel, dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, table, cmask, qminhash, qrow_stride, qlist, nq, ids, qids,
                      meta, qmeta, sp, cand, cand_count, cand_cap, overflow, overflow_count, elements);
 }
 
