@@ -565,8 +565,8 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     if (use_join) {
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
       const int chunk = 8;
-      const int64_t want = ((int64_t)ncand + 4LL * chunk - 1) / (4LL * chunk);
-      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * 4, want));
+      const int64_t want = ((int64_t)ncand + 2LL * chunk - 1) / (2LL * chunk);
+      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * 9, want));
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap_join(h->stream, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                           qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,

@@ -405,12 +405,12 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
 // literally on the group's few entries (oj_group_merge etc., wave-uniform), and its records join the others.  Pairs
 // beyond the caps below (joined k-mers, groups, group length) are appended to `slow` for overlap_kernel's literal merge.
 // =============================================================================================
-constexpr int OJ_WAVES = 4;
-constexpr int OJ_JCAP = 256;           // joined k-mers + group records kept per pair
+constexpr int OJ_WAVES = 2;
+constexpr int OJ_JCAP = 128;           // joined k-mers + group records kept per pair
 constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
 constexpr int OJ_GCAP = 8;             // duplicated-hash groups per pair
 constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
-constexpr int OJ_U = 4;                // 64-entry blocks of the other sketch in flight per wave
+constexpr int OJ_U = 2;                // 64-entry blocks of the other sketch in flight per wave
 constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN);   // ints per wave besides the query hashes
 
 __device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
