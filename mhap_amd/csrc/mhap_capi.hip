@@ -107,6 +107,8 @@ struct mhap_handle {
   std::vector<int32_t> h_order;
   uint8_t* pin_store = nullptr;   // pinned host staging buffer of stage_reads
   size_t pin_cap = 0;
+  uint8_t* pin_io = nullptr;      // pinned bounce buffer of the small device-to-host read-backs (meta rows, records)
+  size_t pin_io_cap = 0;
   std::vector<ReadDesc> h_descs;
   std::vector<ReadDesc> st_descs;   // staged reads (base_off/length/flags); packed bases resident in `store`
   std::vector<int64_t> st_ids;
@@ -117,7 +119,6 @@ struct mhap_handle {
 
   // search scratch
   DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_overflow;
-  std::vector<DevRecord> h_recs;
   std::vector<mhap_record> out_recs;
 
   // timing
@@ -229,6 +230,7 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
   const size_t need = (size_t)std::max<int64_t>(store_bytes, 4);
   if (h->pin_cap < need) {
     if (h->pin_store) (void)hipHostFree(h->pin_store);
+  if (h->pin_io) (void)hipHostFree(h->pin_io);
     h->pin_store = nullptr; h->pin_cap = 0;
     HIPCHK(h, hipHostMalloc((void**)&h->pin_store, need + need / 8, hipHostMallocDefault));
     h->pin_cap = need + need / 8;
@@ -424,9 +426,21 @@ int ensure_index_capacity(mhap_handle* h, int64_t entries) {
 }
 
 // pull meta rows [first, first+count) into the host mirrors
+// pinned scratch of at least `bytes` (grow-only): device-to-host copies into it run at PCIe speed without a staging copy
+static void* pinned_io(mhap_handle* h, size_t bytes) {
+  if (h->pin_io_cap < bytes) {
+    if (h->pin_io) (void)hipHostFree(h->pin_io);
+    h->pin_io = nullptr; h->pin_io_cap = 0;
+    if (hipHostMalloc((void**)&h->pin_io, bytes + bytes / 4 + 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
+    h->pin_io_cap = bytes + bytes / 4 + 4096;
+  }
+  return h->pin_io;
+}
+
 int mirror_meta(mhap_handle* h, const int32_t* d_meta, int64_t first, int64_t count) {
-  std::vector<int32_t> m((size_t)count * META_W);
-  HIPCHK(h, hipMemcpy(m.data(), d_meta + first * META_W, m.size() * 4, hipMemcpyDeviceToHost));
+  int32_t* m = (int32_t*)pinned_io(h, (size_t)count * META_W * 4);
+  if (!m) return fail(h, MHAP_E_HIP, "cannot allocate pinned host memory");
+  HIPCHK(h, hipMemcpy(m, d_meta + first * META_W, (size_t)count * META_W * 4, hipMemcpyDeviceToHost));
   if ((int64_t)h->seqlen.size() < first + count) { h->seqlen.resize((size_t)(first + count)); h->status.resize((size_t)(first + count)); }
   for (int64_t e = 0; e < count; e++) { h->seqlen[(size_t)(first + e)] = m[(size_t)e * META_W + 2]; h->status[(size_t)(first + e)] = (uint8_t)m[(size_t)e * META_W + 3]; }
   return MHAP_OK;
@@ -597,12 +611,13 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     const unsigned long long nrec = counts[1];
     h->stats.candidates_compared += (int64_t)counts[2];
     if (nrec == 0) continue;
-    h->h_recs.resize((size_t)nrec);
-    HIPCHK(h, hipMemcpy(h->h_recs.data(), h->recs.p, (size_t)nrec * sizeof(DevRecord), hipMemcpyDeviceToHost));
+    const DevRecord* hrecs = (const DevRecord*)pinned_io(h, (size_t)nrec * sizeof(DevRecord));
+    if (!hrecs) return fail(h, MHAP_E_HIP, "cannot allocate pinned host memory");
+    HIPCHK(h, hipMemcpy((void*)hrecs, h->recs.p, (size_t)nrec * sizeof(DevRecord), hipMemcpyDeviceToHost));
     h->out_recs.resize((size_t)nrec);
     parallel_for((int64_t)nrec, host_threads(), [&](int64_t lo, int64_t hi) {
       for (int64_t i = lo; i < hi; i++) {
-        const DevRecord& d = h->h_recs[(size_t)i];
+        const DevRecord& d = hrecs[(size_t)i];
         mhap_record& r = h->out_recs[(size_t)i];
         r.from_id = qs.h_ids[d.q]; r.to_id = h->ids[(size_t)d.m];
         r.score = d.score; r.raw = (double)d.raw;
