@@ -396,3 +396,15 @@ def test_index_table_reuse_and_incremental_adds():
         ms.add_data(f2)
         c = sorted(mhap_amd.records_to_lines(ms.find_matches()))          # entry set changed: rebuilt
     assert c == want and 0 < len(first) < len(want)
+
+
+def test_config4_read_shape_slice():
+    """BASELINE configs[3]/[4] read shapes (15 kb and 12 kb reads, H=512, S=1536: more than 12288 k-mers per strand takes the
+    24-k-mers-per-lane weight kernel, 8 bit-sliced MinHash rows) on a slice of reads: full record parity with the oracle."""
+    for L, n, seed in ((15000, 260, 4), (12000, 300, 5)):
+        fa = mhap_amd.synth_reads(n, L, seed=0x4D484150 ^ seed, error_rate=0.15)
+        p = MhapParams()
+        want = O.run_self(fa, nthreads=8)
+        got, st = _self_lines(fa, p)
+        assert got == O.record_lines(want["records"]), L
+        assert len(got) > 20 and st["slow_pairs"] == 0
