@@ -95,7 +95,8 @@ def main():
         loc_mh = torch.zeros((2 * n_pad, H), dtype=torch.int32, device=dev)
         loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
         loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
-        gids, gfwd = mdist.global_entry_ids(n_total, world)
+        gids, gfwd = mdist.rank_major_entry_ids(n_total, world)
+        q_first, q_count = mdist.rank_major_query_range(n_total, world, rank)
 
     def step():
         ms.clear()
@@ -104,12 +105,12 @@ def main():
             recs = ms.find_matches()
         else:
             ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-            g_mh = mdist.gather_global_order(loc_mh, world, dist)    # RCCL all-gather + global read order
-            g_od = mdist.gather_global_order(loc_od, world, dist)
-            g_mt = mdist.gather_global_order(loc_mt, world, dist)
+            g_mh = mdist.gather_rank_major(loc_mh, world, dist)      # RCCL all-gather, tables stay rank after rank
+            g_od = mdist.gather_rank_major(loc_od, world, dist)
+            g_mt = mdist.gather_rank_major(loc_mt, world, dist)
             torch.cuda.synchronize()
             ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
-            recs = ms.find_matches_shard(rank, world)
+            recs = ms.find_matches(q_first, q_count)                  # this rank's own reads against the whole index
             step.keep = (g_mh, g_od, g_mt)
         return recs
 

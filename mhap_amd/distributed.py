@@ -2,9 +2,10 @@
 
 Reads are dealt round-robin: global read r (0-based FASTA order) lives on rank r % world at local slot r // world.
 Each rank sketches its shard into local tables; the tables are exchanged with ONE all-gather per table
-(RCCL over xGMI when the backend is "nccl"; gloo on CPU in the tests) and re-laid out in global read order so
-that entry 2r / 2r+1 is the forward / reverse-complement strand of read r — ids are then monotonic in entry
-order, which the candidate kernel's triangular tile skipping relies on.  Every rank then searches the queries
+(RCCL over xGMI when the backend is "nccl"; gloo on CPU in the tests).  bench.py keeps the gathered tables rank after
+rank (gather_rank_major: no re-layout copy; every rank searches the entry range of its own reads); gather_global_order
+re-lays them out in global read order so that entry 2r / 2r+1 is the forward / reverse-complement strand of read r —
+ids are then monotonic in entry order, which the brute-force candidate kernel's triangular tile skipping relies on.  Every rank then searches the queries
 whose read ordinal is congruent to its rank (mhap_find_matches_self_shard); no collective is needed after that,
 records are concatenated by the host (their order is unspecified in the reference too).
 """
@@ -53,6 +54,37 @@ def gather_global_order(local, world, dist=None):
         gathered = torch.stack(parts, 0).to(local.device)
     g = gathered.view(world, n_pad, 2, -1).permute(1, 0, 2, 3).contiguous()    # [slot][rank][strand] = read slot*world+rank
     return g.view((n_pad * world * 2,) + tail)
+
+
+def rank_major_entry_ids(n_total, world):
+    """(ids, is_fwd) of the gathered index in RANK-MAJOR order: entry rank*2*n_pad + 2*slot + strand is read slot*world+rank.
+    This is the layout all_gather_into_tensor produces by itself, so no re-layout copy of the tables is needed; ids are not
+    monotonic in entry order (only the brute-force candidate kernel's tile skipping cares, the inverted index does not)."""
+    n_pad = shard_size(n_total, world)
+    slot = np.arange(n_pad, dtype=np.int64)
+    ids = np.concatenate([np.repeat(slot * world + r + 1, 2) for r in range(world)])
+    fwd = np.tile(np.array([1, 0], dtype=np.uint8), n_pad * world)
+    return ids, fwd
+
+
+def gather_rank_major(local, world, dist=None):
+    """All-gather a per-rank table [2*n_pad, ...] into [world*2*n_pad, ...], rank after rank (no re-layout)."""
+    if world == 1:
+        return local
+    if local.is_cuda and dist.get_backend() == "nccl":      # RCCL over xGMI
+        gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(gathered.view(world, -1), local.contiguous().view(1, -1))
+        return gathered
+    src = local.contiguous().cpu()                           # gloo (CPU tests; functional multi-rank runs on one GPU)
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src)
+    return torch.cat(parts, 0).to(local.device)
+
+
+def rank_major_query_range(n_total, world, rank):
+    """(first entry, entry count) of rank `rank`'s own reads in the rank-major index = the queries it searches."""
+    n_pad = shard_size(n_total, world)
+    return rank * 2 * n_pad, 2 * n_pad
 
 
 def shard_query_reads(n_total, world, rank):

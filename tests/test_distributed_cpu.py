@@ -39,11 +39,12 @@ def _worker(rank, port, out):
     assert len(shard) == md.shard_size(N_TOTAL, WORLD)
     local = torch.from_numpy(_oracle_rows(shard))
     g = md.gather_global_order(local, WORLD, dist)
+    g_rm = md.gather_rank_major(local, WORLD, dist)
     mine = md.shard_query_reads(N_TOTAL, WORLD, rank)
     allq = [torch.zeros(len(mine), dtype=torch.int64) for _ in range(WORLD)]
     dist.all_gather(allq, torch.from_numpy(mine))
     if rank == 0:
-        torch.save({"table": g, "queries": torch.stack(allq)}, out)
+        torch.save({"table": g, "table_rm": g_rm, "queries": torch.stack(allq)}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,3 +68,16 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     q = got["queries"].numpy()
     assert sorted(q.ravel().tolist()) == list(range(n_pad * WORLD))   # query shards partition the reads
     assert all((q[r] % WORLD == r).all() for r in range(WORLD))
+    # rank-major layout (what bench.py uses: no re-layout copy): entry rank*2*n_pad + 2*slot + strand = read slot*WORLD + rank
+    rm = got["table_rm"].numpy()
+    ids_rm, fwd_rm = md.rank_major_entry_ids(N_TOTAL, WORLD)
+    assert rm.shape == table.shape and len(ids_rm) == rm.shape[0]
+    for e in range(rm.shape[0]):
+        r = int(ids_rm[e]) - 1
+        if r < N_TOTAL:
+            assert np.array_equal(rm[e], want[2 * r + (1 - int(fwd_rm[e]))]), e
+        else:
+            assert not rm[e].any()
+    firsts = [md.rank_major_query_range(N_TOTAL, WORLD, r) for r in range(WORLD)]
+    assert firsts == [(r * 2 * n_pad, 2 * n_pad) for r in range(WORLD)]
+    assert sorted(set(int(i) for i in ids_rm if i <= N_TOTAL)) == list(range(1, N_TOTAL + 1))
