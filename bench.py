@@ -68,7 +68,7 @@ def main():
     local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or (os.environ.get("MHAP_BENCH_FORCE_DIST") and "RANK" in os.environ):   # (1 rank under torchrun: RCCL path on one GPU)
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -97,6 +97,7 @@ def main():
         loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
         gids, gfwd = mdist.rank_major_entry_ids(n_total, world)
         q_first, q_count = mdist.rank_major_query_range(n_total, world, rank)
+    async_gather = dist is not None and backend == "nccl" and os.environ.get("MHAP_BENCH_ASYNC_GATHER", "1") != "0"
 
     def step():
         ms.clear()
@@ -106,10 +107,21 @@ def main():
         else:
             ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
             g_mh = mdist.gather_rank_major(loc_mh, world, dist)      # RCCL all-gather, tables stay rank after rank
-            g_od = mdist.gather_rank_major(loc_od, world, dist)
             g_mt = mdist.gather_rank_major(loc_mt, world, dist)
+            if async_gather:
+                # the ordered-sketch table (85 % of the bytes) is only read by the second stage: its all-gather runs while this
+                # rank builds the inverted index from the MinHash table
+                torch.cuda.current_stream().synchronize()
+                g_od = torch.empty((world * loc_od.shape[0],) + tuple(loc_od.shape[1:]), dtype=loc_od.dtype, device=dev)
+                work = dist.all_gather_into_tensor(g_od.view(world, -1), loc_od.view(1, -1), async_op=True)
+                ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
+                ms.prepare_index()
+                work.wait()
+            else:
+                g_od = mdist.gather_rank_major(loc_od, world, dist)
             torch.cuda.synchronize()
-            ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
+            if not async_gather:
+                ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
             recs = ms.find_matches(q_first, q_count)                  # this rank's own reads against the whole index
             step.keep = (g_mh, g_od, g_mt)
         return recs

@@ -146,6 +146,10 @@ int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids
                       int32_t* minhash, int32_t* ordered, int32_t* ordered_size, int32_t* ordered_seqlen,
                       uint8_t* status);
 int mhap_index_clear(mhap_handle* h);
+/* Build the inverted index (MinHashSearch.addSequence's per-slot maps, J/impl/MinHashSearch.java:123-141) for the current
+   entries now instead of at the first search; only the MinHash and meta tables are read, so a caller that adopted device
+   tables with mhap_index_set_device may still be filling the ordered-sketch table (e.g. an all-gather in flight). */
+int mhap_index_prepare(mhap_handle* h);
 
 /* Multi-GPU plumbing (one process per GPU): the per-rank shard tables live in device memory
  * owned by the CALLER (e.g. torch tensors that RCCL all-gathers over xGMI).

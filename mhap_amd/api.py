@@ -53,7 +53,7 @@ _SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
 # every symbol include/mhap_hip.h declares
 EXPORTED_SYMBOLS = [
     "mhap_create", "mhap_destroy", "mhap_last_error", "mhap_default_params", "mhap_set_filter", "mhap_index_add_reads",
-    "mhap_sketch_batch", "mhap_index_add_sketches", "mhap_index_size", "mhap_index_export", "mhap_index_clear",
+    "mhap_sketch_batch", "mhap_index_add_sketches", "mhap_index_size", "mhap_index_export", "mhap_index_clear", "mhap_index_prepare",
     "mhap_sketch_reads_device", "mhap_index_set_device", "mhap_find_matches_self", "mhap_find_matches_reads",
     "mhap_get_stats", "mhap_get_kernel_times", "mhap_reset_kernel_times", "mhap_set_stream", "mhap_synchronize",
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
@@ -403,6 +403,10 @@ class MinHashSearch:
         cb = _SINK(sink)
         self._chk(call(cb))
         return np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+
+    def prepare_index(self):
+        """Build the inverted index now (reads the MinHash/meta tables only; see mhap_index_prepare)."""
+        self._chk(self._lib.mhap_index_prepare(self._h))
 
     def find_matches(self, q_first=0, q_count=-1):
         """Self overlap of forward entries [q_first, q_first+q_count) against the whole index."""

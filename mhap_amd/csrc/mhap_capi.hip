@@ -455,6 +455,24 @@ struct QuerySide {
 };
 
 // Run candidate + second stage for the query entries in `ql` (entry indices into the query side).
+// (re)build the inverted index for the current entries unless the table in place already covers them
+int ensure_inverted_index(mhap_handle* h) {
+  const int ne = (int)h->n_entries, H = h->P.num_hashes;
+  const uint64_t cap = inv_capacity(ne);
+  const uint32_t cmask = (uint32_t)(cap - 1);
+  if (h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask) return MHAP_OK;
+  const size_t bytes = (size_t)H * (size_t)cap * 8;
+  HIPCHK(h, h->inv_table.ensure(bytes));
+  HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
+  HPROF("index build launch");
+  time_begin(h, MHAP_K_INDEX_BUILD);
+  launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv_table.as<unsigned long long>(), cmask);
+  time_end(h);
+  HIPCHK(h, hipGetLastError());
+  h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
+  return MHAP_OK;
+}
+
 int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>& ql, bool to_self, bool triangular_ok,
                 mhap_record_sink sink, void* user) {
   if (ql.empty() || h->n_entries == 0) return MHAP_OK;
@@ -484,19 +502,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const bool use_index = !(cmode && strcmp(cmode, "bruteforce") == 0);
   uint32_t cmask = 0;
   if (use_index) {
-    const uint64_t cap = inv_capacity(ne);
-    cmask = (uint32_t)(cap - 1);
-    if (!(h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask)) {   // not built yet for these entries
-      const size_t bytes = (size_t)sp.H * (size_t)cap * 8;
-      HIPCHK(h, h->inv_table.ensure(bytes));
-      HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
-      HPROF("index build launch");
-      time_begin(h, MHAP_K_INDEX_BUILD);
-      launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, sp.H, h->inv_table.as<unsigned long long>(), cmask);
-      time_end(h);
-      HIPCHK(h, hipGetLastError());
-      h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
-    }
+    int rcb = ensure_inverted_index(h);
+    if (rcb != MHAP_OK) return rcb;
+    cmask = h->inv_cmask;
   }
 
   for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
@@ -937,6 +945,15 @@ int mhap_index_clear(mhap_handle* h) {
   h->d_minhash = h->own_minhash.as<int32_t>(); h->d_ordered = h->own_ordered.as<int32_t>(); h->d_meta = h->own_meta.as<int32_t>();
   h->stats = mhap_stats{};
   return MHAP_OK;
+}
+
+int mhap_index_prepare(mhap_handle* h) {
+  if (!h) return MHAP_E_INVALID;
+  (void)hipSetDevice(h->device);
+  if (h->n_entries == 0) return MHAP_OK;
+  const int rc = ensure_inverted_index(h);
+  if (rc != MHAP_OK) return rc;
+  return sync_stream(h);
 }
 
 int mhap_sketch_reads_device(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_minhash,

@@ -208,8 +208,12 @@ def test_index_export_roundtrip_and_query_sharding():
     sk = {k: v[keep] for k, v in tables.items() if k != "status"}
     with MinHashSearch(p) as ms2:
         ms2.add_sketches(sk)
+        ms2.prepare_index()                 # explicit inverted-index build (mhap_index_prepare); the searches below reuse it
         again = sorted(mhap_amd.records_to_lines(ms2.find_matches()))
-    assert again == full and len(full) > 50
+        again2 = sorted(mhap_amd.records_to_lines(ms2.find_matches(0, 60))) + sorted(mhap_amd.records_to_lines(ms2.find_matches(60, -1)))
+        kt = ms2.kernel_times()
+    assert again == full and len(full) > 50 and sorted(again2) == full
+    assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 3
 
 
 def test_batching_and_chunking_do_not_change_results(monkeypatch):
