@@ -1,0 +1,59 @@
+"""Randomised end-to-end parity sweep (run on the GPU box): random flags and read mixes, sorted record lines vs the oracle."""
+import os, random, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import mhap_amd
+import oracle_lib as O
+from mhap_amd import FastaData, MhapParams, MinHashSearch
+
+def mutate(rnd, s, rate):
+    out = []
+    for ch in s:
+        r = rnd.random()
+        if r < rate / 3: continue
+        if r < 2 * rate / 3: out.append(rnd.choice("ACGT")); continue
+        out.append(ch)
+        if r < rate: out.append(rnd.choice("ACGT"))
+    return "".join(out)
+
+def main(iters, seed0):
+    bad = 0
+    for it in range(iters):
+        rnd = random.Random(seed0 + it)
+        G = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(6000, 20000)))
+        if rnd.random() < 0.5:   # plant a repeat family
+            unit = "".join(rnd.choice("ACGT") for _ in range(rnd.randrange(20, 400)))
+            g = list(G)
+            for _ in range(rnd.randrange(2, 12)):
+                p = rnd.randrange(0, len(G) - len(unit)); g[p:p + len(unit)] = list(mutate(rnd, unit, 0.02))[:len(unit)]
+            G = "".join(g)
+        seqs = []
+        err = rnd.choice([0.0, 0.02, 0.06, 0.12])
+        for _ in range(rnd.randrange(40, 220)):
+            L = rnd.randrange(30, 4000); o = rnd.randrange(0, max(1, len(G) - L))
+            s = mutate(rnd, G[o:o + L], err)
+            if rnd.random() < 0.5: s = O.rc(s)
+            if rnd.random() < 0.03: s = s[:len(s) // 2] + "N" * rnd.randrange(1, 5) + s[len(s) // 2:]
+            if s: seqs.append(s)
+        fa = FastaData.from_strings(seqs)
+        kw = dict(kmer_size=rnd.choice([16, 16, 16, 12, 14, 18, 21]), num_hashes=rnd.choice([16, 64, 128, 200, 512]),
+                  ordered_kmer_size=rnd.choice([12, 12, 8, 10, 13]), ordered_sketch_size=rnd.choice([32, 100, 300, 512, 1536]),
+                  num_min_matches=rnd.choice([1, 2, 3, 5]), threshold=rnd.choice([0.0, 0.5, 0.78, 0.9]), max_shift=rnd.choice([0.05, 0.2, 0.4]),
+                  min_store_length=rnd.choice([0, 0, 500, 2000]), min_olap_length=rnd.choice([0, 50, 116, 500]))
+        p = MhapParams(**kw)
+        want = O.run_self(fa, k=p.kmer_size, H=p.num_hashes, k2=p.ordered_kmer_size, S=p.ordered_sketch_size, nthreads=8,
+                          num_min_matches=p.num_min_matches, min_store_length=p.min_store_length, min_olap_length=p.min_olap_length,
+                          threshold=p.threshold, max_shift=p.max_shift, cap=1 << 22)
+        with MinHashSearch(p) as ms:
+            ms.add_data(fa)
+            got = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+            st = ms.stats()
+        ok = got == O.record_lines(want["records"])
+        bad += not ok
+        print(("ok  " if ok else "FAIL"), it, len(seqs), "reads err", err, kw, "records", len(got), "slow", st["slow_pairs"], flush=True)
+    print("failures:", bad)
+    return bad
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 20, int(sys.argv[2]) if len(sys.argv) > 2 else 1000) else 0)
