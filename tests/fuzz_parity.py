@@ -2,7 +2,7 @@
 import os, random, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # (test infrastructure: lives under tests/ because it loads the oracle)
 import mhap_amd
 import oracle_lib as O
 from mhap_amd import FastaData, MhapParams, MinHashSearch

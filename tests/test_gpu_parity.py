@@ -412,3 +412,9 @@ def test_config4_read_shape_slice():
         got, st = _self_lines(fa, p)
         assert got == O.record_lines(want["records"]), L
         assert len(got) > 20 and st["slow_pairs"] == 0
+
+
+def test_random_flag_and_read_mixes():
+    """A few draws of tests/fuzz_parity.py (random flags incl. k != 16 and odd k2, repeat families, N runs): 0 mismatches."""
+    import fuzz_parity
+    assert fuzz_parity.main(8, 777) == 0
