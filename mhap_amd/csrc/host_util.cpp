@@ -4,10 +4,12 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -122,57 +124,83 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
     if (!ok) { seterr(std::string("Unknown file format of file ") + path + "."); return MHAP_E_INVALID; }
     FILE* f = fopen(path, "rb");
     if (!f) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
+    if (fseek(f, 0, SEEK_END) == 0) { const long sz = ftell(f); if (sz > 0) data.resize((size_t)sz); rewind(f); }
+    size_t have = data.empty() ? 0 : fread(&data[0], 1, data.size(), f);
+    data.resize(have);
     size_t got;
-    while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
+    while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);   // (a file that grew, or a stream without a size)
     fclose(f);
   }
-  std::string bases;
-  bases.reserve(data.size());
-  std::vector<int64_t> offs, ids;
-  std::vector<int32_t> lens;
-  size_t pos = 0;
+  // BufferedReader.readLine: a line ends at \n, \r or \r\n; a line that starts with '>' opens a record, every other line is
+  // sequence (concatenated, upper-cased :194).  Three passes over the text: record boundaries (memchr, serial), sequence
+  // lengths and the copy (both parallel over records).
   const size_t N = data.size();
-  int64_t count = 0;
-  bool have_record = false;
-  int64_t rec_start = 0;
-  bool first_line = true;
-  auto close_record = [&]() {
-    if (!have_record) return;
-    const int64_t len = (int64_t)bases.size() - rec_start;
-    if (len > 0) { count++; offs.push_back(rec_start); lens.push_back((int32_t)len); ids.push_back(count + id_offset); }   // :180-181
-    have_record = false;
-  };
-  while (pos < N) {
-    // BufferedReader.readLine: a line ends at \n, \r or \r\n
-    size_t e = pos;
-    while (e < N && data[e] != '\n' && data[e] != '\r') e++;
-    const char* line = data.data() + pos;
-    const size_t ll = e - pos;
-    if (ll > 0 && line[0] == '>') {
-      close_record();
-      have_record = true;
-      rec_start = (int64_t)bases.size();
-    } else {
-      if (first_line || !have_record) { seterr("Next sequence does not start with >. Invalid format."); return MHAP_E_INVALID; }   // :150-151
-      for (size_t i = 0; i < ll; i++) {
-        char c = line[i];
-        if (c >= 'a' && c <= 'z') c = (char)(c - 'a' + 'A');       // toUpperCase(Locale.ENGLISH) :194
-        bases.push_back(c);
-      }
-    }
-    first_line = false;
-    pos = e;
-    if (pos < N) { if (data[pos] == '\r' && pos + 1 < N && data[pos + 1] == '\n') pos += 2; else pos += 1; }
+  const char* D = data.data();
+  if (N > 0 && D[0] != '>') { seterr("Next sequence does not start with >. Invalid format."); return MHAP_E_INVALID; }   // :150-151
+  std::vector<size_t> hdr;   // offsets of the '>' that open records
+  for (const char* q = D; q && q < D + N;) {
+    const char* g = (const char*)memchr(q, '>', (size_t)(D + N - q));
+    if (!g) break;
+    if (g == D || g[-1] == '\n' || g[-1] == '\r') hdr.push_back((size_t)(g - D));
+    q = g + 1;
   }
-  close_record();
+  const int64_t nrec = (int64_t)hdr.size();
+  std::vector<size_t> body((size_t)nrec), bend((size_t)nrec);
+  std::vector<int64_t> rlen((size_t)nrec);
+  unsigned hw = std::thread::hardware_concurrency();
+  if (const char* e = getenv("MHAP_HOST_THREADS")) { if (atoi(e) > 0) hw = (unsigned)atoi(e); }
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(hw ? hw : 1), (int64_t)(N >> 22) + 1));   // >= 4 MB of text per thread
+  auto par = [&](const std::function<void(int64_t, int64_t)>& fn) {
+    if (nthreads == 1 || nrec < 2) { fn(0, nrec); return; }
+    std::vector<std::thread> th;
+    const int64_t chunk = (nrec + nthreads - 1) / nthreads;
+    for (int t = 0; t < nthreads; t++) {
+      const int64_t lo = t * chunk, hi = std::min<int64_t>(nrec, lo + chunk);
+      if (lo >= hi) break;
+      th.emplace_back([=, &fn]() { fn(lo, hi); });
+    }
+    for (auto& t : th) t.join();
+  };
+  par([&](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; r++) {
+      const size_t end = (r + 1 < nrec) ? hdr[(size_t)r + 1] : N;
+      size_t p = hdr[(size_t)r];
+      while (p < end && D[p] != '\n' && D[p] != '\r') p++;   // header line
+      body[(size_t)r] = p; bend[(size_t)r] = end;
+      int64_t cnt = 0;
+      for (size_t i = p; i < end; i++) cnt += (D[i] != '\n' && D[i] != '\r') ? 1 : 0;
+      rlen[(size_t)r] = cnt;
+    }
+  });
+  std::vector<int64_t> offs, ids, dst((size_t)nrec);
+  std::vector<int32_t> lens;
+  int64_t total = 0, count = 0;
+  for (int64_t r = 0; r < nrec; r++) {
+    dst[(size_t)r] = total;
+    if (rlen[(size_t)r] > 0) {   // ids count non-empty records only, 1-based (:180-181)
+      if (rlen[(size_t)r] > INT32_MAX) { seterr("sequence longer than 2^31-1"); return MHAP_E_INVALID; }
+      count++; offs.push_back(total); lens.push_back((int32_t)rlen[(size_t)r]); ids.push_back(count + id_offset);
+      total += rlen[(size_t)r];
+    }
+  }
   out->n = (int64_t)offs.size();
-  out->total_bases = (int64_t)bases.size();
-  out->bases = (char*)malloc(std::max<size_t>(bases.size(), 1));
+  out->total_bases = total;
+  out->bases = (char*)malloc(std::max<size_t>((size_t)total, 1));
   out->offsets = (int64_t*)malloc(std::max<size_t>(offs.size(), 1) * 8);
   out->lengths = (int32_t*)malloc(std::max<size_t>(offs.size(), 1) * 4);
   out->ids = (int64_t*)malloc(std::max<size_t>(offs.size(), 1) * 8);
   if (!out->bases || !out->offsets || !out->lengths || !out->ids) { mhap_fasta_free(out); seterr("out of memory"); return MHAP_E_NOMEM; }
-  memcpy(out->bases, bases.data(), bases.size());
+  char* B = out->bases;
+  par([&](int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; r++) {
+      char* w = B + dst[(size_t)r];
+      for (size_t i = body[(size_t)r]; i < bend[(size_t)r]; i++) {
+        const char c = D[i];
+        if (c == '\n' || c == '\r') continue;
+        *w++ = (c >= 'a' && c <= 'z') ? (char)(c - 'a' + 'A') : c;       // toUpperCase(Locale.ENGLISH) :194
+      }
+    }
+  });
   if (!offs.empty()) { memcpy(out->offsets, offs.data(), offs.size() * 8); memcpy(out->lengths, lens.data(), lens.size() * 4); memcpy(out->ids, ids.data(), ids.size() * 8); }
   return MHAP_OK;
 }

@@ -271,3 +271,55 @@ def test_join_formulation_of_the_second_stage_matches_the_literal_merge():
             nonempty += 1
             assert got == {k: (int(want[k]) if k != "empty" else 0) for k in got}, (i, j, got, want)
     assert checked > 5000 and nonempty > 100
+
+
+def test_fasta_reader_line_conventions(tmp_path):
+    """mhap_fasta_read against a line-by-line restatement of FastaData.enqueueNextSequenceInFile: \n, \r and \r\n line
+    ends, multi-line records, lower case, '>' inside a sequence line, empty records (skipped, no id), no final newline."""
+    rnd = random.Random(8)
+
+    def reference(text):
+        seqs, cur = [], None
+        i, lines = 0, []
+        while i < len(text):                      # BufferedReader.readLine
+            j = i
+            while j < len(text) and text[j] not in "\n\r":
+                j += 1
+            lines.append(text[i:j])
+            i = j + 2 if text[j:j + 2] == "\r\n" else j + 1
+        for ln in lines:
+            if ln.startswith(">"):
+                if cur is not None and cur:
+                    seqs.append(cur)
+                cur = ""
+            else:
+                cur += ln.upper()
+        if cur:
+            seqs.append(cur)
+        return seqs
+
+    for trial in range(30):
+        eol = rnd.choice(["\n", "\r\n", "\r"])
+        parts = []
+        for r in range(rnd.randrange(1, 12)):
+            parts.append(">read%d some text" % r + eol)
+            for _ in range(rnd.randrange(0, 4)):
+                ln = "".join(rnd.choice("ACGTacgtNn") for _ in range(rnd.randrange(0, 70)))
+                if ln and rnd.random() < 0.1:
+                    ln = ln[:len(ln) // 2] + ">" + ln[len(ln) // 2:]
+                parts.append(ln + eol)
+            if rnd.random() < 0.2:
+                parts.append(eol)
+        text = "".join(parts)
+        if rnd.random() < 0.5:
+            text = text.rstrip("\r\n")
+        p = tmp_path / ("t%d.fa" % trial)
+        p.write_bytes(text.encode())
+        f = mhap_amd.FastaData.from_file(str(p))
+        want = reference(text)
+        assert [f.sequence(i) for i in range(len(f))] == want, (trial, text)
+        assert f.ids.tolist() == list(range(1, len(want) + 1))
+    bad = tmp_path / "bad.fa"
+    bad.write_bytes(b"ACGT\n>r\nACGT\n")
+    with pytest.raises(mhap_amd.MhapError):
+        mhap_amd.FastaData.from_file(str(bad))
