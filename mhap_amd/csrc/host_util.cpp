@@ -1,6 +1,10 @@
 // host_util.cpp — host-side helpers of libmhaphip.so that need no GPU: the reference's IO conventions
 // (FASTA ingest, overlap-record text format) and the deterministic synthetic read generator.
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -96,6 +100,8 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
   const std::string name(path);
   auto ends = [&](const char* suf) { const size_t n = strlen(suf); return name.size() >= n && name.compare(name.size() - n, n, suf) == 0; };
   std::string data;
+  void* map_base = nullptr;
+  size_t map_len = 0;
   char buf[1 << 16];
   if (ends("bz2")) {
     // libbz2 ships without headers in this image: bind the three stdio-style entry points at run time
@@ -122,20 +128,26 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
     bool ok = false;
     for (const char* suf : suffixes) ok = ok || ends(suf);
     if (!ok) { seterr(std::string("Unknown file format of file ") + path + "."); return MHAP_E_INVALID; }
-    FILE* f = fopen(path, "rb");
-    if (!f) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
-    if (fseek(f, 0, SEEK_END) == 0) { const long sz = ftell(f); if (sz > 0) data.resize((size_t)sz); rewind(f); }
-    size_t have = data.empty() ? 0 : fread(&data[0], 1, data.size(), f);
-    data.resize(have);
-    size_t got;
-    while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);   // (a file that grew, or a stream without a size)
-    fclose(f);
+    // plain text is parsed in place from a read-only mapping (no copy of the file)
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { seterr(std::string("cannot open ") + path); return MHAP_E_INVALID; }
+    struct stat sb;
+    if (fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+      void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+      if (m != MAP_FAILED) { map_base = m; map_len = (size_t)sb.st_size; }
+    }
+    if (!map_base) {   // pipes, empty files, mmap refused: read it
+      ssize_t got;
+      while ((got = read(fd, buf, sizeof buf)) > 0) data.append(buf, (size_t)got);
+    }
+    close(fd);
   }
+  struct Unmap { void* p; size_t n; ~Unmap() { if (p) munmap(p, n); } } unmap{map_base, map_len};
   // BufferedReader.readLine: a line ends at \n, \r or \r\n; a line that starts with '>' opens a record, every other line is
   // sequence (concatenated, upper-cased :194).  Three passes over the text: record boundaries (memchr, serial), sequence
   // lengths and the copy (both parallel over records).
-  const size_t N = data.size();
-  const char* D = data.data();
+  const size_t N = map_base ? map_len : data.size();
+  const char* D = map_base ? (const char*)map_base : data.data();
   if (N > 0 && D[0] != '>') { seterr("Next sequence does not start with >. Invalid format."); return MHAP_E_INVALID; }   // :150-151
   std::vector<size_t> hdr;   // offsets of the '>' that open records
   for (const char* q = D; q && q < D + N;) {
