@@ -206,6 +206,9 @@ int mhap_format_record(const mhap_record* r, char* out, size_t cap);
  * object owns the arrays; free with mhap_fasta_free. */
 typedef struct mhap_fasta {
   char* bases; int64_t* offsets; int32_t* lengths; int64_t* ids; int64_t n; int64_t total_bases;
+  char* headers;            /* n NUL-terminated names back to back: the header line after '>' up to the first white space or comma
+                               (what --store-full-id prints, FastaData.java:155-156) */
+  int64_t headers_bytes;
 } mhap_fasta;
 int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* err, size_t errcap);
 void mhap_fasta_free(mhap_fasta* f);

@@ -42,7 +42,7 @@ class _KTimes(C.Structure):
 
 class _Fasta(C.Structure):
     _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("lengths", C.c_void_p), ("ids", C.c_void_p),
-                ("n", C.c_int64), ("total_bases", C.c_int64)]
+                ("n", C.c_int64), ("total_bases", C.c_int64), ("headers", C.c_void_p), ("headers_bytes", C.c_int64)]
 
 
 RECORD_DTYPE = np.dtype([("from_id", "<i8"), ("to_id", "<i8"), ("score", "<f8"), ("raw", "<f8"), ("a1", "<i4"),

@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cctype>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -195,13 +196,24 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
       total += rlen[(size_t)r];
     }
   }
+  std::string names;
+  for (int64_t r = 0; r < nrec; r++) {
+    if (rlen[(size_t)r] <= 0) continue;
+    size_t a = hdr[(size_t)r] + 1, e = a;
+    while (e < body[(size_t)r] && !(isspace((unsigned char)D[e]) || D[e] == ',')) e++;   // substring(1).split("[\\s,]+", 2)[0]
+    names.append(D + a, e - a);
+    names.push_back('\0');
+  }
   out->n = (int64_t)offs.size();
   out->total_bases = total;
+  out->headers_bytes = (int64_t)names.size();
+  out->headers = (char*)malloc(std::max<size_t>(names.size(), 1));
+  if (out->headers) memcpy(out->headers, names.data(), names.size());
   out->bases = (char*)malloc(std::max<size_t>((size_t)total, 1));
   out->offsets = (int64_t*)malloc(std::max<size_t>(offs.size(), 1) * 8);
   out->lengths = (int32_t*)malloc(std::max<size_t>(offs.size(), 1) * 4);
   out->ids = (int64_t*)malloc(std::max<size_t>(offs.size(), 1) * 8);
-  if (!out->bases || !out->offsets || !out->lengths || !out->ids) { mhap_fasta_free(out); seterr("out of memory"); return MHAP_E_NOMEM; }
+  if (!out->bases || !out->offsets || !out->lengths || !out->ids || !out->headers) { mhap_fasta_free(out); seterr("out of memory"); return MHAP_E_NOMEM; }
   char* B = out->bases;
   par([&](int64_t lo, int64_t hi) {
     for (int64_t r = lo; r < hi; r++) {
@@ -219,7 +231,7 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
 
 void mhap_fasta_free(mhap_fasta* f) {
   if (!f) return;
-  free(f->bases); free(f->offsets); free(f->lengths); free(f->ids);
+  free(f->bases); free(f->offsets); free(f->lengths); free(f->ids); free(f->headers);
   memset(f, 0, sizeof *f);
 }
 

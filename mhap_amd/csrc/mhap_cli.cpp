@@ -98,25 +98,13 @@ std::string header_of(int64_t id) {   // SequenceId.getHeader (J/impl/SequenceId
 }
 
 // --store-full-id: header = first token after '>' split on [\s,]+ (FastaData.java:155-156)
-void collect_headers(const std::string& path, int64_t id_offset) {
-  FILE* f = fopen(path.c_str(), "rb");
-  if (!f) return;
-  std::string data; char buf[1 << 16]; size_t got;
-  while ((got = fread(buf, 1, sizeof buf, f)) > 0) data.append(buf, got);
-  fclose(f);
-  int64_t count = 0; std::string cur; bool have = false; size_t seqlen = 0; size_t pos = 0;
-  auto close = [&]() { if (have && seqlen > 0) { count++; g_headers.byid[count + id_offset] = cur; } have = false; };
-  while (pos < data.size()) {
-    size_t e = pos; while (e < data.size() && data[e] != '\n' && data[e] != '\r') e++;
-    if (e > pos && data[pos] == '>') {
-      close();
-      std::string h = data.substr(pos + 1, e - pos - 1);
-      size_t c = 0; while (c < h.size() && !(isspace((unsigned char)h[c]) || h[c] == ',')) c++;
-      cur = h.substr(0, c); have = true; seqlen = 0;
-    } else seqlen += e - pos;
-    pos = e; if (pos < data.size()) { if (data[pos] == '\r' && pos + 1 < data.size() && data[pos + 1] == '\n') pos += 2; else pos++; }
+// --store-full-id: names of the records just read (mhap_fasta.headers), keyed by the ids they were given
+void collect_headers(const mhap_fasta& fa) {
+  const char* p = fa.headers;
+  for (int64_t i = 0; i < fa.n && p && p < fa.headers + fa.headers_bytes; i++) {
+    g_headers.byid[fa.ids[i]] = std::string(p);
+    p += strlen(p) + 1;
   }
-  close();
 }
 
 struct Sink { FILE* out; std::string buf; int64_t n = 0; };
@@ -230,7 +218,7 @@ int64_t add_file_to_index(mhap_handle* h, const std::string& path, int64_t id_of
   }
   mhap_fasta fa; char err[512];
   if (mhap_fasta_read(path.c_str(), id_offset, &fa, err, sizeof err) != MHAP_OK) die(err);
-  if (g_headers.full) collect_headers(path, id_offset);
+  if (g_headers.full) collect_headers(fa);
   if (fa.n > 0) chk(h, mhap_index_add_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n));
   int64_t n = fa.n;
   mhap_fasta_free(&fa);
@@ -369,7 +357,7 @@ int main(int argc, char** argv) {
       }
       mhap_fasta fa;
       if (mhap_fasta_read(cf.c_str(), seq_processed, &fa, err, sizeof err) != MHAP_OK) die(err);   // id offset = reads so far (MhapMain.java:527)
-      if (g_headers.full) collect_headers(cf, seq_processed);
+      if (g_headers.full) collect_headers(fa);
       if (fa.n > 0) chk(h, mhap_find_matches_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n, sink_cb, &sink));
       nq = fa.n;
       mhap_fasta_free(&fa);

@@ -93,6 +93,12 @@ def test_cli_query_mode_and_full_ids(tmp_path):
     hdr.update({41 + j: f"q{30 + j}" for j in range(30)})
     expect = sorted(" ".join([hdr[int(l.split()[0])], hdr[int(l.split()[1])]] + l.split()[2:]) for l in lines)
     assert full == expect
+    # names also come through for compressed input (they are parsed by mhap_fasta_read, not by a second pass over the file)
+    import gzip
+    sgz, qgz = tmp_path / "index.fasta.gz", tmp_path / "query.fa.gz"
+    sgz.write_bytes(gzip.compress(sfile.read_bytes())); qgz.write_bytes(gzip.compress(qfile.read_bytes()))
+    fullgz, _ = _run(["-s", str(sgz), "-q", str(qgz), "--store-full-id"] + flags)
+    assert fullgz == expect
 
 
 def test_cli_filter_file_and_presets(tmp_path):
