@@ -36,6 +36,10 @@ def main(iters, seed0):
             if rnd.random() < 0.5: s = O.rc(s)
             if rnd.random() < 0.03: s = s[:len(s) // 2] + "N" * rnd.randrange(1, 5) + s[len(s) // 2:]
             if s: seqs.append(s)
+        if rnd.random() < 0.15:   # a few long reads: more k-mers than one LDS table / the register state of the weight kernel holds
+            for _ in range(rnd.randrange(1, 4)):
+                Lg = rnd.randrange(13000, 40000)
+                seqs.append(mutate(rnd, (G * (Lg // len(G) + 2))[rnd.randrange(0, len(G)):][:Lg], 0.05))
         fa = FastaData.from_strings(seqs)
         kw = dict(kmer_size=rnd.choice([16, 16, 16, 12, 14, 18, 21]), num_hashes=rnd.choice([16, 64, 128, 200, 512]),
                   ordered_kmer_size=rnd.choice([12, 12, 8, 10, 13]), ordered_sketch_size=rnd.choice([32, 100, 300, 512, 1536]),
