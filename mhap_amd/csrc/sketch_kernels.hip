@@ -681,7 +681,7 @@ __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t 
 // whenever at least one does (wave-uniform decision).  The row's minimum always survives; after BS_ARGMIN_PLANES planes
 // about 2048 / 2^BS_ARGMIN_PLANES other chains still share its prefix, and the deferred exact update sorts those out,
 // so the walk stops there instead of testing for a single survivor.
-constexpr int BS_ARGMIN_PLANES = 14;
+constexpr int BS_ARGMIN_PLANES = 11;   // measured 9 / 10 / 11 / 12 / 14 planes: 86.9 / 85.9 / 85.8 / 86.9 / 87.2 ms at C2
 __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t ACT) {
   uint32_t cand = ACT & P[63];                 // negative values first (signed compare)
   if (!__any(cand != 0u)) cand = ACT;
