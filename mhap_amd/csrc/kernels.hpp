@@ -60,7 +60,7 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
                     const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
                     int32_t* out_status, int64_t status_stride, const uint64_t* jump, const int32_t* order);
 // GF(2) jump-ahead tables of the xorshift64 step: na tables of 8x256 words (M^(g a), a = 1..na, g = 2^XS_JUMP_LOG2)
-constexpr int XS_JUMP_LOG2 = 4;
+constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 83.9 / 84.5 / 85.8 ms MinHash at C2 (2 MB of tables at H = 512)
 void build_xorshift_jump_tables(int na, uint64_t* out);
 void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
 size_t ordered_lds_bytes(int cap);
