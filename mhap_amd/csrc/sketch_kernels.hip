@@ -830,10 +830,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
           if (PROF) tp[5] += MHAP_TICK() - tr0;
-          int32_t bh_next = besthi[1];
+          int32_t vbh = 0;   // thresholds of 64 slots at a time, one per lane (a drain in between only makes them conservative)
           for (int s = 0; s < H; s++) {
-            const int32_t bh = bh_next;
-            bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
+            if ((s & 63) == 0) vbh = besthi[2 * (s + lane < H ? s + lane : H - 1) + 1];
+            const int32_t bh = __builtin_amdgcn_readlane(vbh, s & 63);
             bs_step(P);
             if (base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
               if (__any(ACT != 0u)) {
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
               }
               continue;
             }
-            const uint32_t nacc = bs_filter(P, ACT, __builtin_amdgcn_readfirstlane(bh));
+            const uint32_t nacc = bs_filter(P, ACT, bh);
             if (__any(nacc != 0xFFFFFFFFu)) {
               const unsigned long long ta = MHAP_TICK();
               bs_defer<PROF>(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane, tf);
