@@ -652,11 +652,17 @@ __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 }
 
 // returns a mask with a 0 bit for every chain that may undercut the slot minimum whose high dword is bhs
-__device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, int32_t bhs) {
-  if (bhs >= 0) return ~ACT;                     // no negative minimum yet: every active chain is a candidate
+// filter depth of a slot whose minimum has the high dword bhs: -1 = no negative minimum yet (every active chain is a candidate),
+// else the leading zero magnitude bits of the minimum, capped at BS_ZMAX
+__device__ __forceinline__ int bs_depth(int32_t bhs) {
+  if (bhs >= 0) return -1;
   const uint32_t mag = (uint32_t)bhs & 0x7fffffffu;
-  int z = mag ? (__builtin_clz(mag) - 1) : 31;   // leading zero magnitude bits of the current minimum
-  if (z > BS_ZMAX) z = BS_ZMAX;
+  const int z = mag ? (__builtin_clz(mag) - 1) : 31;
+  return z > BS_ZMAX ? BS_ZMAX : z;
+}
+
+__device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, int z) {
+  if (z < 0) return ~ACT;
   uint32_t nacc = ~P[63];                        // must be negative
   // ... with planes 62 .. 63-z all zero.  z is wave-uniform.  After the first row z >= 8 practically always: those eight
   // planes are OR-ed straight-line, the remaining depth is a chain of scalar compare+branch, one v_or each.
@@ -830,10 +836,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
           if (PROF) tp[5] += MHAP_TICK() - tr0;
-          int32_t vbh = 0;   // thresholds of 64 slots at a time, one per lane (a drain in between only makes them conservative)
+          int vz = 0;   // filter depths of 64 slots at a time, one per lane (a drain in between only makes them conservative)
           for (int s = 0; s < H; s++) {
-            if ((s & 63) == 0) vbh = besthi[2 * (s + lane < H ? s + lane : H - 1) + 1];
-            const int32_t bh = __builtin_amdgcn_readlane(vbh, s & 63);
+            if ((s & 63) == 0) vz = bs_depth(besthi[2 * (s + lane < H ? s + lane : H - 1) + 1]);
+            const int zs = __builtin_amdgcn_readlane(vz, s & 63);
             bs_step(P);
             if (base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
               if (__any(ACT != 0u)) {
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
               }
               continue;
             }
-            const uint32_t nacc = bs_filter(P, ACT, bh);
+            const uint32_t nacc = bs_filter(P, ACT, zs);
             if (__any(nacc != 0xFFFFFFFFu)) {
               const unsigned long long ta = MHAP_TICK();
               bs_defer<PROF>(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane, tf);
