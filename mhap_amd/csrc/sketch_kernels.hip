@@ -307,6 +307,7 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
           const uint32_t fp = ((uint32_t)((uint64_t)key[u] >> 32)) << 16;
           const uint32_t mine = fp | (uint32_t)(i + 1);
           uint32_t slot = (uint32_t)(uint64_t)key[u] & mask;
+          const uint32_t stride = ((uint32_t)((uint64_t)key[u] >> 20) | 1u) & mask;   // double hashing (odd stride, power-of-two table): no primary clustering
           for (;;) {
             const uint32_t old = atomicCAS(&tab[slot], 0u, mine);
             if (old == 0) break;
@@ -315,7 +316,7 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
               const int64_t okey = (FUSED && fz.on) ? (int64_t)lut_key16(fz.lut, codes_at(fz.codes, op)) : kp[op];
               if (okey == key[u]) { atomicMin(&tab[slot], mine); break; }
             }
-            slot = (slot + 1) & mask;
+            slot = (slot + stride) & mask;
           }
           st[c + u] = fp | slot;
         }
