@@ -402,6 +402,8 @@ class MinHashSearch:
 
         cb = _SINK(sink)
         self._chk(call(cb))
+        if len(chunks) == 1:
+            return chunks[0]
         return np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
 
     def prepare_index(self):
