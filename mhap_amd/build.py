@@ -1,8 +1,10 @@
 """Build libmhaphip.so (gfx950) and the mhap-hip CLI in-tree with hipcc.
 
 No CMake: four translation units, one hipcc command.  The built artefacts live under
-mhap_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).
+mhap_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).  An artefact is rebuilt whenever the SHA-256 of its
+sources + build command differs from the stamp written next to it.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -25,31 +27,58 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm to build the gfx950 kernels)")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(deps, cmd):
+    """SHA-256 over the build command and the bytes of every source/header: an artefact is reused only when the stamp
+    written next to it matches (mtimes do not survive a snapshot copy to the GPU box and say nothing about content)."""
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def _stale(target, digest):
+    stamp = target + ".sha256"
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    with open(stamp) as fh:
+        return fh.read().strip() != digest
+
+
+def _stamp(target, digest):
+    with open(target + ".sha256", "w") as fh:
+        fh.write(digest + "\n")
 
 
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    hipcc = _hipcc()
-    if force or _stale(LIB, deps):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
-               "-Wno-pass-failed", *srcs, "-o", LIB, "-lz", "-ldl"]
+    try:
+        hipcc = _hipcc()
+    except RuntimeError:
+        if os.path.exists(LIB) and not force:   # GPU box without a compiler on PATH: the shipped artefact is all there is
+            return LIB
+        raise
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+           "-Wno-pass-failed", *srcs, "-o", LIB, "-lz", "-ldl"]
+    dg = _digest(deps, cmd[1:])
+    if force or _stale(LIB, dg):
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True, cwd=CSRC)
+        _stamp(LIB, dg)
     cli_src = os.path.join(CSRC, "mhap_cli.cpp")
-    if os.path.exists(cli_src) and (force or _stale(CLI, [cli_src, LIB])):
+    if os.path.exists(cli_src):
         cmd = [hipcc, "-O2", "-std=c++17", "-pthread", cli_src, "-o", CLI, f"-L{LIBDIR}", "-lmhaphip",
                "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.run(cmd, check=True, cwd=CSRC)
+        dg_cli = _digest([cli_src, os.path.join(CSRC, HEADERS[-1])], cmd[1:] + [dg])
+        if force or _stale(CLI, dg_cli):
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.run(cmd, check=True, cwd=CSRC)
+            _stamp(CLI, dg_cli)
     return LIB
 
 

@@ -230,7 +230,6 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
   const size_t need = (size_t)std::max<int64_t>(store_bytes, 4);
   if (h->pin_cap < need) {
     if (h->pin_store) (void)hipHostFree(h->pin_store);
-  if (h->pin_io) (void)hipHostFree(h->pin_io);
     h->pin_store = nullptr; h->pin_cap = 0;
     HIPCHK(h, hipHostMalloc((void**)&h->pin_store, need + need / 8, hipHostMallocDefault));
     h->pin_cap = need + need / 8;
@@ -475,7 +474,7 @@ int ensure_inverted_index(mhap_handle* h) {
 
 int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>& ql, bool to_self, bool triangular_ok,
                 mhap_record_sink sink, void* user) {
-  if (ql.empty() || h->n_entries == 0) return MHAP_OK;
+  if (ql.empty() || h->n_entries == 0) { h->stats.queries_searched += (int64_t)ql.size(); return MHAP_OK; }
   const int S = h->P.ordered_sketch_size;
   SearchParams sp;
   sp.H = h->P.num_hashes; sp.S = S; sp.k2 = h->P.ordered_kmer_size;
@@ -719,6 +718,7 @@ void mhap_destroy(mhap_handle* h) {
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
+  if (h->pin_io) (void)hipHostFree(h->pin_io);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
@@ -887,6 +887,9 @@ int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* i
   if (m <= 0) return MHAP_OK;
   if (!ids || !is_fwd || !seq_length || !minhash || !ordered || !ordered_size || !ordered_seqlen) return fail(h, MHAP_E_INVALID, "null argument");
   (void)hipSetDevice(h->device);
+  if (h->n_entries + m > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
+  for (int64_t e = 0; e < m; e++)
+    if (seq_length[e] < 0 || ordered_seqlen[e] < 0) return fail(h, MHAP_E_INVALID, "negative sequence length in a precomputed sketch");
   int rc = ensure_index_capacity(h, h->n_entries + m);
   if (rc != MHAP_OK) return rc;
   const int64_t first = h->n_entries;

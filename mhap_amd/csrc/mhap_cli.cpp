@@ -220,11 +220,13 @@ int64_t add_file_to_index(mhap_handle* h, const std::string& path, int64_t id_of
   if (mhap_fasta_read(path.c_str(), id_offset, &fa, err, sizeof err) != MHAP_OK) die(err);
   if (g_headers.full) collect_headers(fa);
   if (fa.n > 0) chk(h, mhap_index_add_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n));
-  int64_t n = fa.n;
   mhap_fasta_free(&fa);
   mhap_stats st; chk(h, mhap_get_stats(h, &st));
   *strands = st.strands_indexed;
-  return n;
+  // seqNumberProcessed += seqStreamer.getNumberProcessed()/2 (MhapMain.java:462): the streamer counts the sketches it
+  // produced (SequenceSketchStreamer.java:145,155,268-271), so reads below --min-olap-length and reads without a valid
+  // n-gram do not advance the id offset of the -q files
+  return st.strands_indexed / 2;
 }
 
 }  // namespace
@@ -358,8 +360,10 @@ int main(int argc, char** argv) {
       mhap_fasta fa;
       if (mhap_fasta_read(cf.c_str(), seq_processed, &fa, err, sizeof err) != MHAP_OK) die(err);   // id offset = reads so far (MhapMain.java:527)
       if (g_headers.full) collect_headers(fa);
+      mhap_stats s0; chk(h, mhap_get_stats(h, &s0));
       if (fa.n > 0) chk(h, mhap_find_matches_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n, sink_cb, &sink));
-      nq = fa.n;
+      mhap_stats s1; chk(h, mhap_get_stats(h, &s1));
+      nq = s1.queries_searched - s0.queries_searched;   // forward sketches produced = getNumberProcessed() (MhapMain.java:537)
       mhap_fasta_free(&fa);
       sink_flush(sink);
       seq_processed += nq;

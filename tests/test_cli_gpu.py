@@ -101,6 +101,41 @@ def test_cli_query_mode_and_full_ids(tmp_path):
     assert fullgz == expect
 
 
+def test_cli_query_id_offsets_skip_unsketched_reads(tmp_path):
+    """seqNumberProcessed advances by the sketches PRODUCED (MhapMain.java:462,537; SequenceSketchStreamer.java:129-133,
+    268-271): reads below --min-olap-length get a FASTA id but do not move the id offset of the following -q files."""
+    base = mhap_amd.synth_reads(50, 2000, seed=17, error_rate=0.05)
+    short = "ACGTTGCA" * 10                                     # 80 bp < 116
+
+    def write(path, items):
+        with open(path, "w") as fh:
+            for j, s in enumerate(items):
+                fh.write(f">x{j}\n{s}\n")
+    sfile = tmp_path / "index.fasta"
+    qdir = tmp_path / "q"
+    qdir.mkdir()
+    s_items = [base.sequence(i) for i in range(0, 12)] + [short, short] + [base.sequence(i) for i in range(12, 30)]
+    q1 = [base.sequence(20), short, base.sequence(25), base.sequence(31), short, base.sequence(5)]
+    q2 = [base.sequence(i) for i in range(28, 45)]
+    write(sfile, s_items); write(qdir / "a.fasta", q1); write(qdir / "b.fasta", q2)
+    flags = ["--num-hashes", "64", "--ordered-sketch-size", "400"]
+    lines, err = _run(["-s", str(sfile), "-q", str(qdir)] + flags)
+    index = FastaData.from_file(str(sfile))
+    assert len(index) == 32
+    off1 = 30                                                   # 30 of the 32 -s reads were sketched
+    off2 = off1 + 4                                             # 4 of a.fasta's 6 reads were sketched
+    qa = FastaData.from_file(str(qdir / "a.fasta"), id_offset=off1)
+    qb = FastaData.from_file(str(qdir / "b.fasta"), id_offset=off2)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=400)
+    with MinHashSearch(p) as ms:
+        ms.add_data(index)
+        want = (mhap_amd.records_to_lines(ms.find_matches()) + mhap_amd.records_to_lines(ms.find_matches_stream(qa))
+                + mhap_amd.records_to_lines(ms.find_matches_stream(qb)))
+    assert lines == sorted(want) and len(lines) > 20
+    assert "Processed 4 to sequences." in err and "Processed 17 to sequences." in err
+    assert "Processed 60 unique sequences (fwd and rev)." in err
+
+
 def test_cli_filter_file_and_presets(tmp_path):
     fa = mhap_amd.synth_reads(120, 3000, seed=31, error_rate=0.05)
     fasta = tmp_path / "r.fasta"

@@ -402,6 +402,25 @@ def test_index_table_reuse_and_incremental_adds():
     assert c == want and 0 < len(first) < len(want)
 
 
+def test_growing_batches_keep_the_read_back_buffer():
+    """A small add followed by a much larger one re-allocates the pinned staging buffer; the (separate) pinned bounce buffer of
+    the meta/record read-backs must survive it (round-1 use-after-free), and a destroyed handle frees both."""
+    small = mhap_amd.synth_reads(40, 1500, seed=77, error_rate=0.05)
+    big = mhap_amd.synth_reads(700, 2500, seed=31, error_rate=0.06)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=400)
+    want, _ = _self_lines(big, p)
+    for _ in range(2):
+        with MinHashSearch(p) as ms:
+            ms.add_data(small)
+            assert len(ms.find_matches()) > 0
+            ms.clear()
+            ms.add_data(big)                       # staging grows past 1.125x the first batch
+            got = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+            assert got == want
+            q = ms.find_matches_stream(small)      # and a third, smaller staging round
+            assert q.shape[0] >= 0
+
+
 def test_config4_read_shape_slice():
     """BASELINE configs[3]/[4] read shapes (15 kb and 12 kb reads, H=512, S=1536: more than 12288 k-mers per strand takes the
     24-k-mers-per-lane weight kernel, 8 bit-sliced MinHash rows) on a slice of reads: full record parity with the oracle."""
