@@ -221,6 +221,11 @@ int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, dou
 /* Only reads shard, shard+nshards, ... of that same n-read data set (bases holds ceil((n-shard)/nshards)*len bytes). */
 int mhap_synth_reads_shard(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, int64_t shard,
                            int64_t nshards, char* bases);
+/* The same generator with a planted repeat family in the genome (BASELINE configs[4], the workload of the -f k-mer filter,
+ * J/sketch/FrequencyCounts.java): one random element of rep_len bases, one copy with per-base substitution rate rep_div in
+ * every rep_spacing-base stretch.  rep_len = 0 gives exactly mhap_synth_reads_shard's reads. */
+int mhap_synth_reads_repeats(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, int64_t shard,
+                             int64_t nshards, int32_t rep_len, int32_t rep_spacing, double rep_div, char* bases);
 
 /* murmur3_x64_128(seed 0).h1 of one k-mer line of a `-f` filter file, canonicalised when do_rc != 0
  * (HashUtils.computeSequenceHashesLong(str, len, 0, doRC)[0], J/sketch/FrequencyCounts.java:169). */

@@ -59,6 +59,7 @@ EXPORTED_SYMBOLS = [
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_find_matches_sketches",
+    "mhap_synth_reads_repeats",
 ]
 
 
@@ -179,16 +180,19 @@ class FastaData:
         return FastaData(bases, offsets, lengths, self.ids[idx])
 
 
-def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15, shard=0, nshards=1):
+def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15, shard=0, nshards=1, repeats=None):
     """Deterministic synthetic PacBio-style reads as a FastaData.
 
-    With nshards > 1 only reads shard, shard+nshards, ... of the same n-read data set are generated (ids kept)."""
+    With nshards > 1 only reads shard, shard+nshards, ... of the same n-read data set are generated (ids kept).
+    repeats = (element length, spacing, divergence) plants a repeat family in the genome (BASELINE configs[4])."""
     lib = load_library()
     idx = np.arange(shard, n, nshards, dtype=np.int64)
     m = len(idx)
     bases = np.empty(max(m * length, 1), dtype=np.uint8)
-    rc = lib.mhap_synth_reads_shard(C.c_uint64(seed), C.c_int64(n), C.c_int32(length), C.c_double(coverage),
-                                    C.c_double(error_rate), C.c_int64(shard), C.c_int64(nshards), _ptr(bases))
+    rl, rs, rd = repeats if repeats else (0, 0, 0.0)
+    rc = lib.mhap_synth_reads_repeats(C.c_uint64(seed), C.c_int64(n), C.c_int32(length), C.c_double(coverage),
+                                      C.c_double(error_rate), C.c_int64(shard), C.c_int64(nshards), C.c_int32(rl), C.c_int32(rs),
+                                      C.c_double(rd), _ptr(bases))
     if rc != 0:
         raise MhapError(f"mhap_synth_reads failed ({rc})")
     offsets = np.arange(m, dtype=np.int64) * length

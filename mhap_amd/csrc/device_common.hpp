@@ -12,17 +12,20 @@ namespace mhap {
 // ---- strand descriptors (host builds them, kernels consume them) -----------------------------
 // One descriptor per READ; both strands share the base storage.
 struct ReadDesc {
-  int64_t base_off;   // packed: byte offset into packed2 (4 bases/byte); raw: byte offset into raw bytes
-  int64_t key_off;    // element offset of the forward strand's k-mer key array (rc strand: + key_stride)
-  int64_t h2_off;     // element offset of the forward strand's 32-bit hash array (rc: + h2_stride)
+  int64_t base_off;   // packed: byte offset into packed2 (4 bases/byte, 4-byte aligned); raw: byte offset into raw bytes
+  int64_t key_off;    // MHAP_RD_MAT reads: element offset of the forward strand's k-mer key array (rc strand: + key_stride)
+  int64_t h2_off;     // MHAP_RD_MAT reads: element offset of the forward strand's 32-bit hash array (rc: + h2_stride)
+  int64_t w_off;      // element offset of the forward strand's weight / class-list arrays (rc: + key_stride)
   int32_t length;     // bases
-  int32_t key_stride; // elements between fwd and rc key arrays (aligned nk)
+  int32_t key_stride; // elements between fwd and rc key / weight arrays (aligned nk)
   int32_t h2_stride;  // elements between fwd and rc h32 arrays (aligned nk2)
-  int32_t flags;      // bit0: raw bytes (read has non-ACGT chars); bit1: skipped (too short)
+  int32_t flags;      // MHAP_RD_* bits
 };
-#define MHAP_RD_RAW 1
-#define MHAP_RD_SKIP 2
+#define MHAP_RD_RAW 1       // raw bytes (read has non-ACGT chars)
+#define MHAP_RD_SKIP 2      // skipped (too short)
 #define MHAP_RD_FWDONLY 4   // -q mode: only the forward strand is sketched (AbstractMatchSearch.java:225)
+#define MHAP_RD_MAT 8       // k-mer hashes are materialised in HBM by hash_kmers_kernel (raw bytes, k != 16 / k2 != 12, very long reads);
+                            // every other strand's hashes are recomputed from its 2-bit codes wherever they are consumed
 
 __host__ __device__ inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
 __host__ __device__ inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }

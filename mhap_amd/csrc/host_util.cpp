@@ -244,6 +244,11 @@ int mhap_synth_reads(uint64_t seed, int64_t n, int32_t len, double coverage, dou
 // Reads r = shard, shard+nshards, ... of the n-read data set (identical bytes to the full generation).
 int mhap_synth_reads_shard(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, int64_t shard, int64_t nshards,
                            char* bases) {
+  return mhap_synth_reads_repeats(seed, n, len, coverage, error_rate, shard, nshards, 0, 0, 0.0, bases);
+}
+int mhap_synth_reads_repeats(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, int64_t shard, int64_t nshards,
+                             int32_t rep_len, int32_t rep_spacing, double rep_div, char* bases) {
+  if (rep_len < 0 || (rep_len > 0 && (rep_spacing <= rep_len || rep_div < 0.0 || rep_div >= 1.0))) return MHAP_E_INVALID;
   if (n < 0 || len <= 0 || !bases || coverage <= 0.0 || error_rate < 0.0 || error_rate >= 1.0) return MHAP_E_INVALID;
   if (nshards < 1 || shard < 0 || shard >= nshards) return MHAP_E_INVALID;
   if (n == 0) return MHAP_OK;
@@ -254,6 +259,21 @@ int mhap_synth_reads_shard(uint64_t seed, int64_t n, int32_t len, double coverag
     for (int64_t i = 0; i < G; i += 32) {
       uint64_t r = g.next();
       for (int j = 0; j < 32 && i + j < G; j++) genome[(size_t)(i + j)] = (uint8_t)((r >> (2 * j)) & 3);
+    }
+    // planted repeat family (BASELINE configs[4]: the workload the -f k-mer filter exists for): one random element of
+    // rep_len bases, a copy with rep_div substitutions in every rep_spacing-base stretch of the genome (jittered position)
+    if (rep_len > 0) {
+      Xoshiro256ss e(SplitMix64{seed ^ 0x5245504541545321ULL}.next());
+      std::vector<uint8_t> elem((size_t)rep_len);
+      for (auto& b : elem) b = (uint8_t)(e.next() >> 62);
+      for (int64_t c0 = 0; c0 + rep_spacing <= G; c0 += rep_spacing) {
+        const int64_t at = c0 + (int64_t)e.below((uint64_t)(rep_spacing - rep_len));
+        for (int i = 0; i < rep_len; i++) {
+          uint8_t b = elem[(size_t)i];
+          if (e.unit() < rep_div) b = (uint8_t)((b + 1 + (e.next() >> 62) % 3) & 3);
+          genome[(size_t)(at + i)] = b;
+        }
+      }
     }
   }
   // ins:del:sub = 0.1188:0.0183:0.0129 (J/utils/RandomSequenceGenerator.java:93-96), scaled to error_rate

@@ -16,7 +16,13 @@ constexpr int CAND_KS = 32;          // slots staged per LDS chunk
 constexpr int OVL_THREADS = 128;
 constexpr int INV_CT = 4096;         // LDS hit-count table entries per query (inverted-index path)     // lanes per second-stage workgroup
 
-struct StrandInfo { int32_t valid; int32_t heavy; };   // heavy: 1 = some weight > 1, 2 = all weights 1 and wts[] not written
+// Weight classes of a strand's distinct k-mers (MinHashSketch.java:98-128).  mode > 0: every k-mer position carries the
+// weight `mode` (no repeated k-mer, one tf-idf weight) and neither wts[] nor the class list is read.  mode == 0: the class
+// list holds the positions of the first occurrences sorted by class — cnt[c] positions of weight c+1 for c < BS_WCLASSES,
+// then cnt[BS_WCLASSES] positions of any larger weight (their weights are in wts[]).
+constexpr int BS_WCLASSES = 6;
+constexpr int BS_WMAX = 32;          // largest uniform weight the bit-sliced rows take (queue entries keep the sub-step in 6 bits)
+struct StrandInfo { int32_t valid; int32_t mode; int32_t cnt[BS_WCLASSES + 1]; int32_t pad; };
 
 // Host-built FrequencyCounts table (open addressing; vals[slot]==0.0 marks empty; vals = scaledIdf).
 struct FilterTable {
@@ -47,25 +53,31 @@ struct SearchParams {
 
 // ---- sketch_kernels.hip ----
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store, int64_t* keys,
-                       int32_t* h32, int k, int k2, const uint64_t* luts, int only_raw);
+                       int32_t* h32, int k, int k2, const uint64_t* luts, int only_mat);
 // block-mix tables of the k = 16 / k2 = 12 fast path (768 words: murmur3_x64_128 k1 mix, k2 mix, murmur3_x86_32 pair)
 void build_kmer_hash_luts(uint64_t* out);
 int weight_grid(int num_cus, int64_t nstrands, int max_len, int k);   // persistent workgroups = HBM slabs needed
-bool kmer_weights_can_fuse(int max_len, int k, int k2);   // hashing of packed strands inside the weight kernel (k = 16, k2 = 12, LDS path)
-void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, int64_t* keys,
-                         uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
-                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts,
-                         const int32_t* order);   // order: read indices longest first (or null)
+// A read's hashes can be recomputed from its 2-bit codes (no MHAP_RD_MAT) when k = 16, k2 = 12, the read is pure ACGT and its
+// k-mers fit the weight kernel's LDS path
+bool strand_hashes_from_codes(int length, int k, int k2);
+void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
+                         uint32_t* wts, uint32_t* perm, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k,
+                         const FilterTable& ft, double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store,
+                         const uint64_t* luts, const int32_t* order);   // order: read indices longest first (or null)
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
-                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride, const uint64_t* jump, const int32_t* order);
-// GF(2) jump-ahead tables of the xorshift64 step: na tables of 8x256 words (M^(g a), a = 1..na, g = 2^XS_JUMP_LOG2)
+                    const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
+                    unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
+                    const uint64_t* jump, int jump_na, const int32_t* order);
+// GF(2) jump-ahead tables of the xorshift64 step, two levels: na tables of 8x256 words for M^(g a), a = 1..na (g = 2^XS_JUMP_LOG2),
+// then nq tables for M^(g na q), q = 1..nq (weighted chains run past H steps: one coarse + one fine table application)
 constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 83.9 / 84.5 / 85.8 ms MinHash at C2 (2 MB of tables at H = 512)
-void build_xorshift_jump_tables(int na, uint64_t* out);
+constexpr int XS_JUMP_NQ = BS_WMAX;
+void build_xorshift_jump_tables(int na, int nq, uint64_t* out);
 void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
-size_t ordered_lds_bytes(int cap);
-void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, const int32_t* h32, int k2, int S, int cap,
-                    int32_t* out_rows, int64_t out_stride, int32_t* out_meta, int64_t meta_stride);
+size_t ordered_lds_bytes(int cap, int code_words);
+void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const int32_t* h32, const uint8_t* store,
+                    const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride, int32_t* out_meta,
+                    int64_t meta_stride);
 
 // ---- search_kernels.hip ----
 // All-pairs slot-equality count between query entries qlist[0..nq) and index entries [0..ne).

@@ -15,6 +15,8 @@
 #include "../../include/mhap_hip.h"
 static double hp_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 #define HPROF(tag) do { if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[host] %-28s %.3f ms\n", tag, hp_now()); } while (0)
+// MHAP_DEBUG_SYNC=1: wait for every sketch kernel and say so (which launch hangs or faults)
+#define DBGSYNC(h, tag) do { if (getenv("MHAP_DEBUG_SYNC")) { fprintf(stderr, "[dbg] %s launched\n", tag); hipError_t _e = hipStreamSynchronize((h)->stream); fprintf(stderr, "[dbg] %s done: %s\n", tag, hipGetErrorString(_e)); } } while (0)
 #include "kernels.hpp"
 #include "overlap_lane.hpp"
 
@@ -103,7 +105,8 @@ struct mhap_handle {
   std::vector<uint8_t> status;   // per entry status (host mirror)
 
   // sketch scratch
-  DevBuf store, descs, keys, wts, h32, info, slabs, counters, order;
+  DevBuf store, descs, keys, wts, perm, h32, info, slabs, counters, order;
+  int jump_na = 0;   // fine xorshift jump tables (coarse ones follow them in jump_tbl)
   std::vector<int32_t> h_order;
   uint8_t* pin_store = nullptr;   // pinned host staging buffer of stage_reads
   size_t pin_cap = 0;
@@ -279,34 +282,41 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
-  int64_t batch_bases = 1LL << 30;   // bases per launch group: 32 B of scratch per base (keys, weights, 32-bit hashes of both strands) = 32 GB of the 288 GB;
+  int64_t batch_bases = 1LL << 30;   // bases per launch group: 16 B of scratch per base (weights + class lists of both strands) = 16 GB of the 288 GB;
                                      // fewer, larger launches = fewer drain tails of the persistent MinHash waves (a strand takes ~2 ms)
   if (const char* e = getenv("MHAP_BATCH_BASES")) { long long v = atoll(e); if (v > 0) batch_bases = v; }
+  // Strands whose hashes are recomputed from their 2-bit codes wherever they are consumed need no key / 32-bit hash arrays;
+  // raw-byte reads, k != 16 / k2 != 12 and reads beyond the weight kernel's LDS path are hashed by hash_kmers_kernel (MHAP_RD_MAT).
+  const char* fenv = getenv("MHAP_FUSED_HASH");
+  const bool from_codes_ok = !(fenv && atoi(fenv) == 0);
+  auto is_mat = [&](const ReadDesc& d) { return (d.flags & MHAP_RD_RAW) || !from_codes_ok || !strand_hashes_from_codes(d.length, k, k2); };
   // ---- batch plan + worst-case scratch sizes (allocated once) ----
-  struct Batch { int64_t r0, r1, key_elems, h2_elems; int max_len; };
+  struct Batch { int64_t r0, r1; int max_len; };
   std::vector<Batch> plan;
-  int64_t max_key = 4, max_h2 = 4, max_nb = 1;
+  int64_t max_key = 4, max_h2 = 4, max_w = 4, max_nb = 1;
   int max_len_all = 0;
   for (int64_t r0 = 0; r0 < n;) {
     int64_t r1 = r0, tot = 0;
     while (r1 < n && (r1 == r0 || tot + h->st_descs[(size_t)r1].length <= batch_bases) && (r1 - r0) < (1 << 22)) { tot += h->st_descs[(size_t)r1].length; r1++; }
-    Batch b{r0, r1, 0, 0, 0};
+    Batch b{r0, r1, 0};
+    int64_t key_elems = 0, h2_elems = 0, w_elems = 0;
     for (int64_t i = r0; i < r1; i++) {
       const ReadDesc& d = h->st_descs[(size_t)i];
       if (d.flags & MHAP_RD_SKIP) continue;
-      b.key_elems += 2 * align4(std::max(0, d.length - k + 1));
-      b.h2_elems += 2 * align4(std::max(0, d.length - k2 + 1));
+      w_elems += 2 * align4(std::max(0, d.length - k + 1));
+      if (is_mat(d)) { key_elems += 2 * align4(std::max(0, d.length - k + 1)); h2_elems += 2 * align4(std::max(0, d.length - k2 + 1)); }
       b.max_len = std::max(b.max_len, d.length);
     }
-    max_key = std::max(max_key, b.key_elems); max_h2 = std::max(max_h2, b.h2_elems); max_nb = std::max(max_nb, r1 - r0);
+    max_key = std::max(max_key, key_elems); max_h2 = std::max(max_h2, h2_elems); max_w = std::max(max_w, w_elems); max_nb = std::max(max_nb, r1 - r0);
     max_len_all = std::max(max_len_all, b.max_len);
     plan.push_back(b);
     r0 = r1;
   }
   HIPCHK(h, h->descs.ensure((size_t)max_nb * sizeof(ReadDesc)));
   HIPCHK(h, h->keys.ensure((size_t)max_key * 8));
-  HIPCHK(h, h->wts.ensure((size_t)max_key * 4));
   HIPCHK(h, h->h32.ensure((size_t)max_h2 * 4));
+  HIPCHK(h, h->wts.ensure((size_t)max_w * 4));
+  HIPCHK(h, h->perm.ensure((size_t)max_w * 4));
   HIPCHK(h, h->info.ensure((size_t)(2 * max_nb) * sizeof(StrandInfo)));
   HIPCHK(h, h->counters.ensure(256));
   {
@@ -318,17 +328,24 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
   for (const Batch& B : plan) {
     const int64_t nb = B.r1 - B.r0, nstr = 2 * nb;
     h->h_descs.resize((size_t)nb);
-    int64_t key_elems = 0, h2_elems = 0;
-    bool any_raw = false;
-    int min_len_b = INT32_MAX;
+    int64_t key_elems = 0, h2_elems = 0, w_elems = 0;
+    bool any_mat = false;
+    int min_len_b = INT32_MAX, max_len_codes = 0;
     for (int64_t i = 0; i < nb; i++) {
       ReadDesc d = h->st_descs[(size_t)(B.r0 + i)];
-      if (!(d.flags & MHAP_RD_SKIP)) min_len_b = std::min(min_len_b, d.length);
-      if ((d.flags & MHAP_RD_RAW) && !(d.flags & MHAP_RD_SKIP)) any_raw = true;
+      const bool skip = (d.flags & MHAP_RD_SKIP) != 0;
+      if (!skip) min_len_b = std::min(min_len_b, d.length);
       const int64_t nk = align4(std::max(0, d.length - k + 1)), nk2 = align4(std::max(0, d.length - k2 + 1));
-      d.key_off = key_elems; d.key_stride = (int32_t)nk;
-      d.h2_off = h2_elems; d.h2_stride = (int32_t)nk2;
-      if (!(d.flags & MHAP_RD_SKIP)) { key_elems += 2 * nk; h2_elems += 2 * nk2; }
+      d.key_off = d.h2_off = 0;
+      d.w_off = w_elems; d.key_stride = (int32_t)nk; d.h2_stride = (int32_t)nk2;
+      if (!skip) {
+        w_elems += 2 * nk;
+        if (is_mat(d)) {
+          d.flags |= MHAP_RD_MAT; any_mat = true;
+          d.key_off = key_elems; d.h2_off = h2_elems;
+          key_elems += 2 * nk; h2_elems += 2 * nk2;
+        } else max_len_codes = std::max(max_len_codes, d.length);
+      }
       h->h_descs[(size_t)i] = d;
     }
     // reads of clearly different lengths: hand them out longest first (counting sort on length / 128), so that the persistent
@@ -355,29 +372,29 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     const ReadDesc* dd = h->descs.as<ReadDesc>();
     HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
-    // k = 16 / k2 = 12 and every strand on the LDS path: packed strands are hashed inside the weight kernel, the hash kernel
-    // only runs for raw-byte strands (MHAP_FUSED_HASH=0: always the separate hash kernel)
-    const char* fenv = getenv("MHAP_FUSED_HASH");
-    const bool fuse_ok = !(fenv && atoi(fenv) == 0);
-    const bool fused = fuse_ok && kmer_weights_can_fuse(B.max_len, k, k2);
-    if (!fused || any_raw) {
+    const bool fused = k == 16 && k2 == 12;   // the table path exists: strands without MHAP_RD_MAT are hashed where their hashes are used
+    if (any_mat) {
       time_begin(h, MHAP_K_HASH);
       launch_hash_kmers(h->stream, dd, nstr, B.max_len, h->store.as<uint8_t>(), h->keys.as<int64_t>(), h->h32.as<int32_t>(), k, k2,
-                        h->hash_luts.as<uint64_t>(), fused ? 1 : 0);
+                        h->hash_luts.as<uint64_t>(), 1);
       time_end(h);
+      DBGSYNC(h, "hash_kmers");
     }
     time_begin(h, MHAP_K_DEDUP);
-    launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->slabs.as<uint32_t>(),
-                        slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused, h->store.as<uint8_t>(),
-                        h->h32.as<int32_t>(), h->hash_luts.as<uint64_t>(), d_order);
+    launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(),
+                        h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused,
+                        h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), d_order);
     time_end(h);
+    DBGSYNC(h, "kmer_weights");
     time_begin(h, MHAP_K_MINHASH);
     int per_cu = 8;
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
-    launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->info.as<StrandInfo>(), k, k2, H, ctr + 1,
-                   mh_rows, mh_stride, meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), d_order);
+    launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(), h->info.as<StrandInfo>(),
+                   h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr + 1, mh_rows, mh_stride, meta_rows + 3, META_W,
+                   h->jump_tbl.as<uint64_t>(), h->jump_na, d_order);
     time_end(h);
+    DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
     if (h->eager) {
       // the postings of this launch group go into the inverted index on a second stream while the ordered-sketch kernel runs
@@ -391,8 +408,10 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
     }
     time_begin(h, MHAP_K_ORDERED);
-    launch_ordered(h->stream, dd, nstr, h->h32.as<int32_t>(), k2, S, h->ord_cap, ord_rows, ord_stride, meta_rows, META_W);
+    launch_ordered(h->stream, dd, nstr, max_len_codes, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
+                   ord_rows, ord_stride, meta_rows, META_W);
     time_end(h);
+    DBGSYNC(h, "ordered");
     HIPCHK(h, hipGetLastError());
     int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
@@ -690,8 +709,9 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (rc != MHAP_OK) { seterr(h->err); mhap_destroy(h); return rc; }
   {   // xorshift jump-ahead tables for slots up to H (MinHash kernel's deferred-candidate drain)
     const int na = ((P.num_hashes + 1) >> XS_JUMP_LOG2) + 1;
-    std::vector<uint64_t> jt((size_t)na * 2048);
-    build_xorshift_jump_tables(na, jt.data());
+    std::vector<uint64_t> jt((size_t)(na + XS_JUMP_NQ) * 2048);
+    build_xorshift_jump_tables(na, XS_JUMP_NQ, jt.data());
+    h->jump_na = na;
     if (h->jump_tbl.ensure(jt.size() * 8) != hipSuccess || hipMemcpy(h->jump_tbl.p, jt.data(), jt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
       seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
@@ -714,7 +734,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
-                    &h->keys, &h->wts, &h->h32, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
+                    &h->keys, &h->wts, &h->perm, &h->h32, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
@@ -1133,9 +1153,19 @@ int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out) {
   const int a = nsteps >> XS_JUMP_LOG2, r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
   uint64_t x = key;
   if (a > 0) {
-    std::vector<uint64_t> jt((size_t)a * 2048);
-    build_xorshift_jump_tables(a, jt.data());
-    const uint64_t* T = jt.data() + (size_t)(a - 1) * 2048;
+    // two levels like the drain: fine tables for a <= na, one coarse table application (M^(g na q)) before them beyond that
+    const int na = a < 24 ? a : 24;
+    int qa = 0, af = a;
+    if (af > na) { qa = (af - 1) / na; af -= qa * na; }
+    std::vector<uint64_t> jt((size_t)(na + qa + 1) * 2048);
+    build_xorshift_jump_tables(na, qa + 1, jt.data());
+    if (qa > 0) {
+      const uint64_t* T = jt.data() + (size_t)(na + qa - 1) * 2048;
+      uint64_t y = 0;
+      for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+      x = y;
+    }
+    const uint64_t* T = jt.data() + (size_t)(af - 1) * 2048;
     uint64_t y = 0;
     for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
     x = y;

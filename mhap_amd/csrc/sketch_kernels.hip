@@ -70,6 +70,24 @@ __device__ __forceinline__ uint32_t strand_codes16(const uint8_t* __restrict__ p
 __device__ __forceinline__ uint32_t codes_at(const uint32_t* codes, int p) {
   return __builtin_amdgcn_alignbit(codes[(p >> 4) + 1], codes[p >> 4], (uint32_t)(2 * (p & 15)));
 }
+// 16 base codes from strand position p on (position p+b in bits 2b) straight from the packed read in HBM/L2: W = the read's
+// packed bytes as dwords (16 bases each), nd dwords.  Lanes of a wavefront ask for neighbouring positions, so the two dword
+// loads hit the same few cache lines.  Valid for 0 <= p <= L-12; codes beyond the read come back arbitrary.
+__device__ __forceinline__ uint32_t strand_window16(const uint32_t* __restrict__ W, int nd, int L, int rcs, int p) {
+  int f0 = rcs ? (L - 16 - p) : p;              // lowest forward base of the window
+  int sh = 0;
+  if (f0 < 0) { sh = -2 * f0; f0 = 0; }         // (12-mers at the end of the reverse strand)
+  const int i0 = f0 >> 4;
+  const uint32_t d0 = W[i0 < nd ? i0 : nd - 1], d1 = W[i0 + 1 < nd ? i0 + 1 : nd - 1];
+  uint32_t x = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)(2 * (f0 & 15))) << sh;
+  if (rcs) {
+    x = __builtin_bswap32(x);
+    x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ~x;
+  }
+  return x;
+}
 // murmur3_x64_128(seed 0).h1 of the 16-mer / murmur3_x86_32(seed 0) of the 12-mer that start the 16 codes cw
 __device__ __forceinline__ uint64_t lut_key16(const uint64_t* lut, uint32_t cw) {
   uint64_t h1 = 0, h2 = 0;
@@ -97,14 +115,14 @@ __device__ __forceinline__ uint32_t lut_hash12(const uint64_t* lut, uint32_t cw)
 template <int KT, int K2T>
 __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restrict__ descs, const uint8_t* __restrict__ store,
                                                          int64_t* __restrict__ keys, int32_t* __restrict__ h32, int k_rt,
-                                                         int k2_rt, const uint64_t* __restrict__ luts, int only_raw) {
+                                                         int k2_rt, const uint64_t* __restrict__ luts, int only_mat) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_chars[];
   const int k = KT > 0 ? KT : k_rt, k2 = K2T > 0 ? K2T : k2_rt;
   const int strand = blockIdx.x;
   const ReadDesc rd = descs[strand >> 1];
   const int rcs = strand & 1;
   if (strand_skipped(rd, rcs)) return;
-  if (only_raw && !(rd.flags & MHAP_RD_RAW)) return;   // packed strands are hashed inside kmer_weight_kernel<.., true>
+  if (only_mat && !(rd.flags & MHAP_RD_MAT)) return;   // the other strands' hashes are recomputed from their 2-bit codes where they are used
   const int L = rd.length;
   const int nk = L - k + 1, nk2 = L - k2 + 1;
   const int nmax = nk > nk2 ? nk : nk2;
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256) void hash_kmers_kernel(const ReadDesc* __restr
 }
 
 void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const uint8_t* store,
-                       int64_t* keys, int32_t* h32, int k, int k2, const uint64_t* luts, int only_raw) {
+                       int64_t* keys, int32_t* h32, int k, int k2, const uint64_t* luts, int only_mat) {
   if (nstrands <= 0) return;
   int kmin = k < k2 ? k : k2;
   int nmax = max_len - kmin + 1;
@@ -168,9 +186,9 @@ void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, 
     if (lut_lds > lds) lds = lut_lds;
     // packed strands: the workgroups with blockIdx.y < ceil(windows / HASH_SEG) hash one segment each, the others exit
     // (raw-byte strands of the same launch take the generic path tile by tile, so the grid keeps all tiles)
-    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts, only_raw);
+    hipLaunchKernelGGL((hash_kmers_kernel<16, 12>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts, only_mat);
   } else
-    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts, only_raw);
+    hipLaunchKernelGGL((hash_kmers_kernel<0, 0>), grid, dim3(256), lds, st, descs, store, keys, h32, k, k2, luts, only_mat);
 }
 
 // =============================================================================================
@@ -182,7 +200,9 @@ void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, 
 //     (true duplicate or 2^-16 collision).  ds_cmpst/ds_min atomics, no HBM traffic besides the key stream.
 //   * HBM path (long reads): entry = pos+1 in a per-workgroup slab (stays in L2/MALL), global atomics.
 // Multiplicities are accumulated directly in the output array: wts[first] += 1 per later occurrence.
-// Output wts[i] = weight of k-mer i if i is the first occurrence of its key, else 0.
+// Output wts[i] = weight of k-mer i if i is the first occurrence of its key, else 0 — written only for strands whose k-mers
+// do not all carry the same weight; those strands also get their first occurrences listed by weight class (class_list),
+// which is what lets the MinHash kernel keep weighted k-mers (tf repeats, tf-idf under -f) on its bit-sliced rows.
 // =============================================================================================
 __device__ inline uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -272,9 +292,9 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
 // read-before-CAS), and the post-barrier pass is ONE ds_read per k-mer: the remembered slot holds the smallest
 // position of that key, so `entry == mine` <=> first occurrence.  Requires nk <= MAXIT*WEIGHT_THREADS, ts <= 32768.
 // FUSED (k = 16, k2 = 12, packed strand): the keys are not loaded but hashed here from the strand's base codes in LDS
-// (fz.codes, block-mix tables fz.lut) and written out together with the 32-bit hashes of the ordered sketch, so the
-// separate hash kernel and the 8 B/k-mer key read-back (with its exposed load latency) disappear for such strands.
-struct FusedHash { const uint64_t* lut; const uint32_t* codes; int64_t* kout; int32_t* hout; int nk2; bool on; };
+// (fz.codes, block-mix tables fz.lut).  Nothing is written for them: the MinHash and ordered-sketch kernels recompute
+// the hashes they need from the same 2-bit codes (12 B/k-mer of HBM writes and their read-back are gone).
+struct FusedHash { const uint64_t* lut; const uint32_t* codes; bool on; };
 template <int MAXIT, bool FUSED>
 __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
                                          unsigned int* s_heavy, const FusedHash& fz, bool may_skip) {
@@ -285,19 +305,13 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   constexpr int CH = FUSED ? 2 : ((MAXIT >= 24) ? 8 : 4);   // keys in flight per lane (register budget: two workgroups per CU need <= 64 VGPRs)
 #pragma unroll
   for (int c = 0; c < MAXIT; c += CH) {
-    if (c * WEIGHT_THREADS < ((FUSED && fz.on) ? fz.nk2 : nk)) {
+    if (c * WEIGHT_THREADS < nk) {
       int64_t key[CH];
 #pragma unroll
       for (int u = 0; u < CH; u++) {
         const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
-        if (FUSED && fz.on) {
-          key[u] = 0;
-          if (i < fz.nk2) {
-            const uint32_t cw = codes_at(fz.codes, i);
-            if (i < nk) { key[u] = (int64_t)lut_key16(fz.lut, cw); fz.kout[i] = key[u]; }
-            fz.hout[i] = (int32_t)lut_hash12(fz.lut, cw);
-          }
-        } else key[u] = (i < nk) ? kp[i] : 0;
+        if (FUSED && fz.on) key[u] = (i < nk) ? (int64_t)lut_key16(fz.lut, codes_at(fz.codes, i)) : 0;
+        else key[u] = (i < nk) ? kp[i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < CH; u++) {
@@ -323,8 +337,6 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
       }
     }
   }
-  if (FUSED && fz.on)   // the last k2-mers of a strand that fills all MAXIT rounds
-    for (int i = threadIdx.x + MAXIT * WEIGHT_THREADS; i < fz.nk2; i += WEIGHT_THREADS) fz.hout[i] = (int32_t)lut_hash12(fz.lut, codes_at(fz.codes, i));
   __syncthreads();
   // a strand without a repeated k-mer (nearly all of them) has weight 1 everywhere: when the caller allows it, that is
   // reported through *s_heavy = 2 and the weight array is not written at all (the MinHash kernel then does not read it)
@@ -434,18 +446,61 @@ __device__ inline bool weight_strand_lds_part(uint32_t* tab, uint32_t ts, const 
   return true;
 }
 
+// First occurrences of a strand listed by weight class (see StrandInfo): two passes over the final weights in wp[] — count
+// per class, then scatter — with one LDS atomic per wavefront and class present (ballot + mbcnt ranks).  sv: 3 x 8 words of
+// LDS (counts, segment starts, fill counters), zero on entry; order inside a class is arbitrary (the MinHash update resolves
+// ties by position, not by processing order).
+__device__ inline int weight_class(uint32_t w) { return w == 0u ? -1 : (int)((w > (uint32_t)BS_WCLASSES ? (uint32_t)BS_WCLASSES + 1u : w) - 1u); }
+__device__ inline void class_list(const uint32_t* __restrict__ wp, uint32_t* __restrict__ perm, int nk, uint32_t* sv, int32_t* cnt_out) {
+  const int lane = threadIdx.x & 63;
+  for (int i0 = 0; i0 < nk; i0 += WEIGHT_THREADS) {           // block-uniform trip count (ballots inside)
+    const int i = i0 + (int)threadIdx.x;
+    int c = i < nk ? weight_class(ld_agent(&wp[i])) : -1;
+    unsigned long long rest = __ballot(c >= 0);
+    while (rest) {
+      const int cc = __shfl(c, __builtin_ctzll(rest));
+      const unsigned long long m = __ballot(c == cc);
+      if (lane == (int)__builtin_ctzll(m)) atomicAdd(&sv[cc], (uint32_t)__popcll(m));
+      rest &= ~m;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int c = 0; c <= BS_WCLASSES; c++) { sv[8 + c] = run; cnt_out[c] = (int32_t)sv[c]; run += sv[c]; }
+  }
+  __syncthreads();
+  for (int i0 = 0; i0 < nk; i0 += WEIGHT_THREADS) {
+    const int i = i0 + (int)threadIdx.x;
+    int c = i < nk ? weight_class(ld_agent(&wp[i])) : -1;
+    unsigned long long rest = __ballot(c >= 0);
+    while (rest) {
+      const int cc = __shfl(c, __builtin_ctzll(rest));
+      const unsigned long long m = __ballot(c == cc);
+      uint32_t base = 0;
+      if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(&sv[16 + cc], (uint32_t)__popcll(m));
+      base = __shfl(base, __builtin_ctzll(m));
+      if (c == cc) perm[sv[8 + cc] + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint32_t)i;
+      rest &= ~m;
+    }
+  }
+}
+
+constexpr int WEIGHT_SVARS = 32;   // LDS scalars of kmer_weight_kernel: [0..1] strand index, [2] valid / partition fill, [3] heavy, [4] min weight,
+                                   // [5] max weight, [8..31] class_list scratch
 template <int MAXIT, int WAVES_PER_SIMD, bool FUSED>
 __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
-                                                                     int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
+                                                                     const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
+                                                                     uint32_t* __restrict__ perms,
                                                                      uint32_t* __restrict__ slabs, int64_t slab_entries, uint32_t lds_entries,
                                                                      unsigned long long* __restrict__ counter, int k,
                                                                      FilterTable ft, double repeat_weight,
                                                                      StrandInfo* __restrict__ info, const uint8_t* __restrict__ store,
-                                                                     int32_t* __restrict__ h32, const uint64_t* __restrict__ luts,
+                                                                     const uint64_t* __restrict__ luts,
                                                                      const int32_t* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
-  uint32_t* svars = lds_tab + lds_entries;   // [0..1] strand index, [2] valid, [3] heavy
-  uint64_t* lut = (uint64_t*)(svars + 4);                       // FUSED: block-mix tables, then the strand's base codes
+  uint32_t* svars = lds_tab + lds_entries;
+  uint64_t* lut = (uint64_t*)(svars + WEIGHT_SVARS);            // FUSED: block-mix tables, then the strand's base codes
   uint32_t* codes = (uint32_t*)(lut + HASH_LUT_WORDS);
   if (FUSED) for (int i = threadIdx.x; i < HASH_LUT_WORDS; i += WEIGHT_THREADS) lut[i] = luts[i];
   uint32_t* slab = slabs + (size_t)blockIdx.x * (size_t)slab_entries;
@@ -454,8 +509,9 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned long long sx = atomicAdd(counter, 1ULL);
-      svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32); svars[2] = 0; svars[3] = 0;
+      svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32); svars[2] = 0; svars[3] = 0; svars[4] = 0xFFFFFFFFu; svars[5] = 0;
     }
+    if (threadIdx.x >= 8 && threadIdx.x < WEIGHT_SVARS) svars[threadIdx.x] = 0;
     __syncthreads();
     int64_t strand = (int64_t)(((unsigned long long)svars[1] << 32) | svars[0]);
     if (strand >= nstrands) break;
@@ -464,25 +520,26 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
     const int rcs = (int)(strand & 1);
     const int nk = rd.length - k + 1;
     if (strand_skipped(rd, rcs) || nk < 1) {
-      if (threadIdx.x == 0) { info[strand].valid = 0; info[strand].heavy = 0; }
+      if (threadIdx.x == 0) { info[strand].valid = 0; info[strand].mode = 1; }
       continue;
     }
+    const bool mat = !FUSED || (rd.flags & MHAP_RD_MAT);           // keys materialised by hash_kmers_kernel
     const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
-    uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
+    uint32_t* wp = wts + rd.w_off + (rcs ? rd.key_stride : 0);
+    uint32_t* perm = perms + rd.w_off + (rcs ? rd.key_stride : 0);
     uint32_t ts = 64;
     while (3ull * ts < 4ull * (uint32_t)nk) ts <<= 1;          // load factor <= 0.75
     FusedHash fz;
-    fz.lut = lut; fz.codes = codes; fz.on = false; fz.nk2 = rd.length - 12 + 1;
-    fz.kout = keys + rd.key_off + (rcs ? rd.key_stride : 0);
-    fz.hout = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
-    if (ts <= lds_entries && nk <= MAXIT * WEIGHT_THREADS) {
-      if (FUSED && !(rd.flags & MHAP_RD_RAW)) {
-        fz.on = true;
-        const int ncw = (rd.length + 15) / 16 + 2;
-        for (int wj = threadIdx.x; wj < ncw; wj += WEIGHT_THREADS) codes[wj] = strand_codes16(store + rd.base_off, rd.length, rcs, 16 * wj);
-        // (the table-zeroing barrier inside weight_strand_lds orders these stores before the first hash)
-      }
-      weight_strand_lds<MAXIT, FUSED>(lds_tab, ts, kp, wp, nk, &svars[3], fz, !reweigh);
+    fz.lut = lut; fz.codes = codes; fz.on = false;
+    if (!mat) {
+      // strands without MHAP_RD_MAT always fit the LDS path (strand_hashes_from_codes)
+      fz.on = true;
+      const int ncw = (rd.length + 15) / 16 + 2;
+      for (int wj = threadIdx.x; wj < ncw; wj += WEIGHT_THREADS) codes[wj] = strand_codes16(store + rd.base_off, rd.length, rcs, 16 * wj);
+      // (the table-zeroing barrier inside weight_strand_lds orders these stores before the first hash)
+      weight_strand_lds<MAXIT, FUSED>(lds_tab, ts, kp, wp, nk, &svars[3], fz, true);
+    } else if (ts <= lds_entries && nk <= MAXIT * WEIGHT_THREADS) {
+      weight_strand_lds<MAXIT, FUSED>(lds_tab, ts, kp, wp, nk, &svars[3], fz, true);
     } else {
       // long read: hash-partitioned passes through the LDS table; HBM slab only if a partition overflows it
       int plog = 0;
@@ -498,13 +555,15 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
       if (threadIdx.x == 0) svars[2] = 0;
     }
     __syncthreads();
-    unsigned int myvalid = 0, myheavy = 0;
+    const bool dups = svars[3] == 1u;
+    const bool unwritten = svars[3] == 2u;   // no k-mer repeats and wp[] was not written (every multiplicity is 1)
     if (reweigh) {
       // weights differ from plain multiplicity: v1.0 mode or tf-idf (MinHashSketch.java:101-124)
+      uint32_t mymin = 0xFFFFFFFFu, mymax = 0;
       for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
-        const int count = (int)ld_agent(&wp[i]);
+        const int count = unwritten ? 1 : (int)ld_agent(&wp[i]);
         if (count == 0) continue;
-        const int64_t key = kp[i];
+        const int64_t key = fz.on ? (int64_t)lut_key16(lut, codes_at(codes, i)) : kp[i];
         int weight;
         double v;
         if (repeat_weight < 0.0) {
@@ -517,52 +576,71 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
           if (weight < 1) weight = 1;
         }
         wp[i] = (uint32_t)weight;
-        if (weight > 0) myvalid = 1;
-        if (weight > 1) myheavy = 1;
+        mymin = (uint32_t)weight < mymin ? (uint32_t)weight : mymin;
+        mymax = (uint32_t)weight > mymax ? (uint32_t)weight : mymax;
       }
-      if (myvalid) atomicOr(&svars[2], 1u);
-      if (threadIdx.x == 0) svars[3] = 0;
-      __syncthreads();
-      if (myheavy) atomicOr(&svars[3], 1u);
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t a = __shfl_xor(mymin, off), b = __shfl_xor(mymax, off);
+        mymin = a < mymin ? a : mymin; mymax = b > mymax ? b : mymax;
+      }
+      if ((threadIdx.x & 63) == 0) { atomicMin(&svars[4], mymin); atomicMax(&svars[5], mymax); }
       __threadfence();
       __syncthreads();
-    } else if (threadIdx.x == 0) svars[2] = 1;   // weight = multiplicity >= 1 for every distinct k-mer
-    __syncthreads();
-    if (threadIdx.x == 0) { info[strand].valid = (int)svars[2]; info[strand].heavy = (int)svars[3]; }
+    }
+    // weight classes: one common weight and no repeats -> mode = that weight, nothing else is read downstream
+    int mode = 0, valid = 1;
+    if (reweigh) {
+      valid = svars[5] > 0u;
+      if (!dups && svars[4] == svars[5] && svars[4] > 0u) mode = (int)svars[4];
+    } else if (!dups) {
+      mode = 1;
+      // (partitioned / slab paths write wp[] even without repeats; it is simply not read)
+    }
+    if (valid && mode == 0) {
+      class_list(wp, perm, nk, svars + 8, info[strand].cnt);
+      __threadfence();
+    }
+    if (threadIdx.x == 0) { info[strand].valid = valid; info[strand].mode = mode; }
   }
 }
 
-// fused = the caller guarantees k = 16, k2 = 12 and that every strand of the launch takes the LDS path; packed strands are then
-// hashed here (raw-byte strands must have been hashed by hash_kmers_kernel before).
-bool kmer_weights_can_fuse(int max_len, int k, int k2) { return k == 16 && k2 == 12 && max_len - k + 1 <= WEIGHT_MAXIT * WEIGHT_THREADS; }
+// A read's k-mer hashes are recomputed from its 2-bit codes (no MHAP_RD_MAT) when the table path applies and its k-mers fit the
+// weight kernel's LDS path; the host flags everything else for hash_kmers_kernel.
+bool strand_hashes_from_codes(int length, int k, int k2) { return k == 16 && k2 == 12 && length - k + 1 <= WEIGHT_MAXIT * WEIGHT_THREADS; }
 
-void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, int64_t* keys,
-                         uint32_t* wts, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k, const FilterTable& ft,
-                         double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store, int32_t* h32, const uint64_t* luts,
-                         const int32_t* order) {
+// fused = k = 16 and k2 = 12: strands without MHAP_RD_MAT are hashed here from their base codes (the others must have been
+// hashed by hash_kmers_kernel before).
+void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
+                         uint32_t* wts, uint32_t* perm, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k,
+                         const FilterTable& ft, double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store,
+                         const uint64_t* luts, const int32_t* order) {
   if (nstrands <= 0) return;
   uint32_t need = 64;
   const uint32_t nkmax = (uint32_t)(max_len - k + 1 > 1 ? max_len - k + 1 : 1);
   while (3ull * need < 4ull * nkmax) need <<= 1;
   const uint32_t lds_entries = need > 32768u ? 32768u : need;           // <= 128 KiB of the CU's 160 KiB LDS
-  size_t lds = (size_t)lds_entries * 4 + 16;
-  if (fused) lds += (size_t)HASH_LUT_WORDS * 8 + (size_t)((max_len + 15) / 16 + 4) * 4;   // block-mix tables + base codes of one strand
+  size_t lds = (size_t)lds_entries * 4 + (size_t)WEIGHT_SVARS * 4;
+  if (fused) {   // block-mix tables + base codes of one strand (strands longer than the LDS path are MHAP_RD_MAT)
+    const int code_len = max_len < WEIGHT_MAXIT * WEIGHT_THREADS + k ? max_len : WEIGHT_MAXIT * WEIGHT_THREADS + k;
+    lds += (size_t)HASH_LUT_WORDS * 8 + (size_t)((code_len + 15) / 16 + 4) * 4;
+  }
   const int nblocks = weight_grid(num_cus, nstrands, max_len, k);
   const dim3 g(nblocks), b(WEIGHT_THREADS);
   if (lds_entries <= 16384u) {   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
     if (fused)
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, true>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, true>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, luts, order);
     else
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, false>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, false>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, luts, order);
   } else {
     if (fused)
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, true>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, true>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, luts, order);
     else
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, false>), g, b, lds, st, descs, nstrands, keys, wts, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, h32, luts, order);
+      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, false>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
+                         counter, k, ft, repeat_weight, info, store, luts, order);
   }
 }
 
@@ -583,13 +661,30 @@ int weight_grid(int num_cus, int64_t nstrands, int max_len, int k) {
 // LDS.  Ties (equal chain values of different k-mers; 2^-64) resolve to the earlier first-occurrence position, which
 // is the reference's insertion order.
 //
-// Two row formats walk the xorshift chains of the weight-1 k-mers through all H slots:
-//   * bit-sliced rows (default, strands with >= BS_MINREM k-mers left): 32 chains per lane as 64 bit-planes;
-//   * per-chain rows (strand tails, MHAP_MINHASH=perchain): MH_U chains per lane in 64-bit registers, the hot loop
-//     compares the high dword with the slot threshold (uniform ds_read, prefetched; v_min3 over the chains) and a
-//     ballot sends the wave into the exact update.
-// k-mers with weight > 1 (repeats, tf-idf) take a per-lane w-steps-per-slot pass afterwards.
+// A k-mer of weight w takes w xorshift steps per slot and is compared after every step (:137-152).  The strand's distinct
+// k-mers arrive grouped by weight (StrandInfo: one common weight, or the class list written by kmer_weight_kernel), and
+// two row formats walk their chains through all H slots:
+//   * bit-sliced rows (default, >= BS_MINREM k-mers of one weight left): 32 chains per lane as 64 bit-planes, w steps
+//     and w candidate filters per slot;
+//   * per-chain rows (what is left of every class, weights above BS_WCLASSES, MHAP_MINHASH=perchain): MH_U chains per
+//     lane in 64-bit registers with their own weights, the hot loop compares the high dword of the chain's minimum over
+//     its steps with the slot threshold (uniform ds_read, prefetched) and a ballot sends the wave into the exact update.
+// K-mer keys are not read from memory for packed strands: every consumer (row load, candidate drain, final slot values)
+// recomputes murmur3_x64_128 from the read's 2-bit codes (two dword loads + the LDS block-mix tables), so the sketch
+// phase no longer writes or reads 8 B per k-mer; raw-byte strands and k != 16 read the keys hash_kmers_kernel stored.
 // =============================================================================================
+struct KeySrc {
+  const int64_t* kp;          // materialised keys (MHAP_RD_MAT strands) or null
+  const uint32_t* W;          // packed read as dwords
+  int nd, L, rcs;
+  const uint64_t* lut;        // LDS: k1 / k2 block-mix tables of murmur3_x64_128
+  const uint32_t* perm;       // class list (positions) or null = identity
+};
+__device__ __forceinline__ int ks_pos(const KeySrc& ks, int idx) { return ks.perm ? (int)ks.perm[idx] : idx; }
+__device__ __forceinline__ uint64_t ks_key(const KeySrc& ks, int pos) {
+  if (ks.kp) return (uint64_t)ks.kp[pos];
+  return lut_key16(ks.lut, strand_window16(ks.W, ks.nd, ks.L, ks.rcs, pos));
+}
 
 // Exact update of slot s from the wave's N candidate values per lane.  Wave-uniform control flow; the winner is
 // moved with v_readlane (SGPR lane index from the ballot), no LDS permutes.
@@ -623,12 +718,13 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
 
 // ---- bit-sliced rows ---------------------------------------------------------------------------------------------
 // 32 k-mers per lane are held as 64 bit-planes (P[b] bit j = bit b of k-mer j's chain value), so one xorshift64 step
-// of all 32 chains is 132 full-rate v_xor_b32 (the shifts become register renaming) = 4.1 issue slots per chain step
+// of all 32 chains is 107 full-rate ops (the shifts become register renaming) = 3.3 issue slots per chain step
 // instead of ~10 (2 v_lshlrev_b64 + 6 ops).  A slot's candidates are the chains whose value is negative with at least
 // as many leading zero magnitude bits as the slot's current minimum (necessary for x <= min: 1 + z more VALU ops).
-constexpr int BS_MINREM = 512;   // remaining k-mers needed to start another 2048-chain bit-sliced row
+constexpr int BS_MINREM = 512;   // remaining k-mers of a weight class needed to start another 2048-chain bit-sliced row
 constexpr int BS_ZMAX = 24;
-constexpr int BS_QCAP = 448;     // deferred-candidate queue entries per wave (LDS, 8 bytes each; 4 workgroups per CU fit at H = 512)
+constexpr int BS_QCAP = 320;     // deferred-candidate queue entries per wave (LDS, 8 bytes each; with the 4 KB key tables 4 workgroups per CU fit at H = 512)
+constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash (the murmur3_x86_32 part of the tables is not needed here)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
 //   C[b] = A[b] ^ A[b-4]                      b = 33..63
@@ -652,7 +748,6 @@ __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
   for (int k = 0; k < 4; k++) { P[29 + k] = t[k]; P[k] = u[k]; }
 }
 
-// returns a mask with a 0 bit for every chain that may undercut the slot minimum whose high dword is bhs
 // filter depth of a slot whose minimum has the high dword bhs: -1 = no negative minimum yet (every active chain is a candidate),
 // else the leading zero magnitude bits of the minimum, capped at BS_ZMAX
 __device__ __forceinline__ int bs_depth(int32_t bhs) {
@@ -662,6 +757,7 @@ __device__ __forceinline__ int bs_depth(int32_t bhs) {
   return z > BS_ZMAX ? BS_ZMAX : z;
 }
 
+// returns a mask with a 0 bit for every chain that may undercut the slot minimum of filter depth z
 __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, int z) {
   if (z < 0) return ~ACT;
   uint32_t nacc = ~P[63];                        // must be negative
@@ -706,15 +802,16 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
 }
 
 // Deferred candidates: pulling a candidate's 64-bit value out of the planes would cost 64 v_readlane + ~250 scalar ops
-// (~1600 issue cycles).  Instead a trigger only appends (slot, lane, candidate bit mask) to a wave-private LDS queue;
+// (~1600 issue cycles).  Instead a trigger only appends (slot, sub-step, lane, candidate bit mask) to a wave-private LDS queue;
 // slots are independent within a row, so the queue can be drained later, 64 entries at a time, one per lane: each lane
-// re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 16 steps + <= 15 single steps),
+// re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 4 steps + <= 3 single steps),
 // then ds_min_rtn_i64 lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
 // An entry's mask nearly always has a single bit; the drain loops while any lane has bits left.
+// Queue entry: bits 0-31 candidate mask, 32-37 lane, 38-43 sub-step c, 44- slot s.  Chain value = (s w + c + 1) steps from the key.
 #define MHAP_TICK() (PROF ? (unsigned long long)clock64() : 0ULL)
 template <bool PROF = false>
-__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint64_t* q, int& qn_ref, int rb, const int64_t* __restrict__ kp,
-                                         const uint64_t* __restrict__ jump, int lane, unsigned long long* tf = nullptr) {
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint64_t* q, int& qn_ref, int rb, int w, const KeySrc& ks,
+                                         const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
   const unsigned long long t0 = MHAP_TICK();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
   __builtin_amdgcn_wave_barrier();
@@ -722,16 +819,26 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
   for (int b0 = 0; b0 < qn; b0 += 64) {
     const uint64_t e = (b0 + lane < qn) ? q[b0 + lane] : 0ULL;
     uint32_t mask = (uint32_t)e;
-    const int s = (int)(e >> 38), l = (int)((e >> 32) & 63u);
-    // chain value at slot s = (s+1) steps from the key
-    const int nsteps = s + 1, a = nsteps >> XS_JUMP_LOG2, r0 = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+    const int s = (int)(e >> 44), c = (int)((e >> 38) & 63u), l = (int)((e >> 32) & 63u);
+    const int nsteps = s * w + c + 1;
+    int a = nsteps >> XS_JUMP_LOG2;
+    const int r0 = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+    int qa = 0;                                  // weighted chains run past the fine tables: one coarse jump of qa * na tables first
+    if (a > na) { qa = (a - 1) / na; a -= qa * na; }
     while (__any(mask != 0u)) {
       const bool valid = mask != 0u;
       const int j = valid ? __builtin_ctz(mask) : 0;
       mask &= mask - 1u;
-      const int pos = rb + j * 64 + l;
-      uint64_t x = valid ? (uint64_t)kp[pos] : 0ULL;
+      const int pos = valid ? ks_pos(ks, rb + j * 64 + l) : 0;
+      uint64_t x = valid ? ks_key(ks, pos) : 0ULL;
       const int r = valid ? r0 : 0;
+      if (valid && qa > 0) {
+        const uint64_t* T = jump + (size_t)(na + qa - 1) * 2048;
+        uint64_t y = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+        x = y;
+      }
       if (valid && a > 0) {
         const uint64_t* T = jump + (size_t)(a - 1) * 2048;
         uint64_t y = 0;
@@ -765,68 +872,142 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
 // and queue slots are handed out with ballot + mbcnt (no LDS atomic, no read-back); the queue is drained whenever the
 // next trigger might not fit.
 template <bool PROF = false>
-__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint64_t* q, int& qn, int s, uint32_t cand, int rb,
-                                         const int64_t* __restrict__ kp, const uint64_t* __restrict__ jump, int lane, unsigned long long* tf = nullptr) {
+__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint64_t* q, int& qn, int s, int c, uint32_t cand, int rb, int w,
+                                         const KeySrc& ks, const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
   const unsigned long long m = __ballot(cand != 0u);
-  const int c = __popcll(m);
-  if (qn + c > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, kp, jump, lane, tf);   // at most 64 entries per trigger: fits afterwards
+  const int n = __popcll(m);
+  if (qn + n > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, w, ks, jump, na, lane, tf);   // at most 64 entries per trigger: fits afterwards
   if (cand) {
     const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    q[idx] = ((uint64_t)(((uint32_t)s << 6) | (uint32_t)lane) << 32) | cand;
+    q[idx] = ((uint64_t)(((uint32_t)s << 12) | ((uint32_t)c << 6) | (uint32_t)lane) << 32) | cand;
   }
-  qn += c;
+  qn += n;
 }
 
+// One per-chain row: U chains per lane with their own weights (0 = idle lane slot, x = 0 is a fixed point of the chain).
+// A chain of weight w takes w steps per slot; the minimum over those steps is what the slot sees (:137-152).
+template <int U>
+__device__ __forceinline__ void perchain_row(int64_t* best, int32_t* bpos, const int32_t* besthi, int H, uint64_t (&x)[U], const int (&pv)[U],
+                                             const uint32_t (&wt)[U], int lane) {
+  bool act[U];
+  uint32_t wmax = 0;
+#pragma unroll
+  for (int u = 0; u < U; u++) { act[u] = wt[u] > 0u; wmax = wt[u] > wmax ? wt[u] : wmax; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(wmax, off); wmax = o > wmax ? o : wmax; }
+  if (wmax == 0u) return;
+  int32_t bh_next = besthi[1];
+  if (wmax == 1u) {
+    for (int s = 0; s < H; s++) {
+      const int32_t bh = bh_next;
+      bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];   // prefetch the next slot's threshold (uniform ds_read)
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        x[u] = xorshift_step(x[u]);
+        hit |= ((int32_t)(x[u] >> 32) <= bh);
+      }
+      if (__any(hit)) {
+        int64_t xs[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) xs[u] = (int64_t)x[u];
+        minhash_update<U>(best, bpos, s, xs, pv, act, lane);
+      }
+    }
+    return;
+  }
+  for (int s = 0; s < H; s++) {
+    const int32_t bh = bh_next;
+    bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];
+    int64_t mn[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) mn[u] = INT64_MAX;
+    for (uint32_t c = 0; c < wmax; c++) {
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (c < wt[u]) { x[u] = xorshift_step(x[u]); mn[u] = (int64_t)x[u] < mn[u] ? (int64_t)x[u] : mn[u]; }
+      }
+    }
+    bool hit = false;
+#pragma unroll
+    for (int u = 0; u < U; u++) hit |= act[u] && ((int32_t)(mn[u] >> 32) <= bh);
+    if (__any(hit)) minhash_update<U>(best, bpos, s, mn, pv, act, lane);
+  }
+}
+
+// amdgpu_waves_per_eu(4, 4): the slot loop needs 64 plane registers + the filter ladder's scalar conditions; left alone the
+// allocator keeps loop-invariant table addresses of the (cold) drain in VGPRs and ends at ~150 (3 waves per SIMD).  Capped at
+// 128 it spills those ~25 dwords to scratch and reloads them inside the drain only; the slot loop has no scratch access.
 template <int U, bool BITSLICED, bool PROF = false>
 __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
-                                                      const StrandInfo* __restrict__ info, int k, int k2, int H,
+                                                      const uint32_t* __restrict__ perms, const StrandInfo* __restrict__ info,
+                                                      const uint8_t* __restrict__ store, const uint64_t* __restrict__ luts,
+                                                      int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
-                                                      const uint64_t* __restrict__ jump, const int32_t* __restrict__ order,
+                                                      const uint64_t* __restrict__ jump, int jump_na, const int32_t* __restrict__ order,
                                                       unsigned long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  // PROF: wave-clock attribution {strand total, row-0 total, row-0 argmin, row-0 defer, later-row defer, key load+transpose,
+  // PROF: wave-clock attribution {strand total, first-row total, first-row argmin, first-row defer, later-row defer, key load+transpose,
   // flush (nested in the defers / row ends), flush batches, strands}
   unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tf[2] = {0, 0}, nst = 0;
+  uint64_t* lut = (uint64_t*)smem;                                   // shared by the workgroup's waves
+  for (int i = threadIdx.x; i < MH_LUT_WORDS; i += blockDim.x) lut[i] = luts[i];
+  __syncthreads();
   const size_t per_wave = (size_t)H * 12 + 8 + (BITSLICED ? (size_t)BS_QCAP * 8 : 0);
-  int64_t* best = (int64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15));
+  char* wbase = smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * ((per_wave + 15) & ~(size_t)15);
+  int64_t* best = (int64_t*)wbase;
   int32_t* bpos = (int32_t*)(best + H);
-  uint64_t* bsq = (uint64_t*)(smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15) + (((size_t)H * 12 + 7) & ~(size_t)7));   // deferred-candidate queue
+  uint64_t* bsq = (uint64_t*)(wbase + (((size_t)H * 12 + 7) & ~(size_t)7));   // deferred-candidate queue
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
   for (;;) {
-    long long sidx = 0;
-    if (lane == 0) sidx = (long long)atomicAdd(counter, 1ULL);
-    sidx = __shfl(sidx, 0);
+    unsigned long long tk = 0;
+    if (lane == 0) tk = atomicAdd(counter, 1ULL);
+    // readfirstlane: the strand index — and with it every descriptor field, pointer, count and loop bound below — is provably
+    // wave-uniform, so the strand's control flow compiles to scalar branches instead of EXEC-mask bookkeeping
+    long long sidx = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tk >> 32)) << 32) |
+                                 (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tk));
     if (sidx >= nstrands) break;
     if (order) sidx = 2LL * order[sidx >> 1] + (sidx & 1);   // longest reads first: short drain tail when read lengths vary
     const ReadDesc rd = descs[sidx >> 1];
     const int rcs = (int)(sidx & 1);
     const int nk = rd.length - k + 1;
     int32_t* orow = out_rows + sidx * out_stride;
-    const StrandInfo si = info[sidx];
-    if (strand_skipped(rd, rcs) || nk < 1 || rd.length - k2 + 1 < 1 || !si.valid) {
+    const StrandInfo* sip = info + sidx;
+    const int si_valid = sip->valid, si_mode = sip->mode;
+    if (strand_skipped(rd, rcs) || nk < 1 || rd.length - k2 + 1 < 1 || !si_valid) {
       // too short (status 2) or ZeroNGramsFoundException from either sketch (status 1)
       for (int s = lane; s < H; s += 64) orow[s] = 0;
       if (lane == 0) out_status[sidx * status_stride] = strand_skipped(rd, rcs) ? 2 : 1;
-      continue;
-    }
-    const int64_t* kp = keys + rd.key_off + (rcs ? rd.key_stride : 0);
-    const uint32_t* wp = wts + rd.key_off + (rcs ? rd.key_stride : 0);
-    const bool uni = si.heavy == 2;   // every k-mer has weight 1 and the weight array was not written (kmer_weight_kernel)
+    } else {   // (no `continue` above: the strand loop keeps a single back edge)
+    const bool listed = si_mode == 0;
+    KeySrc ks;
+    ks.kp = (rd.flags & MHAP_RD_MAT) ? keys + rd.key_off + (rcs ? rd.key_stride : 0) : nullptr;
+    ks.W = (const uint32_t*)(store + rd.base_off); ks.nd = (((rd.length + 3) >> 2) + 3) >> 2; ks.L = rd.length; ks.rcs = rcs;
+    ks.lut = lut;
+    const uint32_t* plist = perms + rd.w_off + (rcs ? rd.key_stride : 0);
+    const uint32_t* wp = wts + rd.w_off + (rcs ? rd.key_stride : 0);
     for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
     const unsigned long long ts0 = MHAP_TICK();
     nst++;
-    // ---- pass 1: weight == 1 k-mers ----
-    int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
-    for (int base = 0; base < nk; base += 64 * U) {
-      if (BITSLICED && base == 0) {
-        // ---- bit-sliced rows: 2048 chains per wave, 32 per lane ----
-        while (nk - base >= BS_MINREM) {
+    const int ncls = listed ? BS_WCLASSES : 1;
+    // ---- bit-sliced rows: every weight class (or the whole strand at its common weight), 2048 chains per row ----
+    if (BITSLICED) {
+      int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
+      bool first = true;       // no slot minimum exists yet
+      int off = 0;
+      for (int cl = 0; cl < ncls; cl++) {
+        const int w = listed ? cl + 1 : si_mode;
+        const int count = listed ? sip->cnt[cl] : nk;
+        ks.perm = listed ? plist + off : nullptr;
+        off += count;
+        if (w > BS_WMAX) continue;
+        for (int base = 0; count - base >= BS_MINREM; base += 2048) {
           uint32_t P[64];
           uint32_t ACT = 0;
           const unsigned long long tr0 = MHAP_TICK();
@@ -834,10 +1015,10 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           for (int j = 0; j < 32; j++) {
             const int i = base + j * 64 + lane;
             uint64_t key = 0;
-            if (i < nk && (uni || wp[i] == 1u)) { key = (uint64_t)kp[i]; ACT |= 1u << j; }
+            if (i < count) { key = ks_key(ks, ks_pos(ks, i)); ACT |= 1u << j; }
             P[j] = (uint32_t)key;
             P[32 + j] = (uint32_t)(key >> 32);
-            if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 loads in flight at a time
+            if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 keys in flight at a time
           }
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
@@ -846,102 +1027,86 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           for (int s = 0; s < H; s++) {
             if ((s & 63) == 0) vz = bs_depth(besthi[2 * (s + lane < H ? s + lane : H - 1) + 1]);
             const int zs = __builtin_amdgcn_readlane(vz, s & 63);
-            bs_step(P);
-            if (base == 0) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
-              if (__any(ACT != 0u)) {
+            for (int c = 0; c < w; c++) {
+              bs_step(P);
+              if (first) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
                 const unsigned long long ta = MHAP_TICK();
                 const uint32_t cand = bs_argmin(P, ACT);
                 const unsigned long long tb = MHAP_TICK();
-                bs_defer<PROF>(best, bpos, bsq, bsqn, s, cand, base, kp, jump, lane, tf);
+                bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, cand, base, w, ks, jump, jump_na, lane, tf);
                 if (PROF) { tp[2] += tb - ta; tp[3] += MHAP_TICK() - tb; }
+                continue;
               }
-              continue;
-            }
-            const uint32_t nacc = bs_filter(P, ACT, zs);
-            if (__any(nacc != 0xFFFFFFFFu)) {
-              const unsigned long long ta = MHAP_TICK();
-              bs_defer<PROF>(best, bpos, bsq, bsqn, s, ~nacc, base, kp, jump, lane, tf);
-              if (PROF) tp[4] += MHAP_TICK() - ta;
+              const uint32_t nacc = bs_filter(P, ACT, zs);
+              if (__any(nacc != 0xFFFFFFFFu)) {
+                const unsigned long long ta = MHAP_TICK();
+                bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, ~nacc, base, w, ks, jump, jump_na, lane, tf);
+                if (PROF) tp[4] += MHAP_TICK() - ta;
+              }
             }
           }
-          bs_flush<PROF>(best, bpos, bsq, bsqn, base, kp, jump, lane, tf);
-          if (PROF && base == 0) tp[1] += MHAP_TICK() - tr0;
-          base += 2048;
+          bs_flush<PROF>(best, bpos, bsq, bsqn, base, w, ks, jump, jump_na, lane, tf);
+          if (PROF && first) tp[1] += MHAP_TICK() - tr0;
+          first = false;
         }
-        if (base >= nk) break;
       }
-      // ---- per-chain row: U k-mers per lane ----
+    }
+    // ---- per-chain rows: what the bit-sliced rows left of every class + the weights above BS_WCLASSES, U k-mers per lane ----
+    {
       uint64_t x[U];
       int pv[U];
-      bool act[U];
-      bool anyact = false;
+      uint32_t wt[U];
 #pragma unroll
-      for (int u = 0; u < U; u++) {
-        const int i = base + u * 64 + lane;
-        pv[u] = i;
-        act[u] = false;
-        x[u] = 0;  // 0 is a fixed point of the chain: an idle lane never trips the hot compare
-        if (i < nk && (uni || wp[i] == 1u)) { act[u] = true; x[u] = (uint64_t)kp[i]; anyact = true; }
-      }
-      if (!__any(anyact)) continue;
-      int32_t bh_next = besthi[1];
-      for (int s = 0; s < H; s++) {
-        const int32_t bh = bh_next;
-        bh_next = besthi[2 * (s + 1 < H ? s + 1 : s) + 1];   // prefetch the next slot's threshold (uniform ds_read)
-        bool hit = false;
+      for (int u = 0; u < U; u++) { x[u] = 0; pv[u] = 0; wt[u] = 0; }
+      int pfill = 0;           // chains placed in the pending row (wave-uniform): chain n sits in lane n & 63, register n >> 6
+      int off = 0;
+      for (int cl = 0; cl <= ncls; cl++) {
+        if (cl == ncls && !listed) break;
+        const int w = (cl == ncls) ? 0 : (listed ? cl + 1 : si_mode);          // 0: weights come from wp[]
+        const int count = (cl == ncls) ? sip->cnt[BS_WCLASSES] : (listed ? sip->cnt[cl] : nk);
+        ks.perm = listed ? plist + off : nullptr;
+        off += count;
+        int e0 = 0;
+        if (BITSLICED && cl < ncls && w <= BS_WMAX) while (count - e0 >= BS_MINREM) e0 += 2048;   // done above
+        while (e0 < count) {
+          const int take = (64 * U - pfill) < (count - e0) ? (64 * U - pfill) : (count - e0);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-          x[u] = xorshift_step(x[u]);
-          hit |= ((int32_t)(x[u] >> 32) <= bh);
-        }
-        if (__any(hit)) {
-          int64_t xs[U];
-#pragma unroll
-          for (int u = 0; u < U; u++) xs[u] = (int64_t)x[u];
-          minhash_update<U>(best, bpos, s, xs, pv, act, lane);
-        }
-      }
-    }
-    // ---- pass 2: k-mers with weight > 1 (repeats / tf-idf), one per lane, w steps per slot ----
-    if (si.heavy == 1) {
-      for (int base = 0; base < nk; base += 64) {
-        const int i = base + lane;
-        uint32_t wt = (i < nk) ? wp[i] : 0u;
-        const bool heavy = wt > 1u;
-        if (!__any(heavy)) continue;
-        uint32_t wmax = heavy ? wt : 0u;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) { uint32_t o = __shfl_xor(wmax, off); wmax = o > wmax ? o : wmax; }
-        uint64_t x = heavy ? (uint64_t)kp[i] : 0ULL;
-        for (int s = 0; s < H; s++) {
-          int64_t mn = INT64_MAX;
-          for (uint32_t c = 0; c < wmax; c++) {
-            if (heavy && c < wt) { x = xorshift_step(x); mn = (int64_t)x < mn ? (int64_t)x : mn; }
+          for (int u = 0; u < U; u++) {
+            const int e = u * 64 + lane - pfill;
+            if (e >= 0 && e < take) {
+              const int pos = ks_pos(ks, e0 + e);
+              pv[u] = pos;
+              x[u] = ks_key(ks, pos);
+              wt[u] = w > 0 ? (uint32_t)w : wp[pos];
+            }
           }
-          const int32_t bh = besthi[2 * s + 1];
-          const bool hit = heavy && ((int32_t)(mn >> 32) <= bh);
-          if (__any(hit)) {
-            int64_t xs[1] = {mn};
-            int pp[1] = {i};
-            bool aa[1] = {heavy};
-            minhash_update<1>(best, bpos, s, xs, pp, aa, lane);
+          pfill += take; e0 += take;
+          if (pfill == 64 * U) {
+            perchain_row<U>(best, bpos, besthi, H, x, pv, wt, lane);
+#pragma unroll
+            for (int u = 0; u < U; u++) { x[u] = 0; wt[u] = 0; }
+            pfill = 0;
           }
         }
       }
+      if (pfill > 0) perchain_row<U>(best, bpos, besthi, H, x, pv, wt, lane);
     }
     __builtin_amdgcn_wave_barrier();
+    ks.perm = nullptr;
     for (int s = lane; s < H; s += 64) {
       const int32_t p = bpos[s];
       int32_t v = 0;
       if (p != INT32_MIN) {
-        const uint64_t key = (uint64_t)kp[p];
+        const uint64_t key = ks_key(ks, p);
         v = (s & 1) ? (int32_t)(uint32_t)(key >> 32) : (int32_t)(uint32_t)key;   // MinHashSketch.java:147-150
       }
       orow[s] = v;
     }
     if (lane == 0) out_status[sidx * status_stride] = 0;
     if (PROF) tp[0] += MHAP_TICK() - ts0;
+    }
   }
+  if (lane == 0) atomicAdd(counter + 8, nst);   // strands sketched by this wave (statistics word next to the work counter)
   if (PROF && lane == 0) {
     for (int i = 0; i < 6; i++) atomicAdd(&prof[i], tp[i]);
     atomicAdd(&prof[6], tf[0]); atomicAdd(&prof[7], tf[1]); atomicAdd(&prof[8], nst);
@@ -949,33 +1114,45 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
 }
 
 // Jump-ahead tables for the xorshift64 chain: the step is linear over GF(2), so M^(g a) x (g = 2^XS_JUMP_LOG2) is the XOR of
-// eight byte-indexed table entries.  out[(a-1)*2048 + i*256 + v] = M^(g a) applied to (v << 8i), a = 1..na.
-void build_xorshift_jump_tables(int na, uint64_t* out) {
+// eight byte-indexed table entries.  out[(a-1)*2048 + i*256 + v] = M^(g a) applied to (v << 8i), a = 1..na; then nq coarse
+// tables out[(na+q-1)*2048 + ...] = M^(g na q), q = 1..nq, for chains that run past g na steps (weighted k-mers).
+void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
   uint64_t col[64], nxt[64];
   auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
+  auto emit = [&](const uint64_t* c, uint64_t* T) {
+    for (int i = 0; i < 8; i++)
+      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(c, (uint64_t)v << (8 * i));
+  };
   for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < (1 << XS_JUMP_LOG2); t++) x = xorshift_step(x); col[j] = x; }   // M^g
-  uint64_t base[64];
+  uint64_t base[64], big[64];
   for (int j = 0; j < 64; j++) base[j] = col[j];
   for (int a = 1; a <= na; a++) {
-    uint64_t* T = out + (size_t)(a - 1) * 2048;
-    for (int i = 0; i < 8; i++)
-      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(col, (uint64_t)v << (8 * i));
+    emit(col, out + (size_t)(a - 1) * 2048);
+    if (a == na) for (int j = 0; j < 64; j++) big[j] = col[j];   // M^(g na)
     for (int j = 0; j < 64; j++) nxt[j] = apply(base, col[j]);   // M^(g(a+1)) = M^g o M^(g a)
+    for (int j = 0; j < 64; j++) col[j] = nxt[j];
+  }
+  for (int j = 0; j < 64; j++) col[j] = big[j];
+  for (int q = 1; q <= nq; q++) {
+    emit(col, out + (size_t)(na + q - 1) * 2048);
+    for (int j = 0; j < 64; j++) nxt[j] = apply(big, col[j]);
     for (int j = 0; j < 64; j++) col[j] = nxt[j];
   }
 }
 
 // MHAP_MINHASH=perchain selects the kernel without bit-sliced rows (A/B measurements)
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
-                    const StrandInfo* info, int k, int k2, int H, unsigned long long* counter, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_status, int64_t status_stride, const uint64_t* jump, const int32_t* order) {
+                    const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
+                    unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
+                    const uint64_t* jump, int jump_na, const int32_t* order) {
   if (nstrands <= 0) return;
   static int perchain = -1;
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
   size_t per_wave = (((size_t)H * 12 + 8 + (perchain ? 0 : (size_t)BS_QCAP * 8)) + 15) & ~(size_t)15;
+  const size_t lut_bytes = (size_t)MH_LUT_WORDS * 8;
   int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
-  while (waves > 1 && per_wave * waves > 150 * 1024) waves >>= 1;
-  const size_t lds = per_wave * waves;
+  while (waves > 1 && per_wave * waves + lut_bytes > 150 * 1024) waves >>= 1;
+  const size_t lds = per_wave * waves + lut_bytes;
   const dim3 block(64 * waves);
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
   static int profmode = -1;
@@ -984,8 +1161,8 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
     static unsigned long long* dprof = nullptr;
     if (!dprof) (void)hipMalloc(&dprof, 16 * sizeof(unsigned long long));
     (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
-                       out_stride, out_status, status_stride, jump, order, dprof);
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter, out_rows, out_stride, out_status, status_stride, jump, jump_na, order, dprof);
     unsigned long long hp[16];
     (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
     (void)hipStreamSynchronize(st);
@@ -997,11 +1174,11 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
     return;
   }
   if (perchain)
-    hipLaunchKernelGGL((minhash_kernel<MH_U, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
-                       out_stride, out_status, status_stride, jump, order);
+    hipLaunchKernelGGL((minhash_kernel<MH_U, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter, out_rows, out_stride, out_status, status_stride, jump, jump_na, order);
   else
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, info, k, k2, H, counter, out_rows,
-                       out_stride, out_status, status_stride, jump, order);
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter, out_rows, out_stride, out_status, status_stride, jump, jump_na, order);
 }
 
 
@@ -1015,7 +1192,8 @@ constexpr uint32_t ORD_BUCKET_MAX = 32;   // keys per first-level bin the bucket
 __device__ inline uint64_t okey(int32_t h, int pos) { return ((uint64_t)((uint32_t)h ^ 0x80000000u) << 32) | (uint32_t)pos; }
 
 __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
-                                                              const int32_t* __restrict__ h32, int k2, int S, int cap,
+                                                              const int32_t* __restrict__ h32, const uint8_t* __restrict__ store,
+                                                              const uint64_t* __restrict__ luts, int code_words, int k2, int S, int cap,
                                                               int32_t* __restrict__ out_rows, int64_t out_stride,
                                                               int32_t* __restrict__ out_meta, int64_t meta_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1025,6 +1203,8 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint64_t* buf = (uint64_t*)(svars + 4);                 // cap keys
   uint16_t* bstart = (uint16_t*)(buf + cap);              // bucket path: first buffer slot of every first-level bin (+1 end marker)
   uint32_t* stage = (uint32_t*)(bstart + ORD_BINS + 2);   // one-pass path: positions of the keys below the guessed cut
+  uint64_t* lut = (uint64_t*)(((uintptr_t)(stage + cap) + 7) & ~(uintptr_t)7);   // murmur3_x86_32 block-mix table (256 words), then the strand's base codes
+  uint32_t* codes = (uint32_t*)(lut + 256);
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
   const int64_t strand = blockIdx.x;
   if (strand >= nstrands) return;
@@ -1036,7 +1216,29 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
     if (threadIdx.x == 0) { meta[0] = 0; meta[1] = n; meta[2] = rd.length; }
     return;
   }
+  // 32-bit hashes of the strand's 12-mers: stored by hash_kmers_kernel for MHAP_RD_MAT strands, otherwise recomputed from the
+  // strand's 2-bit codes (staged once in LDS, reverse strand already complemented) wherever a pass needs them
+  const bool mat = (rd.flags & MHAP_RD_MAT) != 0;
   const int32_t* hp = h32 + rd.h2_off + (rcs ? rd.h2_stride : 0);
+  if (!mat) {
+    for (int i = threadIdx.x; i < 256; i += ORD_THREADS) lut[i] = luts[512 + i];
+    const int ncw = (rd.length + 15) / 16 + 2;
+    for (int wj = threadIdx.x; wj < ncw && wj < code_words; wj += ORD_THREADS) codes[wj] = strand_codes16(store + rd.base_off, rd.length, rcs, 16 * wj);
+    __syncthreads();
+  }
+  auto hget = [&](int i) -> int32_t {
+    if (mat) return hp[i];
+    const uint32_t cw = codes_at(codes, i);
+    uint32_t h = 0;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const uint64_t kk = lut[(cw >> (8 * q)) & 255u];
+      h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+      h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+    }
+    h ^= 24u;
+    return (int32_t)fmix32(h);
+  };
   const int K = S < n ? S : n;   // BottomOverlapSketch.java:548
   if (threadIdx.x == 0) { meta[0] = K; meta[1] = n; meta[2] = rd.length; }
   if (K <= 0) return;
@@ -1060,7 +1262,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
     for (int i0 = threadIdx.x; i0 - (int)threadIdx.x < n; i0 += 8 * ORD_THREADS) {   // wave-uniform trip count: ballots inside
       int32_t hv[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hp[i] : 0; }
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hget(i) : 0; }
       unsigned long long bal[8];
       uint32_t total = 0;
 #pragma unroll
@@ -1109,7 +1311,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       __syncthreads();
       for (uint32_t t = threadIdx.x; t < m; t += ORD_THREADS) {
         const int i = (int)stage[t];
-        const uint64_t key = okey(hp[i], i);
+        const uint64_t key = okey(hget(i), i);
         const uint32_t b = (uint32_t)(key >> 53);
         buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
       }
@@ -1153,7 +1355,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       for (int i0 = threadIdx.x; i0 < n; i0 += 8 * ORD_THREADS) {   // eight loads in flight per lane
         int32_t hv[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hp[i] : 0; }
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hget(i) : 0; }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
           const int i = i0 + u * ORD_THREADS;
@@ -1221,7 +1423,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
     for (int i0 = threadIdx.x; i0 < n; i0 += 8 * ORD_THREADS) {
       int32_t hv[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hp[i] : 0; }
+      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hget(i) : 0; }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int i = i0 + u * ORD_THREADS;
@@ -1253,7 +1455,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   // compact candidates into LDS, pad, sort
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += ORD_THREADS) {
-    const uint64_t key = okey(hp[i], i);
+    const uint64_t key = okey(hget(i), i);
     if (key <= bound) { uint32_t slot = atomicAdd(&s_fill, 1u); if (slot < (uint32_t)cap) buf[slot] = key; }
   }
   __syncthreads();
@@ -1282,7 +1484,11 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   }
 }
 
-size_t ordered_lds_bytes(int cap) { return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)cap * 4; }
+// code_words = dwords of base codes staged per strand (0: every strand of the launch is MHAP_RD_MAT)
+size_t ordered_lds_bytes(int cap, int code_words) {
+  return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)(cap + (cap & 1)) * 4 +
+         (code_words > 0 ? (size_t)256 * 8 + (size_t)code_words * 4 : 0) + 8;
+}
 
 // A read whose forward sketch throws ZeroNGramsFoundException is dropped entirely
 // (J/impl/SequenceSketchStreamer.java:123-156,235-238): propagate the forward status to the rc entry.
@@ -1298,11 +1504,14 @@ void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads) {
   hipLaunchKernelGGL(fix_status_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, meta, nreads);
 }
 
-void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, const int32_t* h32, int k2, int S, int cap,
-                    int32_t* out_rows, int64_t out_stride, int32_t* out_meta, int64_t meta_stride) {
+// max_len = longest read of the launch that is not MHAP_RD_MAT (0 if there is none): sizes the LDS code stream
+void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const int32_t* h32, const uint8_t* store,
+                    const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride, int32_t* out_meta,
+                    int64_t meta_stride) {
   if (nstrands <= 0) return;
-  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap), st, descs, nstrands, h32,
-                     k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
+  const int code_words = max_len > 0 ? (max_len + 15) / 16 + 4 : 0;
+  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap, code_words), st, descs, nstrands, h32,
+                     store, luts, code_words, k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
 }
 
 }  // namespace mhap

@@ -1,0 +1,116 @@
+"""Synthetic workloads of BASELINE.json's configs and the `-f` k-mer filter file that goes with config 5.
+
+Measurement/test tooling only: the generator itself is C (mhap_synth_reads_repeats in host_util.cpp); this module names the
+configurations, writes FASTA files and counts k-mers for the filter file the way a k-mer counter (meryl/jellyfish) would.
+"""
+import os
+
+import numpy as np
+
+from .api import FastaData, MhapParams, synth_reads
+
+SEED = 0x4D484150
+
+# name -> (reads, read length, params, generator seed index, planted repeats (element, spacing, divergence) or None, uses -f)
+CONFIGS = {
+    # BASELINE configs[0]: 1k x 5 kb, k=16, --num-hashes 256 (the reference's own CPU-runnable case)
+    "c1": dict(reads=1000, length=5000, hashes=256, seed=SEED ^ 1, repeats=None, filter=False,
+               label="1000 synthetic PacBio-style reads x 5000 bp, --num-hashes 256 (BASELINE configs[0])"),
+    # BASELINE configs[1]: the configuration the metric is quoted on
+    "c2": dict(reads=100000, length=10000, hashes=512, seed=SEED ^ 2, repeats=None, filter=False,
+               label="100000 synthetic PacBio-style reads x 10000 bp (BASELINE configs[1])"),
+    # BASELINE configs[3] read shape (15 kb, 512 hashes) on one GPU's share of the 1M-read job
+    "c4slice": dict(reads=60000, length=15000, hashes=512, seed=SEED ^ 4, repeats=None, filter=False,
+                    label="60000 synthetic reads x 15000 bp: single-GPU slice of BASELINE configs[3] (1M x 15 kb over 8 GPUs)"),
+    # BASELINE configs[4] read shape (12 kb) + planted repeat family + -f filter file + --filter-threshold
+    "c5slice": dict(reads=40000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.01), filter=True,
+                    label="40000 synthetic reads x 12000 bp with a planted 300-bp repeat family (one copy per 3 kb, 1% divergence), "
+                          "-f k-mer filter file, --filter-threshold 1e-5: single-GPU slice of BASELINE configs[4]"),
+}
+
+
+def config_reads(name, shard=0, nshards=1, reads=None, length=None, error_rate=0.15):
+    c = CONFIGS[name]
+    n = reads or c["reads"]
+    L = length or c["length"]
+    return synth_reads(n, L, seed=c["seed"], error_rate=error_rate, shard=shard, nshards=nshards, repeats=c["repeats"])
+
+
+def write_fasta(fasta, path, prefix="r"):
+    """One record per read, header `>r<id>`, the whole sequence on one line."""
+    with open(path, "wb") as fh:
+        for i in range(len(fasta)):
+            o, n = int(fasta.offsets[i]), int(fasta.lengths[i])
+            fh.write(b">" + prefix.encode() + str(int(fasta.ids[i])).encode() + b"\n")
+            fh.write(fasta.bases[o:o + n].tobytes())
+            fh.write(b"\n")
+
+
+_CODE = np.full(256, 255, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+
+
+def count_kmers(fasta, k=16, canonical=True, max_reads=None):
+    """(k-mer values as uint32/uint64 with A<C<G<T = 0..3, first base most significant; counts; total windows).
+    canonical=True counts a k-mer together with its reverse complement under the lexicographically smaller string — what
+    the reference's filter loader assumes (J/sketch/FrequencyCounts.java:169 hashes the line's k-mer canonicalised)."""
+    assert k <= 32
+    n = len(fasta) if max_reads is None else min(len(fasta), max_reads)
+    vals = []
+    for i in range(n):
+        o, L = int(fasta.offsets[i]), int(fasta.lengths[i])
+        if L < k:
+            continue
+        codes = _CODE[fasta.bases[o:o + L]]
+        ok = codes != 255
+        c = codes.astype(np.uint64) & 3
+        nw = L - k + 1
+        v = np.zeros(nw, dtype=np.uint64)
+        r = np.zeros(nw, dtype=np.uint64)
+        good = np.ones(nw, dtype=bool)
+        for j in range(k):
+            v = (v << np.uint64(2)) | c[j:j + nw]
+            r = r | ((np.uint64(3) - c[j:j + nw]) << np.uint64(2 * j))
+            good &= ok[j:j + nw]
+        if canonical:
+            v = np.minimum(v, r)
+        vals.append(v[good])
+    allv = np.concatenate(vals) if vals else np.zeros(0, np.uint64)
+    if k <= 16:
+        allv = allv.astype(np.uint32)
+    u, cnt = np.unique(allv, return_counts=True)
+    return u, cnt, int(allv.shape[0])
+
+
+def kmer_string(v, k):
+    return "".join("ACGT"[(int(v) >> (2 * (k - 1 - j))) & 3] for j in range(k))
+
+
+def write_filter_file(fasta, path, k=16, min_fraction=2.5e-6, canonical=True, max_reads=4000):
+    """The `-f` file: first line "<distinct k-mers> <lines>", then `kmer<TAB>fraction` in descending order of fraction
+    (J/sketch/FrequencyCounts.java:102-104,158-184; docs/source/quickstart.rst).  Counts come from the first max_reads reads
+    (a k-mer counter's output on a sample; fractions are ratios, so a sample estimates them), lines below min_fraction are
+    not written (the loader drops everything under --filter-threshold anyway)."""
+    u, cnt, total = count_kmers(fasta, k, canonical, max_reads)
+    frac = cnt.astype(np.float64) / max(total, 1)
+    keep = np.nonzero(frac >= min_fraction)[0]
+    order = keep[np.lexsort((u[keep], -cnt[keep]))]
+    with open(path, "w") as fh:
+        fh.write(f"{len(u)} {len(order)}\n")
+        for i in order:
+            fh.write(f"{kmer_string(u[i], k)}\t{frac[i]:.10e}\n")
+    return len(order)
+
+
+def params_for(name, device=-1, **over):
+    c = CONFIGS[name]
+    kw = dict(kmer_size=16, num_hashes=c["hashes"], ordered_kmer_size=12, ordered_sketch_size=1536, device=device)
+    kw.update(over)
+    return MhapParams(**kw)
+
+
+def c3_fasta_path():
+    """BASELINE configs[2] (E. coli PacBio P6-C4 reads) is not in either tree: supplied on the box through MHAP_C3_FASTA."""
+    p = os.environ.get("MHAP_C3_FASTA")
+    return p if p and os.path.exists(p) else None

@@ -433,6 +433,61 @@ def test_config4_read_shape_slice():
         assert len(got) > 20 and st["slow_pairs"] == 0
 
 
+def test_config5_shape_filter_and_repeats(tmp_path):
+    """BASELINE configs[4] shape: 12 kb reads with a planted repeat family, a generated -f k-mer filter file and
+    --filter-threshold 1e-5 (tf-idf weights: 3 for k-mers absent from the filter, 1..3 for the popular ones, times the
+    multiplicity) — the weighted k-mers run on the bit-sliced MinHash rows.  Sketch and record parity with the oracle."""
+    from mhap_amd import workloads as W
+    fa = W.config_reads("c5slice", reads=420)
+    ffile = tmp_path / "kmers.txt"
+    nlines = W.write_filter_file(fa, str(ffile), max_reads=420, min_fraction=5e-6)
+    assert nlines > 50
+    flt = mhap_amd.FrequencyCounts.from_file(str(ffile), filter_cutoff=1e-5, repeat_weight=0.9)
+    assert (flt.fractions >= 1e-5).sum() > 20
+    oflt = O.Filter(flt.hashes, flt.fractions, 1e-5, 0.9, 3.0, False)
+    p = MhapParams()
+    _assert_sketch_parity(fa.subset(range(6)), p, flt, oflt)
+    want = O.run_self(fa, nthreads=8, flt=oflt)
+    got, st = _self_lines(fa, p, flt)
+    assert got == O.record_lines(want["records"]) and len(got) > 50
+    # no filter, same reads: plain tf weights (repeated k-mers inside a read take the weight-2.. classes)
+    want2 = O.run_self(fa, nthreads=8)
+    got2, _ = _self_lines(fa, p)
+    assert got2 == O.record_lines(want2["records"])
+
+
+def test_weight_classes_and_large_weights():
+    """Reads built to hit every weight path of the MinHash kernel: tandem repeats (multiplicities 2..40 -> classes 2..6 and the
+    per-chain rows for larger weights), a read that is one k-mer repeated (a single distinct k-mer of weight n), tf-idf with a
+    large --repeat-idf-scale (uniform weight 12 on the bit-sliced rows, past the fine jump tables), and short strands."""
+    rnd = random.Random(11)
+    unit = _rand_seq(rnd, 40)
+    seqs = []
+    for reps in (2, 3, 5, 7, 12, 40):
+        seqs.append(_rand_seq(rnd, 1500) + unit * reps + _rand_seq(rnd, 1200))
+    seqs.append("ACGT" * 500)                      # 4 distinct k-mers, weight ~ 500 each
+    seqs.append("A" * 900 + _rand_seq(rnd, 2500))   # one k-mer of weight 885 next to unique ones
+    seqs.append(_rand_seq(rnd, 130))               # shorter than one per-chain row
+    seqs.append(_rand_seq(rnd, 700))
+    base = _rand_seq(rnd, 6000)
+    seqs += [base[i:i + 3500] for i in (0, 500, 1000, 1500, 2000, 2500)]
+    fa = FastaData.from_strings(seqs)
+    for H in (64, 512):
+        p = MhapParams(num_hashes=H, ordered_sketch_size=600)
+        _assert_sketch_parity(fa, p)
+    # tf-idf: every k-mer outside a (tiny) filter gets weight round(12.0) = 12
+    kmers = [unit[i:i + 16] for i in range(0, 20)]
+    hashes = np.array([int(O.kmer_hashes64(k, 16, True)[0]) for k in kmers], dtype=np.int64)
+    fracs = np.linspace(2e-3, 1e-4, len(kmers))
+    flt = mhap_amd.FrequencyCounts(hashes, fracs, 1e-5, 0.9, 12.0, True)
+    oflt = O.Filter(hashes, fracs, 1e-5, 0.9, 12.0, True)
+    p = MhapParams(num_hashes=256, ordered_sketch_size=600)
+    _assert_sketch_parity(fa, p, flt, oflt)
+    want = O.run_self(fa, H=256, S=600, nthreads=8, flt=oflt)
+    got, _ = _self_lines(fa, p, flt)
+    assert got == O.record_lines(want["records"])
+
+
 def test_random_flag_and_read_mixes():
     """A few draws of tests/fuzz_parity.py (random flags incl. k != 16 and odd k2, repeat families, N runs): 0 mismatches."""
     import fuzz_parity

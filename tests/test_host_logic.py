@@ -81,7 +81,7 @@ def test_xorshift_jump_tables_match_stepping():
         return x
     rnd = random.Random(5)
     out = C.c_uint64()
-    for n in (0, 1, 15, 16, 17, 63, 64, 65, 128, 300, 511, 512, 513, 1000):
+    for n in (0, 1, 15, 16, 17, 63, 64, 65, 96, 97, 128, 192, 193, 300, 511, 512, 513, 1000, 1536, 1537, 3071, 16384):   # past 96 steps: coarse + fine table
         key = rnd.getrandbits(64)
         x = key
         for _ in range(n):
