@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libmhaphip.so")
+_LIB_PATH = os.environ.get("MHAP_LIB_PATH") or os.path.join(_HERE, "lib", "libmhaphip.so")   # MHAP_LIB_PATH: A/B builds of the kernels
 _lib = None
 
 KERNEL_NAMES = ["hash_kmers", "kmer_weight", "minhash", "ordered", "candidate", "overlap", "index_build", "index_query"]

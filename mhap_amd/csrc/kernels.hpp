@@ -63,11 +63,12 @@ bool strand_hashes_from_codes(int length, int k, int k2);
 void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
                          uint32_t* wts, uint32_t* perm, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k,
                          const FilterTable& ft, double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store,
-                         const uint64_t* luts, const int32_t* order);   // order: read indices longest first (or null)
+                         const uint64_t* luts, const int32_t* order, int32_t* slist);   // order: read indices longest first (or null);
+                         // slist: 2 x nstrands work lists of the MinHash launches (counts in counter[4], counter[5])
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
-                    const uint64_t* jump, int jump_na, const int32_t* order);
+                    const uint64_t* jump, int jump_na, const int32_t* slist);   // counter: base of the sketch phase's counter block
 // GF(2) jump-ahead tables of the xorshift64 step, two levels: na tables of 8x256 words for M^(g a), a = 1..na (g = 2^XS_JUMP_LOG2),
 // then nq tables for M^(g na q), q = 1..nq (weighted chains run past H steps: one coarse + one fine table application)
 constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 83.9 / 84.5 / 85.8 ms MinHash at C2 (2 MB of tables at H = 512)

@@ -105,7 +105,7 @@ struct mhap_handle {
   std::vector<uint8_t> status;   // per entry status (host mirror)
 
   // sketch scratch
-  DevBuf store, descs, keys, wts, perm, h32, info, slabs, counters, order;
+  DevBuf store, descs, keys, wts, perm, h32, info, slist, slabs, counters, order;
   int jump_na = 0;   // fine xorshift jump tables (coarse ones follow them in jump_tbl)
   std::vector<int32_t> h_order;
   uint8_t* pin_store = nullptr;   // pinned host staging buffer of stage_reads
@@ -318,6 +318,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
   HIPCHK(h, h->wts.ensure((size_t)max_w * 4));
   HIPCHK(h, h->perm.ensure((size_t)max_w * 4));
   HIPCHK(h, h->info.ensure((size_t)(2 * max_nb) * sizeof(StrandInfo)));
+  HIPCHK(h, h->slist.ensure((size_t)(4 * max_nb) * 4));
   HIPCHK(h, h->counters.ensure(256));
   {
     const int wb = weight_grid(h->num_cus, 2 * max_nb, max_len_all, k);
@@ -383,7 +384,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     time_begin(h, MHAP_K_DEDUP);
     launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(),
                         h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused,
-                        h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), d_order);
+                        h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), d_order, h->slist.as<int32_t>());
     time_end(h);
     DBGSYNC(h, "kmer_weights");
     time_begin(h, MHAP_K_MINHASH);
@@ -391,8 +392,8 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
     launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(), h->info.as<StrandInfo>(),
-                   h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr + 1, mh_rows, mh_stride, meta_rows + 3, META_W,
-                   h->jump_tbl.as<uint64_t>(), h->jump_na, d_order);
+                   h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride, meta_rows + 3, META_W,
+                   h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>());
     time_end(h);
     DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
@@ -734,7 +735,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
-                    &h->keys, &h->wts, &h->perm, &h->h32, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
+                    &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);

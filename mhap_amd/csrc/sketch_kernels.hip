@@ -497,7 +497,9 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
                                                                      FilterTable ft, double repeat_weight,
                                                                      StrandInfo* __restrict__ info, const uint8_t* __restrict__ store,
                                                                      const uint64_t* __restrict__ luts,
-                                                                     const int32_t* __restrict__ order) {
+                                                                     const int32_t* __restrict__ order, int32_t* __restrict__ slist) {
+  // slist: the two work lists of the MinHash launches — [0, nstrands) strands of weight 1 + strands without a sketch,
+  // [nstrands, 2 nstrands) weighted strands; their fill counts are counter[4] and counter[5]
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_tab[];
   uint32_t* svars = lds_tab + lds_entries;
   uint64_t* lut = (uint64_t*)(svars + WEIGHT_SVARS);            // FUSED: block-mix tables, then the strand's base codes
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
     const int rcs = (int)(strand & 1);
     const int nk = rd.length - k + 1;
     if (strand_skipped(rd, rcs) || nk < 1) {
-      if (threadIdx.x == 0) { info[strand].valid = 0; info[strand].mode = 1; }
+      if (threadIdx.x == 0) { info[strand].valid = 0; info[strand].mode = 1; slist[atomicAdd(counter + 4, 1ULL)] = (int32_t)strand; }
       continue;
     }
     const bool mat = !FUSED || (rd.flags & MHAP_RD_MAT);           // keys materialised by hash_kmers_kernel
@@ -601,7 +603,11 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
       class_list(wp, perm, nk, svars + 8, info[strand].cnt);
       __threadfence();
     }
-    if (threadIdx.x == 0) { info[strand].valid = valid; info[strand].mode = mode; }
+    if (threadIdx.x == 0) {
+      info[strand].valid = valid; info[strand].mode = mode;
+      if (!valid || mode == 1) slist[atomicAdd(counter + 4, 1ULL)] = (int32_t)strand;
+      else slist[nstrands + (int64_t)atomicAdd(counter + 5, 1ULL)] = (int32_t)strand;
+    }
   }
 }
 
@@ -614,7 +620,7 @@ bool strand_hashes_from_codes(int length, int k, int k2) { return k == 16 && k2 
 void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int64_t nstrands, int max_len, const int64_t* keys,
                          uint32_t* wts, uint32_t* perm, uint32_t* slabs, int64_t slab_entries, unsigned long long* counter, int k,
                          const FilterTable& ft, double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store,
-                         const uint64_t* luts, const int32_t* order) {
+                         const uint64_t* luts, const int32_t* order, int32_t* slist) {
   if (nstrands <= 0) return;
   uint32_t need = 64;
   const uint32_t nkmax = (uint32_t)(max_len - k + 1 > 1 ? max_len - k + 1 : 1);
@@ -630,17 +636,17 @@ void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int
   if (lds_entries <= 16384u) {   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
     if (fused)
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, true>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order);
+                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
     else
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, false>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order);
+                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
   } else {
     if (fused)
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, true>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order);
+                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
     else
       hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, false>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order);
+                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
   }
 }
 
@@ -722,8 +728,15 @@ __device__ __forceinline__ void minhash_update(int64_t* best, int32_t* bpos, int
 // instead of ~10 (2 v_lshlrev_b64 + 6 ops).  A slot's candidates are the chains whose value is negative with at least
 // as many leading zero magnitude bits as the slot's current minimum (necessary for x <= min: 1 + z more VALU ops).
 constexpr int BS_MINREM = 512;   // remaining k-mers of a weight class needed to start another 2048-chain bit-sliced row
-constexpr int BS_ZMAX = 24;
-constexpr int BS_QCAP = 320;     // deferred-candidate queue entries per wave (LDS, 8 bytes each; with the 4 KB key tables 4 workgroups per CU fit at H = 512)
+#ifndef MH_ZMAX
+#define MH_ZMAX 12
+#endif
+constexpr int BS_ZMAX = MH_ZMAX;   // filter depth cap.  Every plane costs one VALU op per step, every false candidate a queue entry: measured at C2 with
+                                   // caps 10 / 12 / 13 / 16 / 24: 91.4 / 89.5 / 89.6 / 91.6 / 101.7 ms (2048 x 2^-13 = a quarter of the steps pass a false candidate at 12)
+#ifndef MH_QCAP
+#define MH_QCAP 320
+#endif
+constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wave (LDS, 8 bytes each; with the 4 KB key tables 4 workgroups per CU fit at H = 512)
 constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash (the murmur3_x86_32 part of the tables is not needed here)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
@@ -757,26 +770,50 @@ __device__ __forceinline__ int bs_depth(int32_t bhs) {
   return z > BS_ZMAX ? BS_ZMAX : z;
 }
 
-// returns a mask with a 0 bit for every chain that may undercut the slot minimum of filter depth z
-__device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, int z) {
-  if (z < 0) return ~ACT;
-  uint32_t nacc = ~P[63];                        // must be negative
-  // ... with planes 62 .. 63-z all zero.  z is wave-uniform.  After the first row z >= 8 practically always: those eight
-  // planes are OR-ed straight-line, the remaining depth is a chain of scalar compare+branch, one v_or each.
-#define MHAP_BS_OR(K) if (z < K) break; nacc |= P[63 - K];
-  if (z >= 8) {
-    nacc |= (P[62] | P[61]) | (P[60] | P[59]) | ((P[58] | P[57]) | (P[56] | P[55]));
-    do {
-      MHAP_BS_OR(9) MHAP_BS_OR(10) MHAP_BS_OR(11) MHAP_BS_OR(12) MHAP_BS_OR(13) MHAP_BS_OR(14) MHAP_BS_OR(15) MHAP_BS_OR(16)
-      MHAP_BS_OR(17) MHAP_BS_OR(18) MHAP_BS_OR(19) MHAP_BS_OR(20) MHAP_BS_OR(21) MHAP_BS_OR(22) MHAP_BS_OR(23) MHAP_BS_OR(24)
-    } while (0);
-  } else {
-    do {
-      MHAP_BS_OR(1) MHAP_BS_OR(2) MHAP_BS_OR(3) MHAP_BS_OR(4) MHAP_BS_OR(5) MHAP_BS_OR(6) MHAP_BS_OR(7)
-    } while (0);
+// returns a mask with a 0 bit for every chain that may undercut the slot minimum of filter depth z: the chain must be
+// negative with planes 62 .. 63-z all zero.  Branch-free: z (wave-uniform, from the slot's minimum) becomes one scalar
+// enable word per plane (s_bfe_i32 of the depth mask) and every plane costs one v_and_or_b32 — BS_ZMAX + 1 VALU ops per
+// step whatever the depth, no scalar compare/branch ladder (which took ~25 SGPR pairs for its conditions and, with them,
+// the registers of everything else in the slot loop).
+// Once a slot has a minimum its depth is practically always >= BS_ZFIX (the minimum of >= 2048 chain values), so the first
+// BS_ZFIX planes are OR-ed unconditionally (two per v_or3_b32) and only the planes beyond get enable words; a slot whose
+// minimum is shallower than that (z < BS_ZFIX, incl. "no negative minimum yet") takes the generic masked form.
+#ifndef MH_ZFIX
+#define MH_ZFIX 8
+#endif
+constexpr int BS_ZFIX = MH_ZFIX;   // 0: every plane masked (no depth branch in the step)
+struct BsEnable { uint32_t w[BS_ZMAX + 1]; };
+__device__ __forceinline__ BsEnable bs_enable(int z) {
+  const uint32_t m = z < 0 ? 0u : ((2u << z) - 1u);                       // bit 0: sign plane, bits 1..z: magnitude planes 62 .. 63-z
+  BsEnable en;
+#pragma unroll
+  for (int b = 0; b <= BS_ZMAX; b++) {
+    en.w[b] = (uint32_t)((int)(m << (31 - b)) >> 31);
+    if (b > BS_ZFIX) asm volatile("" : "+s"(en.w[b]));   // keep it a scalar mask word (otherwise it is turned back into 64-bit select conditions)
   }
-#undef MHAP_BS_OR
-  return nacc | ~ACT;
+  return en;
+}
+__device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, const BsEnable& en, int z) {
+  uint32_t n0, n1 = ~ACT;
+  if (BS_ZFIX > 0 && z >= BS_ZFIX) {
+    n0 = ~P[63];
+#pragma unroll
+    for (int b = 1; b + 1 <= BS_ZFIX; b += 4) {
+      asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n0) : "v"(P[63 - b]), "v"(P[62 - b]));
+      asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n1) : "v"(P[61 - b]), "v"(P[60 - b]));
+    }
+  } else {
+    n0 = ~P[63] & en.w[0];                       // z < 0 (all words 0): every active chain is a candidate
+#pragma unroll
+    for (int b = 1; b <= BS_ZFIX; b++) n0 |= P[63 - b] & en.w[b];
+  }
+  // planes beyond BS_ZFIX: one v_and_or_b32 (d = (plane & enable) | d) each, two accumulators (asm: the compiler prefers v_and + v_or3)
+#pragma unroll
+  for (int b = BS_ZFIX + 1; b <= BS_ZMAX; b += 2) {
+    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(n0) : "v"(P[63 - b]), "s"(en.w[b]));
+    if (b + 1 <= BS_ZMAX) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(n1) : "v"(P[62 - b]), "s"(en.w[b + 1]));
+  }
+  return n0 | n1;
 }
 
 // First bit-sliced row of a strand (no slot minimum exists yet): bit-serial narrowing towards the row's arg-min.
@@ -938,15 +975,21 @@ __device__ __forceinline__ void perchain_row(int64_t* best, int32_t* bpos, const
 // amdgpu_waves_per_eu(4, 4): the slot loop needs 64 plane registers + the filter ladder's scalar conditions; left alone the
 // allocator keeps loop-invariant table addresses of the (cold) drain in VGPRs and ends at ~150 (3 waves per SIMD).  Capped at
 // 128 it spills those ~25 dwords to scratch and reloads them inside the drain only; the slot loop has no scratch access.
-template <int U, bool BITSLICED, bool PROF = false>
-__global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
+// WEIGHTED = false: the launch takes the strands whose k-mers all have weight 1 (StrandInfo.mode == 1: nearly every strand
+// without -f) — one step per slot, no class list, no inner step loop (control flow inside the slot loop is what this kernel
+// pays most for) — plus the strands without a sketch (their zero rows / status).  WEIGHTED = true: a second launch takes
+// the other strands (class lists, a common weight > 1).  kmer_weight_kernel sorts the strands into the two work lists.
+// (amdgpu_waves_per_eu: the weighted instantiation needs 129 VGPRs left alone — one over four waves per SIMD.)
+template <int U, bool BITSLICED, bool WEIGHTED, bool PROF = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const uint32_t* __restrict__ perms, const StrandInfo* __restrict__ info,
                                                       const uint8_t* __restrict__ store, const uint64_t* __restrict__ luts,
                                                       int k, int k2, int H,
                                                       unsigned long long* __restrict__ counter, int32_t* __restrict__ out_rows,
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
-                                                      const uint64_t* __restrict__ jump, int jump_na, const int32_t* __restrict__ order,
+                                                      const uint64_t* __restrict__ jump, int jump_na, const int32_t* __restrict__ slist,
+                                                      const unsigned long long* __restrict__ slist_count,
                                                       unsigned long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -969,20 +1012,21 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     // wave-uniform, so the strand's control flow compiles to scalar branches instead of EXEC-mask bookkeeping
     long long sidx = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tk >> 32)) << 32) |
                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tk));
-    if (sidx >= nstrands) break;
-    if (order) sidx = 2LL * order[sidx >> 1] + (sidx & 1);   // longest reads first: short drain tail when read lengths vary
+    if (sidx >= (long long)*slist_count) break;
+    sidx = slist[sidx];   // this launch's strands, in the order kmer_weight_kernel finished them (longest reads first when lengths vary)
     const ReadDesc rd = descs[sidx >> 1];
     const int rcs = (int)(sidx & 1);
     const int nk = rd.length - k + 1;
     int32_t* orow = out_rows + sidx * out_stride;
     const StrandInfo* sip = info + sidx;
     const int si_valid = sip->valid, si_mode = sip->mode;
-    if (strand_skipped(rd, rcs) || nk < 1 || rd.length - k2 + 1 < 1 || !si_valid) {
+    const bool nosketch = strand_skipped(rd, rcs) || nk < 1 || rd.length - k2 + 1 < 1 || !si_valid;
+    if (nosketch) {
       // too short (status 2) or ZeroNGramsFoundException from either sketch (status 1)
       for (int s = lane; s < H; s += 64) orow[s] = 0;
       if (lane == 0) out_status[sidx * status_stride] = strand_skipped(rd, rcs) ? 2 : 1;
     } else {   // (no `continue` above: the strand loop keeps a single back edge)
-    const bool listed = si_mode == 0;
+    const bool listed = WEIGHTED && si_mode == 0;
     KeySrc ks;
     ks.kp = (rd.flags & MHAP_RD_MAT) ? keys + rd.key_off + (rcs ? rd.key_stride : 0) : nullptr;
     ks.W = (const uint32_t*)(store + rd.base_off); ks.nd = (((rd.length + 3) >> 2) + 3) >> 2; ks.L = rd.length; ks.rcs = rcs;
@@ -996,13 +1040,14 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     const unsigned long long ts0 = MHAP_TICK();
     nst++;
     const int ncls = listed ? BS_WCLASSES : 1;
+    const int w_uniform = WEIGHTED ? si_mode : 1;
     // ---- bit-sliced rows: every weight class (or the whole strand at its common weight), 2048 chains per row ----
     if (BITSLICED) {
       int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
       bool first = true;       // no slot minimum exists yet
       int off = 0;
       for (int cl = 0; cl < ncls; cl++) {
-        const int w = listed ? cl + 1 : si_mode;
+        const int w = listed ? cl + 1 : w_uniform;
         const int count = listed ? sip->cnt[cl] : nk;
         ks.perm = listed ? plist + off : nullptr;
         off += count;
@@ -1027,6 +1072,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
           for (int s = 0; s < H; s++) {
             if ((s & 63) == 0) vz = bs_depth(besthi[2 * (s + lane < H ? s + lane : H - 1) + 1]);
             const int zs = __builtin_amdgcn_readlane(vz, s & 63);
+            const BsEnable en = bs_enable(zs);
             for (int c = 0; c < w; c++) {
               bs_step(P);
               if (first) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
@@ -1037,7 +1083,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
                 if (PROF) { tp[2] += tb - ta; tp[3] += MHAP_TICK() - tb; }
                 continue;
               }
-              const uint32_t nacc = bs_filter(P, ACT, zs);
+              const uint32_t nacc = bs_filter(P, ACT, en, zs);
               if (__any(nacc != 0xFFFFFFFFu)) {
                 const unsigned long long ta = MHAP_TICK();
                 bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, ~nacc, base, w, ks, jump, jump_na, lane, tf);
@@ -1062,7 +1108,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
       int off = 0;
       for (int cl = 0; cl <= ncls; cl++) {
         if (cl == ncls && !listed) break;
-        const int w = (cl == ncls) ? 0 : (listed ? cl + 1 : si_mode);          // 0: weights come from wp[]
+        const int w = (cl == ncls) ? 0 : (listed ? cl + 1 : w_uniform);        // 0: weights come from wp[]
         const int count = (cl == ncls) ? sip->cnt[BS_WCLASSES] : (listed ? sip->cnt[cl] : nk);
         ks.perm = listed ? plist + off : nullptr;
         off += count;
@@ -1106,7 +1152,7 @@ __global__ __launch_bounds__(256) void minhash_kernel(const ReadDesc* __restrict
     if (PROF) tp[0] += MHAP_TICK() - ts0;
     }
   }
-  if (lane == 0) atomicAdd(counter + 8, nst);   // strands sketched by this wave (statistics word next to the work counter)
+  if (lane == 0) atomicAdd(counter + 8 + (WEIGHTED ? 1 : 0), nst);   // strands sketched by this launch (statistics words next to the work counters)
   if (PROF && lane == 0) {
     for (int i = 0; i < 6; i++) atomicAdd(&prof[i], tp[i]);
     atomicAdd(&prof[6], tf[0]); atomicAdd(&prof[7], tf[1]); atomicAdd(&prof[8], nst);
@@ -1144,7 +1190,9 @@ void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
 void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
-                    const uint64_t* jump, int jump_na, const int32_t* order) {
+                    const uint64_t* jump, int jump_na, const int32_t* slist) {
+  // counter: the sketch phase's counter block — [1] / [2] work counters of the two launches, [4] / [5] lengths of their strand lists
+  // (written by kmer_weight_kernel), [9] / [11] strands sketched
   if (nstrands <= 0) return;
   static int perchain = -1;
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
@@ -1157,28 +1205,42 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
   static int profmode = -1;
   if (profmode < 0) { const char* e = getenv("MHAP_MINHASH_PROF"); profmode = (e && atoi(e)) ? 1 : 0; }
-  if (profmode && !perchain) {   // wave-clock attribution of the bit-sliced kernel (diagnostics; printed per launch)
+  unsigned long long* counter_u = counter + 1; unsigned long long* counter_w = counter + 2;
+  const int32_t* slist_w = slist + nstrands;
+  if (profmode && !perchain) {   // wave-clock attribution of the bit-sliced kernels (diagnostics; printed per launch)
     static unsigned long long* dprof = nullptr;
     if (!dprof) (void)hipMalloc(&dprof, 16 * sizeof(unsigned long long));
-    (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter, out_rows, out_stride, out_status, status_stride, jump, jump_na, order, dprof);
-    unsigned long long hp[16];
-    (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
-    (void)hipStreamSynchronize(st);
-    const double tot = (double)hp[0];
-    fprintf(stderr, "[minhash prof] strands %llu  wave-clocks/strand %.0f  row0 %.1f%% (argmin %.1f%%, defer %.1f%%)  later defers %.1f%%  load+transpose %.1f%%  "
-                    "flush %.1f%% (%.1f batches/strand, %.0f clocks/batch)\n",
-            hp[8], tot / (double)hp[8], 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot,
-            100.0 * hp[6] / tot, (double)hp[7] / (double)hp[8], hp[7] ? (double)hp[6] / (double)hp[7] : 0.0);
+    for (int pass = 0; pass < 2; pass++) {
+      (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
+      if (pass == 0)
+        hipLaunchKernelGGL((minhash_kernel<MH_U, true, false, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                           counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, dprof);
+      else
+        hipLaunchKernelGGL((minhash_kernel<MH_U, true, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                           counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, dprof);
+      unsigned long long hp[16];
+      (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
+      (void)hipStreamSynchronize(st);
+      const double tot = (double)hp[0];
+      if (hp[8])
+        fprintf(stderr, "[minhash prof %s] strands %llu  wave-clocks/strand %.0f  row0 %.1f%% (argmin %.1f%%, defer %.1f%%)  later defers %.1f%%  load+transpose %.1f%%  "
+                        "flush %.1f%% (%.1f batches/strand, %.0f clocks/batch)\n", pass ? "weighted" : "weight-1",
+                hp[8], tot / (double)hp[8], 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot,
+                100.0 * hp[6] / tot, (double)hp[7] / (double)hp[8], hp[7] ? (double)hp[6] / (double)hp[7] : 0.0);
+    }
     return;
   }
-  if (perchain)
-    hipLaunchKernelGGL((minhash_kernel<MH_U, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter, out_rows, out_stride, out_status, status_stride, jump, jump_na, order);
-  else
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter, out_rows, out_stride, out_status, status_stride, jump, jump_na, order);
+  if (perchain) {
+    hipLaunchKernelGGL((minhash_kernel<MH_U, false, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
+    hipLaunchKernelGGL((minhash_kernel<MH_U, false, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
+  } else {
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
+  }
 }
 
 
