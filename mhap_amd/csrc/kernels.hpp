@@ -75,10 +75,10 @@ constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 8
 constexpr int XS_JUMP_NQ = BS_WMAX;
 void build_xorshift_jump_tables(int na, int nq, uint64_t* out);
 void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
-size_t ordered_lds_bytes(int cap, int code_words);
-void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const int32_t* h32, const uint8_t* store,
-                    const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride, int32_t* out_meta,
-                    int64_t meta_stride);
+size_t ordered_lds_bytes(int cap, int code_words, int stage_wide);
+void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len_codes, int max_len, const int32_t* h32,
+                    const uint8_t* store, const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride,
+                    int32_t* out_meta, int64_t meta_stride);
 
 // ---- search_kernels.hip ----
 // All-pairs slot-equality count between query entries qlist[0..nq) and index entries [0..ne).

@@ -409,7 +409,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
     }
     time_begin(h, MHAP_K_ORDERED);
-    launch_ordered(h->stream, dd, nstr, max_len_codes, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
+    launch_ordered(h->stream, dd, nstr, max_len_codes, B.max_len, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
                    ord_rows, ord_stride, meta_rows, META_W);
     time_end(h);
     DBGSYNC(h, "ordered");

@@ -734,9 +734,9 @@ constexpr int BS_MINREM = 512;   // remaining k-mers of a weight class needed to
 constexpr int BS_ZMAX = MH_ZMAX;   // filter depth cap.  Every plane costs one VALU op per step, every false candidate a queue entry: measured at C2 with
                                    // caps 10 / 12 / 13 / 16 / 24: 91.4 / 89.5 / 89.6 / 91.6 / 101.7 ms (2048 x 2^-13 = a quarter of the steps pass a false candidate at 12)
 #ifndef MH_QCAP
-#define MH_QCAP 320
+#define MH_QCAP 640
 #endif
-constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wave (LDS, 8 bytes each; with the 4 KB key tables 4 workgroups per CU fit at H = 512)
+constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wave (LDS, 4 bytes each; with the 4 KB key tables 4 workgroups per CU fit at H = 512)
 constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash (the murmur3_x86_32 part of the tables is not needed here)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
@@ -839,86 +839,85 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
 }
 
 // Deferred candidates: pulling a candidate's 64-bit value out of the planes would cost 64 v_readlane + ~250 scalar ops
-// (~1600 issue cycles).  Instead a trigger only appends (slot, sub-step, lane, candidate bit mask) to a wave-private LDS queue;
+// (~1600 issue cycles).  Instead a trigger only appends (slot, sub-step, lane, chain) words to a wave-private LDS queue;
 // slots are independent within a row, so the queue can be drained later, 64 entries at a time, one per lane: each lane
 // re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 4 steps + <= 3 single steps),
 // then ds_min_rtn_i64 lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
-// An entry's mask nearly always has a single bit; the drain loops while any lane has bits left.
-// Queue entry: bits 0-31 candidate mask, 32-37 lane, 38-43 sub-step c, 44- slot s.  Chain value = (s w + c + 1) steps from the key.
+// Queue entry (32 bits): bits 0-4 chain j of the lane, 5-10 lane, 11-16 sub-step c, 17-29 slot s.  Chain value = (s w + c + 1)
+// steps from the key.  With 4-byte entries the queue holds a whole row's candidates nearly always, so the drain runs at the
+// end of the row — where the 64 plane registers are free and its table loads can all be in flight — rather than inside the
+// slot loop.
 #define MHAP_TICK() (PROF ? (unsigned long long)clock64() : 0ULL)
 template <bool PROF = false>
-__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint64_t* q, int& qn_ref, int rb, int w, const KeySrc& ks,
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, int w, const KeySrc& ks,
                                          const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
   const unsigned long long t0 = MHAP_TICK();
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
   __builtin_amdgcn_wave_barrier();
   const int qn = qn_ref;
   for (int b0 = 0; b0 < qn; b0 += 64) {
-    const uint64_t e = (b0 + lane < qn) ? q[b0 + lane] : 0ULL;
-    uint32_t mask = (uint32_t)e;
-    const int s = (int)(e >> 44), c = (int)((e >> 38) & 63u), l = (int)((e >> 32) & 63u);
+    const bool valid = b0 + lane < qn;
+    const uint32_t e = valid ? q[b0 + lane] : 0u;
+    const int j = (int)(e & 31u), l = (int)((e >> 5) & 63u), c = (int)((e >> 11) & 63u), s = (int)(e >> 17);
     const int nsteps = s * w + c + 1;
     int a = nsteps >> XS_JUMP_LOG2;
-    const int r0 = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+    const int r = valid ? (nsteps & ((1 << XS_JUMP_LOG2) - 1)) : 0;
     int qa = 0;                                  // weighted chains run past the fine tables: one coarse jump of qa * na tables first
     if (a > na) { qa = (a - 1) / na; a -= qa * na; }
-    while (__any(mask != 0u)) {
-      const bool valid = mask != 0u;
-      const int j = valid ? __builtin_ctz(mask) : 0;
-      mask &= mask - 1u;
-      const int pos = valid ? ks_pos(ks, rb + j * 64 + l) : 0;
-      uint64_t x = valid ? ks_key(ks, pos) : 0ULL;
-      const int r = valid ? r0 : 0;
-      if (valid && qa > 0) {
-        const uint64_t* T = jump + (size_t)(na + qa - 1) * 2048;
-        uint64_t y = 0;
+    const int pos = valid ? ks_pos(ks, rb + j * 64 + l) : 0;
+    uint64_t x = valid ? ks_key(ks, pos) : 0ULL;
+    if (valid && qa > 0) {
+      const uint32_t tb = (uint32_t)(na + qa - 1) * 2048u;
+      uint64_t y = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
-        x = y;
-      }
-      if (valid && a > 0) {
-        const uint64_t* T = jump + (size_t)(a - 1) * 2048;
-        uint64_t y = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
-        x = y;
-      }
-      int rmax = r;
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(rmax, off); rmax = o > rmax ? o : rmax; }
-      for (int t = 0; t < rmax; t++) {
-        const uint64_t nx = xorshift_step(x);
-        x = (t < r) ? nx : x;
-      }
-      // exact update, all lanes at once: the lane whose value is the slot's final minimum and that strictly undercut
-      // what it saw owns the slot (chain values of distinct k-mers are distinct)
-      long long old = INT64_MAX;
-      if (valid) old = atomicMin((long long*)&best[s], (long long)x);
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+      x = y;
     }
+    if (valid && a > 0) {
+      const uint32_t tb = (uint32_t)(a - 1) * 2048u;
+      uint64_t y = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+      x = y;
+    }
+#pragma unroll
+    for (int t = 0; t < (1 << XS_JUMP_LOG2) - 1; t++) {
+      const uint64_t nx = xorshift_step(x);
+      x = (t < r) ? nx : x;
+    }
+    // exact update, all lanes at once: the lane whose value is the slot's final minimum and that strictly undercut
+    // what it saw owns the slot (chain values of distinct k-mers are distinct)
+    long long old = INT64_MAX;
+    if (valid) old = atomicMin((long long*)&best[s], (long long)x);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && (long long)x < old && best[s] == (int64_t)x) bpos[s] = pos;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   qn_ref = 0;
   if (PROF) { tf[0] += MHAP_TICK() - t0; tf[1] += (unsigned long long)((qn + 63) >> 6); }
 }
 
-// append this trigger's candidates: one entry per lane that has any.  The fill count lives in a wave-uniform register
-// and queue slots are handed out with ballot + mbcnt (no LDS atomic, no read-back); the queue is drained whenever the
-// next trigger might not fit.
+// append this trigger's candidates: one entry per candidate chain (a lane's mask nearly always has a single bit; the loop
+// runs while any lane has bits left).  The fill count lives in a wave-uniform register and queue slots are handed out with
+// ballot + mbcnt (no LDS atomic, no read-back); the queue is drained whenever the next round might not fit.
 template <bool PROF = false>
-__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint64_t* q, int& qn, int s, int c, uint32_t cand, int rb, int w,
+__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, int& qn, int s, int c, uint32_t cand, int rb, int w,
                                          const KeySrc& ks, const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
-  const unsigned long long m = __ballot(cand != 0u);
-  const int n = __popcll(m);
-  if (qn + n > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, w, ks, jump, na, lane, tf);   // at most 64 entries per trigger: fits afterwards
-  if (cand) {
-    const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    q[idx] = ((uint64_t)(((uint32_t)s << 12) | ((uint32_t)c << 6) | (uint32_t)lane) << 32) | cand;
-  }
-  qn += n;
+  const uint32_t head = ((uint32_t)s << 17) | ((uint32_t)c << 11) | ((uint32_t)lane << 5);
+  unsigned long long m = __ballot(cand != 0u);
+  do {
+    const int n = __popcll(m);
+    if (qn + n > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, w, ks, jump, na, lane, tf);   // at most 64 entries per round: fits afterwards
+    if (cand) {
+      const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      q[idx] = head | (uint32_t)__builtin_ctz(cand);
+      cand &= cand - 1u;
+    }
+    qn += n;
+    m = __ballot(cand != 0u);
+  } while (m);
 }
 
 // One per-chain row: U chains per lane with their own weights (0 = idle lane slot, x = 0 is a fixed point of the chain).
@@ -999,11 +998,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   uint64_t* lut = (uint64_t*)smem;                                   // shared by the workgroup's waves
   for (int i = threadIdx.x; i < MH_LUT_WORDS; i += blockDim.x) lut[i] = luts[i];
   __syncthreads();
-  const size_t per_wave = (size_t)H * 12 + 8 + (BITSLICED ? (size_t)BS_QCAP * 8 : 0);
+  const size_t per_wave = (size_t)H * 12 + 8 + (BITSLICED ? (size_t)BS_QCAP * 4 : 0);
   char* wbase = smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * ((per_wave + 15) & ~(size_t)15);
   int64_t* best = (int64_t*)wbase;
   int32_t* bpos = (int32_t*)(best + H);
-  uint64_t* bsq = (uint64_t*)(wbase + (((size_t)H * 12 + 7) & ~(size_t)7));   // deferred-candidate queue
+  uint32_t* bsq = (uint32_t*)(wbase + (((size_t)H * 12 + 7) & ~(size_t)7));   // deferred-candidate queue
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
   for (;;) {
     unsigned long long tk = 0;
@@ -1196,7 +1195,7 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
   if (nstrands <= 0) return;
   static int perchain = -1;
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
-  size_t per_wave = (((size_t)H * 12 + 8 + (perchain ? 0 : (size_t)BS_QCAP * 8)) + 15) & ~(size_t)15;
+  size_t per_wave = (((size_t)H * 12 + 8 + (perchain ? 0 : (size_t)BS_QCAP * 4)) + 15) & ~(size_t)15;
   const size_t lut_bytes = (size_t)MH_LUT_WORDS * 8;
   int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
   while (waves > 1 && per_wave * waves + lut_bytes > 150 * 1024) waves >>= 1;
@@ -1255,7 +1254,7 @@ __device__ inline uint64_t okey(int32_t h, int pos) { return ((uint64_t)((uint32
 
 __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                               const int32_t* __restrict__ h32, const uint8_t* __restrict__ store,
-                                                              const uint64_t* __restrict__ luts, int code_words, int k2, int S, int cap,
+                                                              const uint64_t* __restrict__ luts, int code_words, int stage_wide, int k2, int S, int cap,
                                                               int32_t* __restrict__ out_rows, int64_t out_stride,
                                                               int32_t* __restrict__ out_meta, int64_t meta_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1264,8 +1263,9 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint32_t* svars = part + ORD_THREADS;                   // 4 scalars (kept in the dynamic region: 16-B aligned base)
   uint64_t* buf = (uint64_t*)(svars + 4);                 // cap keys
   uint16_t* bstart = (uint16_t*)(buf + cap);              // bucket path: first buffer slot of every first-level bin (+1 end marker)
-  uint32_t* stage = (uint32_t*)(bstart + ORD_BINS + 2);   // one-pass path: positions of the keys below the guessed cut
-  uint64_t* lut = (uint64_t*)(((uintptr_t)(stage + cap) + 7) & ~(uintptr_t)7);   // murmur3_x86_32 block-mix table (256 words), then the strand's base codes
+  uint32_t* stage = (uint32_t*)(bstart + ORD_BINS + 2);   // one-pass path: positions of the keys below the guessed cut (16-bit unless the
+  uint16_t* stage16 = (uint16_t*)stage;                   // launch has a strand with more than 65535 k-mers: 4 KB instead of 8 at S = 1536)
+  uint64_t* lut = (uint64_t*)(((uintptr_t)stage + (size_t)cap * (stage_wide ? 4 : 2) + 7) & ~(uintptr_t)7);   // murmur3_x86_32 block-mix table (256 words), then the strand's base codes
   uint32_t* codes = (uint32_t*)(lut + 256);
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
   const int64_t strand = blockIdx.x;
@@ -1341,7 +1341,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
         for (int u = 0; u < 8; u++) {
           if ((bal[u] >> lane) & 1ULL) {
             const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-            if (idx < (uint32_t)cap) stage[idx] = (uint32_t)(i0 + u * ORD_THREADS);
+            if (idx < (uint32_t)cap) { if (stage_wide) stage[idx] = (uint32_t)(i0 + u * ORD_THREADS); else stage16[idx] = (uint16_t)(i0 + u * ORD_THREADS); }
             atomicAdd(&hist[((uint32_t)hv[u] ^ 0x80000000u) >> 21], 1u);
           }
           base += (uint32_t)__popcll(bal[u]);
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       for (uint32_t b = threadIdx.x; b <= cutbin; b += ORD_THREADS) hist[b] = 0;   // becomes the bins' fill counters
       __syncthreads();
       for (uint32_t t = threadIdx.x; t < m; t += ORD_THREADS) {
-        const int i = (int)stage[t];
+        const int i = stage_wide ? (int)stage[t] : (int)stage16[t];
         const uint64_t key = okey(hget(i), i);
         const uint32_t b = (uint32_t)(key >> 53);
         buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
@@ -1547,8 +1547,8 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
 }
 
 // code_words = dwords of base codes staged per strand (0: every strand of the launch is MHAP_RD_MAT)
-size_t ordered_lds_bytes(int cap, int code_words) {
-  return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)(cap + (cap & 1)) * 4 +
+size_t ordered_lds_bytes(int cap, int code_words, int stage_wide) {
+  return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)cap * (stage_wide ? 4 : 2) +
          (code_words > 0 ? (size_t)256 * 8 + (size_t)code_words * 4 : 0) + 8;
 }
 
@@ -1566,14 +1566,16 @@ void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads) {
   hipLaunchKernelGGL(fix_status_kernel, dim3((unsigned)((nreads + 255) / 256)), dim3(256), 0, st, meta, nreads);
 }
 
-// max_len = longest read of the launch that is not MHAP_RD_MAT (0 if there is none): sizes the LDS code stream
-void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len, const int32_t* h32, const uint8_t* store,
-                    const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride, int32_t* out_meta,
-                    int64_t meta_stride) {
+// max_len_codes = longest read of the launch that is not MHAP_RD_MAT (0 if there is none): sizes the LDS code stream;
+// max_len = longest read of the launch
+void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len_codes, int max_len, const int32_t* h32,
+                    const uint8_t* store, const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride,
+                    int32_t* out_meta, int64_t meta_stride) {
   if (nstrands <= 0) return;
-  const int code_words = max_len > 0 ? (max_len + 15) / 16 + 4 : 0;
-  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap, code_words), st, descs, nstrands, h32,
-                     store, luts, code_words, k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
+  const int code_words = max_len_codes > 0 ? (max_len_codes + 15) / 16 + 4 : 0;
+  const int stage_wide = max_len - k2 + 1 > 65535 ? 1 : 0;
+  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap, code_words, stage_wide), st, descs, nstrands, h32,
+                     store, luts, code_words, stage_wide, k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
 }
 
 }  // namespace mhap
