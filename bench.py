@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py — MHAP hot path on MI355X: self-overlap of synthetic PacBio-style reads (BASELINE.json configs[1]).
+"""bench.py — MHAP hot path on MI355X: self-overlap of synthetic PacBio-style reads (default: BASELINE.json configs[1]).
 
 A "step" is ONE full pass of the hot path over the whole data set: sketch every read (both strands: k-mer
-murmur hashes, tf weights, weighted MinHash, ordered bottom-S sketch), build the index tables in HBM, all-pairs
+murmur hashes, tf / tf-idf weights, weighted MinHash, ordered bottom-S sketch), build the index tables in HBM, inverted-index
 candidate count, second-stage overlap scoring, accepted records delivered to the host.  The packed reads are
 resident in HBM before the timed region starts (mhap_stage_reads); record text formatting is outside it.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W [--config c1|c2|c4slice|c5slice|c3]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1 (strong scaling, same 100k reads): rank r sketches reads r, r+N, ...; the per-rank sketch tables are
-all-gathered with RCCL over xGMI; every rank searches its round-robin query shard against the full index.
-Prints ONE JSON line on rank 0.
+N > 1 (strong scaling, same data set): rank r sketches reads r, r+N, ...; the per-rank sketch tables are
+all-gathered with RCCL over xGMI; every rank searches its own reads against the full index.
+Prints ONE JSON line on rank 0.  At N = 1 the line also carries
+  parity_check : the GPU path and the CPU oracle run on the SAME sample reads, sorted-record SHA-256 compared;
+  cpu_baseline : the oracle timed on this box's host cores on that sample (threads = the cgroup CPU quota);
+  end_to_end   : the native driver (mhap-hip) from FASTA open to the last record flushed, on the bench data set.
 """
 import argparse
 import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -28,13 +34,14 @@ sys.path.insert(0, ROOT)
 import mhap_amd  # noqa: E402
 from mhap_amd import MhapParams, MinHashSearch  # noqa: E402
 from mhap_amd import distributed as mdist  # noqa: E402
+from mhap_amd import workloads as W  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# MinHash instruction ceilings measured on MI355X (profiles/r01_valu_microbench.txt):
+# Integer ceilings of the MinHash kernel (it is VALU-bound, not HBM-bound: SURVEY F12).
+VALU_SPEC = 256 * 4 * 32 * 2.4e9       # lane-ops/s at spec: 256 CUs x 4 SIMD-32 x 2.4 GHz = 7.86e13
+VALU_MEASURED = 6.5e13                 # tools/valu_ops.hip on MI355X (profiles/r01_valu_microbench.txt): sustained clock under an all-VALU load
 XORSHIFT_CEILING_PER_CHAIN = 4.79e12   # tools/valu_peak.hip: one chain per lane-register pair (2 v_lshlrev_b64 + 6 ops per step)
-VALU_FULL_RATE = 6.5e13               # lane-ops/s of a full-rate 32-bit VALU op chip-wide (v_fma_f32 / v_xor_b32, tools/valu_ops.hip)
-BITSLICED_OPS_PER_32_STEPS = 107 + 15  # 43 v_xor + 64 v_xor/v_bitop3 per step of 32 chains + ~15 ops of candidate filter
-XORSHIFT_CEILING_BITSLICED = 32 * VALU_FULL_RATE / BITSLICED_OPS_PER_32_STEPS   # 1.70e13 steps/s
+BITSLICED_OPS_PER_32_STEPS = 107 + 9 + 4  # 43 v_xor + 64 v_xor/v_bitop3 per step of 32 chains + 9 ops of depth filter + compare/loop
 
 
 def sketch_bytes_per_read(L, H, S, k2):
@@ -43,17 +50,40 @@ def sketch_bytes_per_read(L, H, S, k2):
     return (L + 3) // 4 + 2 * 4 * H + 2 * 8 * sp
 
 
+def host_cpus():
+    """(affinity, cgroup quota in cores or None, threads to use).  `nproc` / os.cpu_count() report the machine; the container's
+    cgroup cpu.max is what the process can actually burn."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except Exception:
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    use = aff if quota is None else max(1, min(aff, int(round(quota))))
+    return aff, quota, use
+
+
+def sorted_sha(lines):
+    return hashlib.sha256("\n".join(sorted(lines)).encode()).hexdigest()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100000)
-    ap.add_argument("--length", type=int, default=10000)
-    ap.add_argument("--hashes", type=int, default=512)
+    ap.add_argument("--config", default="c2", choices=sorted(W.CONFIGS) + ["c3"])
+    ap.add_argument("--reads", type=int, default=0, help="override the configuration's read count")
+    ap.add_argument("--length", type=int, default=0, help="override the configuration's read length")
+    ap.add_argument("--hashes", type=int, default=0)
     ap.add_argument("--error-rate", type=float, default=0.15)
-    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 10-30 s of CPU work)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-20 s of CPU work)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip parity_check / cpu_baseline / end_to_end (kernel A/B runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,17 +105,48 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    n_total, L, H, S, k, k2 = args.reads, args.length, args.hashes, 1536, 16, 12
-    p = MhapParams(kmer_size=k, num_hashes=H, ordered_kmer_size=k2, ordered_sketch_size=S, device=local_rank)
-    seed = 0x4D484150 ^ 2
+    S, k, k2 = 1536, 16, 12
+    flt = None
+    filter_path = None
+    tmpdir = tempfile.mkdtemp(prefix="mhap_bench_")
     t_gen = time.time()
-    fa = mhap_amd.synth_reads(n_total, L, seed=seed, error_rate=args.error_rate, shard=rank, nshards=world)
+    if args.config == "c3":
+        # BASELINE configs[2]: real E. coli reads are in neither tree; they are supplied on the box through MHAP_C3_FASTA
+        path = W.c3_fasta_path()
+        if path is None:
+            if rank == 0:
+                print(json.dumps({"metric": "overlaps/sec", "value": None, "unit": "overlaps/s", "n_gpus": world,
+                                  "config": {"workload": "E. coli PacBio P6-C4 reads (BASELINE configs[2])"},
+                                  "c3": "C3 skipped: MHAP_C3_FASTA is not set / not readable"}), flush=True)
+            return
+        whole = mhap_amd.FastaData.from_file(path)
+        n_total, H = len(whole), args.hashes or 512
+        L = int(np.median(whole.lengths))
+        idx = np.arange(rank, n_total, world)
+        fa = whole.subset(idx) if world > 1 else whole
+        cfg_label = f"{n_total} reads of {os.path.basename(path)} (median {L} bp), default flags (BASELINE configs[2])"
+        cfg = dict(repeats=None, filter=False, seed=0)
+    else:
+        cfg = W.CONFIGS[args.config]
+        n_total, L, H = args.reads or cfg["reads"], args.length or cfg["length"], args.hashes or cfg["hashes"]
+        fa = W.config_reads(args.config, shard=rank, nshards=world, reads=n_total, length=L, error_rate=args.error_rate)
+        cfg_label = cfg["label"] if (n_total, L, H) == (cfg["reads"], cfg["length"], cfg["hashes"]) else \
+            f"{n_total} synthetic reads x {L} bp, --num-hashes {H} ({args.config} generator)"
+        if cfg["filter"]:
+            # the -f file of configs[4]: k-mer counts of a sample of the reads (every rank derives the same file)
+            stride = max(1, n_total // 2000)      # reads 0, stride, 2 stride, ... of the same data set
+            head = fa if world == 1 else W.config_reads(args.config, shard=0, nshards=stride, reads=n_total, length=L, error_rate=args.error_rate)
+            filter_path = os.path.join(tmpdir, "kmers.txt")
+            W.write_filter_file(head, filter_path, max_reads=2000)
+            flt = mhap_amd.FrequencyCounts.from_file(filter_path, filter_cutoff=1e-5, repeat_weight=0.9)
+    p = MhapParams(kmer_size=k, num_hashes=H, ordered_kmer_size=k2, ordered_sketch_size=S, device=local_rank)
     n_local = len(fa)
     n_pad = mdist.shard_size(n_total, world)    # equal shard size for the all-gather (pad = zero-length reads)
+    fa_bench = fa
     fa = mdist.pad_shard(fa, n_total, world)
     t_gen = time.time() - t_gen
 
-    ms = MinHashSearch(p)
+    ms = MinHashSearch(p, kmer_filter=flt)
     t_stage = time.perf_counter()
     ms.stage(fa)                                  # 2-bit pack on the host + H2D: packed reads now resident in HBM
     t_stage = time.perf_counter() - t_stage
@@ -98,14 +159,26 @@ def main():
         gids, gfwd = mdist.rank_major_entry_ids(n_total, world)
         q_first, q_count = mdist.rank_major_query_range(n_total, world, rank)
     async_gather = dist is not None and backend == "nccl" and os.environ.get("MHAP_BENCH_ASYNC_GATHER", "1") != "0"
+    phase = {"sketch": 0.0, "exchange": 0.0, "search": 0.0}
 
-    def step():
+    def step(timed_phases=False):
         ms.clear()
+        t0 = time.perf_counter()
         if not force_dist:
             ms.add_staged()
+            if timed_phases:
+                ms.synchronize()
+                phase["sketch"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
             recs = ms.find_matches()
+            if timed_phases:
+                phase["search"] += time.perf_counter() - t0
         else:
             ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+            if timed_phases:
+                ms.synchronize()
+                phase["sketch"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
             g_mh = mdist.gather_rank_major(loc_mh, world, dist)      # RCCL all-gather, tables stay rank after rank
             g_mt = mdist.gather_rank_major(loc_mt, world, dist)
             if async_gather:
@@ -122,7 +195,12 @@ def main():
             torch.cuda.synchronize()
             if not async_gather:
                 ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
+            if timed_phases:
+                phase["exchange"] += time.perf_counter() - t0
+                t0 = time.perf_counter()
             recs = ms.find_matches(q_first, q_count)                  # this rank's own reads against the whole index
+            if timed_phases:
+                phase["search"] += time.perf_counter() - t0
             step.keep = (g_mh, g_od, g_mt)
         return recs
 
@@ -146,6 +224,10 @@ def main():
     elapsed = time.perf_counter() - t0
     st = ms.stats()
     kt = ms.kernel_times()
+    # one more, untimed, step with a fence between the phases: wall time of the sketch phase (packed reads in HBM -> both tables in
+    # HBM, host bookkeeping included), of the table exchange (N > 1) and of the search phase (tables in HBM -> records on the host)
+    step(timed_phases=True)
+    fence()
     # output fingerprint of the last step (outside the timed region): SHA-256 of the sorted record lines on one GPU, and an
     # order- and shard-independent checksum (sum of the first 8 digest bytes of every line, mod 2^64) that is comparable across N
     lines = sorted(mhap_amd.records_to_lines(recs))
@@ -159,10 +241,12 @@ def main():
     tot_rec = torch.tensor([nrec], dtype=torch.int64, device=rdev)
     csum_t = torch.tensor([csum & 0xFFFF, (csum >> 16) & 0xFFFF, (csum >> 32) & 0xFFFF, csum >> 48], dtype=torch.int64, device=rdev)   # 16-bit limbs
     kms = torch.tensor([kt[kname]["ms"] for kname in mhap_amd.KERNEL_NAMES], dtype=torch.float64, device=rdev)
+    pht = torch.tensor([phase["sketch"], phase["exchange"], phase["search"]], dtype=torch.float64, device=rdev)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot_rec, op=dist.ReduceOp.SUM)
         dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pht, op=dist.ReduceOp.MAX)
         dist.all_reduce(csum_t, op=dist.ReduceOp.SUM)
     elapsed = float(tmax.item())
     total_records = int(tot_rec.item())
@@ -189,42 +273,53 @@ def main():
         else:
             alg_bytes = sketch_bytes_per_read(L, H, S, k2) * reads_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(dom + "_kernel", n_total, L, world)
+        traffic, traffic_src = pmc_traffic(dom + "_kernel", args.config, n_total, L, world)
         roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
-                    "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches)}
+                    "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
+                    "note": "SURVEY §8(d) recipe (algorithmic HBM bytes / launch time vs 8 TB/s).  The dominant kernel is integer-VALU "
+                            "bound, not HBM bound: its honest ceiling is the `valu` object (bound: valu)"}
         # measured HBM rate of every kernel (PMC bytes per launch x launches / its summed time): which ones are memory-side
         hbm_by_kernel = {}
         for kname in mhap_amd.KERNEL_NAMES:
-            tb, _ = pmc_traffic(("overlap_join" if kname == "overlap" else kname) + "_kernel", n_total, L, world)
+            tb, _ = pmc_traffic(("overlap_join" if kname == "overlap" else kname) + "_kernel", args.config, n_total, L, world)
             if tb and kt[kname]["ms"] > 0:
                 hbm_by_kernel[kname] = {"GB_per_step": round(tb * kt[kname]["launches"] / K / 1e9, 2),
                                         "GB_per_s": round(tb * kt[kname]["launches"] / (kt[kname]["ms"] / 1e3) / 1e9, 1)}
-        # integer-VALU view of the MinHash kernel (the path is integer min-reduction work, not HBM-bound: SURVEY F12)
-        steps_per_read = 2 * (L - k + 1) * H
+        # integer-VALU view of the MinHash kernel: xorshift steps actually taken (weight x H per distinct k-mer; ~3x under -f)
+        wfac = 3.0 if (cfg.get("filter")) else 1.0
+        steps_per_read = 2 * (L - k + 1) * H * wfac
         mh_s = kernel_ms_per_step["minhash"] / 1e3
         xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
-        valu = {"kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
-                "ceiling_steps_per_s": XORSHIFT_CEILING_BITSLICED, "frac_of_ceiling": round(xs_rate / XORSHIFT_CEILING_BITSLICED, 4),
+        ceil_spec = 32 * VALU_SPEC / BITSLICED_OPS_PER_32_STEPS
+        ceil_meas = 32 * VALU_MEASURED / BITSLICED_OPS_PER_32_STEPS
+        valu = {"bound": "valu", "kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
+                "ceiling_spec_steps_per_s": round(ceil_spec, 1), "frac_of_spec_ceiling": round(xs_rate / ceil_spec, 4),
+                "ceiling_measured_clock_steps_per_s": round(ceil_meas, 1), "frac_of_measured_ceiling": round(xs_rate / ceil_meas, 4),
                 "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes): one step of 32 chains is 107 full-rate ops "
-                                "(43 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32) + ~15 ops of candidate filter; ceiling = 32 x 6.5e13 "
-                                "lane-ops/s / 122 with every issue slot used.  The per-chain formulation (2 v_lshlrev_b64 + 6 ops "
-                                "per step) tops out at 4.79e12 steps/s (tools/valu_peak.hip)",
-                "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4)}
-        if kernel_ms_per_step["candidate"] > 0 and st["slot_compares"] > 0:   # stats are per step (the index is cleared every step)
-            valu["candidate_slot_compares_per_s"] = round(st["slot_compares"] / (kernel_ms_per_step["candidate"] / 1e3), 1)
+                                "(43 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32) + 9 ops of depth filter + ~4 of compare/loop = 120.  Spec "
+                                "ceiling = 32 x (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 7.86e13 lane-ops/s) / 120; the measured one uses the "
+                                "6.5e13 lane-ops/s an all-VALU probe sustains (tools/valu_ops.hip).  Per-chain formulation: 4.79e12 steps/s",
+                "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4),
+                "weight_factor_assumed": wfac}
 
+        strands = 2 * n_total
         out = {
             "metric": "overlaps/sec", "value": round(total_records / sec_per_step, 2), "unit": "overlaps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(sec_per_step * 1e3, 3),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"{n_total} synthetic PacBio-style reads x {L} bp (30x, {args.error_rate:.0%} error), k={k}, "
-                                   f"--num-hashes {H}, ordered sketch k2={k2} S={S}, self-overlap (BASELINE configs[1])",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int64", "data": "synthetic" if args.config != "c3" else "real",
+            "config": {"workload": f"{cfg_label}, k={k}, --num-hashes {H}, ordered sketch k2={k2} S={S}, self-overlap"
+                                   + (", -f k-mer filter, --filter-threshold 1e-5" if cfg.get("filter") else ""),
+                       "name": args.config, "error_rate": args.error_rate,
                        "parallelism": f"reads round-robin over {world} GPU(s); RCCL all-gather of sketch tables" if world > 1 else "1 GPU"},
             "records_per_step": total_records,
-            "sketches_per_sec": round(2 * n_total / (sketch_ms / 1e3), 1) if sketch_ms > 0 else None,
-            "sketches_per_sec_note": "strands / summed sketch-kernel time (rank max)",
-            "overlaps_per_sec_search_only": round(total_records / (search_ms / 1e3), 1) if search_ms > 0 else None,
+            "sketches_per_sec": round(strands / float(pht[0].item()), 1) if float(pht[0].item()) > 0 else None,
+            "sketches_per_sec_note": "2N strands / wall time of the sketch phase (packed reads in HBM -> MinHash + ordered tables in HBM, host "
+                                     "bookkeeping of the add included; rank max), SURVEY §8(d)",
+            "sketches_per_sec_kernels_only": round(strands / (sketch_ms / 1e3), 1) if sketch_ms > 0 else None,
+            "overlaps_per_sec_search_phase": round(total_records / float(pht[2].item()), 1) if float(pht[2].item()) > 0 else None,
+            "phase_wall_ms": {"sketch": round(float(pht[0].item()) * 1e3, 3), "exchange": round(float(pht[1].item()) * 1e3, 3),
+                              "search": round(float(pht[2].item()) * 1e3, 3)},
             "kernel_ms_per_step": {kk: round(v, 3) for kk, v in kernel_ms_per_step.items()},
             "candidates_per_step": int(st["candidates_compared"]),
             "index_elements_per_step": int(st["table_elements"]),
@@ -235,52 +330,118 @@ def main():
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),
             "value_incl_host_pack_and_pcie": round(total_records / (sec_per_step + t_stage), 2),
+            "c3": "C3 skipped: MHAP_C3_FASTA is not set" if (args.config != "c3" and W.c3_fasta_path() is None) else
+                  ("this run" if args.config == "c3" else "available: run --config c3"),
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, L, H, S, k, k2)
+            out.update(host_legs(args, cfg, p, flt, filter_path, fa_bench, L, H, S, k, k2, total_records, sha, tmpdir))
         print(json.dumps(out), flush=True)
     ms.close()
+    shutil.rmtree(tmpdir, ignore_errors=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel, n_total, L, world):
+def pmc_traffic(kernel, config, n_total, L, world):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (tools/pmc_summary.py).  The counters
-    were collected on the default workload (100k x 10kb, 1 GPU); for any other shape the field stays null."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if not (os.path.exists(path) and n_total == 100000 and L == 10000 and world == 1):
+    were collected on the default workload (c2: 100k x 10kb, 1 GPU); for any other shape the field stays null."""
+    if not (config == "c2" and n_total == 100000 and L == 10000 and world == 1):
         return None, None
-    try:
-        d = json.load(open(path))["kernels"].get(kernel)
-        return (int(d["hbm_bytes_per_launch"]), "profiles/r01_pmc_traffic.json (" + d["fetch_rule"] + ")") if d else (None, None)
-    except Exception:
-        return None, None
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            continue
+        try:
+            d = json.load(open(path))["kernels"].get(kernel)
+            if d:
+                return int(d["hbm_bytes_per_launch"]), "profiles/" + name + " (" + d["fetch_rule"] + ")"
+        except Exception:
+            pass
+    return None, None
 
 
-def cpu_baseline(args, L, H, S, k, k2):
-    """The CPU oracle (a C++ restatement of the reference's Java, kind "port") timed on this box's host cores on a
-    bounded sample of the same workload: same read length, coverage, error model and flags, fewer reads."""
+def host_legs(args, cfg, p, flt, filter_path, fa_bench, L, H, S, k, k2, total_records, bench_sha, tmpdir):
+    """N = 1 only: (a) GPU vs oracle on the same sample reads, (b) the oracle timed as the CPU baseline, (c) the native driver end to end."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = os.cpu_count() or 1
+    out = {}
+    aff, quota, threads = host_cpus()
     n = args.cpu_sample_reads
+    wfac = 3.0 if cfg.get("filter") else 1.0
     if n <= 0:
-        # ~2*(L-k+1)*H xorshift steps per read at ~1.5e9 steps/s/core; aim at ~15 s
-        per_read_s = 2.0 * (L - k + 1) * H / 1.5e9
-        n = int(max(200, min(20000, 15.0 * cores / per_read_s)))
-    fa = mhap_amd.synth_reads(n, L, seed=(0x4D484150 ^ 2) + 1, error_rate=args.error_rate)
+        # ~2*(L-k+1)*H*w xorshift steps per read at ~3.5e8 steps/s/thread; aim at ~15 s
+        per_read_s = 2.0 * (L - k + 1) * H * wfac / 3.5e8
+        n = int(max(200, min(20000, 15.0 * threads / per_read_s)))
+    if args.config == "c3":
+        sample = fa_bench.subset(np.arange(min(n, len(fa_bench))))
+        sample_desc = f"first {len(sample)} reads of the C3 file"
+    else:
+        sample = mhap_amd.synth_reads(n, L, seed=cfg["seed"] + 1, error_rate=args.error_rate, repeats=cfg["repeats"])
+        sample_desc = (f"{n} reads x {L} bp from the same generator at the same 30x coverage / error model (own genome, seed+1)"
+                       + (", same -f filter" if flt is not None else ""))
+    oflt = None
+    if flt is not None:
+        oflt = O.Filter(flt.hashes, flt.fractions, flt.filter_cutoff, flt.offset, flt.range, flt.no_tf)
+    # (a) same-input parity: the GPU path on the sample ...
+    with MinHashSearch(p, kmer_filter=flt) as ms2:
+        ms2.add_data(sample)
+        g_lines = mhap_amd.records_to_lines(ms2.find_matches())
+    # ... (b) and the oracle on it, timed: the CPU baseline
+    one = min(len(sample), max(8, int(1.2 * 3.5e8 / (2.0 * (L - k + 1) * H * wfac))))      # ~1 s single-thread micro-sample
+    t1 = O.run_self(sample.subset(np.arange(one)), k=k, H=H, k2=k2, S=S, nthreads=1, flt=oflt, cap=1 << 22)
     t = time.perf_counter()
-    res = O.run_self(fa, k=k, H=H, k2=k2, S=S, nthreads=cores, cap=1 << 24)
+    res = O.run_self(sample, k=k, H=H, k2=k2, S=S, nthreads=threads, flt=oflt, cap=1 << 24)
     wall = time.perf_counter() - t
-    nrec = len(res["records"])
+    o_lines = O.record_lines(res["records"])
+    g_sha, o_sha = sorted_sha(g_lines), sorted_sha(o_lines)
+    out["parity_check"] = {"reads": len(sample), "records": len(o_lines), "gpu_records": len(g_lines), "equal": g_sha == o_sha,
+                           "sha256_sorted_lines": o_sha, "what": "GPU path (C ABI) and CPU oracle on the same sample reads, sorted record lines"}
+    nrec = len(o_lines)
     busy = res["sketch_s"] + res["search_s"]
-    return {"value": round(nrec / busy, 2) if busy > 0 else None, "unit": "overlaps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} reads x {L} bp at the same 30x coverage/error model (own genome), same flags; "
-                      f"{nrec} records in {busy:.2f} s ({res['sketch_s']:.2f} s sketch + {res['search_s']:.2f} s search)",
-            "sketches_per_sec": round(2 * n / res["sketch_s"], 1) if res["sketch_s"] > 0 else None,
-            "reads_per_sec": round(n / busy, 2) if busy > 0 else None, "wall_s": round(wall, 2),
-            "note": "C++ restatement of MHAP's Java path (no JVM on this box), std::thread on all host cores"}
+    sk1 = 2 * one / t1["sketch_s"] if t1["sketch_s"] > 0 else None
+    skn = 2 * len(sample) / res["sketch_s"] if res["sketch_s"] > 0 else None
+    out["cpu_baseline"] = {
+        "value": round(nrec / busy, 2) if busy > 0 else None, "unit": "overlaps/s", "cores": threads, "kind": "port",
+        "sample": f"{sample_desc}, same flags; {nrec} records in {busy:.2f} s ({res['sketch_s']:.2f} s sketch + {res['search_s']:.2f} s search)",
+        "sketches_per_sec": round(skn, 1) if skn else None, "reads_per_sec": round(len(sample) / busy, 2) if busy > 0 else None,
+        "wall_s": round(wall, 2),
+        "host": {"os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_max_cores": quota, "threads_used": threads},
+        "single_thread_sketches_per_sec": round(sk1, 2) if sk1 else None,
+        "parallel_efficiency": round(skn / (sk1 * threads), 3) if (sk1 and skn) else None,
+        "note": "CPU stand-in: C++ restatement of MHAP's Java path (oracle/), std::thread; threads = cgroup CPU quota of this container "
+                "(the machine reports more cores than the process may use).  Not Java: no JVM on this box" + jvm_probe()}
+    # (c) end to end through the native driver: FASTA open -> last record flushed (parse, pack, H2D, sketch, search, text formatting)
+    cli = os.path.join(ROOT, "mhap_amd", "lib", "mhap-hip")
+    if os.path.exists(cli) and args.config != "c3":
+        fasta = os.path.join(tmpdir, "reads.fasta")
+        W.write_fasta(fa_bench, fasta)
+        cmd = [cli, "-s", fasta, "--num-hashes", str(H)] + (["-f", filter_path, "--filter-threshold", "1e-5"] if filter_path else [])
+        outp = os.path.join(tmpdir, "records.txt")
+        best = None
+        for _ in range(2):   # second run: page cache and HIP context warm, as a resident service would be
+            t = time.perf_counter()
+            with open(outp, "w") as fh:
+                r = subprocess.run(cmd, stdout=fh, stderr=subprocess.PIPE, text=True)
+            w = time.perf_counter() - t
+            best = w if best is None else min(best, w)
+        nlines, e2e_sha = 0, None
+        if r.returncode == 0:
+            ls = [x for x in open(outp).read().split("\n") if x]
+            nlines, e2e_sha = len(ls), sorted_sha(ls)
+        out["end_to_end"] = {"wall_s": round(best, 3), "records": nlines, "records_per_s": round(nlines / best, 1) if best else None,
+                             "equal_to_bench_records": (e2e_sha == bench_sha) if bench_sha else None, "rc": r.returncode,
+                             "what": "mhap-hip -s reads.fasta (process start, FASTA parse, 2-bit pack, H2D, sketch, search, record text to a file); best of 2"}
+    return out
+
+
+def jvm_probe():
+    """If a JVM and MHAP_JAR are present, diff the golden fixture against the real jar (tests/golden/verify_against_jar.sh)."""
+    jar = os.environ.get("MHAP_JAR")
+    if not (shutil.which("java") and jar and os.path.exists(jar)):
+        return "; jvm_diff: unavailable (no java / MHAP_JAR)"
+    r = subprocess.run(["sh", os.path.join(ROOT, "tests", "golden", "verify_against_jar.sh")], capture_output=True, text=True)
+    return "; jvm_diff: " + ("ok" if r.returncode == 0 else "mismatch") + " (" + (r.stdout.strip().split("\n")[-1] if r.stdout.strip() else r.stderr.strip()[-120:]) + ")"
 
 
 if __name__ == "__main__":

@@ -204,6 +204,12 @@ void launch_hash_kmers(hipStream_t st, const ReadDesc* descs, int64_t nstrands, 
 // do not all carry the same weight; those strands also get their first occurrences listed by weight class (class_list),
 // which is what lets the MinHash kernel keep weighted k-mers (tf repeats, tf-idf under -f) on its bit-sliced rows.
 // =============================================================================================
+// Ordering between the waves of ONE workgroup over data in global memory: every cross-thread read in this kernel is an L2 access
+// (atomics, sc1 loads through ld_agent) and the vector L1 is write-through, so the producer only has to wait until its stores
+// and atomics have left the CU — a workgroup-scope release (s_waitcnt) before the barrier.  An agent-scope fence
+// (__threadfence) would write back the whole XCD's dirty L2 lines each time: with every workgroup writing weights (tf-idf under
+// -f) that cost ~0.9 ms per strand.
+__device__ inline void wg_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ inline uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -236,7 +242,7 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
                                      unsigned int* s_heavy) {
   const uint32_t mask = ts - 1;
   for (uint32_t j = threadIdx.x; j < ts; j += WEIGHT_THREADS) tab[j] = 0;
-  if (!PACKED) __threadfence();
+  if (!PACKED) wg_release();
   __syncthreads();
   for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
     const int64_t key = kp[i];
@@ -253,7 +259,7 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
       slot = (slot + 1) & mask;
     }
   }
-  if (!PACKED) __threadfence();
+  if (!PACKED) wg_release();
   __syncthreads();
   // pass A: first occurrences get 1, later occurrences remember their first position
   bool anydup = false;
@@ -274,7 +280,7 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
     wp[i] = w;
   }
   if (anydup) atomicOr(s_heavy, 1u);
-  __threadfence();
+  wg_release();
   __syncthreads();
   // pass B (only strands with duplicates): fold multiplicities into the first occurrence
   if (*(volatile unsigned int*)s_heavy) {
@@ -282,7 +288,7 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
       const uint32_t w = wp[i];
       if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
     }
-    __threadfence();
+    wg_release();
     __syncthreads();
   }
 }
@@ -371,13 +377,13 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
     }
   }
   if (*(volatile unsigned int*)s_heavy) {
-    __threadfence();
+    wg_release();
     __syncthreads();
     for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
       const uint32_t w = wp[i];
       if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
     }
-    __threadfence();
+    wg_release();
     __syncthreads();
   }
 }
@@ -434,13 +440,13 @@ __device__ inline bool weight_strand_lds_part(uint32_t* tab, uint32_t ts, const 
   if (anydup) atomicOr(s_heavy, 1u);
   __syncthreads();
   if (*(volatile unsigned int*)s_heavy) {
-    __threadfence();
+    wg_release();
     __syncthreads();
     for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
       const uint32_t w = wp[i];
       if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
     }
-    __threadfence();
+    wg_release();
     __syncthreads();
   }
   return true;
@@ -587,7 +593,7 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
         mymin = a < mymin ? a : mymin; mymax = b > mymax ? b : mymax;
       }
       if ((threadIdx.x & 63) == 0) { atomicMin(&svars[4], mymin); atomicMax(&svars[5], mymax); }
-      __threadfence();
+      wg_release();
       __syncthreads();
     }
     // weight classes: one common weight and no repeats -> mode = that weight, nothing else is read downstream
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
     }
     if (valid && mode == 0) {
       class_list(wp, perm, nk, svars + 8, info[strand].cnt);
-      __threadfence();
+      wg_release();
     }
     if (threadIdx.x == 0) {
       info[strand].valid = valid; info[strand].mode = mode;
