@@ -68,9 +68,10 @@ typedef struct mhap_stats {
   int64_t queries_searched;       /* getNumberSequencesSearched()                */
   int64_t candidates_compared;    /* getNumberSequencesFullyCompared()           */
   int64_t matches_found;          /* getMatchesProcessed()                       */
-  int64_t slot_compares;          /* slot comparisons done by the brute-force (fallback) candidate kernel */
+  int64_t slot_compares;          /* slot comparisons done by the brute-force candidate kernel (MHAP_CANDIDATES=bruteforce) */
   int64_t table_elements;         /* getNumberElementsProcessed(): inverted-index hits walked             */
   int64_t slow_pairs;             /* candidates the wave-per-pair second stage handed to the per-lane merge */
+  int64_t index_splits;           /* query hit sets too large for the LDS count table that were split into hash-partition passes */
 } mhap_stats;
 
 /* Per-kernel HIP-event timings accumulated on the handle's stream (for bench/roofline). */

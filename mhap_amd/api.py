@@ -33,7 +33,7 @@ class _Params(C.Structure):
 class _Stats(C.Structure):
     _fields_ = [("strands_indexed", C.c_int64), ("queries_searched", C.c_int64), ("candidates_compared", C.c_int64),
                 ("matches_found", C.c_int64), ("slot_compares", C.c_int64), ("table_elements", C.c_int64),
-                ("slow_pairs", C.c_int64)]
+                ("slow_pairs", C.c_int64), ("index_splits", C.c_int64)]
 
 
 class _KTimes(C.Structure):

@@ -88,13 +88,18 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
                        const int32_t* qlist, int nq, int ne, const int64_t* ids, const int64_t* qids, const int32_t* meta,
                        const int32_t* qmeta, const SearchParams& sp, const long long* rowstart, long long nblocks_tri, Candidate* cand,
                        unsigned long long* cand_count, unsigned long long cand_cap);
-// Inverted index (one open-addressing table of 2^k (value,entry+1) words per MinHash slot) + per-query lookup.
-void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H,
-                        unsigned long long* table, uint32_t cmask);
-void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_t cmask, const int32_t* qminhash, int64_t qrow_stride,
+// Inverted index: one open-addressing table of 2^k (value, entry+1) words per MinHash slot; a value's entries beyond the run cap
+// live on a linked list in the overflow pool (heads in a second hash table keyed by (slot, value)).
+struct InvIndex {
+  unsigned long long* table; uint32_t cmask;
+  unsigned long long* ovf_keys; uint32_t* ovf_heads; uint32_t ovf_mask;
+  uint2* pool; unsigned long long* pool_count; uint32_t pool_cap;
+};
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H, const InvIndex& ix);
+void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        int32_t* overflow, unsigned long long* overflow_count, unsigned long long* elements);
+                        unsigned long long* split_count, unsigned long long* elements);
 // Second stage: one lane per candidate.
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,

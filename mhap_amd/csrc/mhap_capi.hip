@@ -121,7 +121,8 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_overflow;
+  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_ovf;
+  InvIndex inv{};   // device view of the inverted index in inv_table / inv_ovf
   std::vector<mhap_record> out_recs;
 
   // timing
@@ -278,6 +279,32 @@ static uint64_t inv_capacity(int64_t ne) {
   return cap;
 }
 
+// (Re)allocate and zero the inverted index for `ne` entries on stream st: H slot tables of inv_capacity(ne) words, the overflow
+// heads table (one slot per 8 postings) and the overflow pool (one node per 4 postings; beyond that inserts stay in their runs).
+static int inv_reset(mhap_handle* h, int64_t ne, hipStream_t st) {
+  const int H = h->P.num_hashes;
+  const uint64_t cap = inv_capacity(ne);
+  const size_t tbytes = (size_t)H * (size_t)cap * 8;
+  const uint64_t postings = (uint64_t)ne * (uint64_t)H;
+  uint64_t oslots = 1024;
+  while (oslots < postings / 8) oslots <<= 1;
+  const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(postings / 4, 1u << 16), 0xFFFFFFF0ull);
+  const size_t obytes = 64 + (size_t)oslots * 8 + (size_t)oslots * 4 + (size_t)pool_cap * 8;
+  HIPCHK(h, h->inv_table.ensure(tbytes));
+  HIPCHK(h, h->inv_ovf.ensure(obytes));
+  HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, tbytes, st));
+  HIPCHK(h, hipMemsetAsync(h->inv_ovf.p, 0, 64 + (size_t)oslots * 12, st));
+  char* o = h->inv_ovf.as<char>();
+  h->inv.table = h->inv_table.as<unsigned long long>(); h->inv.cmask = (uint32_t)(cap - 1);
+  h->inv.pool_count = (unsigned long long*)o;
+  h->inv.ovf_keys = (unsigned long long*)(o + 64);
+  h->inv.ovf_heads = (uint32_t*)(o + 64 + (size_t)oslots * 8);
+  h->inv.ovf_mask = (uint32_t)(oslots - 1);
+  h->inv.pool = (uint2*)(o + 64 + (size_t)oslots * 12);
+  h->inv.pool_cap = (uint32_t)pool_cap;
+  return MHAP_OK;
+}
+
 int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
@@ -403,7 +430,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
       time_begin(h, MHAP_K_INDEX_BUILD, h->side_stream);
       launch_index_build(h->side_stream, d_minhash - h->eager_first * mh_stride, mh_stride, d_meta - h->eager_first * META_W,
-                         (int)(h->eager_first + 2 * B.r0), (int)nstr, H, h->inv_table.as<unsigned long long>(), h->eager_cmask);
+                         (int)(h->eager_first + 2 * B.r0), (int)nstr, H, h->inv);
       time_end(h, h->side_stream);
       h->pending_side.push_back(h->pending.back()); h->pending.pop_back();
       HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
@@ -480,12 +507,10 @@ int ensure_inverted_index(mhap_handle* h) {
   const uint64_t cap = inv_capacity(ne);
   const uint32_t cmask = (uint32_t)(cap - 1);
   if (h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask) return MHAP_OK;
-  const size_t bytes = (size_t)H * (size_t)cap * 8;
-  HIPCHK(h, h->inv_table.ensure(bytes));
-  HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->stream));
+  { const int rr = inv_reset(h, ne, h->stream); if (rr != MHAP_OK) return rr; }
   HPROF("index build launch");
   time_begin(h, MHAP_K_INDEX_BUILD);
-  launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv_table.as<unsigned long long>(), cmask);
+  launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv);
   time_end(h);
   HIPCHK(h, hipGetLastError());
   h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
@@ -551,11 +576,10 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       HIPCHK(h, h->cand.ensure(cand_cap * sizeof(Candidate)));
       HIPCHK(h, hipMemsetAsync(ctr, 0, 64, h->stream));
       if (use_index) {
-        HIPCHK(h, h->inv_overflow.ensure((size_t)nq * 4));
         time_begin(h, MHAP_K_INDEX_QUERY);
-        launch_index_query(h->stream, h->inv_table.as<unsigned long long>(), cmask, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
+        launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                           (unsigned long long)cand_cap, h->inv_overflow.as<int32_t>(), ctr + 3, ctr + 4);
+                           (unsigned long long)cand_cap, ctr + 3, ctr + 4);
         time_end(h);
         HIPCHK(h, hipGetLastError());
         unsigned long long c5[5] = {0, 0, 0, 0, 0};
@@ -563,21 +587,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return rc;
         ncand = c5[0];
-        const unsigned long long nover = c5[3];
-        if (ncand <= cand_cap && nover > 0) {
-          // queries whose hit set outgrew the LDS count table: exact brute-force count for just those
-          time_begin(h, MHAP_K_CANDIDATE);
-          launch_candidates(h->stream, h->d_minhash, h->Hrow, qs.d_minhash, qs.mh_stride, h->inv_overflow.as<int32_t>(), (int)nover, ne,
-                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, nullptr, 0, h->cand.as<Candidate>(), ctr + 0,
-                            (unsigned long long)cand_cap);
-          time_end(h);
-          HIPCHK(h, hipGetLastError());
-          HIPCHK(h, hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
-          rc = sync_stream(h);
-          if (rc != MHAP_OK) return rc;
-          if (ncand <= cand_cap) h->stats.slot_compares += (long long)((nover + CAND_TQ - 1) / CAND_TQ) * ntu * CAND_TQ * CAND_TM * sp.H;
-        }
-        if (ncand <= cand_cap) h->stats.table_elements += (int64_t)c5[4];
+        if (ncand <= cand_cap) { h->stats.table_elements += (int64_t)c5[4]; h->stats.index_splits += (int64_t)c5[3]; }
       } else {
         time_begin(h, MHAP_K_CANDIDATE);
         launch_candidates(h->stream, h->d_minhash, h->Hrow, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq, ne,
@@ -736,7 +746,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_overflow};
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_ovf};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->pin_io) (void)hipHostFree(h->pin_io);
@@ -848,11 +858,8 @@ int mhap_index_add_staged(mhap_handle* h) {
   h->inv_ready = false;
   const char* cmode = getenv("MHAP_CANDIDATES");
   if (first == 0 && !(cmode && strcmp(cmode, "bruteforce") == 0) && !getenv("MHAP_NO_EAGER_INDEX")) {
-    const uint64_t cap = inv_capacity(2 * n);
-    const size_t bytes = (size_t)h->P.num_hashes * (size_t)cap * 8;
-    HIPCHK(h, h->inv_table.ensure(bytes));
-    HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, bytes, h->side_stream));
-    h->eager = true; h->eager_first = first; h->eager_cmask = (uint32_t)(cap - 1);
+    { const int rr = inv_reset(h, 2 * n, h->side_stream); if (rr != MHAP_OK) return rr; }
+    h->eager = true; h->eager_first = first; h->eager_cmask = h->inv.cmask;
   }
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
   const bool built = h->eager && rc == MHAP_OK;

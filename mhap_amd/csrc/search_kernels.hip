@@ -180,14 +180,40 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // Inverted index on the GPU (the reference's own structure, J/impl/MinHashSearch.java:100-147,161-181):
 // one open-addressing table per MinHash slot holding (value, entry+1) words; entries with equal values sit in
 // one probe run.  A query does H probes and counts hits per stored entry in an LDS count table; the hit count
-// of a pair equals the number of equal slots, so the candidate set is identical to the brute-force count.
+// of a pair equals the number of slots with equal values, so the candidate set is identical to the brute-force count.
 // Work ~ N*H probes + hits instead of N*2N*H/2 compares.
+//
+// Repeats (the reference keeps value -> ArrayList, :123-141): a value shared by n entries would cost n^2/2 CAS probes to
+// insert into one run, so a run holds at most ~INV_RUN_CAP entries of one value; further entries of that value go to a
+// per-(slot, value) linked list in an overflow pool (find-or-claim of the list head in a second hash table, one
+// atomicExch to push) — O(1) per insert however popular the value.  A query that finds INV_RUN_CAP entries of its value in
+// the run also walks the value's overflow list.  A query whose distinct hits outgrow the LDS count table is not handed to
+// the brute-force kernel any more: it is re-run in passes over hash-partitions of the stored entries (split in two until
+// every part fits), which bounds its cost by its own postings.
 // =============================================================================================
 __device__ inline uint32_t inv_hash(uint32_t v) { return fmix32(v); }
+constexpr int INV_RUN_CAP = 16;
+
+__device__ inline void inv_overflow_push(const InvIndex& ix, int s, uint32_t v, int e, unsigned long long* T, uint32_t pos, unsigned long long word) {
+  const unsigned long long pidx = atomicAdd(ix.pool_count, 1ULL);
+  if (pidx >= (unsigned long long)ix.pool_cap) {
+    // pool exhausted (pathological input): keep probing the run uncapped — slower, still exact
+    for (;;) { pos = (pos + 1) & ix.cmask; if (atomicCAS(&T[pos], 0ULL, word) == 0ULL) return; }
+  }
+  const unsigned long long key = (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL;
+  uint32_t hp = (uint32_t)fmix64(key) & ix.ovf_mask;
+  for (;;) {
+    const unsigned long long old = atomicCAS(&ix.ovf_keys[hp], 0ULL, key);
+    if (old == 0ULL || old == key) break;
+    hp = (hp + 1) & ix.ovf_mask;
+  }
+  const uint32_t prev = atomicExch(&ix.ovf_heads[hp], (uint32_t)pidx + 1u);
+  ix.pool[pidx] = make_uint2((uint32_t)e, prev);     // (entry, next + 1); read by later kernels only
+}
 
 constexpr int IB_S = 4, IB_E = 256 / IB_S;   // slots x entries of one workgroup (1x256 / 4x64 / 8x32 / 16x16: 6.2 / 6.1 / 6.3 / 6.5 ms at C2)
 __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta,
-                                                          int e0, int ne, int H, unsigned long long* __restrict__ table, uint32_t cmask) {
+                                                          int e0, int ne, int H, InvIndex ix) {
   // slot-group-major order: a workgroup inserts IB_E entries x IB_S slots, and consecutive workgroups walk the entries of one
   // group of IB_S slots, so only those few tables (8 MB each at C2) are written at a time — they stay in the memory-side cache
   // instead of every CAS going to a random line of the whole 2.1 GB
@@ -197,119 +223,170 @@ __global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restr
   if (e >= e0 + ne || s >= H) return;
   if (meta[(int64_t)e * META_W + 3] != 0) return;                       // skipped strands are not stored (addSequence never sees them)
   const uint32_t v = (uint32_t)minhash[(int64_t)e * row_stride + s];
-  unsigned long long* T = table + (size_t)s * ((size_t)cmask + 1);
+  unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
   const unsigned long long word = ((unsigned long long)v << 32) | (unsigned long long)(uint32_t)(e + 1);
-  uint32_t pos = inv_hash(v) & cmask;
+  uint32_t pos = inv_hash(v) & ix.cmask;
+  int same = 0;
   for (;;) {
     const unsigned long long old = atomicCAS(&T[pos], 0ULL, word);
     if (old == 0ULL) break;
-    pos = (pos + 1) & cmask;
+    if ((uint32_t)(old >> 32) == v && ++same >= INV_RUN_CAP) { inv_overflow_push(ix, s, v, e, T, pos, word); break; }
+    pos = (pos + 1) & ix.cmask;
   }
 }
 
-void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H,
-                        unsigned long long* table, uint32_t cmask) {
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H, const InvIndex& ix) {
   const int64_t total = (int64_t)ne * H;
   if (total <= 0) return;
-  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)(((ne + IB_E - 1) / IB_E) * ((H + IB_S - 1) / IB_S))), dim3(256), 0, st, minhash, row_stride, meta, e0, ne, H, table, cmask);
+  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)(((ne + IB_E - 1) / IB_E) * ((H + IB_S - 1) / IB_S))), dim3(256), 0, st, minhash, row_stride, meta, e0, ne, H, ix);
 }
 
-// One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].  A query whose distinct-hit set outgrows the table is
-// appended to `overflow` (the caller re-runs those through candidate_kernel).
+// One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].
 constexpr int IQ_THREADS = 128;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
                                   // CU by LDS either way: more probe chains in flight per CU only thrash the memory side)
-__global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(const unsigned long long* __restrict__ table, uint32_t cmask,
-                                                          const int32_t* __restrict__ qminhash, int64_t qrow_stride,
+constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
+__global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
                                                           const int32_t* __restrict__ qmeta, SearchParams sp,
                                                           Candidate* __restrict__ cand, unsigned long long* __restrict__ cand_count,
-                                                          unsigned long long cand_cap, int32_t* __restrict__ overflow,
-                                                          unsigned long long* __restrict__ overflow_count,
+                                                          unsigned long long cand_cap, unsigned long long* __restrict__ split_count,
                                                           unsigned long long* __restrict__ elements) {
   __shared__ uint32_t keys[INV_CT];
   __shared__ uint32_t cnts[INV_CT];
-  __shared__ uint32_t s_distinct, s_over;
+  __shared__ uint32_t s_distinct, s_over, s_top, s_prefix, s_bits;
+  __shared__ uint32_t stack[2 * IQ_STACK];
+  __shared__ unsigned long long s_base;
   const int qi = blockIdx.x;
   if (qi >= nq) return;
   const int qe = qlist[qi];
-  for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) { keys[j] = 0; cnts[j] = 0; }
-  if (threadIdx.x == 0) { s_distinct = 0; s_over = 0; }
-  __syncthreads();
   const int32_t* qm = qmeta + (int64_t)qe * META_W;
   const int64_t qid = qids[qe];
   const int qlen = qm[2];
-  unsigned long long mine = 0;
-  for (int s = threadIdx.x; s < sp.H; s += IQ_THREADS) {
-    const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
-    const unsigned long long* T = table + (size_t)s * ((size_t)cmask + 1);
-    uint32_t pos = inv_hash(v) & cmask;
-    for (;;) {
-      const unsigned long long w = T[pos];
-      if (w == 0ULL) break;
-      pos = (pos + 1) & cmask;
-      if ((uint32_t)(w >> 32) != v) continue;
-      mine++;                                                              // "table elements processed" (:173)
-      const int me = (int)(uint32_t)w - 1;
-      // count the hit (the id/length rules do not depend on the count: they are applied to the few entries that reach
-      // numMinMatches, below, so that the probe loop's only global load is the table word)
-      uint32_t slot = inv_hash((uint32_t)me) & (INV_CT - 1);
-      for (int tries = 0; tries < INV_CT; tries++) {
-        uint32_t k = *(volatile uint32_t*)&keys[slot];
-        if (k == 0) {
-          if (*(volatile uint32_t*)&s_distinct >= (INV_CT * 3) / 4) { s_over = 1; break; }
-          const uint32_t old = atomicCAS(&keys[slot], 0u, (uint32_t)me + 1u);
-          if (old == 0) { atomicAdd(&s_distinct, 1u); k = (uint32_t)me + 1u; } else k = old;
+  if (threadIdx.x == 0) { stack[0] = 0; stack[1] = 0; s_top = 1; }
+  __syncthreads();
+  for (;;) {
+    // ---- next part of the stored entries: those whose hash has `bits` low bits equal to `prefix` (the whole index first) ----
+    if (threadIdx.x == 0) {
+      if (s_top == 0) s_bits = 0xFFFFFFFFu;
+      else { s_top--; s_prefix = stack[2 * s_top]; s_bits = stack[2 * s_top + 1]; }
+      s_distinct = 0; s_over = 0;
+    }
+    for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) { keys[j] = 0; cnts[j] = 0; }
+    __syncthreads();
+    const uint32_t bits = s_bits, prefix = s_prefix;
+    if (bits == 0xFFFFFFFFu) break;
+    const uint32_t pmask = bits >= 20 ? 0xFFFFFu : ((1u << bits) - 1u);
+    unsigned long long mine = 0;
+    for (int s = threadIdx.x; s < sp.H; s += IQ_THREADS) {
+      const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
+      const unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
+      uint32_t pos = inv_hash(v) & ix.cmask;
+      int same = 0;
+      uint32_t chain = 0;          // overflow list cursor (pool index + 1), entered after the run
+      for (;;) {
+        int me;
+        if (chain == 0) {
+          const unsigned long long w = T[pos];
+          if (w == 0ULL) {
+            if (same < INV_RUN_CAP) break;
+            // the run holds its cap of this value: the rest of the value's entries are on its overflow list
+            const unsigned long long key = (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL;
+            uint32_t hp = (uint32_t)fmix64(key) & ix.ovf_mask;
+            for (;;) {
+              const unsigned long long k = ix.ovf_keys[hp];
+              if (k == 0ULL) break;
+              if (k == key) { chain = ix.ovf_heads[hp]; break; }
+              hp = (hp + 1) & ix.ovf_mask;
+            }
+            if (chain == 0) break;
+            same = -0x40000000;     // (do not come back here)
+            continue;
+          }
+          pos = (pos + 1) & ix.cmask;
+          if ((uint32_t)(w >> 32) != v) continue;
+          same++;
+          me = (int)(uint32_t)w - 1;
+        } else {
+          const uint2 pe = ix.pool[chain - 1];
+          me = (int)pe.x;
+          chain = pe.y;
+          if (chain == 0) { pos = 0xFFFFFFFFu; }
         }
-        if (k == (uint32_t)me + 1u) { atomicAdd(&cnts[slot], 1u); break; }
-        slot = (slot + 1) & (INV_CT - 1);
+        if (bits == 0) mine++;                                               // "table elements processed" (:173), counted once
+        // count the hit (the id/length rules do not depend on the count: they are applied to the few entries that reach
+        // numMinMatches, below, so that the probe loop's only global load is the table word)
+        const uint32_t hm = inv_hash((uint32_t)me);
+        if (((hm >> 12) & pmask) == prefix) {
+          uint32_t slot = hm & (INV_CT - 1);
+          for (int tries = 0; tries < INV_CT; tries++) {
+            uint32_t k = *(volatile uint32_t*)&keys[slot];
+            if (k == 0) {
+              if (*(volatile uint32_t*)&s_distinct >= (INV_CT * 3) / 4) { s_over = 1; break; }
+              const uint32_t old = atomicCAS(&keys[slot], 0u, (uint32_t)me + 1u);
+              if (old == 0) { atomicAdd(&s_distinct, 1u); k = (uint32_t)me + 1u; } else k = old;
+            }
+            if (k == (uint32_t)me + 1u) { atomicAdd(&cnts[slot], 1u); break; }
+            slot = (slot + 1) & (INV_CT - 1);
+          }
+        }
+        if (chain == 0 && pos == 0xFFFFFFFFu) break;                          // end of the overflow list
       }
     }
-  }
-  if (mine) atomicAdd(elements, mine);
-  __syncthreads();
-  if (s_over) {
-    if (threadIdx.x == 0) { const unsigned long long o = atomicAdd(overflow_count, 1ULL); overflow[o] = qe; }
-    return;
-  }
-  // emit this query's candidates as ONE contiguous block (one global atomic per query): the second stage then finds
-  // the lanes of a wave sharing the query's ordered-sketch row
-  uint32_t mymask = 0;   // bit t set -> table slot threadIdx.x + IQ_THREADS*t is a candidate
-  int mycount = 0;
-#pragma unroll
-  for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
-    const int j = threadIdx.x + IQ_THREADS * t;
-    if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) {                                    // MinHashSearch.java:204
-      const int me = (int)keys[j] - 1;
-      if (pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1u << t; mycount++; }   // :200-225
+    if (mine) atomicAdd(elements, mine);
+    __syncthreads();
+    if (s_over) {
+      // the part's distinct hits outgrow the count table: split it in two and run both halves (exact; every stored entry
+      // belongs to exactly one leaf part)
+      if (threadIdx.x == 0) {
+        if (bits < 20 && s_top + 2 <= IQ_STACK) {
+          stack[2 * s_top] = prefix; stack[2 * s_top + 1] = bits + 1; s_top++;
+          stack[2 * s_top] = prefix | (1u << bits); stack[2 * s_top + 1] = bits + 1; s_top++;
+        }
+        atomicAdd(split_count, 1ULL);
+      }
+      __syncthreads();
+      continue;
     }
-  }
-  __syncthreads();            // s_distinct is dead from here on: reuse it as the block's emit counter
-  if (threadIdx.x == 0) s_distinct = 0;
-  __syncthreads();
-  uint32_t local = 0;
-  if (mycount) local = atomicAdd(&s_distinct, (uint32_t)mycount);
-  __syncthreads();
-  __shared__ unsigned long long s_base;
-  if (threadIdx.x == 0) s_base = s_distinct ? atomicAdd(cand_count, (unsigned long long)s_distinct) : 0ULL;
-  __syncthreads();
-  unsigned long long slot = s_base + local;
+    // emit this part's candidates as ONE contiguous block (one global atomic): the second stage then finds
+    // the lanes of a wave sharing the query's ordered-sketch row
+    uint32_t mymask = 0;   // bit t set -> table slot threadIdx.x + IQ_THREADS*t is a candidate
+    int mycount = 0;
 #pragma unroll
-  for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
-    if (mymask & (1u << t)) {
-      if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)keys[threadIdx.x + IQ_THREADS * t] - 1; }
-      slot++;
+    for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
+      const int j = threadIdx.x + IQ_THREADS * t;
+      if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) {                                    // MinHashSearch.java:204
+        const int me = (int)keys[j] - 1;
+        if (pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1u << t; mycount++; }   // :200-225
+      }
     }
+    __syncthreads();            // s_distinct is dead from here on: reuse it as the block's emit counter
+    if (threadIdx.x == 0) s_distinct = 0;
+    __syncthreads();
+    uint32_t local = 0;
+    if (mycount) local = atomicAdd(&s_distinct, (uint32_t)mycount);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_distinct ? atomicAdd(cand_count, (unsigned long long)s_distinct) : 0ULL;
+    __syncthreads();
+    unsigned long long slot = s_base + local;
+#pragma unroll
+    for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
+      if (mymask & (1u << t)) {
+        if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)keys[threadIdx.x + IQ_THREADS * t] - 1; }
+        slot++;
+      }
+    }
+    __syncthreads();
   }
 }
 
-void launch_index_query(hipStream_t st, const unsigned long long* table, uint32_t cmask, const int32_t* qminhash, int64_t qrow_stride,
+void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        int32_t* overflow, unsigned long long* overflow_count, unsigned long long* elements) {
+                        unsigned long long* split_count, unsigned long long* elements) {
   if (nq <= 0) return;
-  hipLaunchKernelGGL(index_query_kernel, dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, table, cmask, qminhash, qrow_stride, qlist, nq, ids, qids,
-                     meta, qmeta, sp, cand, cand_count, cand_cap, overflow, overflow_count, elements);
+  hipLaunchKernelGGL(index_query_kernel, dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
+                     meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements);
 }
 
 // =============================================================================================

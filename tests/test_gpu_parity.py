@@ -264,8 +264,9 @@ def _sorted_records(recs):
 
 
 def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
-    """Inverted-index candidates (default) == brute-force all-pairs candidates == oracle, including queries whose hit
-    set overflows the per-query LDS count table (3072 distinct entries) and falls back to the brute-force kernel."""
+    """Inverted-index candidates (default) == brute-force all-pairs candidates == oracle, including values shared by thousands
+    of entries (run cap + overflow lists) and queries whose hit set overflows the per-query LDS count table (3072 distinct
+    entries: split into hash-partition passes)."""
     rnd = random.Random(41)
     base = _rand_seq(rnd, 220)
     seqs = [base] * 3300 + [_rand_seq(rnd, 220) for _ in range(20)]
@@ -277,7 +278,7 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
         ms.add_data(fa)
         got = ms.find_matches()
         st = ms.stats()
-    assert st["slot_compares"] > 0          # some queries took the fallback
+    assert st["index_splits"] > 0 and st["slot_compares"] == 0   # large hit sets were split, nothing went to the brute-force kernel
     assert np.array_equal(_sorted_records(got), _sorted_records(want["records"]))
     small = mhap_amd.synth_reads(400, 2500, seed=12, error_rate=0.05)
     p2 = MhapParams(num_hashes=96, ordered_sketch_size=300)
@@ -287,6 +288,31 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     assert a == b and len(a) > 100
     assert sa["table_elements"] > 0 and sa["slot_compares"] == 0 and sb["slot_compares"] > 0
     assert sa["candidates_compared"] == sb["candidates_compared"]
+
+
+def test_inverted_index_with_a_shared_repeat():
+    """5 200 reads that all carry the same 2 kb repeat at H = 512 (the repeat's k-mers win most MinHash slots, so thousands of
+    entries share the value of a slot): insertion stays O(1) per posting (overflow lists), large hit sets are split, records
+    equal the oracle's and the index build time stays bounded."""
+    rnd = random.Random(77)
+    rep = _rand_seq(rnd, 2000)
+    seqs = []
+    for i in range(5200):
+        s = list(rep)
+        for _ in range(60):                       # 3 % point differences per copy
+            s[rnd.randrange(2000)] = rnd.choice("ACGT")
+        seqs.append(_rand_seq(rnd, 300) + "".join(s) + _rand_seq(rnd, 300))
+    fa = FastaData.from_strings(seqs)
+    p = MhapParams(num_hashes=512, ordered_sketch_size=512, threshold=0.96)
+    want = O.run_self(fa, H=512, S=512, threshold=0.96, nthreads=16, cap=1 << 24)
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        got = ms.find_matches()
+        st, kt = ms.stats(), ms.kernel_times()
+    assert np.array_equal(_sorted_records(got), _sorted_records(want["records"]))
+    assert st["table_elements"] == want["elements"] and st["candidates_compared"] == want["compared"]
+    assert st["index_splits"] > 0
+    assert kt["index_build"]["ms"] < 200.0, kt["index_build"]      # 5.3 M postings; quadratic runs took seconds
 
 
 def test_minhash_large_num_hashes_and_short_strands():
