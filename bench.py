@@ -9,8 +9,8 @@ resident in HBM before the timed region starts (mhap_stage_reads); record text f
   python bench.py --gpus 1 --steps K --warmup W [--config c1|c2|c4slice|c5slice|c3]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1 (strong scaling, same data set): rank r sketches reads r, r+N, ...; the per-rank sketch tables are
-all-gathered with RCCL over xGMI; every rank searches its own reads against the full index.
+N > 1 (strong scaling, same data set): rank r sketches reads r, r+N, ... and indexes them — only them; the forward
+query sketches of the ranks travel round a ring (RCCL point-to-point over xGMI) and visit every rank's index.
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries
   parity_check : the GPU path and the CPU oracle run on the SAME sample reads, sorted-record SHA-256 compared;
   cpu_baseline : the oracle timed on this box's host cores on that sample (threads = the cgroup CPU quota);
@@ -156,9 +156,7 @@ def main():
         loc_mh = torch.zeros((2 * n_pad, H), dtype=torch.int32, device=dev)
         loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
         loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
-        gids, gfwd = mdist.rank_major_entry_ids(n_total, world)
-        q_first, q_count = mdist.rank_major_query_range(n_total, world, rank)
-    async_gather = dist is not None and backend == "nccl" and os.environ.get("MHAP_BENCH_ASYNC_GATHER", "1") != "0"
+        lids, lfwd = mdist.local_entry_ids(n_total, world, rank)
     phase = {"sketch": 0.0, "exchange": 0.0, "search": 0.0}
 
     def step(timed_phases=False):
@@ -173,36 +171,36 @@ def main():
             recs = ms.find_matches()
             if timed_phases:
                 phase["search"] += time.perf_counter() - t0
-        else:
-            ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+            return recs
+        # N > 1: this rank's reads are sketched into its own tables, indexed here and nowhere else (1/N of the inverted-index
+        # build); the forward query sketches of all ranks then visit every rank's index round a ring (mhap_amd/distributed.py)
+        ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+        ms.set_device_index(lids, lfwd, loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+        ms.prepare_index()
+        if timed_phases:
+            ms.synchronize()
+            phase["sketch"] += time.perf_counter() - t0
+        cur = (mdist.forward_rows(loc_mh), mdist.forward_rows(loc_od), mdist.forward_rows(loc_mt))
+        torch.cuda.current_stream().synchronize()
+        parts = []
+        for t in range(world):
+            pending = None
+            if t + 1 < world:      # pass the bundle on while it is searched here (it is only read)
+                pending = mdist.ring_post(cur, world, rank, dist)
+            t1 = time.perf_counter()
+            origin = (rank - t) % world
+            parts.append(ms.find_matches_device(cur[0].data_ptr(), cur[1].data_ptr(), cur[2].data_ptr(),
+                                                mdist.bundle_ids(n_total, world, origin), to_self=True))
             if timed_phases:
-                ms.synchronize()
-                phase["sketch"] += time.perf_counter() - t0
-                t0 = time.perf_counter()
-            g_mh = mdist.gather_rank_major(loc_mh, world, dist)      # RCCL all-gather, tables stay rank after rank
-            g_mt = mdist.gather_rank_major(loc_mt, world, dist)
-            if async_gather:
-                # the ordered-sketch table (85 % of the bytes) is only read by the second stage: its all-gather runs while this
-                # rank builds the inverted index from the MinHash table
-                torch.cuda.current_stream().synchronize()
-                g_od = torch.empty((world * loc_od.shape[0],) + tuple(loc_od.shape[1:]), dtype=loc_od.dtype, device=dev)
-                work = dist.all_gather_into_tensor(g_od.view(world, -1), loc_od.view(1, -1), async_op=True)
-                ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
-                ms.prepare_index()
-                work.wait()
-            else:
-                g_od = mdist.gather_rank_major(loc_od, world, dist)
-            torch.cuda.synchronize()
-            if not async_gather:
-                ms.set_device_index(gids, gfwd, g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr())
-            if timed_phases:
-                phase["exchange"] += time.perf_counter() - t0
-                t0 = time.perf_counter()
-            recs = ms.find_matches(q_first, q_count)                  # this rank's own reads against the whole index
-            if timed_phases:
-                phase["search"] += time.perf_counter() - t0
-            step.keep = (g_mh, g_od, g_mt)
-        return recs
+                phase["search"] += time.perf_counter() - t1
+            if pending is not None:
+                t1 = time.perf_counter()
+                nxt = mdist.ring_wait(*pending)
+                if timed_phases:
+                    phase["exchange"] += time.perf_counter() - t1      # what the transfer was NOT hidden behind the search
+                step.keep = cur
+                cur = nxt
+        return np.concatenate(parts) if len(parts) > 1 else parts[0]
 
     def fence():
         ms.synchronize()
@@ -311,7 +309,7 @@ def main():
             "config": {"workload": f"{cfg_label}, k={k}, --num-hashes {H}, ordered sketch k2={k2} S={S}, self-overlap"
                                    + (", -f k-mer filter, --filter-threshold 1e-5" if cfg.get("filter") else ""),
                        "name": args.config, "error_rate": args.error_rate,
-                       "parallelism": f"reads round-robin over {world} GPU(s); RCCL all-gather of sketch tables" if world > 1 else "1 GPU"},
+                       "parallelism": f"reads round-robin over {world} GPU(s); per-rank index of own reads, forward query sketches rotate round a ring (RCCL send/recv)" if world > 1 else "1 GPU"},
             "records_per_step": total_records,
             "sketches_per_sec": round(strands / float(pht[0].item()), 1) if float(pht[0].item()) > 0 else None,
             "sketches_per_sec_note": "2N strands / wall time of the sketch phase (packed reads in HBM -> MinHash + ordered tables in HBM, host "

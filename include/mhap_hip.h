@@ -188,6 +188,14 @@ int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* of
 int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t* seq_length, const int32_t* minhash,
                                const int32_t* ordered, const int32_t* ordered_size, const int32_t* ordered_seqlen, int64_t m,
                                mhap_record_sink sink, void* user);
+/* Query sketches that already sit in device memory (the layout mhap_sketch_staged_device / mhap_sketch_reads_device write:
+ * minhash int32[m][--num-hashes], ordered int32[m][--ordered-sketch-size][2], meta int32[m][4]) against the index — the
+ * multi-GPU exchange step: every rank keeps the index of its OWN reads and the forward query sketches of the other ranks
+ * visit it one after the other.  ids: host array, one id per query row; rows whose meta status is not 0 are
+ * skipped.  to_self != 0 applies findMatches(hashes, toSelf = true)'s id rules (J/impl/MinHashSearch.java:200-225), so every
+ * unordered pair of one data set is reported once however its two reads are spread over ranks. */
+int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                             int64_t m, int to_self, mhap_record_sink sink, void* user);
 
 int mhap_get_stats(mhap_handle* h, mhap_stats* out);
 int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out);

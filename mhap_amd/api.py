@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_find_matches_sketches",
-    "mhap_synth_reads_repeats",
+    "mhap_synth_reads_repeats", "mhap_find_matches_device",
 ]
 
 
@@ -434,6 +434,13 @@ class MinHashSearch:
         od = a["ordered"].astype(np.int32); osz = a["ordered_size"].astype(np.int32); osl = a["ordered_seqlen"].astype(np.int32)
         return self._collect(lambda cb: self._lib.mhap_find_matches_sketches(self._h, _ptr(ids), _ptr(sl), _ptr(mh), _ptr(od), _ptr(osz),
                                                                             _ptr(osl), C.c_int64(len(ids)), cb, None))
+
+    def find_matches_device(self, d_q_minhash_ptr, d_q_ordered_ptr, d_q_meta_ptr, ids, to_self=True):
+        """Device-resident query sketches (forward rows of another rank's tables) against this handle's index."""
+        ids = np.ascontiguousarray(ids, dtype=np.int64)
+        return self._collect(lambda cb: self._lib.mhap_find_matches_device(self._h, C.c_void_p(d_q_minhash_ptr), C.c_void_p(d_q_ordered_ptr),
+                                                                          C.c_void_p(d_q_meta_ptr), _ptr(ids), C.c_int64(len(ids)),
+                                                                          C.c_int(1 if to_self else 0), cb, None))
 
     # -- counters -------------------------------------------------------------------------------
     def stats(self):

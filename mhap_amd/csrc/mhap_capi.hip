@@ -1107,6 +1107,28 @@ int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t
   return search_core(h, qs, ql, false, false, sink, user);
 }
 
+int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                             int64_t m, int to_self, mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  if (m <= 0) return MHAP_OK;
+  if (!d_q_minhash || !d_q_ordered || !d_q_meta || !ids) return fail(h, MHAP_E_INVALID, "null argument");
+  if (m > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "too many query rows");
+  (void)hipSetDevice(h->device);
+  const int S = h->P.ordered_sketch_size;
+  std::vector<int32_t> meta((size_t)m * META_W);
+  HIPCHK(h, hipMemcpy(meta.data(), d_q_meta, meta.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<int32_t> qlen((size_t)m), ql;
+  for (int64_t e = 0; e < m; e++) {
+    qlen[(size_t)e] = meta[(size_t)e * META_W + 2];
+    if (meta[(size_t)e * META_W + 3] == 0) ql.push_back((int32_t)e);
+  }
+  HIPCHK(h, h->q_ids.ensure((size_t)m * 8));
+  HIPCHK(h, hipMemcpy(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
+  QuerySide qs{(const int32_t*)d_q_minhash, h->Hrow, (const int32_t*)d_q_ordered, 2LL * S, (const int32_t*)d_q_meta, h->q_ids.as<int64_t>(), ids,
+               qlen.data()};
+  return search_core(h, qs, ql, to_self != 0, false, sink, user);
+}
+
 int mhap_get_stats(mhap_handle* h, mhap_stats* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->stats; return MHAP_OK; }
 int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->ktimes; return MHAP_OK; }
 int mhap_reset_kernel_times(mhap_handle* h) { if (!h) return MHAP_E_INVALID; h->ktimes = mhap_kernel_times{}; return MHAP_OK; }

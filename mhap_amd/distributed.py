@@ -13,6 +13,54 @@ import numpy as np
 import torch
 
 
+# ---- query rotation (the N > 1 exchange step) ------------------------------------------------------------------------
+# Every rank builds the inverted index of its OWN reads only (1/N of the inserts) and keeps its MinHash / ordered tables
+# resident; the forward-strand query sketches of the ranks travel round a ring (rank r sends to r+1, receives from r-1), and
+# each rank runs candidates + second stage for the visiting queries against its shard.  A pair's hit count only involves the
+# postings of its stored entry, which all live on that entry's rank, so counts are complete locally; toSelf's id rule
+# (J/impl/MinHashSearch.java:215-219) reports every unordered pair exactly once.  Per rank: 1/N of the index build, N probe
+# passes over small tables, 2 query bundles + its own shard in memory (C5: ~70 GB of the 288), (N-1)/N of the forward
+# tables received point-to-point over xGMI while the previous bundle is being searched.
+
+def forward_rows(table):
+    """[2*n_pad, ...] per-rank table (entry 2j = forward strand of local read j) -> contiguous [n_pad, ...] forward rows."""
+    return table.view((table.shape[0] // 2, 2) + tuple(table.shape[1:]))[:, 0].contiguous()
+
+
+def bundle_ids(n_total, world, origin):
+    """ids of the forward query rows of rank `origin`'s bundle (local read slot j is global read j*world + origin, 1-based ids)."""
+    n_pad = shard_size(n_total, world)
+    return np.arange(n_pad, dtype=np.int64) * world + origin + 1
+
+
+def local_entry_ids(n_total, world, rank):
+    """(ids, is_fwd) of rank `rank`'s own index entries (both strands of its reads)."""
+    ids = np.repeat(bundle_ids(n_total, world, rank), 2)
+    fwd = np.tile(np.array([1, 0], dtype=np.uint8), shard_size(n_total, world))
+    return ids, fwd
+
+
+def ring_post(bundle, world, rank, dist):
+    """Start passing `bundle` (a tuple of tensors) to rank+1 and receiving the next one from rank-1.
+    Returns (requests, received tensors); call ring_wait before touching the received tensors."""
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    if bundle[0].is_cuda and dist.get_backend() == "nccl":       # RCCL point-to-point over xGMI
+        recv = tuple(torch.empty_like(t) for t in bundle)
+        ops = [dist.P2POp(dist.isend, t, nxt) for t in bundle] + [dist.P2POp(dist.irecv, t, prv) for t in recv]
+        return dist.batch_isend_irecv(ops), recv, None
+    send_cpu = tuple(t.cpu().contiguous() for t in bundle)       # gloo (CPU tests; functional multi-rank runs on one GPU)
+    recv_cpu = tuple(torch.empty_like(t) for t in send_cpu)
+    reqs = [dist.isend(t, nxt) for t in send_cpu] + [dist.irecv(t, prv) for t in recv_cpu]
+    return reqs, recv_cpu, bundle[0].device
+
+
+def ring_wait(reqs, recv, device):
+    for r in reqs:
+        r.wait()
+    return recv if device is None else tuple(t.to(device) for t in recv)
+
+
+
 def shard_size(n_total, world):
     """Equal shard size (reads per rank) — shards are padded with zero-length reads, which sketch to status 2."""
     return (n_total + world - 1) // world

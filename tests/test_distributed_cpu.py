@@ -81,3 +81,52 @@ def test_two_rank_gather_equals_single_process(tmp_path):
     firsts = [md.rank_major_query_range(N_TOTAL, WORLD, r) for r in range(WORLD)]
     assert firsts == [(r * 2 * n_pad, 2 * n_pad) for r in range(WORLD)]
     assert sorted(set(int(i) for i in ids_rm if i <= N_TOTAL)) == list(range(1, N_TOTAL + 1))
+
+
+# ---- query rotation (what bench.py's N > 1 step does): ring helpers over gloo, 3 ranks --------------------------------------
+RING_WORLD = 3
+
+
+def _ring_worker(rank, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=RING_WORLD)
+    import mhap_amd
+    from mhap_amd import distributed as md
+    shard = md.pad_shard(mhap_amd.synth_reads(N_TOTAL, LEN, seed=9, shard=rank, nshards=RING_WORLD), N_TOTAL, RING_WORLD)
+    local = torch.from_numpy(_oracle_rows(shard))                    # [2*n_pad, H], fwd/rc interleaved
+    cur = (md.forward_rows(local), torch.full((md.shard_size(N_TOTAL, RING_WORLD), 4), rank, dtype=torch.int32))
+    seen = []
+    for t in range(RING_WORLD):
+        pending = md.ring_post(cur, RING_WORLD, rank, dist) if t + 1 < RING_WORLD else None
+        origin = (rank - t) % RING_WORLD
+        assert int(cur[1][0, 0]) == origin                             # the bundle visiting at step t comes from rank - t
+        seen.append((origin, cur[0].clone(), md.bundle_ids(N_TOTAL, RING_WORLD, origin)))
+        if pending is not None:
+            cur = md.ring_wait(*pending)
+    ids, fwd = md.local_entry_ids(N_TOTAL, RING_WORLD, rank)
+    torch.save({"seen": seen, "ids": ids, "fwd": fwd}, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_bundles_visit_every_rank(tmp_path):
+    import mhap_amd
+    from mhap_amd import distributed as md
+    out = str(tmp_path / "ring")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_ring_worker, args=(port, out), nprocs=RING_WORLD, join=True)
+    full = mhap_amd.synth_reads(N_TOTAL, LEN, seed=9)
+    want = _oracle_rows(full)
+    all_ids = []
+    for rank in range(RING_WORLD):
+        got = torch.load(out + str(rank), weights_only=False)
+        assert sorted(o for o, _, _ in got["seen"]) == list(range(RING_WORLD))      # every rank's queries came by exactly once
+        for origin, rows, qids in got["seen"]:
+            for j, qid in enumerate(qids):
+                if qid <= N_TOTAL:
+                    assert np.array_equal(rows[j].numpy(), want[2 * (int(qid) - 1)]), (rank, origin, j)   # forward row of read qid
+                else:
+                    assert not rows[j].any()
+        assert got["fwd"].tolist() == [1, 0] * md.shard_size(N_TOTAL, RING_WORLD)
+        all_ids += [int(i) for i in got["ids"][::2] if i <= N_TOTAL]
+    assert sorted(all_ids) == list(range(1, N_TOTAL + 1))                            # the per-rank indexes partition the reads
