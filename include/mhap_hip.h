@@ -30,6 +30,7 @@ extern "C" {
 #define MHAP_E_HIP (-2)         /* HIP runtime error, no device, kernel failure */
 #define MHAP_E_NOMEM (-3)
 #define MHAP_E_STATE (-4)       /* call sequence error (e.g. search before index) */
+#define MHAP_E_IO (-5)          /* a file could not be opened / read */
 
 /* Per-strand sketch status (mirrors the streamer's skip rules). */
 #define MHAP_STRAND_OK 0
@@ -109,6 +110,17 @@ void mhap_default_params(mhap_params* p);
  * Only --supress-noise 0 is supported.  n == 0 clears the filter. */
 int mhap_set_filter(mhap_handle* h, const int64_t* hashes, const double* fractions, int64_t n,
                     double filter_cutoff, double offset, double range, int no_tf);
+/* --supress-noise 1|2 (FrequencyCounts removeUnique, J/sketch/FrequencyCounts.java:66-68,137,192,272-278,297): the Bloom filter
+ * over EVERY k-mer of the filter file (hashes: all n lines, not only the ones above the cutoff), built exactly like Guava 19.0's
+ * BloomFilter.create(funnel(putLong), size_bloom, 1e-5) (strategy MURMUR128_MITZ_64).  mode 1: k-mers that are not in the
+ * file are dropped from the MinHash sketch; mode 2: they get idf 1; mode 0 removes the whitelist.  Call after mhap_set_filter. */
+int mhap_set_filter_whitelist(mhap_handle* h, const int64_t* hashes, int64_t n, int64_t size_bloom, int32_t mode);
+/* new FrequencyCounts(reader, filterCutoff, offset, removeUnique, noTf, numThreads, range, doReverseCompliment)
+ * (J/sketch/FrequencyCounts.java:63-229, called from J/main/MhapMain.java:337-361): reads the -f file (first line
+ * "sizeBloom sizeRepeat", then `kmer fraction ...` lines), hashes the k-mers (canonical when do_rc) and installs the table
+ * (+ the whitelist when remove_unique > 0).  kmer_sizes (may be NULL) receives the distinct k-mer lengths, e.g. "16". */
+int mhap_set_filter_file(mhap_handle* h, const char* path, double filter_cutoff, double offset, int32_t remove_unique, int32_t no_tf,
+                         double range, int32_t do_rc, char* kmer_sizes, size_t kmer_sizes_cap);
 
 /* Sketch `n` reads (both strands) and append them to the index.  Replaces
  * SequenceSketchStreamer.enqueue/getSketch (J/impl/SequenceSketchStreamer.java:123-177,262-266)
@@ -243,6 +255,8 @@ int mhap_hash_kmer(const char* kmer, int32_t len, int32_t do_rc, int64_t* out);
 /* ---- test hooks: the kernels' __host__ __device__ arithmetic executed on the host (never used by the
  * product path; lets a GPU-less container check the hash and second-stage lane logic) --------------------- */
 int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t k2, int64_t* out64, int32_t* out32);
+int mhap_selftest_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, const int64_t* probes, int64_t np, uint8_t* out_flags,
+                        int64_t* out2);
 int mhap_selftest_transpose32(uint32_t* a32);
 int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out);
 /* out8 = {empty, valid(rawScore), a1, a2, b1, b2, inter, k} */

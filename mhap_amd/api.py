@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_find_matches_sketches",
-    "mhap_synth_reads_repeats", "mhap_find_matches_device",
+    "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom",
 ]
 
 
@@ -201,38 +201,43 @@ def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15, shar
 
 
 class FrequencyCounts:
-    """Parsed `-f` filter file (J/sketch/FrequencyCounts.java:63-229): k-mer hash -> fraction."""
+    """Parsed `-f` filter file (J/sketch/FrequencyCounts.java:63-229): k-mer hash -> fraction (+ the --supress-noise whitelist)."""
 
-    def __init__(self, hashes, fractions, filter_cutoff=1.0e-5, offset=0.0, repeat_idf_scale=3.0, no_tf=False):
+    def __init__(self, hashes, fractions, filter_cutoff=1.0e-5, offset=0.0, repeat_idf_scale=3.0, no_tf=False, supress_noise=0,
+                 whitelist=None, size_bloom=0):
         self.hashes = np.ascontiguousarray(hashes, dtype=np.int64)
         self.fractions = np.ascontiguousarray(fractions, dtype=np.float64)
         self.filter_cutoff = filter_cutoff
         self.offset = offset
         self.range = repeat_idf_scale
         self.no_tf = no_tf
+        self.supress_noise = supress_noise            # removeUnique: 1 drop k-mers absent from the file, 2 give them idf 1
+        self.whitelist = np.ascontiguousarray(whitelist if whitelist is not None else self.hashes, dtype=np.int64)
+        self.size_bloom = size_bloom or max(1, len(self.whitelist))   # first number of the file's first line
 
     @classmethod
     def from_file(cls, path, filter_cutoff=1.0e-5, repeat_weight=0.9, repeat_idf_scale=3.0, no_tf=False, do_rc=True,
                   supress_noise=0):
-        if supress_noise != 0:
-            raise MhapError("--supress-noise 1|2 (Guava BloomFilter whitelist) is not supported")
         lib = load_library()
         offset = repeat_weight if 0.0 <= repeat_weight < 1.0 else 0.0   # MhapMain.java:346-350
-        hs, fr = [], []
+        hs, fr, allh = [], [], []
         out = C.c_int64()
         with open(path, "r") as fh:
-            fh.readline()  # "sizeBloom sizeRepeat" (FrequencyCounts.java:102-104)
+            first = fh.readline().split()                  # "sizeBloom sizeRepeat" (FrequencyCounts.java:102-104)
+            size_bloom = int(first[0]) if first else 1
             for line in fh:
                 parts = line.split(None, 2)
-                if len(parts) < 2:
+                if len(parts) < 1:
                     continue
                 kmer = parts[0].encode("latin-1")
                 if lib.mhap_hash_kmer(kmer, C.c_int32(len(kmer)), C.c_int32(1 if do_rc else 0), C.byref(out)) != 0:
                     raise MhapError("cannot hash filter k-mer " + parts[0])
-                hs.append(out.value)
-                fr.append(float(parts[1]))
+                allh.append(out.value)
+                if len(parts) >= 2:
+                    hs.append(out.value)
+                    fr.append(float(parts[1]))
         return cls(np.array(hs, dtype=np.int64), np.array(fr, dtype=np.float64), filter_cutoff, offset,
-                   repeat_idf_scale, no_tf)
+                   repeat_idf_scale, no_tf, supress_noise, np.array(allh, dtype=np.int64), size_bloom)
 
 
 class MatchResult:
@@ -321,6 +326,9 @@ class MinHashSearch:
         self._chk(self._lib.mhap_set_filter(self._h, _ptr(fc.hashes), _ptr(fc.fractions), C.c_int64(len(fc.hashes)),
                                             C.c_double(fc.filter_cutoff), C.c_double(fc.offset), C.c_double(fc.range),
                                             C.c_int(1 if fc.no_tf else 0)))
+        if getattr(fc, "supress_noise", 0):
+            self._chk(self._lib.mhap_set_filter_whitelist(self._h, _ptr(fc.whitelist), C.c_int64(len(fc.whitelist)),
+                                                          C.c_int64(fc.size_bloom), C.c_int32(fc.supress_noise)))
 
     def set_stream(self, hip_stream_ptr):
         self._chk(self._lib.mhap_set_stream(self._h, C.c_void_p(hip_stream_ptr)))

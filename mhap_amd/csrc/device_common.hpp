@@ -129,6 +129,29 @@ __host__ __device__ inline uint32_t murmur32_chars(const uint32_t* W, int p, int
   return fmix32(h1);
 }
 
+// murmur3_x64_128(seed 0) of the 8 little-endian bytes of a long — what Guava's BloomFilter<Long> with the funnel
+// `sink.putLong(value)` hashes (J/sketch/FrequencyCounts.java:137; BloomFilterStrategies.MURMUR128_MITZ_64): an 8-byte tail, no block.
+__host__ __device__ inline void murmur128_long(uint64_t v, uint64_t& h1, uint64_t& h2) {
+  uint64_t k1 = v * 0x87c37b91114253d5ULL; k1 = rotl64(k1, 31); k1 *= 0x4cf5ad432745937fULL;
+  h1 = k1; h2 = 0;
+  h1 ^= 8ULL; h2 ^= 8ULL;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2; h2 += h1;
+}
+// Guava 19.0 BloomFilter.mightContain for that strategy: bit i = ((h1 + i h2) & Long.MAX_VALUE) % bitSize, i = 0..k-1
+__host__ __device__ inline bool bloom_might_contain(const unsigned long long* words, uint64_t bit_size, int k, uint64_t v) {
+  uint64_t h1, h2;
+  murmur128_long(v, h1, h2);
+  uint64_t c = h1;
+  for (int i = 0; i < k; i++) {
+    const uint64_t bit = (c & 0x7fffffffffffffffULL) % bit_size;
+    if (!((words[bit >> 6] >> (bit & 63)) & 1ULL)) return false;
+    c += h2;
+  }
+  return true;
+}
+
 // The --num-hashes hash family: one xorshift64 step (J/sketch/MinHashSketch.java:140-142).
 __host__ __device__ inline uint64_t xorshift_step(uint64_t x) {
   x ^= x << 21; x ^= x >> 35; x ^= x << 4;

@@ -310,4 +310,46 @@ int mhap_synth_reads_repeats(uint64_t seed, int64_t n, int32_t len, double cover
   return MHAP_OK;
 }
 
+// new FrequencyCounts(reader, filterCutoff, offset, removeUnique, noTf, numThreads, range, doRC) (J/sketch/FrequencyCounts.java:63-229)
+int mhap_set_filter_file(mhap_handle* h, const char* path, double filter_cutoff, double offset, int32_t remove_unique, int32_t no_tf,
+                         double range, int32_t do_rc, char* kmer_sizes, size_t kmer_sizes_cap) {
+  if (!h || !path) return MHAP_E_INVALID;
+  if (kmer_sizes && kmer_sizes_cap) kmer_sizes[0] = 0;
+  FILE* f = fopen(path, "r");
+  if (!f) return MHAP_E_IO;
+  std::vector<int64_t> hs; std::vector<double> fr;
+  std::vector<int64_t> all;                       // every line's k-mer goes into the whitelist (:192), with or without a fraction
+  char* line = nullptr; size_t cap = 0; ssize_t len; bool first = true;
+  long long size_bloom = 1;
+  std::vector<int> sizes;
+  int rc = MHAP_OK;
+  while ((len = getline(&line, &cap, f)) > 0) {
+    if (first) {   // "sizeBloom sizeRepeat" (:102-121): the first number sizes the Bloom filter
+      first = false;
+      long long a = 0, b = 0;
+      if (sscanf(line, "%lld %lld", &a, &b) < 2 || a < 0 || b < 0) { rc = MHAP_E_INVALID; break; }   // :139-142
+      size_bloom = a == 0 ? 1 : a;
+      continue;
+    }
+    char kmer[4096]; double frac = 0.0;
+    const int got = sscanf(line, "%4095s %lf", kmer, &frac);
+    if (got < 1) continue;
+    int64_t hv; const int kl = (int)strlen(kmer);
+    if (mhap_hash_kmer(kmer, kl, do_rc, &hv) != MHAP_OK) continue;
+    if (std::find(sizes.begin(), sizes.end(), kl) == sizes.end()) sizes.push_back(kl);
+    if (remove_unique > 0) all.push_back(hv);
+    if (got >= 2) { hs.push_back(hv); fr.push_back(frac); }
+  }
+  free(line); fclose(f);
+  if (rc != MHAP_OK) return rc;
+  rc = mhap_set_filter(h, hs.data(), fr.data(), (int64_t)hs.size(), filter_cutoff, offset, range, no_tf);
+  if (rc == MHAP_OK && remove_unique > 0) rc = mhap_set_filter_whitelist(h, all.data(), (int64_t)all.size(), size_bloom, remove_unique);
+  if (kmer_sizes && kmer_sizes_cap) {
+    std::sort(sizes.begin(), sizes.end());
+    std::string ks; for (int v : sizes) ks += (ks.empty() ? "" : ", ") + std::to_string(v);
+    snprintf(kmer_sizes, kmer_sizes_cap, "%s", ks.c_str());
+  }
+  return rc;
+}
+
 }  // extern "C"

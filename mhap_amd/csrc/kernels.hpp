@@ -33,6 +33,8 @@ struct FilterTable {
   int32_t enabled;
   int32_t no_tf;
   double range;
+  // --supress-noise (FrequencyCounts removeUnique 1|2): Bloom filter over every k-mer of the filter file
+  const unsigned long long* bloom; uint64_t bloom_bits; int32_t bloom_k; int32_t bloom_mode;
 };
 
 // Per-entry metadata row: {ordered_size, ordered_seqlen (L-k2+1), seq_length (bases), status}

@@ -64,6 +64,11 @@ void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int
   for (auto& t : th) t.join();
 }
 
+// Guava 19.0 BloomFilter.create(funnel(putLong), expectedInsertions, fpp = 1e-5) + put of every value (strategy MURMUR128_MITZ_64):
+// optimalNumOfBits / optimalNumOfHashFunctions, BitArray of ceil(bits / 64) longs (J/sketch/FrequencyCounts.java:137,192; a zero
+// size is bumped to 1, :117-121)
+void build_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, std::vector<unsigned long long>& out, uint64_t& bit_size, int& k);
+
 int host_threads() {
   const char* e = getenv("MHAP_HOST_THREADS");
   if (e && atoi(e) > 0) return atoi(e);
@@ -71,6 +76,33 @@ int host_threads() {
   return (int)std::max(1u, std::min(hc, 32u));
 }
 
+}  // namespace
+
+namespace {
+void build_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, std::vector<unsigned long long>& out, uint64_t& bit_size, int& k) {
+  const double nn = (double)(size_bloom <= 0 ? 1 : size_bloom), p = 1.0e-5;
+  const int64_t m = (int64_t)(-nn * std::log(p) / (std::log(2.0) * std::log(2.0)));
+  k = std::max(1, (int)java_round((double)m / nn * std::log(2.0)));
+  const size_t nwords = (size_t)((m + 63) / 64);
+  bit_size = (uint64_t)nwords * 64;
+  std::vector<std::atomic<unsigned long long>> words(nwords);
+  for (auto& w : words) w.store(0ULL, std::memory_order_relaxed);
+  const uint64_t bs = bit_size; const int kk = k;
+  parallel_for(n, host_threads(), [&](int64_t lo, int64_t hi) {
+    for (int64_t i = lo; i < hi; i++) {
+      uint64_t h1, h2;
+      murmur128_long((uint64_t)hashes[i], h1, h2);
+      uint64_t c = h1;
+      for (int t = 0; t < kk; t++) {
+        const uint64_t bit = (c & 0x7fffffffffffffffULL) % bs;
+        words[(size_t)(bit >> 6)].fetch_or(1ULL << (bit & 63), std::memory_order_relaxed);
+        c += h2;
+      }
+    }
+  }, 4096);
+  out.resize(nwords);
+  for (size_t i = 0; i < nwords; i++) out[i] = words[i].load(std::memory_order_relaxed);
+}
 }  // namespace
 
 struct mhap_handle {
@@ -89,7 +121,7 @@ struct mhap_handle {
   int ord_cap = 0;   // ordered-kernel sort capacity
 
   // filter
-  DevBuf f_keys, f_vals;
+  DevBuf f_keys, f_vals, f_bloom;
   FilterTable ft{};
   DevBuf score_tbl, jump_tbl, hash_luts;
 
@@ -744,7 +776,7 @@ void mhap_destroy(mhap_handle* h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
-  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
+  DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_ovf};
   for (DevBuf* b : bufs) b->release();
@@ -792,6 +824,24 @@ int mhap_set_filter(mhap_handle* h, const int64_t* hashes, const double* fractio
   HIPCHK(h, hipMemcpy(h->f_vals.p, tv.data(), (size_t)ts * 8, hipMemcpyHostToDevice));
   h->ft.keys = h->f_keys.as<int64_t>(); h->ft.vals = h->f_vals.as<double>();
   h->ft.mask = ts - 1; h->ft.size = (uint32_t)kk.size(); h->ft.enabled = 1; h->ft.no_tf = no_tf ? 1 : 0; h->ft.range = range;
+  h->ft.bloom = nullptr; h->ft.bloom_bits = 0; h->ft.bloom_k = 0; h->ft.bloom_mode = 0;   // a new filter has no whitelist until one is set
+  return MHAP_OK;
+}
+
+int mhap_set_filter_whitelist(mhap_handle* h, const int64_t* hashes, int64_t n, int64_t size_bloom, int32_t mode) {
+  if (!h) return MHAP_E_INVALID;
+  if (mode < 0 || mode > 2) return fail(h, MHAP_E_INVALID, "Unknown removeUnique option.");   // FrequencyCounts.java:71-72
+  if (mode == 0) { h->ft.bloom = nullptr; h->ft.bloom_bits = 0; h->ft.bloom_k = 0; h->ft.bloom_mode = 0; return MHAP_OK; }
+  if (!h->ft.enabled) return fail(h, MHAP_E_STATE, "set the k-mer filter (mhap_set_filter) before its whitelist");
+  if (n < 0 || (n > 0 && !hashes) || size_bloom < 0) return fail(h, MHAP_E_INVALID, "bad whitelist arguments");
+  (void)hipSetDevice(h->device);
+  std::vector<unsigned long long> words;
+  uint64_t bit_size = 0; int k = 0;
+  build_bloom(hashes, n, size_bloom, words, bit_size, k);
+  const size_t nwords = words.size();
+  HIPCHK(h, h->f_bloom.ensure(nwords * 8));
+  HIPCHK(h, hipMemcpy(h->f_bloom.p, words.data(), nwords * 8, hipMemcpyHostToDevice));
+  h->ft.bloom = h->f_bloom.as<unsigned long long>(); h->ft.bloom_bits = bit_size; h->ft.bloom_k = k; h->ft.bloom_mode = mode;
   return MHAP_OK;
 }
 
@@ -1202,6 +1252,17 @@ int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out) {
   }
   for (int t = 0; t < r; t++) x = xorshift_step(x);
   *out = x;
+  return MHAP_OK;
+}
+
+// The --supress-noise whitelist built the way mhap_set_filter_whitelist builds it, probed with the kernels' own lookup:
+// out_flags[i] = mightContain(probes[i]); out2 = {bit size, number of hash functions}
+int mhap_selftest_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, const int64_t* probes, int64_t np, uint8_t* out_flags, int64_t* out2) {
+  if ((n > 0 && !hashes) || (np > 0 && (!probes || !out_flags)) || !out2) return MHAP_E_INVALID;
+  std::vector<unsigned long long> words; uint64_t bit_size = 0; int k = 0;
+  build_bloom(hashes, n, size_bloom, words, bit_size, k);
+  for (int64_t i = 0; i < np; i++) out_flags[i] = bloom_might_contain(words.data(), bit_size, k, (uint64_t)probes[i]) ? 1 : 0;
+  out2[0] = (int64_t)bit_size; out2[1] = k;
   return MHAP_OK;
 }
 

@@ -129,29 +129,15 @@ void sink_flush(Sink& s) { if (!s.buf.empty()) fwrite(s.buf.data(), 1, s.buf.siz
 
 // FrequencyCounts file -> (hash, fraction) arrays (J/sketch/FrequencyCounts.java:63-229)
 void load_filter(mhap_handle* h, const Options& o) {
-  const std::string path = o.s("-f");
-  if (o.i("--supress-noise") != 0) die("--supress-noise 1|2 (Guava BloomFilter whitelist) is not supported by mhap-hip");
-  FILE* f = fopen(path.c_str(), "r");
-  if (!f) die("Could not parse k-mer filter file.");
-  std::vector<int64_t> hs; std::vector<double> fr;
-  char* line = nullptr; size_t cap = 0; ssize_t len; bool first = true;
-  const int do_rc = o.b("--no-rc") ? 0 : 1;
-  std::map<int, int> sizes;
-  while ((len = getline(&line, &cap, f)) > 0) {
-    if (first) { first = false; continue; }   // "sizeBloom sizeRepeat" (:102-104)
-    char kmer[4096]; double frac;
-    int got = sscanf(line, "%4095s %lf", kmer, &frac);
-    if (got < 2) continue;
-    int64_t hv; int kl = (int)strlen(kmer);
-    if (mhap_hash_kmer(kmer, kl, do_rc, &hv) != MHAP_OK) continue;
-    sizes[kl]++; hs.push_back(hv); fr.push_back(frac);
-  }
-  free(line); fclose(f);
   const double rw = o.d("--repeat-weight");
   const double offset = (rw >= 0.0 && rw < 1.0) ? rw : 0.0;   // MhapMain.java:346-350
-  chk(h, mhap_set_filter(h, hs.data(), fr.data(), (int64_t)hs.size(), o.d("--filter-threshold"), offset, o.d("--repeat-idf-scale"), o.b("--no-tf") ? 1 : 0));
-  std::string ks; for (auto& kv : sizes) ks += (ks.empty() ? "" : ", ") + std::to_string(kv.first);
-  fprintf(stderr, "Read in k-mer filter for sizes: [%s]\n", ks.c_str());
+  char sizes[256];
+  const int rc = mhap_set_filter_file(h, o.s("-f").c_str(), o.d("--filter-threshold"), offset, o.i("--supress-noise"), o.b("--no-tf") ? 1 : 0,
+                                      o.d("--repeat-idf-scale"), o.b("--no-rc") ? 0 : 1, sizes, sizeof sizes);
+  if (rc == MHAP_E_IO) die("Could not parse k-mer filter file.");
+  if (rc == MHAP_E_INVALID && !*mhap_last_error(h)) die("K-mer filter file first line must contain estimated number of k-mers in the file (long).");
+  chk(h, rc);
+  fprintf(stderr, "Read in k-mer filter for sizes: [%s]\n", sizes);
 }
 
 // `.dat` reader (SequenceSketchStreamer.readFromBinary :278-320 + SequenceSketch.fromByteStream :61-96)
@@ -253,7 +239,7 @@ int main(int argc, char** argv) {
   o.add("--min-olap-length", "[int], The minimum length of the read that used for overlapping.", "116");
   o.add("--no-self", "Do not compute the overlaps between sequences inside a box.", "false", true);
   o.add("--store-full-id", "Store full IDs as seen in FASTA files, rather than storing just the sequence position in the file.", "false", true);
-  o.add("--supress-noise", "[int] 0) Does nothing. 1|2 (Bloom-filter whitelist) are not supported by mhap-hip.", "0");
+  o.add("--supress-noise", "[int] 0) Does nothing, 1) completely removes any k-mers not specified in the filter file, 2) supresses k-mers not specified in the filter file, similar to repeats.", "0");
   o.add("--no-tf", "Do not perform the tf weighing, in the tf-idf weighing.", "false", true);
   o.add("--no-rc", "Do not store or do comparison of the reverse compliment strings (in this MHAP version it only changes how -f k-mers are hashed).", "false", true);
   o.add("--settings", "Set all unset parameters for the default settings. 0) None, 1) Default, 2) Fast, 3) Sensitive.", "0");

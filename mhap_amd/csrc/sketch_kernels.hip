@@ -512,7 +512,7 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
   uint32_t* codes = (uint32_t*)(lut + HASH_LUT_WORDS);
   if (FUSED) for (int i = threadIdx.x; i < HASH_LUT_WORDS; i += WEIGHT_THREADS) lut[i] = luts[i];
   uint32_t* slab = slabs + (size_t)blockIdx.x * (size_t)slab_entries;
-  const bool reweigh = (repeat_weight < 0.0) || (ft.enabled && repeat_weight < 1.0);
+  const bool reweigh = (repeat_weight < 0.0) || (ft.enabled && repeat_weight < 1.0) || (ft.enabled && ft.bloom_mode == 1);
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -574,15 +574,19 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
         const int64_t key = fz.on ? (int64_t)lut_key16(lut, codes_at(codes, i)) : kp[i];
         int weight;
         double v;
-        if (repeat_weight < 0.0) {
+        const bool listed = ft.bloom_mode == 0 || bloom_might_contain(ft.bloom, ft.bloom_bits, ft.bloom_k, (uint64_t)key);
+        if (ft.bloom_mode == 1 && !listed) {
+          weight = 0;                                                          // keepKmer false: the k-mer never enters the map (MinHashSketch.java:72-73)
+        } else if (repeat_weight < 0.0) {
           weight = (ft.size > 0 && filter_lookup(ft, key, v)) ? 0 : 1;
-        } else {
+        } else if (ft.enabled && repeat_weight < 1.0) {
           double idf = ft.range;
-          if (ft.size > 0 && filter_lookup(ft, key, v)) idf = v;
+          if (ft.bloom_mode == 2 && !listed) idf = 1.0;                        // FrequencyCounts.java:297-298
+          else if (ft.size > 0 && filter_lookup(ft, key, v)) idf = v;
           const double tf = ft.no_tf ? 1.0 : (double)count;
           weight = (int)java_round(tf * idf);
           if (weight < 1) weight = 1;
-        }
+        } else weight = count;                                                 // tf only (repeat weight >= 1) behind a whitelist
         wp[i] = (uint32_t)weight;
         mymin = (uint32_t)weight < mymin ? (uint32_t)weight : mymin;
         mymax = (uint32_t)weight > mymax ? (uint32_t)weight : mymax;

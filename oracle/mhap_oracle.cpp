@@ -192,11 +192,42 @@ inline int64_t java_round(double x) {
 // J/sketch/FrequencyCounts.java:63-319 (removeUnique==0 only; the Guava BloomFilter
 // whitelist used by --supress-noise 1|2 is not restated).
 // ---------------------------------------------------------------------------
+// Guava 19.0 BloomFilter<Long> as FrequencyCounts builds it (J/sketch/FrequencyCounts.java:137):
+//   BloomFilter.create((value, sink) -> sink.putLong(value), sizeBloom, 1.0e-5)  — strategy MURMUR128_MITZ_64:
+//   numBits = (long)(-n ln p / (ln 2)^2), k = max(1, round(numBits / n * ln 2)), bit array of ceil(numBits / 64) longs,
+//   (h1, h2) = murmur3_x64_128(seed 0) of the 8 little-endian bytes of the value; bit i = ((h1 + i h2) & Long.MAX_VALUE) % bitSize.
+// (third-party algorithm, restated from its published source; the reference only calls create / put / mightContain)
+struct Bloom {
+  std::vector<uint64_t> words; uint64_t bitSize = 0; int k = 0;
+  void create(int64_t n, double p) {
+    if (n < 1) n = 1;
+    int64_t m = (int64_t)(-(double)n * std::log(p) / (std::log(2.0) * std::log(2.0)));
+    k = std::max(1, (int)java_round((double)m / (double)n * std::log(2.0)));
+    words.assign((size_t)((m + 63) / 64), 0ULL); bitSize = (uint64_t)words.size() * 64;
+  }
+  static void hash(int64_t v, uint64_t& h1, uint64_t& h2) {
+    uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)((uint64_t)v >> (8 * i));
+    uint64_t out[2]; murmur3_x64_128(b, 8, 0, out); h1 = out[0]; h2 = out[1];
+  }
+  void put(int64_t v) {
+    uint64_t h1, h2; hash(v, h1, h2); uint64_t c = h1;
+    for (int i = 0; i < k; i++) { const uint64_t bit = (c & 0x7fffffffffffffffULL) % bitSize; words[bit >> 6] |= 1ULL << (bit & 63); c += h2; }
+  }
+  bool mightContain(int64_t v) const {
+    uint64_t h1, h2; hash(v, h1, h2); uint64_t c = h1;
+    for (int i = 0; i < k; i++) { const uint64_t bit = (c & 0x7fffffffffffffffULL) % bitSize; if (!((words[bit >> 6] >> (bit & 63)) & 1ULL)) return false; c += h2; }
+    return true;
+  }
+};
+
 struct Filter {
   std::unordered_map<int64_t, double> frac;
   double filterCutoff = 0, offset = 0, range = 3.0, maxValue = 0, minValue = 0;
   double minIdf = 0, maxIdf = 0;
   bool noTf = false;
+  int removeUnique = 0;     // --supress-noise: 1 = k-mers absent from the file are dropped, 2 = they get idf 1 (:66-68)
+  Bloom validMers;
+  bool keepKmer(int64_t h) const { return removeUnique == 1 ? validMers.mightContain(h) : true; }   // :272-278
   double idf_of(double freq) const { return std::log(maxValue / freq - offset); }  // :250-254
   void finish() {
     minValue = filterCutoff;          // :224
@@ -205,6 +236,7 @@ struct Filter {
   }
   bool isPopular(int64_t h) const { return frac.count(h) != 0; }                    // :267-270
   double scaledIdf(int64_t h) const {                                               // :290-311
+    if (removeUnique == 2 && !validMers.mightContain(h)) return 1.0;                // :297-298
     auto it = frac.find(h);
     if (it == frac.end()) return range;
     double idf = idf_of(it->second);
@@ -232,6 +264,7 @@ bool minhash_sketch(const char* seq, int L, int k, int H, const Filter* filter, 
     size_t ts = 64; while (ts < keys.size() * 2) ts <<= 1;
     std::vector<int32_t> slot_of(ts, -1);
     for (int64_t key : keys) {
+      if (filter && !filter->keepKmer(key)) continue;                 // :72-73
       size_t s = (size_t)fmix64((uint64_t)key) & (ts - 1);
       for (;;) {
         const int32_t e = slot_of[s];
@@ -525,6 +558,20 @@ void* orc_filter_create(const int64_t* hashes, const double* fractions, int64_t 
   for (int64_t i = 0; i < n; i++) if (fractions[i] >= filterCutoff) { mx = std::max(mx, fractions[i]); f->frac[hashes[i]] = fractions[i]; }
   f->maxValue = mx; f->finish(); return f;
 }
+// FrequencyCounts with --supress-noise (removeUnique 1|2): every line's k-mer hash goes into the Bloom filter (:192), sized by
+// the file's first number (sizeBloom, :102-137)
+void* orc_filter_create2(const int64_t* hashes, const double* fractions, int64_t n, double filterCutoff, double offset,
+                         double range, int noTf, int removeUnique, int64_t sizeBloom) {
+  Filter* f = (Filter*)orc_filter_create(hashes, fractions, n, filterCutoff, offset, range, noTf);
+  f->removeUnique = removeUnique;
+  if (removeUnique > 0) {
+    f->validMers.create(sizeBloom == 0 ? 1 : sizeBloom, 1.0e-5);
+    for (int64_t i = 0; i < n; i++) f->validMers.put(hashes[i]);
+  }
+  return f;
+}
+void orc_bloom_params(int64_t n, double p, int64_t* bits, int32_t* k) { Bloom b; b.create(n, p); *bits = (int64_t)b.bitSize; *k = b.k; }
+int orc_filter_might_contain(void* f, int64_t h) { return ((Filter*)f)->validMers.mightContain(h) ? 1 : 0; }
 void orc_filter_destroy(void* f) { delete (Filter*)f; }
 double orc_filter_scaled_idf(void* f, int64_t h) { return ((Filter*)f)->scaledIdf(h); }
 

@@ -25,6 +25,7 @@ def lib():
         L.orc_java_round.restype = C.c_int64
         L.orc_jaccard_to_identity.restype = C.c_double
         L.orc_filter_create.restype = C.c_void_p
+        L.orc_filter_create2.restype = C.c_void_p
         L.orc_filter_scaled_idf.restype = C.c_double
         L.orc_run_self.restype = C.c_int64
         _LIB = L
@@ -67,11 +68,23 @@ def rc(seq):
 
 
 class Filter:
-    def __init__(self, hashes, fractions, cutoff, offset, rng, no_tf=False):
+    def __init__(self, hashes, fractions, cutoff, offset, rng, no_tf=False, remove_unique=0, whitelist=None, size_bloom=0):
         h = np.ascontiguousarray(hashes, dtype=np.int64)
         f = np.ascontiguousarray(fractions, dtype=np.float64)
-        self.h = C.c_void_p(lib().orc_filter_create(_p(h), _p(f), C.c_int64(len(h)), C.c_double(cutoff), C.c_double(offset),
-                                                    C.c_double(rng), 1 if no_tf else 0))
+        if remove_unique:
+            # --supress-noise: the Bloom filter holds every k-mer of the file; k-mers without a fraction carry one below the cutoff
+            wl = np.ascontiguousarray(whitelist if whitelist is not None else h, dtype=np.int64)
+            extra = np.setdiff1d(wl, h)
+            h2 = np.concatenate([h, extra]); f2 = np.concatenate([f, np.full(len(extra), -1.0)])
+            self.h = C.c_void_p(lib().orc_filter_create2(_p(h2), _p(f2), C.c_int64(len(h2)), C.c_double(cutoff), C.c_double(offset),
+                                                         C.c_double(rng), 1 if no_tf else 0, C.c_int(remove_unique),
+                                                         C.c_int64(size_bloom or max(1, len(wl)))))
+        else:
+            self.h = C.c_void_p(lib().orc_filter_create(_p(h), _p(f), C.c_int64(len(h)), C.c_double(cutoff), C.c_double(offset),
+                                                        C.c_double(rng), 1 if no_tf else 0))
+
+    def might_contain(self, key):
+        return bool(lib().orc_filter_might_contain(self.h, C.c_int64(key)))
 
     def scaled_idf(self, key):
         return lib().orc_filter_scaled_idf(self.h, C.c_int64(key))
@@ -81,6 +94,12 @@ class Filter:
             lib().orc_filter_destroy(self.h)
         except Exception:
             pass
+
+
+def bloom_params(n, p=1.0e-5):
+    bits, k = C.c_int64(), C.c_int32()
+    lib().orc_bloom_params(C.c_int64(n), C.c_double(p), C.byref(bits), C.byref(k))
+    return bits.value, k.value
 
 
 def minhash(seq, k, H, repeat_weight=0.9, flt=None):

@@ -161,6 +161,12 @@ def test_cli_filter_file_and_presets(tmp_path):
     want = O.record_lines(O.run_self(FastaData.from_file(str(fasta)), H=128, S=512, nthreads=8, flt=oflt)["records"])
     assert lines == want and len(lines) > 50
     assert "Read in k-mer filter for sizes: [16]" in err
+    for mode in ("1", "2"):                                          # --supress-noise: the file's k-mers as a Bloom-filter whitelist
+        sup, _ = _run(["-s", str(fasta), "-f", str(ffile), "--supress-noise", mode] + flags)
+        f2 = mhap_amd.FrequencyCounts.from_file(str(ffile), filter_cutoff=1e-5, repeat_weight=0.9, supress_noise=int(mode))
+        o2 = O.Filter(f2.hashes, f2.fractions, 1e-5, 0.9, 3.0, False, remove_unique=int(mode), whitelist=f2.whitelist, size_bloom=f2.size_bloom)
+        wants = O.record_lines(O.run_self(FastaData.from_file(str(fasta)), H=128, S=512, nthreads=8, flt=o2)["records"])
+        assert sup == wants, mode
     fast, _ = _run(["-s", str(fasta), "--settings", "2"])          # fast preset: H 256, thr 0.80, S 1000, k2 14
     wantf = O.record_lines(O.run_self(FastaData.from_file(str(fasta)), H=256, S=1000, k2=14, threshold=0.80, nthreads=8)["records"])
     assert fast == wantf

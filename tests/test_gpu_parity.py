@@ -156,6 +156,35 @@ def test_self_overlap_with_repeat_filter():
         assert lines == O.record_lines(want["records"]), (rw, no_tf)
 
 
+def test_supress_noise_whitelist():
+    """--supress-noise 1|2 (FrequencyCounts removeUnique): the Bloom-filter whitelist of the filter file's k-mers.  Mode 1 drops
+    every k-mer that is not in the file (a read without any listed k-mer has no sketch), mode 2 gives them idf 1."""
+    rnd = random.Random(15)
+    fa = mhap_amd.synth_reads(90, 2500, seed=44, error_rate=0.04)
+    seqs = [fa.sequence(i) for i in range(len(fa))] + [_rand_seq(rnd, 800)]      # the last read shares nothing with the whitelist
+    counts = {}
+    for s in seqs[:-1]:
+        for i in range(0, len(s) - 15, 3):                                         # a third of the k-mers is "in the file"
+            counts[s[i:i + 16]] = counts.get(s[i:i + 16], 0) + 1
+    total = sum(counts.values())
+    items = sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))
+    kmers = [k for k, _ in items]
+    fracs = np.array([c / total for _, c in items])
+    hashes = np.array([int(O.kmer_hashes64(k, 16, True)[0]) for k in kmers], dtype=np.int64)
+    fa2 = FastaData.from_strings(seqs)
+    for mode, rw in ((1, 0.9), (2, 0.9), (1, 1.0), (1, -1.0)):
+        offset = rw if 0.0 <= rw < 1.0 else 0.0
+        flt = mhap_amd.FrequencyCounts(hashes, fracs, 1e-4, offset, 3.0, False, supress_noise=mode, size_bloom=len(hashes))
+        oflt = O.Filter(hashes, fracs, 1e-4, offset, 3.0, False, remove_unique=mode, whitelist=hashes, size_bloom=len(hashes))
+        p = MhapParams(num_hashes=128, ordered_sketch_size=512, repeat_weight=rw)
+        _assert_sketch_parity(FastaData.from_strings(seqs[:4] + seqs[-1:]), p, flt, oflt)
+        want = O.run_self(fa2, H=128, S=512, nthreads=8, repeat_weight=rw, flt=oflt)
+        got, _ = _self_lines(fa2, p, flt)
+        assert got == O.record_lines(want["records"]) and len(got) > 20, (mode, rw)
+        if mode == 1:
+            assert want["status"][2 * (len(seqs) - 1)] == 1      # ZeroNGramsFoundException: nothing of that read is whitelisted
+
+
 def test_index_vs_stream_mode():
     """-s index -q queries (toSelf=false): brute-force expectation built from oracle primitives."""
     base = mhap_amd.synth_reads(60, 2500, seed=91, error_rate=0.05)
