@@ -323,3 +323,41 @@ def test_fasta_reader_line_conventions(tmp_path):
     bad.write_bytes(b"ACGT\n>r\nACGT\n")
     with pytest.raises(mhap_amd.MhapError):
         mhap_amd.FastaData.from_file(str(bad))
+
+
+def test_jni_shim_and_java_class_agree():
+    """jni/HipMinHashSearch.java (extends AbstractMatchSearch) and jni/mhap_jni.c are shipped uncompiled (no JDK here): every
+    native method must have its Java_... function with the same number of arguments, every mhap_* function the shim calls must be
+    declared in include/mhap_hip.h and exported by the library, the Java class must override the reference's driver methods, and
+    the C file must at least compile (syntax + types against the real mhap_hip.h and a stand-in jni.h)."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    java = open(os.path.join(root, "jni", "HipMinHashSearch.java")).read()
+    csrc = open(os.path.join(root, "jni", "mhap_jni.c")).read()
+    header = open(os.path.join(root, "include", "mhap_hip.h")).read()
+    natives = {m.group(2): len([a for a in m.group(3).split(",") if a.strip()])
+               for m in re.finditer(r"private static native\s+([\w\[\]]+)\s+(\w+)\(([^)]*)\)\s*;", java, flags=re.S)}
+    assert len(natives) >= 8
+    cfuncs = {m.group(1): len([a for a in m.group(2).split(",") if a.strip()]) - 2      # minus JNIEnv*, jclass
+              for m in re.finditer(r"Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_(\w+)\(\s*([^)]*)\)\s*\{", csrc, flags=re.S)}
+    assert natives == cfuncs, (natives, cfuncs)
+    called = set(re.findall(r"\b(mhap_[a-z_0-9]+)\s*\(", csrc)) - {"mhap_record", "mhap_handle", "mhap_params", "mhap_stats"}
+    declared = set(re.findall(r"\b(mhap_[a-z_0-9]+)\s*\(", header))
+    assert called and called <= declared, called - declared
+    assert called <= set(api.EXPORTED_SYMBOLS)
+    for needed in ("mhap_create", "mhap_index_add_reads", "mhap_find_matches_self", "mhap_find_matches_reads", "mhap_find_matches_sketches",
+                   "mhap_set_filter_file", "mhap_get_stats", "mhap_destroy"):
+        assert needed in called, needed
+    # the reference's seams (AbstractMatchSearch.java:119,121,201,203,312,314,340) are all overridden
+    assert "extends AbstractMatchSearch" in java
+    body = java.split("public final class HipMinHashSearch", 1)[1]
+    assert " ... " not in body and "/* ... */" not in body          # complete code, no elisions
+    for sig in ("protected boolean addSequence(SequenceSketch", "public ArrayList<MatchResult> findMatches()",
+                "public ArrayList<MatchResult> findMatches(final SequenceSketchStreamer", "protected List<MatchResult> findMatches(SequenceSketch",
+                "public List<SequenceId> getStoredForwardSequenceIds()", "public SequenceSketch getStoredSequenceHash(SequenceId", "public int size()"):
+        assert sig in java, sig
+    assert "fromNative" not in java
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(root, "tests", "jni_stub"), "-I", os.path.join(root, "include"),
+                        os.path.join(root, "jni", "mhap_jni.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
