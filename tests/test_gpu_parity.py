@@ -476,6 +476,27 @@ def test_growing_batches_keep_the_read_back_buffer():
             assert q.shape[0] >= 0
 
 
+@pytest.mark.timeout(2400)
+def test_full_config2_against_oracle():
+    """BASELINE configs[1] at FULL size (100 000 reads x 10 kb, H = 512): every record of the GPU run against the CPU oracle's run of
+    the same reads (a few minutes of host time on the container's CPU quota), and against the fingerprint bench.py prints."""
+    import hashlib
+    from mhap_amd import workloads as W
+    fa = W.config_reads("c2")
+    assert len(fa) == 100000
+    got, st = _self_lines(fa, MhapParams())
+    sha = hashlib.sha256("\n".join(got).encode()).hexdigest()
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        threads = max(1, int(round(float(q) / float(per)))) if q != "max" else len(os.sched_getaffinity(0))
+    except Exception:
+        threads = len(os.sched_getaffinity(0))
+    want = O.run_self(fa, nthreads=threads, cap=1 << 22)
+    assert got == O.record_lines(want["records"])
+    assert st["candidates_compared"] == want["compared"] and st["table_elements"] == want["elements"]
+    assert len(got) == 41915 and sha.startswith("8f75366010aaae7d")      # the fingerprint of the round-1 and round-2 bench lines
+
+
 def test_config4_read_shape_slice():
     """BASELINE configs[3]/[4] read shapes (15 kb and 12 kb reads, H=512, S=1536: more than 12288 k-mers per strand takes the
     24-k-mers-per-lane weight kernel, 8 bit-sliced MinHash rows) on a slice of reads: full record parity with the oracle."""

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic per launch.
 
   python tools/pmc_summary.py gpurun_out/pmc_FETCH_SIZE/pmc_counter_collection.csv \
-                              gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv > profiles/r01_pmc_traffic.json
+                              gpurun_out/pmc_WRITE_SIZE/pmc_counter_collection.csv > profiles/r02_pmc_traffic.json
 
 Units and gfx950 corrections follow /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE/WRITE_SIZE are in KiB;
 FETCH_SIZE counts 128-B requests at 64 B for wide coalesced streaming reads, so it is reported both raw and doubled
@@ -20,7 +20,12 @@ WIDE_STREAM = {"candidate_kernel", "hash_kmers_kernel", "ordered_kernel", "index
 def short(name):
     n = name.split("(")[0]
     n = n.replace("void ", "").replace("mhap::", "")
-    return n.split("<")[0]
+    base = n.split("<")[0]
+    if base == "minhash_kernel" and "<" in n:      # <U, BITSLICED, WEIGHTED, PROF>: the weight-1 launch and the weighted launch are different kernels
+        args = [a.strip() for a in n.split("<", 1)[1].rstrip(">").split(",")]
+        if len(args) >= 3 and args[2] in ("true", "1"):
+            base += "_weighted"
+    return base
 
 
 def main():

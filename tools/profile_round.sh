@@ -1,9 +1,20 @@
-# final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload (run on the GPU box)
+# final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload (run on the GPU box); ROUND=r02 bash tools/profile_round.sh
 export TMPDIR=/tmp
-mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+R=${ROUND:-r02}
+mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o prof --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_final/bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc_$c -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$c/bench.log 2>&1
 done
-timeout 400 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err
-tail -1 gpurun_out/bench_final.json | cut -c1-600
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d gpurun_out/pmc_mix -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_mix/bench.log 2>&1
+mkdir -p gpurun_out/$R
+cp $(find gpurun_out/prof_final -name "prof_kernel_stats.csv" | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats.csv
+python tools/pmc_summary.py $(find gpurun_out/pmc_FETCH_SIZE -name "pmc_counter_collection.csv" | head -1) $(find gpurun_out/pmc_WRITE_SIZE -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_traffic.json
+grep -h "minhash_kernel" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) | cut -c1-60,400- | head -20 > /dev/null
+head -1 $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_minhash_instmix.csv
+grep -h "minhash_kernel" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) >> gpurun_out/$R/${R}_pmc_minhash_instmix.csv
+timeout 600 python bench.py > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
+tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
+MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
+for c in c1 c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_out/$R/${R}_bench_$c.json 2>/dev/null; done
+ls -la gpurun_out/$R
