@@ -48,15 +48,16 @@ void build_kmer_hash_luts(uint64_t* out) {
 // 2-bit groups reversed, complemented (3 - code = ~code).  Bases outside the read come back as arbitrary codes (callers
 // never hash a window that touches them); the loads stay inside the read's bytes.
 __device__ __forceinline__ uint32_t strand_codes16(const uint8_t* __restrict__ pk, int L, int rcs, int i0) {
-  const int f0 = rcs ? (L - 16 - i0) : i0;          // lowest forward base of the window (may be negative / beyond L)
-  const int q0 = f0 >> 2, nbytes = (L + 3) >> 2;
-  uint64_t w = 0;
-#pragma unroll
-  for (int b = 0; b < 5; b++) {
-    const int q = q0 + b;
-    if (q >= 0 && q < nbytes) w |= (uint64_t)pk[q] << (8 * b);
-  }
-  uint32_t x = (uint32_t)(w >> (2 * (f0 & 3)));
+  // dword loads (reads are 4-byte aligned and padded to whole dwords): two aligned loads + a funnel shift instead of five byte loads
+  const uint32_t* W = (const uint32_t*)pk;
+  const int nd = (((L + 3) >> 2) + 3) >> 2;
+  int f0 = rcs ? (L - 16 - i0) : i0;          // lowest forward base of the window (may be negative / beyond L)
+  if (f0 <= -16 || f0 >= 16 * nd) return 0u;
+  int sh = 0;
+  if (f0 < 0) { sh = -2 * f0; f0 = 0; }
+  const int d = f0 >> 4;
+  const uint32_t d0 = W[d], d1 = W[d + 1 < nd ? d + 1 : nd - 1];
+  uint32_t x = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)(2 * (f0 & 15))) << sh;
   if (rcs) {
     x = __builtin_bswap32(x);
     x = ((x >> 4) & 0x0f0f0f0fu) | ((x & 0x0f0f0f0fu) << 4);
@@ -305,7 +306,12 @@ template <int MAXIT, bool FUSED>
 __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
                                          unsigned int* s_heavy, const FusedHash& fz, bool may_skip) {
   const uint32_t mask = ts - 1;
-  for (uint32_t j = threadIdx.x * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
+  // The lane's k-mer positions (tx + it * 1024) must be recomputed inside the strand loop: left to the compiler they are hoisted
+  // out of it — two dozen loop-invariant values per lane — and, at 64 VGPRs, spilled to scratch and reloaded for every strand
+  // (18 GB of HBM traffic per step at C2).  The empty asm makes tx opaque, so nothing derived from it can be hoisted.
+  int tx = (int)threadIdx.x;
+  asm volatile("" : "+v"(tx));
+  for (uint32_t j = (uint32_t)tx * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   uint32_t st[MAXIT];
   constexpr int CH = FUSED ? 2 : ((MAXIT >= 24) ? 8 : 4);   // keys in flight per lane (register budget: two workgroups per CU need <= 64 VGPRs)
@@ -315,13 +321,13 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
       int64_t key[CH];
 #pragma unroll
       for (int u = 0; u < CH; u++) {
-        const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
+        const int i = tx + (c + u) * WEIGHT_THREADS;
         if (FUSED && fz.on) key[u] = (i < nk) ? (int64_t)lut_key16(fz.lut, codes_at(fz.codes, i)) : 0;
         else key[u] = (i < nk) ? kp[i] : 0;
       }
 #pragma unroll
       for (int u = 0; u < CH; u++) {
-        const int i = threadIdx.x + (c + u) * WEIGHT_THREADS;
+        const int i = tx + (c + u) * WEIGHT_THREADS;
         st[c + u] = 0;
         if (i < nk) {
           const uint32_t fp = ((uint32_t)((uint64_t)key[u] >> 32)) << 16;
@@ -349,7 +355,7 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   bool anydup = false;
 #pragma unroll
   for (int it = 0; it < MAXIT; it++) {
-    const int i = threadIdx.x + it * WEIGHT_THREADS;
+    const int i = tx + it * WEIGHT_THREADS;
     if (i < nk) {
       const uint32_t e = tab[st[it] & 0xFFFFu];
       const uint32_t mine = (st[it] & 0xFFFF0000u) | (uint32_t)(i + 1);
@@ -363,12 +369,12 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   if (may_skip) {
     if (*(volatile unsigned int*)s_heavy == 0u) {
       __syncthreads();
-      if (threadIdx.x == 0) *s_heavy = 2u;
+      if (tx == 0) *s_heavy = 2u;
       return;
     }
 #pragma unroll
     for (int it = 0; it < MAXIT; it++) {
-      const int i = threadIdx.x + it * WEIGHT_THREADS;
+      const int i = tx + it * WEIGHT_THREADS;
       if (i < nk) {
         const uint32_t e = tab[st[it] & 0xFFFFu];
         const uint32_t mine = (st[it] & 0xFFFF0000u) | (uint32_t)(i + 1);
@@ -379,7 +385,7 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   if (*(volatile unsigned int*)s_heavy) {
     wg_release();
     __syncthreads();
-    for (int i = threadIdx.x; i < nk; i += WEIGHT_THREADS) {
+    for (int i = tx; i < nk; i += WEIGHT_THREADS) {
       const uint32_t w = wp[i];
       if (w & DUP_MARK) { atomicAdd(&wp[w & ~DUP_MARK], 1u); wp[i] = 0u; }
     }
