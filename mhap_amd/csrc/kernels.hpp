@@ -91,12 +91,15 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
                        const int32_t* qmeta, const SearchParams& sp, const long long* rowstart, long long nblocks_tri, Candidate* cand,
                        unsigned long long* cand_count, unsigned long long cand_cap);
 // Inverted index: one open-addressing table of 2^k (value, entry+1) words per MinHash slot; a value's entries beyond the run cap
-// live on a linked list in the overflow pool (heads in a second hash table keyed by (slot, value)).
+// are stored contiguously in the overflow pool (CSR: per-(slot, value) start / count in a second hash table).  During the build
+// they are appended to `tmp` and counted; launch_index_finalize lays them out once all entries are in.
 struct InvIndex {
   unsigned long long* table; uint32_t cmask;
-  unsigned long long* ovf_keys; uint32_t* ovf_heads; uint32_t ovf_mask;
-  uint2* pool; unsigned long long* pool_count; uint32_t pool_cap;
+  unsigned long long* ovf_keys; uint32_t* ovf_cnt; uint32_t* ovf_start; uint32_t* ovf_fill; uint32_t ovf_mask;
+  uint2* tmp; uint32_t* pool; unsigned long long* counters;   // counters[0]: tmp items, counters[1]: pool words allocated
+  uint32_t tmp_cap;
 };
+void launch_index_finalize(hipStream_t st, const InvIndex& ix, unsigned long long n_tmp);
 void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H, const InvIndex& ix);
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,

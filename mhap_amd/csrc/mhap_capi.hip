@@ -115,6 +115,7 @@ struct mhap_handle {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // inverted index state: the table in inv_table covers entries [0, inv_ne) with mask inv_cmask when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0; uint32_t inv_cmask = 0;
+  bool inv_finalized = false;   // the overflow postings of the table in place have been laid out (launch_index_finalize)
   bool eager = false; int64_t eager_first = 0; uint32_t eager_cmask = 0;   // set by mhap_index_add_staged around sketch_staged
   std::string err;
   int Hrow = 1;      // minhash row stride (ints)
@@ -311,8 +312,9 @@ static uint64_t inv_capacity(int64_t ne) {
   return cap;
 }
 
-// (Re)allocate and zero the inverted index for `ne` entries on stream st: H slot tables of inv_capacity(ne) words, the overflow
-// heads table (one slot per 8 postings) and the overflow pool (one node per 4 postings; beyond that inserts stay in their runs).
+// (Re)allocate and zero the inverted index for `ne` entries on stream st: H slot tables of inv_capacity(ne) words, the per-value
+// overflow table (one slot per 8 postings: key, count, segment start, fill), the temporary overflow list and the overflow pool
+// (one item per 4 postings; beyond that inserts stay in their runs).
 static int inv_reset(mhap_handle* h, int64_t ne, hipStream_t st) {
   const int H = h->P.num_hashes;
   const uint64_t cap = inv_capacity(ne);
@@ -320,20 +322,24 @@ static int inv_reset(mhap_handle* h, int64_t ne, hipStream_t st) {
   const uint64_t postings = (uint64_t)ne * (uint64_t)H;
   uint64_t oslots = 1024;
   while (oslots < postings / 8) oslots <<= 1;
-  const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>(postings / 4, 1u << 16), 0xFFFFFFF0ull);
-  const size_t obytes = 64 + (size_t)oslots * 8 + (size_t)oslots * 4 + (size_t)pool_cap * 8;
+  const uint64_t tmp_cap = std::min<uint64_t>(std::max<uint64_t>(postings / 4, 1u << 16), 0xFFFFFFF0ull);
+  const size_t obytes = 64 + (size_t)oslots * 20 + (size_t)tmp_cap * 12;
   HIPCHK(h, h->inv_table.ensure(tbytes));
   HIPCHK(h, h->inv_ovf.ensure(obytes));
   HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, tbytes, st));
-  HIPCHK(h, hipMemsetAsync(h->inv_ovf.p, 0, 64 + (size_t)oslots * 12, st));
+  HIPCHK(h, hipMemsetAsync(h->inv_ovf.p, 0, 64 + (size_t)oslots * 12, st));      // counters, keys, counts
   char* o = h->inv_ovf.as<char>();
   h->inv.table = h->inv_table.as<unsigned long long>(); h->inv.cmask = (uint32_t)(cap - 1);
-  h->inv.pool_count = (unsigned long long*)o;
+  h->inv.counters = (unsigned long long*)o;
   h->inv.ovf_keys = (unsigned long long*)(o + 64);
-  h->inv.ovf_heads = (uint32_t*)(o + 64 + (size_t)oslots * 8);
+  h->inv.ovf_cnt = (uint32_t*)(o + 64 + (size_t)oslots * 8);
+  h->inv.ovf_start = (uint32_t*)(o + 64 + (size_t)oslots * 12);
+  h->inv.ovf_fill = (uint32_t*)(o + 64 + (size_t)oslots * 16);
   h->inv.ovf_mask = (uint32_t)(oslots - 1);
-  h->inv.pool = (uint2*)(o + 64 + (size_t)oslots * 12);
-  h->inv.pool_cap = (uint32_t)pool_cap;
+  h->inv.tmp = (uint2*)(o + 64 + (size_t)oslots * 20);
+  h->inv.pool = (uint32_t*)(o + 64 + (size_t)oslots * 20 + (size_t)tmp_cap * 8);
+  h->inv.tmp_cap = (uint32_t)tmp_cap;
+  h->inv_finalized = false;
   return MHAP_OK;
 }
 
@@ -538,14 +544,29 @@ int ensure_inverted_index(mhap_handle* h) {
   const int ne = (int)h->n_entries, H = h->P.num_hashes;
   const uint64_t cap = inv_capacity(ne);
   const uint32_t cmask = (uint32_t)(cap - 1);
-  if (h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask) return MHAP_OK;
-  { const int rr = inv_reset(h, ne, h->stream); if (rr != MHAP_OK) return rr; }
-  HPROF("index build launch");
-  time_begin(h, MHAP_K_INDEX_BUILD);
-  launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv);
-  time_end(h);
-  HIPCHK(h, hipGetLastError());
-  h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
+  if (!(h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask)) {
+    { const int rr = inv_reset(h, ne, h->stream); if (rr != MHAP_OK) return rr; }
+    HPROF("index build launch");
+    time_begin(h, MHAP_K_INDEX_BUILD);
+    launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv);
+    time_end(h);
+    HIPCHK(h, hipGetLastError());
+    h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
+  }
+  if (!h->inv_finalized) {
+    // every entry is in: lay the overflow postings (values shared by more than a run's cap of entries) out per value
+    unsigned long long ntmp = 0;
+    HIPCHK(h, hipMemcpyAsync(&ntmp, h->inv.counters, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (ntmp > 0) {
+      if (ntmp > h->inv.tmp_cap) ntmp = h->inv.tmp_cap;
+      time_begin(h, MHAP_K_INDEX_BUILD);
+      launch_index_finalize(h->stream, h->inv, ntmp);
+      time_end(h);
+      HIPCHK(h, hipGetLastError());
+    }
+    h->inv_finalized = true;
+  }
   return MHAP_OK;
 }
 

@@ -184,31 +184,57 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // Work ~ N*H probes + hits instead of N*2N*H/2 compares.
 //
 // Repeats (the reference keeps value -> ArrayList, :123-141): a value shared by n entries would cost n^2/2 CAS probes to
-// insert into one run, so a run holds at most ~INV_RUN_CAP entries of one value; further entries of that value go to a
-// per-(slot, value) linked list in an overflow pool (find-or-claim of the list head in a second hash table, one
-// atomicExch to push) — O(1) per insert however popular the value.  A query that finds INV_RUN_CAP entries of its value in
-// the run also walks the value's overflow list.  A query whose distinct hits outgrow the LDS count table is not handed to
+// insert into one run, so a run holds at most ~INV_RUN_CAP (64) entries of one value; further entries of that value are counted
+// per (slot, value) in a second hash table and appended to a temporary list — O(1) per insert however popular the value —
+// and index_finalize lays them out contiguously per value (segment from a bump allocator, fill with one atomic each): the
+// reference's value -> postings list as CSR.  A query that finds INV_RUN_CAP entries of its value in the run has its whole
+// wavefront stream the value's segment (coalesced loads, 64 postings per step) instead of one lane chasing pointers.  A query whose distinct hits outgrow the LDS count table is not handed to
 // the brute-force kernel any more: it is re-run in passes over hash-partitions of the stored entries (split in two until
 // every part fits), which bounds its cost by its own postings.
 // =============================================================================================
 __device__ inline uint32_t inv_hash(uint32_t v) { return fmix32(v); }
-constexpr int INV_RUN_CAP = 16;
+constexpr int INV_RUN_CAP = 64;   // a run absorbs the values ordinary coverage shares (30x: a few dozen entries); beyond that a value is a repeat
 
-__device__ inline void inv_overflow_push(const InvIndex& ix, int s, uint32_t v, int e, unsigned long long* T, uint32_t pos, unsigned long long word) {
-  const unsigned long long pidx = atomicAdd(ix.pool_count, 1ULL);
-  if (pidx >= (unsigned long long)ix.pool_cap) {
-    // pool exhausted (pathological input): keep probing the run uncapped — slower, still exact
-    for (;;) { pos = (pos + 1) & ix.cmask; if (atomicCAS(&T[pos], 0ULL, word) == 0ULL) return; }
-  }
-  const unsigned long long key = (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL;
+__device__ inline uint32_t inv_ovf_slot(const InvIndex& ix, unsigned long long key, bool claim) {
   uint32_t hp = (uint32_t)fmix64(key) & ix.ovf_mask;
   for (;;) {
-    const unsigned long long old = atomicCAS(&ix.ovf_keys[hp], 0ULL, key);
-    if (old == 0ULL || old == key) break;
+    const unsigned long long old = claim ? atomicCAS(&ix.ovf_keys[hp], 0ULL, key) : ix.ovf_keys[hp];
+    if (old == key || (claim && old == 0ULL)) return hp;
+    if (!claim && old == 0ULL) return 0xFFFFFFFFu;
     hp = (hp + 1) & ix.ovf_mask;
   }
-  const uint32_t prev = atomicExch(&ix.ovf_heads[hp], (uint32_t)pidx + 1u);
-  ix.pool[pidx] = make_uint2((uint32_t)e, prev);     // (entry, next + 1); read by later kernels only
+}
+
+__device__ inline void inv_overflow_push(const InvIndex& ix, int s, uint32_t v, int e, unsigned long long* T, uint32_t pos, unsigned long long word) {
+  const unsigned long long t = atomicAdd(&ix.counters[0], 1ULL);
+  if (t >= (unsigned long long)ix.tmp_cap) {
+    // temporary list exhausted (pathological input): keep probing the run uncapped — slower, still exact
+    for (;;) { pos = (pos + 1) & ix.cmask; if (atomicCAS(&T[pos], 0ULL, word) == 0ULL) return; }
+  }
+  const uint32_t hp = inv_ovf_slot(ix, (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL, true);
+  atomicAdd(&ix.ovf_cnt[hp], 1u);
+  ix.tmp[t] = make_uint2(hp, (uint32_t)e);
+}
+
+// Finalize, pass 1: every (slot, value) with overflow postings gets a contiguous segment of the pool.
+__global__ void index_segments_kernel(InvIndex ix) {
+  const uint32_t hp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hp > ix.ovf_mask) return;
+  const uint32_t c = ix.ovf_cnt[hp];
+  if (c) { ix.ovf_start[hp] = (uint32_t)atomicAdd(&ix.counters[1], (unsigned long long)c); ix.ovf_fill[hp] = 0; }
+}
+// Finalize, pass 2: the temporary (value slot, entry) items go to their segments.
+__global__ void index_fill_kernel(InvIndex ix, unsigned long long n_tmp) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tmp) return;
+  const uint2 it = ix.tmp[t];
+  ix.pool[ix.ovf_start[it.x] + atomicAdd(&ix.ovf_fill[it.x], 1u)] = it.y;
+}
+void launch_index_finalize(hipStream_t st, const InvIndex& ix, unsigned long long n_tmp) {
+  if (n_tmp == 0) return;
+  (void)hipMemsetAsync(&ix.counters[1], 0, 8, st);
+  hipLaunchKernelGGL(index_segments_kernel, dim3((ix.ovf_mask + 256) / 256), dim3(256), 0, st, ix);
+  hipLaunchKernelGGL(index_fill_kernel, dim3((unsigned)((n_tmp + 255) / 256)), dim3(256), 0, st, ix, n_tmp);
 }
 
 constexpr int IB_S = 4, IB_E = 256 / IB_S;   // slots x entries of one workgroup (1x256 / 4x64 / 8x32 / 16x16: 6.2 / 6.1 / 6.3 / 6.5 ms at C2)
@@ -278,59 +304,54 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     if (bits == 0xFFFFFFFFu) break;
     const uint32_t pmask = bits >= 20 ? 0xFFFFFu : ((1u << bits) - 1u);
     unsigned long long mine = 0;
-    for (int s = threadIdx.x; s < sp.H; s += IQ_THREADS) {
-      const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
-      const unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
-      uint32_t pos = inv_hash(v) & ix.cmask;
-      int same = 0;
-      uint32_t chain = 0;          // overflow list cursor (pool index + 1), entered after the run
-      for (;;) {
-        int me;
-        if (chain == 0) {
+    const int lane = threadIdx.x & 63;
+    // count one hit of stored entry `me` (the id/length rules do not depend on the count: they are applied to the few entries that
+    // reach numMinMatches, below, so that the probe loop's only global loads are the index words)
+    auto count_hit = [&](int me) {
+      const uint32_t hm = inv_hash((uint32_t)me);
+      if (((hm >> 12) & pmask) != prefix) return;
+      uint32_t slot = hm & (INV_CT - 1);
+      for (int tries = 0; tries < INV_CT; tries++) {
+        uint32_t k = *(volatile uint32_t*)&keys[slot];
+        if (k == 0) {
+          if (*(volatile uint32_t*)&s_distinct >= (INV_CT * 3) / 4) { s_over = 1; break; }
+          const uint32_t old = atomicCAS(&keys[slot], 0u, (uint32_t)me + 1u);
+          if (old == 0) { atomicAdd(&s_distinct, 1u); k = (uint32_t)me + 1u; } else k = old;
+        }
+        if (k == (uint32_t)me + 1u) { atomicAdd(&cnts[slot], 1u); break; }
+        slot = (slot + 1) & (INV_CT - 1);
+      }
+    };
+    for (int s0 = 0; s0 < sp.H; s0 += IQ_THREADS) {       // workgroup-uniform trip count: the wavefront cooperates on overflow segments below
+      const int s = s0 + (int)threadIdx.x;
+      uint32_t seg_start = 0, seg_len = 0;
+      if (s < sp.H) {
+        const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
+        const unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
+        uint32_t pos = inv_hash(v) & ix.cmask;
+        int same = 0;
+        for (;;) {
           const unsigned long long w = T[pos];
-          if (w == 0ULL) {
-            if (same < INV_RUN_CAP) break;
-            // the run holds its cap of this value: the rest of the value's entries are on its overflow list
-            const unsigned long long key = (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL;
-            uint32_t hp = (uint32_t)fmix64(key) & ix.ovf_mask;
-            for (;;) {
-              const unsigned long long k = ix.ovf_keys[hp];
-              if (k == 0ULL) break;
-              if (k == key) { chain = ix.ovf_heads[hp]; break; }
-              hp = (hp + 1) & ix.ovf_mask;
-            }
-            if (chain == 0) break;
-            same = -0x40000000;     // (do not come back here)
-            continue;
-          }
+          if (w == 0ULL) break;
           pos = (pos + 1) & ix.cmask;
           if ((uint32_t)(w >> 32) != v) continue;
           same++;
-          me = (int)(uint32_t)w - 1;
-        } else {
-          const uint2 pe = ix.pool[chain - 1];
-          me = (int)pe.x;
-          chain = pe.y;
-          if (chain == 0) { pos = 0xFFFFFFFFu; }
+          if (bits == 0) mine++;                                               // "table elements processed" (:173), counted once
+          count_hit((int)(uint32_t)w - 1);
         }
-        if (bits == 0) mine++;                                               // "table elements processed" (:173), counted once
-        // count the hit (the id/length rules do not depend on the count: they are applied to the few entries that reach
-        // numMinMatches, below, so that the probe loop's only global load is the table word)
-        const uint32_t hm = inv_hash((uint32_t)me);
-        if (((hm >> 12) & pmask) == prefix) {
-          uint32_t slot = hm & (INV_CT - 1);
-          for (int tries = 0; tries < INV_CT; tries++) {
-            uint32_t k = *(volatile uint32_t*)&keys[slot];
-            if (k == 0) {
-              if (*(volatile uint32_t*)&s_distinct >= (INV_CT * 3) / 4) { s_over = 1; break; }
-              const uint32_t old = atomicCAS(&keys[slot], 0u, (uint32_t)me + 1u);
-              if (old == 0) { atomicAdd(&s_distinct, 1u); k = (uint32_t)me + 1u; } else k = old;
-            }
-            if (k == (uint32_t)me + 1u) { atomicAdd(&cnts[slot], 1u); break; }
-            slot = (slot + 1) & (INV_CT - 1);
-          }
+        if (same >= INV_RUN_CAP) {
+          // the run holds its cap of this value: the rest of the value's entries are a contiguous segment of the overflow pool
+          const uint32_t hp = inv_ovf_slot(ix, (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL, false);
+          if (hp != 0xFFFFFFFFu) { seg_start = ix.ovf_start[hp]; seg_len = ix.ovf_cnt[hp]; }
         }
-        if (chain == 0 && pos == 0xFFFFFFFFu) break;                          // end of the overflow list
+      }
+      unsigned long long m = __ballot(seg_len > 0);
+      while (m) {                                                               // the whole wavefront streams each segment
+        const int l = __builtin_ctzll(m);
+        m &= m - 1;
+        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)seg_start, l), ln = (uint32_t)__builtin_amdgcn_readlane((int)seg_len, l);
+        if (bits == 0 && lane == l) mine += ln;
+        for (uint32_t i = (uint32_t)lane; i < ln; i += 64) count_hit((int)ix.pool[st + i]);
       }
     }
     if (mine) atomicAdd(elements, mine);

@@ -45,11 +45,32 @@ def main(iters, seed0):
                   ordered_kmer_size=rnd.choice([12, 12, 8, 10, 13]), ordered_sketch_size=rnd.choice([32, 100, 300, 512, 1536]),
                   num_min_matches=rnd.choice([1, 2, 3, 5]), threshold=rnd.choice([0.0, 0.5, 0.78, 0.9]), max_shift=rnd.choice([0.05, 0.2, 0.4]),
                   min_store_length=rnd.choice([0, 0, 500, 2000]), min_olap_length=rnd.choice([0, 50, 116, 500]))
+        kw["repeat_weight"] = rnd.choice([0.9, 0.9, 0.9, 0.5, 1.0, -1.0])
         p = MhapParams(**kw)
+        flt = oflt = None
+        if rnd.random() < 0.4:   # a -f filter over the reads' own k-mers: tf-idf weights, optionally the --supress-noise whitelist
+            k = p.kmer_size
+            counts = {}
+            for sq in seqs[::2]:
+                for i in range(0, max(0, len(sq) - k + 1), rnd.choice([1, 2, 5])):
+                    km = sq[i:i + k]
+                    if "N" not in km: counts[km] = counts.get(km, 0) + 1
+            items = sorted(counts.items(), key=lambda kv: (-kv[1], kv[0]))[:rnd.choice([20, 300, 3000])]
+            if items:
+                total = float(sum(c for _, c in items))
+                hashes = np.array([int(O.kmer_hashes64(km, k, True)[0]) for km, _ in items], dtype=np.int64)
+                fracs = np.array([c / total for _, c in items])
+                cutoff = float(np.quantile(fracs, rnd.choice([0.0, 0.5, 0.9])))
+                rw = p.repeat_weight
+                offset = rw if 0.0 <= rw < 1.0 else 0.0
+                rng, no_tf, mode = rnd.choice([3.0, 3.0, 1.0, 7.5]), rnd.random() < 0.3, rnd.choice([0, 0, 1, 2])
+                flt = mhap_amd.FrequencyCounts(hashes, fracs, cutoff, offset, rng, no_tf, supress_noise=mode, size_bloom=len(hashes))
+                oflt = O.Filter(hashes, fracs, cutoff, offset, rng, no_tf, remove_unique=mode, whitelist=hashes, size_bloom=len(hashes))
+                kw["filter"] = (len(items), round(cutoff, 6), rng, no_tf, mode)
         want = O.run_self(fa, k=p.kmer_size, H=p.num_hashes, k2=p.ordered_kmer_size, S=p.ordered_sketch_size, nthreads=8,
                           num_min_matches=p.num_min_matches, min_store_length=p.min_store_length, min_olap_length=p.min_olap_length,
-                          threshold=p.threshold, max_shift=p.max_shift, cap=1 << 22)
-        with MinHashSearch(p) as ms:
+                          threshold=p.threshold, max_shift=p.max_shift, repeat_weight=p.repeat_weight, flt=oflt, cap=1 << 22)
+        with MinHashSearch(p, kmer_filter=flt) as ms:
             ms.add_data(fa)
             got = sorted(mhap_amd.records_to_lines(ms.find_matches()))
             st = ms.stats()

@@ -242,7 +242,7 @@ def test_index_export_roundtrip_and_query_sharding():
         again2 = sorted(mhap_amd.records_to_lines(ms2.find_matches(0, 60))) + sorted(mhap_amd.records_to_lines(ms2.find_matches(60, -1)))
         kt = ms2.kernel_times()
     assert again == full and len(full) > 50 and sorted(again2) == full
-    assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 3
+    assert kt["index_build"]["launches"] in (1, 2) and kt["index_query"]["launches"] == 3   # (2: + the overflow-segment layout pass)
 
 
 def test_batching_and_chunking_do_not_change_results(monkeypatch):
@@ -445,7 +445,7 @@ def test_index_table_reuse_and_incremental_adds():
         b = sorted(mhap_amd.records_to_lines(ms.find_matches()))          # second search: table reused
         kt = ms.kernel_times()
     assert a == want and b == want
-    assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 2
+    assert kt["index_build"]["launches"] in (1, 2) and kt["index_query"]["launches"] == 2
     half = len(fa) // 2
     f1 = FastaData.from_strings([fa.sequence(i) for i in range(half)])
     f2 = FastaData.from_strings([fa.sequence(i) for i in range(half, len(fa))], id_offset=half)
