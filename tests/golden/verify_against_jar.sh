@@ -1,16 +1,31 @@
 #!/bin/sh
 # Re-derives the golden records with a real MHAP jar when a JVM is available and diffs them against the
-# committed oracle-derived fixture.  Usage: MHAP_JAR=/path/mhap-2.1.3.jar sh tests/golden/verify_against_jar.sh
+# committed oracle-derived fixture: the self overlap, the -q index-vs-stream run (queries below --min-olap-length included:
+# id offsets), the -f filter run and both --supress-noise modes.
+# Usage: MHAP_JAR=/path/mhap-2.1.3.jar sh tests/golden/verify_against_jar.sh
 set -e
 cd "$(dirname "$0")"
 command -v java >/dev/null 2>&1 || { echo "no java on PATH: cannot verify (fixture stays oracle-derived)"; exit 2; }
 [ -n "$MHAP_JAR" ] || { echo "set MHAP_JAR"; exit 2; }
-java -jar "$MHAP_JAR" -s small_reads.fasta -k 16 --num-hashes 64 --ordered-kmer-size 12 --ordered-sketch-size 256 \
-     --min-olap-length 116 --num-threads 1 2>/dev/null | sort > /tmp/jar_records.txt
-python3 - <<'PY'
-import json
-want = json.load(open("small_reads.json"))["sorted_records"]
-got = [l.rstrip("\n") for l in open("/tmp/jar_records.txt")]
-assert sorted(got) == sorted(want), "MISMATCH between mhap.jar and the oracle-derived fixture"
-print("fixture matches mhap.jar:", len(got), "records")
+FLAGS="-k 16 --num-hashes 64 --ordered-kmer-size 12 --ordered-sketch-size 256 --min-olap-length 116 --num-threads 1"
+T=$(mktemp -d)
+java -jar "$MHAP_JAR" -s small_reads.fasta $FLAGS 2>/dev/null | sort > $T/self.txt
+java -jar "$MHAP_JAR" -s small_reads.fasta -q small_queries.fasta --no-self $FLAGS 2>/dev/null | sort > $T/query.txt
+THR=$(python3 -c 'import json; print(json.load(open("small_reads.json"))["filter_threshold"])')
+java -jar "$MHAP_JAR" -s small_reads.fasta -f small_kmers.txt --filter-threshold $THR $FLAGS 2>/dev/null | sort > $T/filter.txt
+java -jar "$MHAP_JAR" -s small_reads.fasta -f small_kmers.txt --filter-threshold $THR --supress-noise 1 $FLAGS 2>/dev/null | sort > $T/sup1.txt
+java -jar "$MHAP_JAR" -s small_reads.fasta -f small_kmers.txt --filter-threshold $THR --supress-noise 2 $FLAGS 2>/dev/null | sort > $T/sup2.txt
+python3 - "$T" <<'PY'
+import json, sys
+T = sys.argv[1]
+g = json.load(open("small_reads.json"))
+bad = 0
+for name, key in (("self", "sorted_records"), ("query", "query_records_no_self"), ("filter", "filter_records"),
+                  ("sup1", "supress_noise_1_records"), ("sup2", "supress_noise_2_records")):
+    got = sorted(l.rstrip("\n") for l in open(f"{T}/{name}.txt") if l.strip())
+    ok = got == sorted(g[key])
+    print(("ok      " if ok else "MISMATCH"), name, len(got), "records from mhap.jar,", len(g[key]), "in the fixture")
+    bad += not ok
+assert bad == 0, "MISMATCH between mhap.jar and the oracle-derived fixture"
+print("fixture matches mhap.jar")
 PY

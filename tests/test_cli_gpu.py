@@ -31,6 +31,21 @@ def test_cli_self_overlap_matches_golden():
     assert "Time (s) to read and hash from file:" in err and "Total matches found: %d" % len(lines) in err
 
 
+def test_cli_matches_the_extended_golden_fixture():
+    """The fixture's other cases (what tests/golden/verify_against_jar.sh diffs against a real mhap.jar when a JVM exists): -q with
+    reads below --min-olap-length in the query file, -f with a filter file, --supress-noise 1 and 2."""
+    g = json.load(open(os.path.join(GOLD, "small_reads.json")))
+    s, q, f = (os.path.join(GOLD, x) for x in ("small_reads.fasta", "small_queries.fasta", "small_kmers.txt"))
+    lines, err = _run(["-s", s, "-q", q, "--no-self"] + GFLAGS)
+    assert lines == g["query_records_no_self"] and len(lines) > 50
+    assert "Processed 10 to sequences." in err                    # 12 query reads, two below --min-olap-length
+    thr = ["--filter-threshold", repr(g["filter_threshold"])]
+    assert _run(["-s", s, "-f", f] + thr + GFLAGS)[0] == g["filter_records"]
+    assert _run(["-s", s, "-f", f, "--supress-noise", "1"] + thr + GFLAGS)[0] == g["supress_noise_1_records"]
+    assert _run(["-s", s, "-f", f, "--supress-noise", "2"] + thr + GFLAGS)[0] == g["supress_noise_2_records"]
+    assert g["filter_records"] != g["sorted_records"] and g["supress_noise_1_records"] != g["filter_records"]
+
+
 def test_cli_dat_roundtrip_and_format(tmp_path):
     """-p writes MHAP's `.dat` (big-endian framing, Appendix B); -s x.dat reproduces the FASTA run."""
     indir, outdir = tmp_path / "in", tmp_path / "out"
