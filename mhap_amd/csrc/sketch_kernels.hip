@@ -779,11 +779,15 @@ __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 
 // filter depth of a slot whose minimum has the high dword bhs: -1 = no negative minimum yet (every active chain is a candidate),
 // else the leading zero magnitude bits of the minimum, capped at BS_ZMAX
+#ifndef MH_ZDEEP
+#define MH_ZDEEP 20
+#endif
+constexpr int BS_ZDEEP = MH_ZDEEP;   // planes the second look of a triggered step goes down to (>= BS_ZMAX)
 __device__ __forceinline__ int bs_depth(int32_t bhs) {
   if (bhs >= 0) return -1;
   const uint32_t mag = (uint32_t)bhs & 0x7fffffffu;
   const int z = mag ? (__builtin_clz(mag) - 1) : 31;
-  return z > BS_ZMAX ? BS_ZMAX : z;
+  return z > BS_ZDEEP ? BS_ZDEEP : z;
 }
 
 // returns a mask with a 0 bit for every chain that may undercut the slot minimum of filter depth z: the chain must be
@@ -830,6 +834,17 @@ __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t 
     if (b + 1 <= BS_ZMAX) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(n1) : "v"(P[62 - b]), "s"(en.w[b + 1]));
   }
   return n0 | n1;
+}
+
+// Second look at a step whose first BS_ZMAX planes let a candidate through (a quarter of the steps at depth 12): the planes down to
+// the slot's real depth (<= BS_ZDEEP) are checked before anything is queued, which removes nearly all false candidates — and with them
+// most of the queueing and draining — for 8 more masked ORs in the triggered steps only.
+__device__ __forceinline__ uint32_t bs_filter_deep(const uint32_t (&P)[64], uint32_t nacc, int z) {
+  if (z <= BS_ZMAX) return nacc;
+  const uint32_t m = (2u << z) - 1u;
+#pragma unroll
+  for (int b = BS_ZMAX + 1; b <= BS_ZDEEP; b++) nacc |= P[63 - b] & (uint32_t)((int)(m << (31 - b)) >> 31);
+  return nacc;
 }
 
 // First bit-sliced row of a strand (no slot minimum exists yet): bit-serial narrowing towards the row's arg-min.
@@ -1098,10 +1113,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 if (PROF) { tp[2] += tb - ta; tp[3] += MHAP_TICK() - tb; }
                 continue;
               }
-              const uint32_t nacc = bs_filter(P, ACT, en, zs);
+              uint32_t nacc = bs_filter(P, ACT, en, zs);
               if (__any(nacc != 0xFFFFFFFFu)) {
                 const unsigned long long ta = MHAP_TICK();
-                bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, ~nacc, base, w, ks, jump, jump_na, lane, tf);
+                nacc = bs_filter_deep(P, nacc, zs);
+                if (__any(nacc != 0xFFFFFFFFu)) bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, ~nacc, base, w, ks, jump, jump_na, lane, tf);
                 if (PROF) tp[4] += MHAP_TICK() - ta;
               }
             }
