@@ -10,7 +10,8 @@ resident in HBM before the timed region starts (mhap_stage_reads); record text f
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 N > 1 (strong scaling, same data set): rank r sketches reads r, r+N, ... and indexes them — only them; the forward
-query sketches of the ranks travel round a ring (RCCL point-to-point over xGMI) and visit every rank's index.
+query sketches of all ranks are all-gathered (RCCL over xGMI; the ordered rows asynchronously, under the candidate stage) and every
+rank searches them against its own index (MHAP_BENCH_RING=1: the query bundles rotate round a ring instead, 2 bundles in HBM).
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries
   parity_check : the GPU path and the CPU oracle run on the SAME sample reads, sorted-record SHA-256 compared;
   cpu_baseline : the oracle timed on this box's host cores on that sample (threads = the cgroup CPU quota);
@@ -157,6 +158,8 @@ def main():
         loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
         loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
         lids, lfwd = mdist.local_entry_ids(n_total, world, rank)
+        all_ids = mdist.all_bundle_ids(n_total, world)
+    use_ring = bool(os.environ.get("MHAP_BENCH_RING"))     # rotate the query bundles round a ring (2 bundles in HBM) instead of gathering them
     phase = {"sketch": 0.0, "exchange": 0.0, "search": 0.0}
 
     def step(timed_phases=False):
@@ -173,15 +176,38 @@ def main():
                 phase["search"] += time.perf_counter() - t0
             return recs
         # N > 1: this rank's reads are sketched into its own tables, indexed here and nowhere else (1/N of the inverted-index
-        # build); the forward query sketches of all ranks then visit every rank's index round a ring (mhap_amd/distributed.py)
+        # build); the forward query sketches of all ranks are gathered (or rotate round a ring) and searched against it
         ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-        ms.set_device_index(lids, lfwd, loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-        ms.prepare_index()
+        if use_ring:
+            ms.set_device_index(lids, lfwd, loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+            ms.prepare_index()
         if timed_phases:
             ms.synchronize()
             phase["sketch"] += time.perf_counter() - t0
         cur = (mdist.forward_rows(loc_mh), mdist.forward_rows(loc_od), mdist.forward_rows(loc_mt))
         torch.cuda.current_stream().synchronize()
+        if not use_ring:
+            # default exchange: all-gather the forward query rows — MinHash + meta first (all the candidate stage needs), the ordered
+            # rows asynchronously; the index build and the candidate stage run meanwhile, the second stage waits for them (gate)
+            t1 = time.perf_counter()
+            g_mh, _ = mdist.gather_forward(cur[0], world, dist)
+            g_mt, _ = mdist.gather_forward(cur[2], world, dist)
+            g_od, work = mdist.gather_forward(cur[1], world, dist, async_op=True)
+            ms.set_device_index(lids, lfwd, loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
+            ms.prepare_index()
+            if timed_phases:
+                phase["exchange"] += time.perf_counter() - t1
+
+            def wait_ordered():
+                if work is not None:
+                    work.wait()
+                torch.cuda.current_stream().synchronize()
+            t1 = time.perf_counter()
+            recs = ms.find_matches_device(g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr(), all_ids, to_self=True, before_second_stage=wait_ordered)
+            if timed_phases:
+                phase["search"] += time.perf_counter() - t1
+            step.keep = (g_mh, g_od, g_mt)
+            return recs
         parts = []
         for t in range(world):
             pending = None
@@ -309,7 +335,7 @@ def main():
             "config": {"workload": f"{cfg_label}, k={k}, --num-hashes {H}, ordered sketch k2={k2} S={S}, self-overlap"
                                    + (", -f k-mer filter, --filter-threshold 1e-5" if cfg.get("filter") else ""),
                        "name": args.config, "error_rate": args.error_rate,
-                       "parallelism": f"reads round-robin over {world} GPU(s); per-rank index of own reads, forward query sketches rotate round a ring (RCCL send/recv)" if world > 1 else "1 GPU"},
+                       "parallelism": f"reads round-robin over {world} GPU(s); per-rank index of own reads, RCCL all-gather of the forward query sketches" if world > 1 else "1 GPU"},
             "records_per_step": total_records,
             "sketches_per_sec": round(strands / float(pht[0].item()), 1) if float(pht[0].item()) > 0 else None,
             "sketches_per_sec_note": "2N strands / wall time of the sketch phase (packed reads in HBM -> MinHash + ordered tables in HBM, host "

@@ -96,6 +96,11 @@ typedef struct mhap_handle mhap_handle;
  * the library and valid only during the call.  Replaces AbstractMatchSearch.outputResults
  * (J/impl/AbstractMatchSearch.java:316-338).  Return non-zero to abort the search. */
 typedef int (*mhap_record_sink)(const mhap_record* recs, int64_t n, void* user);
+/* Optional gate between the two stages of a search: called (from the calling thread) after the candidates of a batch of queries
+ * are known and before their ordered sketches are read.  A multi-GPU host uses it to wait for the asynchronous exchange of the
+ * ordered-sketch rows, which then overlaps the candidate stage.  Non-zero aborts the search.  NULL removes the gate. */
+typedef int (*mhap_stage_gate)(void* user);
+int mhap_set_second_stage_gate(mhap_handle* h, mhap_stage_gate gate, void* user);
 
 /* Replaces `new MinHashSearch(...)` argument plumbing (J/impl/MinHashSearch.java:63-98). */
 int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t errcap);

@@ -49,6 +49,7 @@ RECORD_DTYPE = np.dtype([("from_id", "<i8"), ("to_id", "<i8"), ("score", "<f8"),
                          ("a2", "<i4"), ("alen", "<i4"), ("b1", "<i4"), ("b2", "<i4"), ("blen", "<i4"),
                          ("to_rc", "<i4"), ("pad", "<i4")])
 _SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p)
+_GATE = C.CFUNCTYPE(C.c_int, C.c_void_p)
 
 # every symbol include/mhap_hip.h declares
 EXPORTED_SYMBOLS = [
@@ -59,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_find_matches_sketches",
-    "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom",
+    "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
 ]
 
 
@@ -443,12 +444,31 @@ class MinHashSearch:
         return self._collect(lambda cb: self._lib.mhap_find_matches_sketches(self._h, _ptr(ids), _ptr(sl), _ptr(mh), _ptr(od), _ptr(osz),
                                                                             _ptr(osl), C.c_int64(len(ids)), cb, None))
 
-    def find_matches_device(self, d_q_minhash_ptr, d_q_ordered_ptr, d_q_meta_ptr, ids, to_self=True):
-        """Device-resident query sketches (forward rows of another rank's tables) against this handle's index."""
+    def find_matches_device(self, d_q_minhash_ptr, d_q_ordered_ptr, d_q_meta_ptr, ids, to_self=True, before_second_stage=None):
+        """Device-resident query sketches (forward rows of the ranks' tables) against this handle's index.
+        before_second_stage: callable run once the candidates are known and before the ordered rows are read (e.g. the wait
+        for their asynchronous all-gather)."""
         ids = np.ascontiguousarray(ids, dtype=np.int64)
-        return self._collect(lambda cb: self._lib.mhap_find_matches_device(self._h, C.c_void_p(d_q_minhash_ptr), C.c_void_p(d_q_ordered_ptr),
-                                                                          C.c_void_p(d_q_meta_ptr), _ptr(ids), C.c_int64(len(ids)),
-                                                                          C.c_int(1 if to_self else 0), cb, None))
+        gate = None
+        if before_second_stage is not None:
+            done = [False]
+
+            def _gate(user):
+                if not done[0]:
+                    before_second_stage()
+                    done[0] = True
+                return 0
+            gate = _GATE(_gate)
+            self._chk(self._lib.mhap_set_second_stage_gate(self._h, gate, None))
+        try:
+            return self._collect(lambda cb: self._lib.mhap_find_matches_device(self._h, C.c_void_p(d_q_minhash_ptr), C.c_void_p(d_q_ordered_ptr),
+                                                                              C.c_void_p(d_q_meta_ptr), _ptr(ids), C.c_int64(len(ids)),
+                                                                              C.c_int(1 if to_self else 0), cb, None))
+        finally:
+            if gate is not None:
+                self._chk(self._lib.mhap_set_second_stage_gate(self._h, _GATE(0), None))
+                if not done[0]:
+                    before_second_stage()       # no candidates at all: the caller still expects the wait to have happened
 
     # -- counters -------------------------------------------------------------------------------
     def stats(self):

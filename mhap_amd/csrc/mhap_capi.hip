@@ -156,6 +156,7 @@ struct mhap_handle {
   // search scratch
   DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_ovf;
   InvIndex inv{};   // device view of the inverted index in inv_table / inv_ovf
+  mhap_stage_gate gate = nullptr; void* gate_user = nullptr;   // mhap_set_second_stage_gate
   std::vector<mhap_record> out_recs;
 
   // timing
@@ -664,6 +665,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     HIPCHK(h, h->recs.ensure((size_t)ncand * sizeof(DevRecord)));
     // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
     // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
+    if (h->gate && h->gate(h->gate_user) != 0) return fail(h, MHAP_E_STATE, "second-stage gate aborted the search");
     const bool use_join = !lane_only && S <= OJ_MAX_S && overlap_join_lds_bytes(S) <= 64 * 1024;
     unsigned long long nslow = use_join ? 0 : ncand;
     if (use_join) {
@@ -1198,6 +1200,12 @@ int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void
   QuerySide qs{(const int32_t*)d_q_minhash, h->Hrow, (const int32_t*)d_q_ordered, 2LL * S, (const int32_t*)d_q_meta, h->q_ids.as<int64_t>(), ids,
                qlen.data()};
   return search_core(h, qs, ql, to_self != 0, false, sink, user);
+}
+
+int mhap_set_second_stage_gate(mhap_handle* h, mhap_stage_gate gate, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  h->gate = gate; h->gate_user = user;
+  return MHAP_OK;
 }
 
 int mhap_get_stats(mhap_handle* h, mhap_stats* out) { if (!h || !out) return MHAP_E_INVALID; *out = h->stats; return MHAP_OK; }

@@ -13,14 +13,36 @@ import numpy as np
 import torch
 
 
-# ---- query rotation (the N > 1 exchange step) ------------------------------------------------------------------------
+# ---- the N > 1 exchange step: entry-sharded index, forward query sketches exchanged ------------------------------------------
 # Every rank builds the inverted index of its OWN reads only (1/N of the inserts) and keeps its MinHash / ordered tables
-# resident; the forward-strand query sketches of the ranks travel round a ring (rank r sends to r+1, receives from r-1), and
-# each rank runs candidates + second stage for the visiting queries against its shard.  A pair's hit count only involves the
+# resident; what is exchanged are the forward-strand QUERY sketches (half of a rank's table bytes).  Default: one all-gather
+# per table (gather_forward: MinHash rows and meta first, the ordered rows asynchronously while the candidates are computed)
+# and ONE search call per rank.  When HBM is short (or MHAP_BENCH_RING=1) the bundles travel round a ring instead (rank r
+# sends to r+1, receives from r-1: 2 bundles in memory), and each rank searches the visiting bundle against its shard.  A pair's hit count only involves the
 # postings of its stored entry, which all live on that entry's rank, so counts are complete locally; toSelf's id rule
 # (J/impl/MinHashSearch.java:215-219) reports every unordered pair exactly once.  Per rank: 1/N of the index build, N probe
 # passes over small tables, 2 query bundles + its own shard in memory (C5: ~70 GB of the 288), (N-1)/N of the forward
 # tables received point-to-point over xGMI while the previous bundle is being searched.
+
+def gather_forward(rows, world, dist, async_op=False):
+    """All-gather the ranks' forward query rows [n_pad, ...] into [world*n_pad, ...], rank after rank (row o*n_pad + j = forward
+    strand of read j*world + o).  Returns (tensor, work) — work is None unless async_op on the RCCL path."""
+    if world == 1:
+        return rows, None
+    if rows.is_cuda and dist.get_backend() == "nccl":      # RCCL over xGMI
+        out = torch.empty((world * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+        work = dist.all_gather_into_tensor(out.view(world, -1), rows.contiguous().view(1, -1), async_op=async_op)
+        return out, (work if async_op else None)
+    src = rows.contiguous().cpu()                           # gloo (CPU tests; functional multi-rank runs on one GPU)
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src)
+    return torch.cat(parts, 0).to(rows.device), None
+
+
+def all_bundle_ids(n_total, world):
+    """ids of the gathered forward rows (gather_forward's row order)."""
+    return np.concatenate([bundle_ids(n_total, world, o) for o in range(world)])
+
 
 def forward_rows(table):
     """[2*n_pad, ...] per-rank table (entry 2j = forward strand of local read j) -> contiguous [n_pad, ...] forward rows."""

@@ -207,3 +207,10 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank():
     assert r2["records_per_step"] == r1["records_per_step"] and r1["records_per_step"] > 1000
     # order- and shard-independent fingerprint of the record lines: the sharded run emits exactly the single-rank records
     assert r2["records_checksum"] == r1["records_checksum"] and r1["records_sha256_sorted_lines"]
+    # the ring variant of the exchange (query bundles rotate, two in memory) gives the same records
+    ring = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                           "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
+                          capture_output=True, text=True, timeout=900, env=dict(env, MHAP_BENCH_RING="1"))
+    assert ring.returncode == 0, ring.stderr[-3000:]
+    r3 = json.loads([l for l in ring.stdout.strip().split("\n") if l.startswith("{")][-1])
+    assert r3["records_checksum"] == r1["records_checksum"] and r3["records_per_step"] == r1["records_per_step"]
