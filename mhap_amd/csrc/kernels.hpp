@@ -104,7 +104,10 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        unsigned long long* split_count, unsigned long long* elements);
+                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, bool big_tier);
+bool index_query_tiers();   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
+// (two tiers: the first launch appends the queries whose hit set outgrows its 4096-entry LDS table to `big`; a second launch with
+//  big_tier = true re-runs those with a 16384-entry table, one workgroup per CU)
 // Second stage: one lane per candidate.
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,

@@ -154,7 +154,7 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_ovf;
+  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_ovf, inv_big;
   InvIndex inv{};   // device view of the inverted index in inv_table / inv_ovf
   mhap_stage_gate gate = nullptr; void* gate_user = nullptr;   // mhap_set_second_stage_gate
   std::vector<mhap_record> out_recs;
@@ -630,16 +630,31 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       HIPCHK(h, h->cand.ensure(cand_cap * sizeof(Candidate)));
       HIPCHK(h, hipMemsetAsync(ctr, 0, 64, h->stream));
       if (use_index) {
+        HIPCHK(h, h->inv_big.ensure((size_t)nq * 4));
+        const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
+        const bool tiers = index_query_tiers() && !(tv && tv[0] == '1');
         time_begin(h, MHAP_K_INDEX_QUERY);
         launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                           (unsigned long long)cand_cap, ctr + 3, ctr + 4);
+                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers ? h->inv_big.as<int32_t>() : nullptr, ctr + 6, false);
         time_end(h);
         HIPCHK(h, hipGetLastError());
-        unsigned long long c5[5] = {0, 0, 0, 0, 0};
-        HIPCHK(h, hipMemcpyAsync(c5, ctr, 40, hipMemcpyDeviceToHost, h->stream));
+        unsigned long long c5[7] = {0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(c5, ctr, 56, hipMemcpyDeviceToHost, h->stream));
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return rc;
+        if (c5[6] > 0 && c5[0] <= cand_cap) {
+          // queries whose distinct hits outgrew the small LDS table (repeats): second tier with the 16384-entry table
+          time_begin(h, MHAP_K_INDEX_QUERY);
+          launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->inv_big.as<int32_t>(), (int)c5[6],
+                             h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
+                             (unsigned long long)cand_cap, ctr + 3, ctr + 4, nullptr, nullptr, true);
+          time_end(h);
+          HIPCHK(h, hipGetLastError());
+          HIPCHK(h, hipMemcpyAsync(c5, ctr, 56, hipMemcpyDeviceToHost, h->stream));
+          rc = sync_stream(h);
+          if (rc != MHAP_OK) return rc;
+        }
         ncand = c5[0];
         if (ncand <= cand_cap) { h->stats.table_elements += (int64_t)c5[4]; h->stats.index_splits += (int64_t)c5[3]; }
       } else {
@@ -801,7 +816,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_ovf};
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_ovf, &h->inv_big};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->pin_io) (void)hipHostFree(h->pin_io);

@@ -271,17 +271,29 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 constexpr int IQ_THREADS = 128;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
                                   // CU by LDS either way: more probe chains in flight per CU only thrash the memory side)
 constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
+#ifndef MH_IQ_BIG_CT
+#define MH_IQ_BIG_CT 16384
+#endif
+constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = INV_CT_BIG / 32;   // second tier: 128 KB count table, one workgroup per CU
+// Two tiers.  <INV_CT, IQ_THREADS> (32 KB of LDS, four workgroups per CU) takes every query; one whose distinct hits outgrow its
+// table (repeats: thousands of stored entries share a MinHash value with the query) is appended to `big` and re-run by
+// <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in one pass; only beyond that a hit set is split into
+// hash-partition passes.  big == nullptr: split right away.
+template <int INV_CT, int IQ_THREADS>
 __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
                                                           const int32_t* __restrict__ qmeta, SearchParams sp,
                                                           Candidate* __restrict__ cand, unsigned long long* __restrict__ cand_count,
                                                           unsigned long long cand_cap, unsigned long long* __restrict__ split_count,
-                                                          unsigned long long* __restrict__ elements) {
+                                                          unsigned long long* __restrict__ elements, int32_t* __restrict__ big,
+                                                          unsigned long long* __restrict__ big_count) {
   __shared__ uint32_t keys[INV_CT];
   __shared__ uint32_t cnts[INV_CT];
   __shared__ uint32_t s_distinct, s_over, s_top, s_prefix, s_bits;
   __shared__ uint32_t stack[2 * IQ_STACK];
+  __shared__ uint32_t s_nseg[2];
+  __shared__ uint2 seglist[IQ_THREADS];
   __shared__ unsigned long long s_base;
   const int qi = blockIdx.x;
   if (qi >= nq) return;
@@ -296,20 +308,20 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     if (threadIdx.x == 0) {
       if (s_top == 0) s_bits = 0xFFFFFFFFu;
       else { s_top--; s_prefix = stack[2 * s_top]; s_bits = stack[2 * s_top + 1]; }
-      s_distinct = 0; s_over = 0;
+      s_distinct = 0; s_over = 0; s_nseg[0] = 0; s_nseg[1] = 0;
     }
     for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) { keys[j] = 0; cnts[j] = 0; }
     __syncthreads();
     const uint32_t bits = s_bits, prefix = s_prefix;
     if (bits == 0xFFFFFFFFu) break;
-    const uint32_t pmask = bits >= 20 ? 0xFFFFFu : ((1u << bits) - 1u);
+    constexpr int CT_LOG = __builtin_ctz((unsigned)INV_CT), MAX_BITS = 32 - CT_LOG;   // part bits sit above the home-slot bits
+    const uint32_t pmask = bits >= (uint32_t)MAX_BITS ? (0xFFFFFFFFu >> CT_LOG) : ((1u << bits) - 1u);
     unsigned long long mine = 0;
-    const int lane = threadIdx.x & 63;
     // count one hit of stored entry `me` (the id/length rules do not depend on the count: they are applied to the few entries that
     // reach numMinMatches, below, so that the probe loop's only global loads are the index words)
     auto count_hit = [&](int me) {
       const uint32_t hm = inv_hash((uint32_t)me);
-      if (((hm >> 12) & pmask) != prefix) return;
+      if (((hm >> CT_LOG) & pmask) != prefix) return;
       uint32_t slot = hm & (INV_CT - 1);
       for (int tries = 0; tries < INV_CT; tries++) {
         uint32_t k = *(volatile uint32_t*)&keys[slot];
@@ -322,45 +334,71 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         slot = (slot + 1) & (INV_CT - 1);
       }
     };
-    for (int s0 = 0; s0 < sp.H; s0 += IQ_THREADS) {       // workgroup-uniform trip count: the wavefront cooperates on overflow segments below
+    bool handed_over = false;
+    for (int s0 = 0, it = 0; s0 < sp.H; s0 += IQ_THREADS, it++) {   // workgroup-uniform trip count (barriers inside)
       const int s = s0 + (int)threadIdx.x;
-      uint32_t seg_start = 0, seg_len = 0;
       if (s < sp.H) {
         const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
         const unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
         uint32_t pos = inv_hash(v) & ix.cmask;
         int same = 0;
-        for (;;) {
-          const unsigned long long w = T[pos];
-          if (w == 0ULL) break;
-          pos = (pos + 1) & ix.cmask;
-          if ((uint32_t)(w >> 32) != v) continue;
-          same++;
-          if (bits == 0) mine++;                                               // "table elements processed" (:173), counted once
-          count_hit((int)(uint32_t)w - 1);
+        for (bool open = true; open;) {
+          unsigned long long w[4];                                              // four probe words per round trip to memory
+#pragma unroll
+          for (int u = 0; u < 4; u++) w[u] = T[(pos + (uint32_t)u) & ix.cmask];
+          pos = (pos + 4) & ix.cmask;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (!open) break;
+            if (w[u] == 0ULL) { open = false; break; }
+            if ((uint32_t)(w[u] >> 32) != v) continue;
+            same++;
+            if (bits == 0) mine++;                                             // "table elements processed" (:173), counted once
+            count_hit((int)(uint32_t)w[u] - 1);
+          }
         }
         if (same >= INV_RUN_CAP) {
-          // the run holds its cap of this value: the rest of the value's entries are a contiguous segment of the overflow pool
+          // the run holds its cap of this value: the rest of the value's entries are a contiguous segment of the overflow pool,
+          // queued for the whole workgroup (a repeat's segment holds tens of thousands of entries: one wave would stream it alone)
           const uint32_t hp = inv_ovf_slot(ix, (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL, false);
-          if (hp != 0xFFFFFFFFu) { seg_start = ix.ovf_start[hp]; seg_len = ix.ovf_cnt[hp]; }
+          if (hp != 0xFFFFFFFFu) {
+            const uint32_t ln = ix.ovf_cnt[hp];
+            if (ln) { seglist[atomicAdd(&s_nseg[it & 1], 1u)] = make_uint2(ix.ovf_start[hp], ln); if (bits == 0) mine += ln; }
+          }
         }
       }
-      unsigned long long m = __ballot(seg_len > 0);
-      while (m) {                                                               // the whole wavefront streams each segment
-        const int l = __builtin_ctzll(m);
-        m &= m - 1;
-        const uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)seg_start, l), ln = (uint32_t)__builtin_amdgcn_readlane((int)seg_len, l);
-        if (bits == 0 && lane == l) mine += ln;
-        for (uint32_t i = (uint32_t)lane; i < ln; i += 64) count_hit((int)ix.pool[st + i]);
+      __syncthreads();
+      const uint32_t nseg = s_nseg[it & 1];
+      const uint32_t over_now = s_over;
+      if (threadIdx.x == 0) s_nseg[(it + 1) & 1] = 0;
+      __syncthreads();                       // every lane holds the same (nseg, over_now) before anyone counts again
+      if (big != nullptr && over_now) { handed_over = true; break; }            // first tier: the query is handed over, stop counting
+      for (uint32_t g = 0; g < nseg; g++) {
+        const uint2 sg = seglist[g];
+        // four independent pool loads in flight per lane
+        for (uint32_t i = threadIdx.x; i < sg.y; i += IQ_THREADS * 4) {
+          uint32_t e[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) e[u] = i + (uint32_t)IQ_THREADS * u < sg.y ? ix.pool[sg.x + i + (uint32_t)IQ_THREADS * u] : 0xFFFFFFFFu;
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (e[u] != 0xFFFFFFFFu) count_hit((int)e[u]);
+        }
       }
     }
-    if (mine) atomicAdd(elements, mine);
+    (void)handed_over;
     __syncthreads();
+    if (mine && !(s_over && big != nullptr)) atomicAdd(elements, mine);
+    if (s_over && big != nullptr) {
+      // first tier: hand the query to the launch with the large count table (it starts over; nothing was emitted yet)
+      if (threadIdx.x == 0) big[atomicAdd(big_count, 1ULL)] = qe;
+      return;
+    }
     if (s_over) {
       // the part's distinct hits outgrow the count table: split it in two and run both halves (exact; every stored entry
       // belongs to exactly one leaf part)
       if (threadIdx.x == 0) {
-        if (bits < 20 && s_top + 2 <= IQ_STACK) {
+        if (bits < (uint32_t)MAX_BITS && s_top + 2 <= IQ_STACK) {
           stack[2 * s_top] = prefix; stack[2 * s_top + 1] = bits + 1; s_top++;
           stack[2 * s_top] = prefix | (1u << bits); stack[2 * s_top + 1] = bits + 1; s_top++;
         }
@@ -401,13 +439,19 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   }
 }
 
+bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
+
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        unsigned long long* split_count, unsigned long long* elements) {
+                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, bool big_tier) {
   if (nq <= 0) return;
-  hipLaunchKernelGGL(index_query_kernel, dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
-                     meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements);
+  if (!big_tier)
+    hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
+                       meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
+  else
+    hipLaunchKernelGGL((index_query_kernel<INV_CT_BIG, IQ_THREADS_BIG>), dim3((unsigned)nq), dim3(IQ_THREADS_BIG), 0, st, ix, qminhash, qrow_stride, qlist, nq,
+                       ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, nullptr, nullptr);
 }
 
 // =============================================================================================

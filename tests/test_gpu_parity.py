@@ -303,12 +303,18 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     p = MhapParams(num_hashes=16, ordered_sketch_size=32, min_olap_length=50)
     want = O.run_self(fa, H=16, S=32, min_olap_length=50, nthreads=8, cap=1 << 23)
     assert len(want["records"]) > 5_000_000
-    with MinHashSearch(p) as ms:
-        ms.add_data(fa)
-        got = ms.find_matches()
-        st = ms.stats()
-    assert st["index_splits"] > 0 and st["slot_compares"] == 0   # large hit sets were split, nothing went to the brute-force kernel
-    assert np.array_equal(_sorted_records(got), _sorted_records(want["records"]))
+    want_sorted = _sorted_records(want["records"])
+    for tiers, splits in (("2", False), ("1", True)):
+        # default: a hit set that outgrows the 4096-entry table is re-run by the second tier's 16384-entry table (no split at
+        # 3320 distinct hits); first tier alone: it is split into hash-partition passes
+        monkeypatch.setenv("MHAP_INDEX_TIERS", tiers)
+        with MinHashSearch(p) as ms:
+            ms.add_data(fa)
+            got = ms.find_matches()
+            st = ms.stats()
+        assert (st["index_splits"] > 0) == splits and st["slot_compares"] == 0   # nothing went to the brute-force kernel
+        assert np.array_equal(_sorted_records(got), want_sorted)
+    monkeypatch.delenv("MHAP_INDEX_TIERS")
     small = mhap_amd.synth_reads(400, 2500, seed=12, error_rate=0.05)
     p2 = MhapParams(num_hashes=96, ordered_sketch_size=300)
     a, sa = _self_lines(small, p2)
@@ -321,7 +327,7 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
 
 def test_inverted_index_with_a_shared_repeat():
     """5 200 reads that all carry the same 2 kb repeat at H = 512 (the repeat's k-mers win most MinHash slots, so thousands of
-    entries share the value of a slot): insertion stays O(1) per posting (overflow lists), large hit sets are split, records
+    entries share the value of a slot): insertion stays O(1) per posting (overflow lists), large hit sets go to the second query tier, records
     equal the oracle's and the index build time stays bounded."""
     rnd = random.Random(77)
     rep = _rand_seq(rnd, 2000)
@@ -340,7 +346,7 @@ def test_inverted_index_with_a_shared_repeat():
         st, kt = ms.stats(), ms.kernel_times()
     assert np.array_equal(_sorted_records(got), _sorted_records(want["records"]))
     assert st["table_elements"] == want["elements"] and st["candidates_compared"] == want["compared"]
-    assert st["index_splits"] > 0
+    assert st["index_splits"] == 0      # hit sets of 10 400 entries: over the first tier's table, within the second tier's
     assert kt["index_build"]["ms"] < 200.0, kt["index_build"]      # 5.3 M postings; quadratic runs took seconds
 
 
