@@ -553,7 +553,10 @@ constexpr int OJ_JCAP = 128;           // joined k-mers + group records kept per
 constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
 constexpr int OJ_GCAP = 8;             // duplicated-hash groups per pair
 constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
-constexpr int OJ_U = 2;                // 64-entry blocks of the other sketch in flight per wave
+#ifndef MH_OJ_U
+#define MH_OJ_U 3
+#endif
+constexpr int OJ_U = MH_OJ_U;          // 64-entry blocks of the other sketch in flight per wave
 constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN);   // ints per wave besides the query hashes
 
 __device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
