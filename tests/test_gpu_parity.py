@@ -325,6 +325,42 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     assert sa["candidates_compared"] == sb["candidates_compared"]
 
 
+def test_index_query_second_tier_splits_huge_hit_sets(monkeypatch):
+    """14 000 crafted entries that all share the values of two MinHash slots (2 hits < numMinMatches: counted, never a candidate)
+    plus 40 identical entries: every query's hit set holds 14 000 distinct entries — over the second tier's 16384-entry table at
+    its 3/4 fill limit — so it is split into hash-partition passes there; candidates and records equal the all-pairs path's and
+    the processed-elements statistic equals its closed form."""
+    fa = mhap_amd.synth_reads(1, 1500, seed=3, error_rate=0.0)
+    p = MhapParams(num_hashes=16, ordered_sketch_size=32, min_olap_length=50)
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        base = ms.export()
+    n, ncopy = 14000, 40
+    rng = np.random.default_rng(5)
+    mh = rng.integers(-2**31, 2**31, size=(n, 16), dtype=np.int64).astype(np.int32)
+    mh[:, 0] = base["minhash"][0, 0]
+    mh[:, 1] = base["minhash"][0, 1]
+    mh[:ncopy] = base["minhash"][0]
+    for s in range(2, 16):   # the random slots must not collide by accident (the closed form below assumes it)
+        assert len(np.unique(mh[ncopy:, s])) == n - ncopy and base["minhash"][0, s] not in mh[ncopy:, s]
+    sk = {"ids": np.arange(n, dtype=np.int64), "is_fwd": np.ones(n, np.uint8), "seq_length": np.repeat(base["seq_length"][:1], n),
+          "minhash": mh, "ordered": np.repeat(base["ordered"][:1], n, axis=0), "ordered_size": np.repeat(base["ordered_size"][:1], n),
+          "ordered_seqlen": np.repeat(base["ordered_seqlen"][:1], n)}
+    out = {}
+    for mode in ("index", "bruteforce"):
+        if mode == "bruteforce":
+            monkeypatch.setenv("MHAP_CANDIDATES", "bruteforce")
+        with MinHashSearch(p) as ms:
+            ms.add_sketches(sk)
+            out[mode] = (_sorted_records(ms.find_matches()), ms.stats())
+    monkeypatch.delenv("MHAP_CANDIDATES")
+    (ri, si), (rb, sb) = out["index"], out["bruteforce"]
+    assert np.array_equal(ri, rb) and len(ri) == ncopy * (ncopy - 1) // 2
+    assert si["index_splits"] > 0 and si["slot_compares"] == 0 and sb["slot_compares"] > 0
+    assert si["candidates_compared"] == sb["candidates_compared"] == ncopy * (ncopy - 1) // 2
+    assert si["table_elements"] == 2 * n * n + 14 * (ncopy * ncopy + (n - ncopy))
+
+
 def test_inverted_index_with_a_shared_repeat():
     """5 200 reads that all carry the same 2 kb repeat at H = 512 (the repeat's k-mers win most MinHash slots, so thousands of
     entries share the value of a slot): insertion stays O(1) per posting (overflow lists), large hit sets go to the second query tier, records
