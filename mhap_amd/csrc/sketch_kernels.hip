@@ -1281,6 +1281,12 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
 // radix select (11/11/10 bits of hash, then 11/11/10 bits of pos) narrows the S smallest keys down to
 // at most CAP candidates, which are then bitonic-sorted in LDS.
 // =============================================================================================
+#ifdef MH_ORD_PROF
+__device__ unsigned long long g_ord_prof[8];
+#define ORD_TICK(k) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_ord_prof[k], t_ - ord_t0); ord_t0 = t_; } } while (0)
+#else
+#define ORD_TICK(k) do { } while (0)
+#endif
 constexpr uint32_t ORD_BUCKET_MAX = 32;   // keys per first-level bin the bucket path sorts by insertion
 __device__ inline uint64_t okey(int32_t h, int pos) { return ((uint64_t)((uint32_t)h ^ 0x80000000u) << 32) | (uint32_t)pos; }
 
@@ -1302,6 +1308,9 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
   const int64_t strand = blockIdx.x;
   if (strand >= nstrands) return;
+#ifdef MH_ORD_PROF
+  unsigned long long ord_t0 = wall_clock64();
+#endif
   const ReadDesc rd = descs[strand >> 1];
   const int rcs = (int)(strand & 1);
   const int n = rd.length - k2 + 1;
@@ -1320,6 +1329,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
     for (int wj = threadIdx.x; wj < ncw && wj < code_words; wj += ORD_THREADS) codes[wj] = strand_codes16(store + rd.base_off, rd.length, rcs, 16 * wj);
     __syncthreads();
   }
+  ORD_TICK(0);
   auto hget = [&](int i) -> int32_t {
     if (mat) return hp[i];
     const uint32_t cw = codes_at(codes, i);
@@ -1353,16 +1363,44 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
     if (threadIdx.x == 0) { s_fill = 0; s_cnt = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int i0 = threadIdx.x; i0 - (int)threadIdx.x < n; i0 += 8 * ORD_THREADS) {   // wave-uniform trip count: ballots inside
+    // A lane hashes the eight 12-mers p0, p0+4, .., p0+28 (p0 = 32 (thread / 4) + thread % 4 inside the 2048 positions of one
+    // trip): they are made of ten consecutive 4-base groups, and a group's block-mix table entry serves the three 12-mers it
+    // belongs to — 10 table reads + 4 code dwords per eight hashes instead of 24 + 16 (the pass is bound by LDS reads).
+    for (int ib = 0; ib < n; ib += 8 * ORD_THREADS) {   // wave-uniform trip count: ballots inside
+      const int p0 = ib + 32 * (int)(threadIdx.x >> 2) + (int)(threadIdx.x & 3);
       int32_t hv[8];
+      if (mat) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) { const int i = i0 + u * ORD_THREADS; hv[u] = i < n ? hget(i) : 0; }
+        for (int u = 0; u < 8; u++) { const int i = p0 + 4 * u; hv[u] = i < n ? hp[i] : 0; }
+      } else if (p0 < n) {
+        const int d = p0 >> 4;
+        const uint32_t sh = (uint32_t)(2 * (p0 & 15));
+        const uint32_t w0 = codes[d], w1 = codes[d + 1], w2 = codes[d + 2], w3 = codes[d + 3];
+        const uint32_t a[3] = {__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh), __builtin_amdgcn_alignbit(w3, w2, sh)};
+        uint64_t g[10];
+#pragma unroll
+        for (int j = 0; j < 10; j++) g[j] = lut[(a[j >> 2] >> (8 * (j & 3))) & 255u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          uint32_t h = 0;
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const uint64_t kk = g[u + q];
+            h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+            h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+          }
+          h ^= 24u;
+          hv[u] = (int32_t)fmix32(h);
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; u++) hv[u] = 0;
+      }
       unsigned long long bal[8];
       uint32_t total = 0;
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * ORD_THREADS;
-        bal[u] = __ballot(i < n && ((uint32_t)hv[u] ^ 0x80000000u) < cut_u);
+        bal[u] = __ballot(p0 + 4 * u < n && ((uint32_t)hv[u] ^ 0x80000000u) < cut_u);
         total += (uint32_t)__popcll(bal[u]);
       }
       if (total) {   // one queue reservation per wavefront and group of eight
@@ -1373,7 +1411,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
         for (int u = 0; u < 8; u++) {
           if ((bal[u] >> lane) & 1ULL) {
             const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-            if (idx < (uint32_t)cap) { if (stage_wide) stage[idx] = (uint32_t)(i0 + u * ORD_THREADS); else stage16[idx] = (uint16_t)(i0 + u * ORD_THREADS); }
+            if (idx < (uint32_t)cap) { if (stage_wide) stage[idx] = (uint32_t)(p0 + 4 * u); else stage16[idx] = (uint16_t)(p0 + 4 * u); }
             atomicAdd(&hist[((uint32_t)hv[u] ^ 0x80000000u) >> 21], 1u);
           }
           base += (uint32_t)__popcll(bal[u]);
@@ -1381,6 +1419,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       }
     }
     __syncthreads();
+    ORD_TICK(1);
     const uint32_t m = s_fill;
     bool ok = m >= (uint32_t)K && m <= (uint32_t)cap;
     if (ok) {
@@ -1400,6 +1439,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       ok = s_cnt == 0;
       __syncthreads();
     }
+    ORD_TICK(2);
     if (ok) {
       for (uint32_t b = threadIdx.x; b <= cutbin; b += ORD_THREADS) hist[b] = 0;   // becomes the bins' fill counters
       __syncthreads();
@@ -1410,22 +1450,22 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
         buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
       }
       __syncthreads();
-      for (uint32_t b = threadIdx.x; b <= cutbin; b += ORD_THREADS) {   // insertion sort inside a bin (a handful of keys)
-        const uint32_t s0 = bstart[b], c = hist[b];
-        for (uint32_t a = 1; a < c; a++) {
-          const uint64_t key = buf[s0 + a];
-          int q = (int)a - 1;
-          while (q >= 0 && buf[s0 + q] > key) { buf[s0 + q + 1] = buf[s0 + q]; q--; }
-          buf[s0 + q + 1] = key;
-        }
-      }
-      __syncthreads();
+      ORD_TICK(3);
+      // every key finds its rank inside its bin (<= ORD_BUCKET_MAX keys, all reads independent) and goes straight to its place in
+      // the output row: one key per lane instead of one bin per lane walking a serial insertion sort
       int32_t* orow = out_rows + strand * out_stride;
-      for (int j = threadIdx.x; j < K; j += ORD_THREADS) {
-        const uint64_t key = buf[j];
-        orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
-        orow[2 * j + 1] = (int32_t)(uint32_t)key;
+      for (uint32_t t = threadIdx.x; t < m; t += ORD_THREADS) {
+        const uint64_t key = buf[t];
+        const uint32_t b = (uint32_t)(key >> 53), s0 = bstart[b], c = hist[b];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < c; q++) rank += buf[s0 + q] < key ? 1u : 0u;
+        const uint32_t j = s0 + rank;
+        if (j < (uint32_t)K) { orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); orow[2 * j + 1] = (int32_t)(uint32_t)key; }
       }
+      ORD_TICK(5);
+#ifdef MH_ORD_PROF
+      if (threadIdx.x == 0) atomicAdd(&g_ord_prof[7], 1ULL);
+#endif
       return;
     }
     __syncthreads();
@@ -1527,22 +1567,14 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b <= bk_bin; b += ORD_THREADS) {   // insertion sort inside a bin (a handful of keys)
-      const uint32_t s0 = bstart[b], c = hist[b];
-      for (uint32_t a = 1; a < c; a++) {
-        const uint64_t key = buf[s0 + a];
-        int q = (int)a - 1;
-        while (q >= 0 && buf[s0 + q] > key) { buf[s0 + q + 1] = buf[s0 + q]; q--; }
-        buf[s0 + q + 1] = key;
-      }
-    }
-    __syncthreads();
-    (void)bk_total;
     int32_t* orow = out_rows + strand * out_stride;
-    for (int j = threadIdx.x; j < K; j += ORD_THREADS) {
-      const uint64_t key = buf[j];
-      orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u);
-      orow[2 * j + 1] = (int32_t)(uint32_t)key;
+    for (uint32_t t = threadIdx.x; t < bk_total; t += ORD_THREADS) {   // rank inside the bin = place in the row (see the one-pass path)
+      const uint64_t key = buf[t];
+      const uint32_t b = (uint32_t)(key >> 53), s0 = bstart[b], c = hist[b];
+      uint32_t rank = 0;
+      for (uint32_t q = 0; q < c; q++) rank += buf[s0 + q] < key ? 1u : 0u;
+      const uint32_t j = s0 + rank;
+      if (j < (uint32_t)K) { orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); orow[2 * j + 1] = (int32_t)(uint32_t)key; }
     }
     return;
   }
@@ -1608,6 +1640,16 @@ void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int
   const int stage_wide = max_len - k2 + 1 > 65535 ? 1 : 0;
   hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap, code_words, stage_wide), st, descs, nstrands, h32,
                      store, luts, code_words, stage_wide, k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
+#ifdef MH_ORD_PROF
+  (void)hipStreamSynchronize(st);
+  unsigned long long hp[8];
+  (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_ord_prof), sizeof(hp));
+  fprintf(stderr, "[ordered prof] cap %d lds %zu strands(one-pass) %llu  100MHz ticks/strand: stage %.1f pass1 %.1f scan %.1f fill %.1f isort %.1f out %.1f\n", cap,
+          ordered_lds_bytes(cap, code_words, stage_wide), hp[7], (double)hp[0] / hp[7], (double)hp[1] / hp[7], (double)hp[2] / hp[7], (double)hp[3] / hp[7],
+          (double)hp[4] / hp[7], (double)hp[5] / hp[7]);
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ord_prof), z, sizeof(z));
+#endif
 }
 
 }  // namespace mhap
