@@ -761,20 +761,79 @@ constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash 
 //   C[b] = A[b] ^ A[b-4] ^ C[b+35]            b =  4..28   (A[b+35] ^ A[b+31] is C[b+35])
 //   C[b] = A[b] ^ A[b+35]                     b =  0..3
 // = 43 + 64 = 107 full-rate ops (v_xor_b32 / three-input v_bitop3_b32) instead of the 132 two-input xors of the three
-// shifts done one after the other.
+// shifts done one after the other.  Every plane is updated IN PLACE: "C[b] may overwrite A[b] once the other readers of A[b]
+// are done" has one cycle through all 64 planes, which a copy of plane 35 breaks; the order below is the topological sort
+// (tools/gen_bs_step.py derives it and checks it against the 64-bit step).  Eight temporaries and, at the back edge of the
+// slot loop, four v_mov_b32 per step are gone with it.
 __device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 #pragma unroll
   for (int b = 63; b >= 21; b--) P[b] ^= P[b - 21];                       // A
-  uint32_t t[4], u[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { t[k] = bs_xor3(P[29 + k], P[25 + k], P[60 + k]); u[k] = P[k] ^ P[k + 35]; }
-#pragma unroll
-  for (int b = 63; b >= 33; b--) P[b] ^= P[b - 4];
-#pragma unroll
-  for (int b = 28; b >= 4; b--) P[b] = bs_xor3(P[b], P[b - 4], P[b + 35]);
-#pragma unroll
-  for (int k = 0; k < 4; k++) { P[29 + k] = t[k]; P[k] = u[k]; }
+  const uint32_t T = P[35];
+  P[35] ^= P[31];
+  P[31] = bs_xor3(P[31], P[27], P[62]);
+  P[62] ^= P[58];
+  P[58] ^= P[54];
+  P[54] ^= P[50];
+  P[50] ^= P[46];
+  P[46] ^= P[42];
+  P[42] ^= P[38];
+  P[27] = bs_xor3(P[27], P[23], P[62]);
+  P[23] = bs_xor3(P[23], P[19], P[58]);
+  P[19] = bs_xor3(P[19], P[15], P[54]);
+  P[15] = bs_xor3(P[15], P[11], P[50]);
+  P[11] = bs_xor3(P[11], P[7], P[46]);
+  P[7] = bs_xor3(P[7], P[3], P[42]);
+  P[3] ^= P[38];
+  P[38] ^= P[34];
+  P[34] ^= P[30];
+  P[30] = bs_xor3(P[30], P[26], P[61]);
+  P[61] ^= P[57];
+  P[57] ^= P[53];
+  P[53] ^= P[49];
+  P[49] ^= P[45];
+  P[45] ^= P[41];
+  P[41] ^= P[37];
+  P[26] = bs_xor3(P[26], P[22], P[61]);
+  P[22] = bs_xor3(P[22], P[18], P[57]);
+  P[18] = bs_xor3(P[18], P[14], P[53]);
+  P[14] = bs_xor3(P[14], P[10], P[49]);
+  P[10] = bs_xor3(P[10], P[6], P[45]);
+  P[6] = bs_xor3(P[6], P[2], P[41]);
+  P[2] ^= P[37];
+  P[37] ^= P[33];
+  P[33] ^= P[29];
+  P[29] = bs_xor3(P[29], P[25], P[60]);
+  P[60] ^= P[56];
+  P[56] ^= P[52];
+  P[52] ^= P[48];
+  P[48] ^= P[44];
+  P[44] ^= P[40];
+  P[40] ^= P[36];
+  P[25] = bs_xor3(P[25], P[21], P[60]);
+  P[21] = bs_xor3(P[21], P[17], P[56]);
+  P[17] = bs_xor3(P[17], P[13], P[52]);
+  P[13] = bs_xor3(P[13], P[9], P[48]);
+  P[9] = bs_xor3(P[9], P[5], P[44]);
+  P[5] = bs_xor3(P[5], P[1], P[40]);
+  P[1] ^= P[36];
+  P[36] ^= P[32];
+  P[32] = bs_xor3(P[32], P[28], P[63]);
+  P[63] ^= P[59];
+  P[59] ^= P[55];
+  P[55] ^= P[51];
+  P[51] ^= P[47];
+  P[47] ^= P[43];
+  P[43] ^= P[39];
+  P[39] ^= T;
+  P[28] = bs_xor3(P[28], P[24], P[63]);
+  P[24] = bs_xor3(P[24], P[20], P[59]);
+  P[20] = bs_xor3(P[20], P[16], P[55]);
+  P[16] = bs_xor3(P[16], P[12], P[51]);
+  P[12] = bs_xor3(P[12], P[8], P[47]);
+  P[8] = bs_xor3(P[8], P[4], P[43]);
+  P[4] = bs_xor3(P[4], P[0], P[39]);
+  P[0] ^= T;
 }
 
 // filter depth of a slot whose minimum has the high dword bhs: -1 = no negative minimum yet (every active chain is a candidate),
@@ -814,15 +873,24 @@ __device__ __forceinline__ BsEnable bs_enable(int z) {
   return en;
 }
 __device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, const BsEnable& en, int z) {
-  uint32_t n0, n1 = ~ACT;
-  if (BS_ZFIX > 0 && z >= BS_ZFIX) {
-    n0 = ~P[63];
+  uint32_t n0, n1;
+  if (BS_ZFIX == 8 && z >= BS_ZFIX) {
+    // eight magnitude planes in three v_or3_b32 whose results land in fresh registers (no copy of a loop-invariant start value),
+    // the sign plane and the inactive chains folded into one three-input op: n1 = t1 | ~P[63] | ~ACT
+    uint32_t t1;
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(n0) : "v"(P[62]), "v"(P[61]), "v"(P[60]));
+    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(t1) : "v"(P[59]), "v"(P[58]), "v"(P[57]));
+    asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n0) : "v"(P[56]), "v"(P[55]));
+    n1 = __builtin_amdgcn_bitop3_b32(t1, P[63], ~ACT, 0xFB);
+  } else if (BS_ZFIX > 0 && z >= BS_ZFIX) {
+    n0 = ~P[63]; n1 = ~ACT;
 #pragma unroll
     for (int b = 1; b + 1 <= BS_ZFIX; b += 4) {
       asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n0) : "v"(P[63 - b]), "v"(P[62 - b]));
       asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n1) : "v"(P[61 - b]), "v"(P[60 - b]));
     }
   } else {
+    n1 = ~ACT;
     n0 = ~P[63] & en.w[0];                       // z < 0 (all words 0): every active chain is a candidate
 #pragma unroll
     for (int b = 1; b <= BS_ZFIX; b++) n0 |= P[63 - b] & en.w[b];
@@ -1458,7 +1526,13 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
         const uint64_t key = buf[t];
         const uint32_t b = (uint32_t)(key >> 53), s0 = bstart[b], c = hist[b];
         uint32_t rank = 0;
-        for (uint32_t q = 0; q < c; q++) rank += buf[s0 + q] < key ? 1u : 0u;
+        for (uint32_t q = 0; q < c; q += 4) {   // four independent reads per trip (the bin's slice is followed by valid buffer words)
+          uint64_t o[4];
+#pragma unroll
+          for (int x = 0; x < 4; x++) o[x] = buf[s0 + q + (uint32_t)x < (uint32_t)cap ? s0 + q + (uint32_t)x : s0];
+#pragma unroll
+          for (int x = 0; x < 4; x++) rank += (q + (uint32_t)x < c && o[x] < key) ? 1u : 0u;
+        }
         const uint32_t j = s0 + rank;
         if (j < (uint32_t)K) { orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); orow[2 * j + 1] = (int32_t)(uint32_t)key; }
       }
@@ -1572,7 +1646,13 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
       const uint64_t key = buf[t];
       const uint32_t b = (uint32_t)(key >> 53), s0 = bstart[b], c = hist[b];
       uint32_t rank = 0;
-      for (uint32_t q = 0; q < c; q++) rank += buf[s0 + q] < key ? 1u : 0u;
+      for (uint32_t q = 0; q < c; q += 4) {   // four independent reads per trip (the bin's slice is followed by valid buffer words)
+        uint64_t o[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++) o[x] = buf[s0 + q + (uint32_t)x < (uint32_t)cap ? s0 + q + (uint32_t)x : s0];
+#pragma unroll
+        for (int x = 0; x < 4; x++) rank += (q + (uint32_t)x < c && o[x] < key) ? 1u : 0u;
+      }
       const uint32_t j = s0 + rank;
       if (j < (uint32_t)K) { orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); orow[2 * j + 1] = (int32_t)(uint32_t)key; }
     }
