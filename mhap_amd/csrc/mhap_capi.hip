@@ -309,7 +309,10 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
 // issue slots and LDS, so it was removed.)
 static uint64_t inv_capacity(int64_t ne) {
   uint64_t cap = 1024;
-  while (cap < 4ull * (uint64_t)ne) cap <<= 1;   // load factor <= 0.25: short probe chains (a wave walks the longest chain of its 64 lanes)
+#ifndef MH_INV_SLOTS_PER_ENTRY
+#define MH_INV_SLOTS_PER_ENTRY 4
+#endif
+  while (cap < (uint64_t)MH_INV_SLOTS_PER_ENTRY * (uint64_t)ne) cap <<= 1;   // load factor <= 0.25: short probe chains (a wave walks the longest chain of its 64 lanes)
   return cap;
 }
 

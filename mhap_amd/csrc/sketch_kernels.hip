@@ -90,12 +90,18 @@ __device__ __forceinline__ uint32_t strand_window16(const uint32_t* __restrict__
   return x;
 }
 // murmur3_x64_128(seed 0).h1 of the 16-mer / murmur3_x86_32(seed 0) of the 12-mer that start the 16 codes cw
+__device__ __forceinline__ uint64_t mul5(uint64_t x) {
+  uint64_t r;
+  asm("v_lshl_add_u64 %0, %1, 2, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 __device__ __forceinline__ uint64_t lut_key16(const uint64_t* lut, uint32_t cw) {
   uint64_t h1 = 0, h2 = 0;
-  h1 ^= lut[cw & 255u];                 h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-  h2 ^= lut[256 + ((cw >> 8) & 255u)];  h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
-  h1 ^= lut[(cw >> 16) & 255u];         h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
-  h2 ^= lut[256 + (cw >> 24)];          h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  // (x * 5 as shift + add: v_lshl_add_u64 runs at full rate, the 64-bit multiply is three quarter-rate ops)
+  h1 ^= lut[cw & 255u];                 h1 = rotl64(h1, 27); h1 += h2; h1 = mul5(h1) + 0x52dce729;
+  h2 ^= lut[256 + ((cw >> 8) & 255u)];  h2 = rotl64(h2, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5;
+  h1 ^= lut[(cw >> 16) & 255u];         h1 = rotl64(h1, 27); h1 += h2; h1 = mul5(h1) + 0x52dce729;
+  h2 ^= lut[256 + (cw >> 24)];          h2 = rotl64(h2, 31); h2 += h1; h2 = mul5(h2) + 0x38495ab5;
   h1 ^= 32ULL; h2 ^= 32ULL;
   h1 += h2; h2 += h1;
   h1 = fmix64(h1); h2 = fmix64(h2);
