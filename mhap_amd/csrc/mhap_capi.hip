@@ -113,6 +113,8 @@ struct mhap_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;      // eager inverted-index build next to the ordered-sketch kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
+  hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
   // inverted index state: the table in inv_table covers entries [0, inv_ne) with mask inv_cmask when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0; uint32_t inv_cmask = 0;
   bool inv_finalized = false;   // the overflow postings of the table in place have been laid out (launch_index_finalize)
@@ -460,9 +462,18 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     int per_cu = 8;
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
-    launch_minhash(h->stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(), h->info.as<StrandInfo>(),
+    // The strands with weighted k-mers are a second launch (own instantiation).  On the same stream a handful of such strands (C2:
+    // under 1 %) hold the GPU for one strand's duration (3 ms) after the weight-1 launch has drained; on a second stream their
+    // workgroups move into the slots the weight-1 launch frees while it drains (measured: the tail shrinks from 3 to 2 ms).  The
+    // other way round — weighted launch first in line, weight-1 launch on the second stream — costs 8 ms: the weighted launch's full
+    // grid takes every slot before most of its workgroups find their list empty.
+    HIPCHK(h, hipEventRecord(h->ev_mh_fork, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->mh_stream, h->ev_mh_fork, 0));
+    launch_minhash(h->stream, h->mh_stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(), h->info.as<StrandInfo>(),
                    h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride, meta_rows + 3, META_W,
                    h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>());
+    HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
     time_end(h);
     DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
@@ -784,7 +795,9 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { seterr(hipGetErrorString(e)); delete h; return MHAP_E_HIP; }
   h->stream = h->own_stream;
   if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { seterr("cannot create the side stream"); mhap_destroy(h); return MHAP_E_HIP; }
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->mh_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_mh_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_mh_join, hipEventDisableTiming) != hipSuccess) { seterr("cannot create the side streams"); mhap_destroy(h); return MHAP_E_HIP; }
   h->Hrow = std::max(1, P.num_hashes);
   int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
   h->ord_cap = cap;
@@ -826,6 +839,9 @@ void mhap_destroy(mhap_handle* h) {
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  if (h->ev_mh_fork) (void)hipEventDestroy(h->ev_mh_fork);
+  if (h->ev_mh_join) (void)hipEventDestroy(h->ev_mh_join);
+  if (h->mh_stream) (void)hipStreamDestroy(h->mh_stream);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }

@@ -1292,7 +1292,7 @@ void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
 }
 
 // MHAP_MINHASH=perchain selects the kernel without bit-sliced rows (A/B measurements)
-void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
                     const uint64_t* jump, int jump_na, const int32_t* slist) {
@@ -1336,15 +1336,16 @@ void launch_minhash(hipStream_t st, int nblocks, const ReadDesc* descs, int64_t 
     return;
   }
   if (perchain) {
+    hipLaunchKernelGGL((minhash_kernel<MH_U, false, true>), dim3(nblocks), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
                        counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
-    hipLaunchKernelGGL((minhash_kernel<MH_U, false, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
   } else {
+    // (weighted strands first and on their own stream — the caller orders st_weighted after the weight kernel and st after it again)
+    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
     hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
                        counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
   }
 }
 
