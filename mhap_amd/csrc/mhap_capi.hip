@@ -458,20 +458,22 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
                         h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), d_order, h->slist.as<int32_t>());
     time_end(h);
     DBGSYNC(h, "kmer_weights");
-    time_begin(h, MHAP_K_MINHASH);
     int per_cu = 8;
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
     // The strands with weighted k-mers are a second launch (own instantiation).  On the same stream a handful of such strands (C2:
-    // under 1 %) hold the GPU for one strand's duration (3 ms) after the weight-1 launch has drained; on a second stream their
-    // workgroups move into the slots the weight-1 launch frees while it drains (measured: the tail shrinks from 3 to 2 ms).  The
-    // other way round — weighted launch first in line, weight-1 launch on the second stream — costs 8 ms: the weighted launch's full
-    // grid takes every slot before most of its workgroups find their list empty.
-    HIPCHK(h, hipEventRecord(h->ev_mh_fork, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->mh_stream, h->ev_mh_fork, 0));
-    launch_minhash(h->stream, h->mh_stream, mblocks, dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(), h->info.as<StrandInfo>(),
-                   h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride, meta_rows + 3, META_W,
-                   h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>());
+    // under 1 %) hold the GPU for one strand's duration (3 ms) after the weight-1 launch has drained.  So the two list lengths are
+    // read back (one 16-byte copy: the weight kernel has to be complete anyway), each launch gets only the workgroups its list
+    // can feed, and the weighted one goes first, on its own stream: its few workgroups take their slots, the weight-1 launch fills
+    // the rest of the GPU.  (Full grids side by side do not work: whichever launch is first in line takes every slot before most of
+    // its workgroups find their list empty, +8 ms; the weighted launch second in line only moves into the draining tail, -1 ms.)
+    unsigned long long lens[2] = {0, 0};
+    HIPCHK(h, hipMemcpyAsync(lens, ctr + 4, 16, hipMemcpyDeviceToHost, h->stream));
+    { const int rs = sync_stream(h); if (rs != MHAP_OK) return rs; }
+    time_begin(h, MHAP_K_MINHASH);
+    launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
+                   h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
+                   meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>());
     HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
     time_end(h);

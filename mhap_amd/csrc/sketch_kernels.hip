@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "kernels.hpp"
+#include <algorithm>
 
 namespace mhap {
 
@@ -1292,7 +1293,7 @@ void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
 }
 
 // MHAP_MINHASH=perchain selects the kernel without bit-sliced rows (A/B measurements)
-void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
                     const uint64_t* jump, int jump_na, const int32_t* slist) {
@@ -1341,11 +1342,18 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, const 
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
                        counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
   } else {
-    // (weighted strands first and on their own stream — the caller orders st_weighted after the weight kernel and st after it again)
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nblocks), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
-    hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
+    // n_unweighted / n_weighted >= 0: the lengths of the two work lists (the caller read them back): each launch gets only the
+    // workgroups its list can feed, the weighted one first, on its own stream — its few workgroups take their slots, the weight-1
+    // launch fills the rest of the GPU, and nothing is left to run alone at the end.  < 0: unknown, full grids.
+    const int waves_wg = (int)block.x / 64;
+    const int nb_w = n_weighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, (n_weighted + waves_wg - 1) / waves_wg);
+    const int nb_u = n_unweighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, (n_unweighted + waves_wg - 1) / waves_wg);
+    if (nb_w > 0)
+      hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nb_w), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
+    if (nb_u > 0)
+      hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nb_u), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                         counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
   }
 }
 
