@@ -113,6 +113,7 @@ struct mhap_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;      // eager inverted-index build next to the ordered-sketch kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int oj_per_cu = 0, oj_per_cu_S = -1;    // resident join-kernel workgroups per CU at ordered sketch size oj_per_cu_S
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
   // inverted index state: the table in inv_table covers entries [0, inv_ne) with mask inv_cmask when inv_ready
@@ -703,11 +704,12 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
       const int chunk = 8;
       const int64_t want = ((int64_t)ncand + 2LL * chunk - 1) / (2LL * chunk);
-      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * 9, want));
+      if (h->oj_per_cu_S != S) { h->oj_per_cu = overlap_join_blocks_per_cu(S); h->oj_per_cu_S = S; }
+      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * h->oj_per_cu, want));
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap_join(h->stream, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                           qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,
-                          (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5);
+                          (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7);
       time_end(h);
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipMemcpyAsync(&nslow, ctr + 5, 8, hipMemcpyDeviceToHost, h->stream));

@@ -548,10 +548,16 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
 // literally on the group's few entries (oj_group_merge etc., wave-uniform), and its records join the others.  Pairs
 // beyond the caps below (joined k-mers, groups, group length) are appended to `slow` for overlap_kernel's literal merge.
 // =============================================================================================
-constexpr int OJ_WAVES = 2;
+#ifndef MH_OJ_WAVES
+#define MH_OJ_WAVES 2
+#endif
+constexpr int OJ_WAVES = MH_OJ_WAVES;
 constexpr int OJ_JCAP = 128;           // joined k-mers + group records kept per pair
 constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
-constexpr int OJ_GCAP = 8;             // duplicated-hash groups per pair
+#ifndef MH_OJ_GCAP
+#define MH_OJ_GCAP 12
+#endif
+constexpr int OJ_GCAP = MH_OJ_GCAP;    // duplicated-hash groups per pair
 constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
 #ifndef MH_OJ_U
 #define MH_OJ_U 3
@@ -724,7 +730,8 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
                                                                      const double* __restrict__ score_table, DevRecord* __restrict__ recs,
                                                                      unsigned long long* __restrict__ rec_count, unsigned long long rec_cap,
                                                                      unsigned long long* __restrict__ compared, Candidate* __restrict__ slow,
-                                                                     unsigned long long* __restrict__ slow_count, int chunk) {
+                                                                     unsigned long long* __restrict__ slow_count, int chunk,
+                                                                     unsigned long long* __restrict__ work) {
   extern __shared__ int32_t oj_lds[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int32_t* ah = oj_lds + (size_t)wv * ((size_t)sp.S + OJ_LDS_EXTRA);   // the query sketch's hashes
@@ -737,11 +744,17 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
   int32_t* gpb = gpa + OJ_GCAP * OJ_GLEN;                              // ... and in the other sketch
   unsigned long long n = *cand_count;
   if (n > cand_cap) n = cand_cap;
-  const unsigned long long W = (unsigned long long)gridDim.x * OJ_WAVES, w = (unsigned long long)blockIdx.x * OJ_WAVES + wv;
   int curq = -1, nA = 0, len1 = 0;
   const int32_t* qrow = nullptr;
   unsigned long long mine = 0;
-  for (unsigned long long c0 = w * (unsigned long long)chunk; c0 < n; c0 += W * (unsigned long long)chunk) {
+  // chunks of consecutive candidates (one query's candidates are contiguous) are pulled from a counter: a static split makes the
+  // launch's duration depend on every workgroup of the grid being resident at once (one more per CU than fit = a second round)
+  for (;;) {
+    unsigned long long c0 = 0;
+    if (lane == 0) c0 = atomicAdd(work, (unsigned long long)chunk);
+    c0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c0 >> 32)) << 32) |
+         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c0);
+    if (c0 >= n) break;
     const unsigned long long c1 = c0 + (unsigned long long)chunk < n ? c0 + (unsigned long long)chunk : n;
     for (unsigned long long c = c0; c < c1; c++) {
       Candidate cd = cand[c];   // wave-uniform values are pinned to SGPRs: loop bounds and branches below become scalar
@@ -1052,13 +1065,21 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
 }
 
 size_t overlap_join_lds_bytes(int S) { return (size_t)OJ_WAVES * ((size_t)S + OJ_LDS_EXTRA) * 4; }
+// workgroups of the join kernel one CU holds at this sketch size (the launch is a persistent grid with a static split of the
+// candidates: one workgroup more per CU than fit would run as a second round)
+int overlap_join_blocks_per_cu(int S) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel, 64 * OJ_WAVES, overlap_join_lds_bytes(S)) != hipSuccess || n < 1) n = 1;
+  return n;
+}
 
 void launch_overlap_join(hipStream_t st, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                          const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
                          const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs, unsigned long long* rec_count,
-                         unsigned long long rec_cap, unsigned long long* compared, Candidate* slow, unsigned long long* slow_count) {
+                         unsigned long long rec_cap, unsigned long long* compared, Candidate* slow, unsigned long long* slow_count,
+                         unsigned long long* work) {
   hipLaunchKernelGGL(overlap_join_kernel, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S), st, cand, cand_count, cand_cap, ordered,
-                     ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk);
+                     ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk, work);
 }
 
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
