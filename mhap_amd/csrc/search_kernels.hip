@@ -184,7 +184,7 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // Work ~ N*H probes + hits instead of N*2N*H/2 compares.
 //
 // Repeats (the reference keeps value -> ArrayList, :123-141): a value shared by n entries would cost n^2/2 CAS probes to
-// insert into one run, so a run holds at most ~INV_RUN_CAP (64) entries of one value; further entries of that value are counted
+// insert into one run, so a run holds at most ~INV_RUN_CAP (16) entries of one value; further entries of that value are counted
 // per (slot, value) in a second hash table and appended to a temporary list — O(1) per insert however popular the value —
 // and index_finalize lays them out contiguously per value (segment from a bump allocator, fill with one atomic each): the
 // reference's value -> postings list as CSR.  A query that finds INV_RUN_CAP entries of its value in the run has its whole
@@ -193,7 +193,12 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // every part fits), which bounds its cost by its own postings.
 // =============================================================================================
 __device__ inline uint32_t inv_hash(uint32_t v) { return fmix32(v); }
-constexpr int INV_RUN_CAP = 64;   // a run absorbs the values ordinary coverage shares (30x: a few dozen entries); beyond that a value is a repeat
+#ifndef MH_INV_RUN_CAP
+#define MH_INV_RUN_CAP 16
+#endif
+constexpr int INV_RUN_CAP = MH_INV_RUN_CAP;   // a run absorbs the values ordinary coverage shares (30x with 15 % errors: a handful of entries); beyond that a value is a repeat.
+                                               // Measured with 64 / 32 / 16 / 8: C2 and the C4 slice unchanged, C5 slice query 89.7 / 82.1 / 78.2 / 77.3 ms and build 14.3 / 11.0 / 8.8 / 8.6 ms
+                                               // (long runs are walked by ONE lane, and they grow the clusters every other probe has to cross)
 
 __device__ inline uint32_t inv_ovf_slot(const InvIndex& ix, unsigned long long key, bool claim) {
   uint32_t hp = (uint32_t)fmix64(key) & ix.ovf_mask;
@@ -294,6 +299,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   __shared__ uint32_t stack[2 * IQ_STACK];
   __shared__ uint32_t s_nseg[2];
   __shared__ uint2 seglist[IQ_THREADS];
+  __shared__ uint32_t segpre[IQ_THREADS + 1];
+  __shared__ uint32_t wsum[IQ_THREADS / 64];
   __shared__ unsigned long long s_base;
   const int qi = blockIdx.x;
   if (qi >= nq) return;
@@ -342,7 +349,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         const unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
         uint32_t pos = inv_hash(v) & ix.cmask;
         int same = 0;
-        for (bool open = true; open;) {
+        bool open = true;
+        {
           unsigned long long w[4];                                              // four probe words per round trip to memory
 #pragma unroll
           for (int u = 0; u < 4; u++) w[u] = T[(pos + (uint32_t)u) & ix.cmask];
@@ -354,6 +362,22 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
             if ((uint32_t)(w[u] >> 32) != v) continue;
             same++;
             if (bits == 0) mine++;                                             // "table elements processed" (:173), counted once
+            count_hit((int)(uint32_t)w[u] - 1);
+          }
+        }
+        while (open) {                                                          // a run that goes on (a value many entries share): 16 words per trip
+          if (big != nullptr && *(volatile uint32_t*)&s_over) break;            // first tier, table already overflowed: the query starts over in the second
+          unsigned long long w[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) w[u] = T[(pos + (uint32_t)u) & ix.cmask];
+          pos = (pos + 16) & ix.cmask;
+#pragma unroll
+          for (int u = 0; u < 16; u++) {
+            if (!open) break;
+            if (w[u] == 0ULL) { open = false; break; }
+            if ((uint32_t)(w[u] >> 32) != v) continue;
+            same++;
+            if (bits == 0) mine++;
             count_hit((int)(uint32_t)w[u] - 1);
           }
         }
@@ -373,15 +397,37 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       if (threadIdx.x == 0) s_nseg[(it + 1) & 1] = 0;
       __syncthreads();                       // every lane holds the same (nseg, over_now) before anyone counts again
       if (big != nullptr && over_now) { handed_over = true; break; }            // first tier: the query is handed over, stop counting
-      for (uint32_t g = 0; g < nseg; g++) {
-        const uint2 sg = seglist[g];
-        // four independent pool loads in flight per lane
-        for (uint32_t i = threadIdx.x; i < sg.y; i += IQ_THREADS * 4) {
-          uint32_t e[4];
+      if (nseg) {
+        // all queued segments as ONE index space (exclusive prefix of their lengths in segpre): a trip of the loop below has
+        // 8 x IQ_THREADS pool loads in flight whatever the segments' lengths — one segment per trip cost a memory round trip per
+        // segment, and repeat-rich queries queue a hundred short ones
+        uint32_t len = threadIdx.x < nseg ? seglist[threadIdx.x].y : 0u, incl = len;
 #pragma unroll
-          for (int u = 0; u < 4; u++) e[u] = i + (uint32_t)IQ_THREADS * u < sg.y ? ix.pool[sg.x + i + (uint32_t)IQ_THREADS * u] : 0xFFFFFFFFu;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, total = 0;
+        for (unsigned w = 0; w < IQ_THREADS / 64; w++) { const uint32_t t = wsum[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
+        if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
+        if (threadIdx.x == 0) segpre[nseg] = total;
+        __syncthreads();
+        // first tier: segments that hold more than four tables' worth of postings between them (a repeat) will outgrow this table —
+        // hand the query over before streaming them
+        if (big != nullptr && total > 4u * (uint32_t)INV_CT) { if (threadIdx.x == 0) s_over = 1; handed_over = true; break; }
+        uint32_t g = 0;   // segment of this lane's current element (its elements come in ascending order)
+        for (uint32_t i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
+          uint32_t e[8];
 #pragma unroll
-          for (int u = 0; u < 4; u++)
+          for (int u = 0; u < 8; u++) {
+            const uint32_t i = i0 + (uint32_t)IQ_THREADS * u;
+            e[u] = 0xFFFFFFFFu;
+            if (i < total) {
+              while (i >= segpre[g + 1]) g++;
+              e[u] = ix.pool[seglist[g].x + (i - segpre[g])];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
             if (e[u] != 0xFFFFFFFFu) count_hit((int)e[u]);
         }
       }
