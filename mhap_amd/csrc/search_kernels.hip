@@ -279,7 +279,10 @@ constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query who
 #ifndef MH_IQ_BIG_CT
 #define MH_IQ_BIG_CT 16384
 #endif
-constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = INV_CT_BIG / 32;   // second tier: 128 KB count table, one workgroup per CU
+#ifndef MH_IQ_BIG_THREADS
+#define MH_IQ_BIG_THREADS 1024   // 512 / 1024 lanes: 79.0 / 62.8 ms on the C5 slice (one workgroup per CU: more wavefronts hide more of the pool-load and LDS-probe latency)
+#endif
+constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = MH_IQ_BIG_THREADS;   // second tier: 128 KB count table, one workgroup per CU
 // Two tiers.  <INV_CT, IQ_THREADS> (32 KB of LDS, four workgroups per CU) takes every query; one whose distinct hits outgrow its
 // table (repeats: thousands of stored entries share a MinHash value with the query) is appended to `big` and re-run by
 // <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in one pass; only beyond that a hit set is split into
