@@ -97,6 +97,7 @@ struct InvIndex {
   unsigned long long* table; uint32_t cmask;
   unsigned long long* ovf_keys; uint32_t* ovf_cnt; uint32_t* ovf_start; uint32_t* ovf_fill; uint32_t ovf_mask;
   uint2* tmp; uint32_t* pool; unsigned long long* counters;   // counters[0]: tmp items, counters[1]: pool words allocated
+  uint32_t ne;   // entries the tables were sized for (an upper bound of any query's distinct hits)
   uint32_t tmp_cap;
 };
 void launch_index_finalize(hipStream_t st, const InvIndex& ix, unsigned long long n_tmp);

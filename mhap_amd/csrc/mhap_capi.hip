@@ -346,6 +346,7 @@ static int inv_reset(mhap_handle* h, int64_t ne, hipStream_t st) {
   h->inv.tmp = (uint2*)(o + 64 + (size_t)oslots * 20);
   h->inv.pool = (uint32_t*)(o + 64 + (size_t)oslots * 20 + (size_t)tmp_cap * 8);
   h->inv.tmp_cap = (uint32_t)tmp_cap;
+  h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
   h->inv_finalized = false;
   return MHAP_OK;
 }

@@ -417,6 +417,10 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         // first tier: segments that hold more than four tables' worth of postings between them (a repeat) will outgrow this table —
         // hand the query over before streaming them
         if (big != nullptr && total > 4u * (uint32_t)INV_CT) { if (threadIdx.x == 0) s_over = 1; handed_over = true; break; }
+        // second tier, whole index, every slot probed: segments with more than twice the table's capacity between them (and an
+        // index with that many entries) are split before they are streamed: the pass would overflow after streaming everything
+        // (its elements are already counted)
+        if (big == nullptr && bits == 0 && s0 + IQ_THREADS >= sp.H && (total < ix.ne ? total : ix.ne) > 2u * ((uint32_t)INV_CT * 3u / 4u)) { if (threadIdx.x == 0) s_over = 1; break; }
         uint32_t g = 0;   // segment of this lane's current element (its elements come in ascending order)
         for (uint32_t i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
           uint32_t e[8];
