@@ -474,6 +474,24 @@ def test_fused_and_separate_kmer_hashing_agree(monkeypatch):
         assert np.array_equal(a[key], b[key]), key
 
 
+def test_perchain_minhash_switch_agrees(monkeypatch):
+    """MHAP_MINHASH=perchain (every row in 64-bit registers, both launches) gives the bit-sliced rows' sketches — weight-1 strands
+    and strands with repeated k-mers (second launch, own stream) alike."""
+    rnd = random.Random(123)
+    unit = _rand_seq(rnd, 150)
+    seqs = [_rand_seq(rnd, rnd.randrange(300, 7000)) for _ in range(40)] + [unit * 12 + _rand_seq(rnd, 2500) for _ in range(6)]
+    fa = FastaData.from_strings(seqs)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=256)
+    _assert_sketch_parity(fa, p)
+    with MinHashSearch(p) as ms:
+        a = ms.sketch(fa)
+    monkeypatch.setenv("MHAP_MINHASH", "perchain")
+    with MinHashSearch(p) as ms:
+        b = ms.sketch(fa)
+    for key in ("minhash", "ordered", "ordered_size", "status"):
+        assert np.array_equal(a[key], b[key]), key
+
+
 def test_index_table_reuse_and_incremental_adds():
     """The inverted index of a fresh add is built while its reads are sketched and reused by later searches; an index that
     grows by a second add is rebuilt at search time.  Both give the one-shot result."""
