@@ -361,3 +361,20 @@ def test_jni_shim_and_java_class_agree():
     r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(root, "tests", "jni_stub"), "-I", os.path.join(root, "include"),
                         os.path.join(root, "jni", "mhap_jni.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_bit_sliced_step_order_matches_its_generator():
+    """bs_step() in sketch_kernels.hip is generated: tools/gen_bs_step.py derives the in-place evaluation order (topological sort,
+    one saved plane), checks it against the 64-bit xorshift step on random values, and prints the statements.  The kernel source
+    must hold exactly those statements."""
+    pytest.importorskip("networkx")
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_bs_step.py")], capture_output=True, text=True, check=True).stdout
+    stmts = [ln.strip() for ln in gen.splitlines() if ln.strip()]
+    assert len(stmts) == 65 and stmts[0] == "const uint32_t T = P[35];"
+    src = open(os.path.join(root, "mhap_amd", "csrc", "sketch_kernels.hip")).read()
+    body = src[src.index("__device__ __forceinline__ void bs_step("):]
+    body = body[:body.index("\n}\n")]
+    have = [ln.strip() for ln in body.splitlines() if ln.strip().startswith(("const uint32_t T", "P["))]
+    assert have == stmts
