@@ -30,6 +30,25 @@ int fmt6(double v, char* out, size_t cap) {
   if (std::isinf(v)) return snprintf(out, cap, v > 0 ? "Infinity" : "-Infinity");
   const bool neg = std::signbit(v);
   const double a = std::fabs(v);
+  // Fast path (every record pays for two of these): unless the value sits within 10^-9 of a HALF_UP tie at the sixth decimal, the
+  // shortest round-trip digits (which differ from the exact value by < 1 ulp) round like the exact value, so a multiply and a floor
+  // decide.  Ties and huge values take the digit-string path below.
+  if (a < 1e9) {
+    const double x = a * 1e6, fl = std::floor(x), frac = x - fl;
+    if (std::fabs(frac - 0.5) > 1e-3) {
+      unsigned long long q = (unsigned long long)fl + (frac > 0.5 ? 1ULL : 0ULL);
+      char tmp[40];
+      int n = 0;
+      for (int i = 0; i < 6; i++) { tmp[n++] = (char)('0' + q % 10); q /= 10; }
+      tmp[n++] = '.';
+      do { tmp[n++] = (char)('0' + q % 10); q /= 10; } while (q);
+      if (neg) tmp[n++] = '-';
+      if ((size_t)n + 1 > cap) return -1;
+      for (int i = 0; i < n; i++) out[i] = tmp[n - 1 - i];
+      out[n] = 0;
+      return n;
+    }
+  }
   // shortest digit string d1.d2...dn x 10^e that parses back to a
   char sci[40];
   int nd = 1;
@@ -84,11 +103,30 @@ extern "C" {
 int mhap_format_record(const mhap_record* r, char* out, size_t cap) {
   if (!r || !out || cap == 0) return -1;
   const double score = r->score > 1.0 ? 1.0 : r->score;            // MatchResult.java:61-64
-  char e[48], s[48];
-  fmt6(1.0 - score, e, sizeof e);
-  fmt6(r->raw, s, sizeof s);
-  return snprintf(out, cap, "%lld %lld %s %s %d %d %d %d %d %d %d %d", (long long)r->from_id, (long long)r->to_id, e, s, 0, r->a1, r->a2,
-                  r->alen, r->to_rc ? 1 : 0, r->b1, r->b2, r->blen);   // MatchResult.java:98-113
+  // "%d %d %f %f %d %d %d %d %d %d %d %d" (MatchResult.java:98-113), digits written by hand: a snprintf of twelve fields costs more
+  // than the GPU spends on the record
+  char buf[320];
+  char* p = buf;
+  auto put = [&p](long long v) {
+    char t[24];
+    int n = 0;
+    unsigned long long u = v < 0 ? 0ULL - (unsigned long long)v : (unsigned long long)v;
+    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *p++ = '-';
+    while (n) *p++ = t[--n];
+  };
+  put((long long)r->from_id); *p++ = ' ';
+  put((long long)r->to_id); *p++ = ' ';
+  int k = fmt6(1.0 - score, p, 64); if (k < 0) return -1; p += k; *p++ = ' ';
+  k = fmt6(r->raw, p, 64); if (k < 0) return -1; p += k; *p++ = ' ';
+  *p++ = '0'; *p++ = ' ';
+  put(r->a1); *p++ = ' '; put(r->a2); *p++ = ' '; put(r->alen); *p++ = ' ';
+  *p++ = r->to_rc ? '1' : '0'; *p++ = ' ';
+  put(r->b1); *p++ = ' '; put(r->b2); *p++ = ' '; put(r->blen);
+  const size_t len = (size_t)(p - buf);
+  if (len + 1 > cap) { if (cap) { memcpy(out, buf, cap - 1); out[cap - 1] = 0; } return (int)len; }   // snprintf semantics: truncated, full length returned
+  memcpy(out, buf, len); out[len] = 0;
+  return (int)len;
 }
 
 // FastaData.enqueueNextSequenceInFile (J/impl/FastaData.java:125-204).  Deviation (documented in DESIGN.md):

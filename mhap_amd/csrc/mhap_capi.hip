@@ -915,14 +915,12 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
   (void)hipSetDevice(h->device);
   if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
   for (int64_t i = 0; i < n; i++) if (lengths[i] < 0) return fail(h, MHAP_E_INVALID, "negative read length");
-  int rc = ensure_index_capacity(h, h->n_entries + 2 * n);
+  // = mhap_stage_reads + mhap_index_add_staged (a fresh index is filled while its reads are being sketched), staging released afterwards
+  int rc = mhap_stage_reads(h, bases, offsets, lengths, ids, n);
   if (rc != MHAP_OK) return rc;
-  const int64_t first = h->n_entries;
-  const int S = h->P.ordered_sketch_size;
-  rc = sketch_into(h, bases, offsets, lengths, n, false, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S,
-                   h->d_meta + first * META_W);
-  if (rc != MHAP_OK) return rc;
-  return finish_add(h, first, ids, n);
+  rc = mhap_index_add_staged(h);
+  h->st_n = 0;
+  return rc;
 }
 
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran

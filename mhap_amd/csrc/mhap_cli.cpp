@@ -206,7 +206,19 @@ int64_t add_file_to_index(mhap_handle* h, const std::string& path, int64_t id_of
   if (mhap_fasta_read(path.c_str(), id_offset, &fa, err, sizeof err) != MHAP_OK) die(err);
   if (g_headers.full) collect_headers(fa);
   if (fa.n > 0) chk(h, mhap_index_add_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n));
-  mhap_fasta_free(&fa);
+  // The parsed reads (1 byte per base) are released after the search, not here: unmapping a gigabyte takes ~0.13 s, and doing it on
+  // another thread only moves the stall (the unmap holds the address-space lock the search's allocations need).  Bounded: beyond
+  // 8 GB of parked reads the oldest are released right away.
+  static std::vector<mhap_fasta> parked;
+  static int64_t parked_bytes = 0;
+  parked.push_back(fa);
+  parked_bytes += fa.n > 0 ? fa.offsets[fa.n - 1] + fa.lengths[fa.n - 1] : 0;
+  while (parked_bytes > (8LL << 30) && parked.size() > 1) {
+    mhap_fasta& f = parked.front();
+    parked_bytes -= f.n > 0 ? f.offsets[f.n - 1] + f.lengths[f.n - 1] : 0;
+    mhap_fasta_free(&f);
+    parked.erase(parked.begin());
+  }
   mhap_stats st; chk(h, mhap_get_stats(h, &st));
   *strands = st.strands_indexed;
   // seqNumberProcessed += seqStreamer.getNumberProcessed()/2 (MhapMain.java:462): the streamer counts the sketches it

@@ -155,6 +155,27 @@ def test_record_text_format_matches_java_semantics():
         rec["raw"] = float(rnd.randint(0, 3000))
         assert mhap_amd.format_record(rec) == O.format_record(rec)
     assert mhap_amd.format_record({**rec, "score": 1.5}).split()[2] == "0.000000"      # clamp (MatchResult.java:61-64)
+    # the formatter's fast path (multiply + floor away from HALF_UP ties) against the oracle's digit-string formatter: random values,
+    # values on and next to ties at the sixth decimal, negative ids / coordinates, large counts
+    import struct
+    for i in range(20000):
+        kind = i % 5
+        if kind == 0:
+            sc = rnd.random()
+        elif kind == 1:
+            sc = 1.0 - (rnd.randint(0, 999999) + 0.5) * 1e-6                      # error column on a tie
+        elif kind == 2:
+            t = 1.0 - (rnd.randint(0, 999999) + 0.5) * 1e-6
+            sc = struct.unpack("<d", struct.pack("<q", struct.unpack("<q", struct.pack("<d", t))[0] + rnd.randint(-3, 3)))[0]   # a few ulps off a tie
+        elif kind == 3:
+            sc = rnd.choice([0.0, 1.0, 0.5, 0.999999, 0.9999995, 1e-7, 1 - 1e-7, 0.78])
+        else:
+            sc = round(rnd.random(), rnd.randint(1, 9))
+        r2 = {"from_id": rnd.choice([1, -5, 2**40 + 3, rnd.randint(0, 10**7)]), "to_id": rnd.randint(0, 10**9), "score": sc,
+              "raw": float(rnd.choice([0, 1, 57, 1536, rnd.randint(0, 10**6)])), "a1": rnd.randint(0, 70000), "a2": rnd.randint(0, 70000),
+              "alen": rnd.randint(0, 2**31 - 1), "b1": rnd.randint(-3, 70000), "b2": rnd.randint(0, 70000), "blen": rnd.randint(0, 70000),
+              "to_rc": rnd.randint(0, 1)}
+        assert mhap_amd.format_record(r2) == O.format_record(r2), r2
 
 
 def test_fasta_reader_follows_fastadata(tmp_path):
