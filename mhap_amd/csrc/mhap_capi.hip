@@ -241,6 +241,7 @@ static inline uint32_t base_code(uint8_t c) { const uint32_t x = (c >> 1) & 3u; 
 static inline bool is_base(uint8_t c) { return ((0x54474341u >> (8 * base_code(c))) & 0xFFu) == c; }
 
 int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, bool fwd_only) {
+  HPROF("stage_reads begin");
   const int nthreads = host_threads();
   h->st_descs.resize((size_t)n);
   h->st_n = n;
@@ -303,6 +304,7 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
   HIPCHK(h, hipMemcpyAsync(h->store.p, hs, need, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   h->st_bytes = (int64_t)need;
+  HPROF("stage_reads end (packed + h2d)");
   return MHAP_OK;
 }
 
@@ -785,6 +787,7 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (P.min_store_length < 0) { seterr("The minimum read length stored must be >=0."); return MHAP_E_INVALID; }
   if (P.max_shift < -1.0) { seterr("The minimum shift must be greater than -1."); return MHAP_E_INVALID; }
   if (P.threshold < 0.0 || P.threshold > 1.0) { seterr("The second stage filter threshold must be 0<=threshold<=1.0."); return MHAP_E_INVALID; }
+  HPROF("create begin");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) { seterr(std::string("no HIP device available: ") + hipGetErrorString(e)); return MHAP_E_HIP; }
@@ -807,8 +810,10 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
   h->ord_cap = cap;
   h->ft = FilterTable{nullptr, nullptr, 0, 0, 0, 0, 3.0};
+  HPROF("create: device + streams");
   int rc = build_score_table(h);
   if (rc != MHAP_OK) { seterr(h->err); mhap_destroy(h); return rc; }
+  HPROF("create: score table");
   {   // xorshift jump-ahead tables for slots up to H (MinHash kernel's deferred-candidate drain)
     const int na = ((P.num_hashes + 1) >> XS_JUMP_LOG2) + 1;
     std::vector<uint64_t> jt((size_t)(na + XS_JUMP_NQ) * 2048);
@@ -818,6 +823,7 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
       seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
   }
+  HPROF("create: jump tables");
   {   // block-mix tables of the k-mer hash kernel's k = 16 / k2 = 12 path
     std::vector<uint64_t> lt(768);
     build_kmer_hash_luts(lt.data());
