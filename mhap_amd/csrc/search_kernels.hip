@@ -302,8 +302,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   __shared__ uint32_t stack[2 * IQ_STACK];
   __shared__ uint32_t s_nseg[2];
   __shared__ uint2 seglist[IQ_THREADS];
-  __shared__ uint32_t segpre[IQ_THREADS + 1];
-  __shared__ uint32_t wsum[IQ_THREADS / 64];
+  __shared__ unsigned long long segpre[IQ_THREADS + 1];
+  __shared__ unsigned long long wsum[IQ_THREADS / 64];
   __shared__ unsigned long long s_base;
   const int qi = blockIdx.x;
   if (qi >= nq) return;
@@ -404,33 +404,34 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         // all queued segments as ONE index space (exclusive prefix of their lengths in segpre): a trip of the loop below has
         // 8 x IQ_THREADS pool loads in flight whatever the segments' lengths — one segment per trip cost a memory round trip per
         // segment, and repeat-rich queries queue a hundred short ones
-        uint32_t len = threadIdx.x < nseg ? seglist[threadIdx.x].y : 0u, incl = len;
+        // (64-bit sums: a thousand segments of a huge index can hold more than 2^32 postings between them)
+        unsigned long long len = threadIdx.x < nseg ? seglist[threadIdx.x].y : 0u, incl = len;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
         if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
         __syncthreads();
-        uint32_t wbase = 0, total = 0;
-        for (unsigned w = 0; w < IQ_THREADS / 64; w++) { const uint32_t t = wsum[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
+        unsigned long long wbase = 0, total = 0;
+        for (unsigned w = 0; w < IQ_THREADS / 64; w++) { const unsigned long long t = wsum[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
         if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
         if (threadIdx.x == 0) segpre[nseg] = total;
         __syncthreads();
         // first tier: segments that hold more than four tables' worth of postings between them (a repeat) will outgrow this table —
         // hand the query over before streaming them
-        if (big != nullptr && total > 4u * (uint32_t)INV_CT) { if (threadIdx.x == 0) s_over = 1; handed_over = true; break; }
+        if (big != nullptr && total > 4ULL * INV_CT) { if (threadIdx.x == 0) s_over = 1; handed_over = true; break; }
         // second tier, whole index, every slot probed: segments with more than twice the table's capacity between them (and an
         // index with that many entries) are split before they are streamed: the pass would overflow after streaming everything
         // (its elements are already counted)
-        if (big == nullptr && bits == 0 && s0 + IQ_THREADS >= sp.H && (total < ix.ne ? total : ix.ne) > 2u * ((uint32_t)INV_CT * 3u / 4u)) { if (threadIdx.x == 0) s_over = 1; break; }
+        if (big == nullptr && bits == 0 && s0 + IQ_THREADS >= sp.H && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; break; }
         uint32_t g = 0;   // segment of this lane's current element (its elements come in ascending order)
-        for (uint32_t i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
+        for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
           uint32_t e[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
-            const uint32_t i = i0 + (uint32_t)IQ_THREADS * u;
+            const unsigned long long i = i0 + (unsigned long long)IQ_THREADS * u;
             e[u] = 0xFFFFFFFFu;
             if (i < total) {
               while (i >= segpre[g + 1]) g++;
-              e[u] = ix.pool[seglist[g].x + (i - segpre[g])];
+              e[u] = ix.pool[(size_t)seglist[g].x + (size_t)(i - segpre[g])];
             }
           }
 #pragma unroll
