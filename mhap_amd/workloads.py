@@ -22,6 +22,9 @@ CONFIGS = {
     # BASELINE configs[3] read shape (15 kb, 512 hashes) on one GPU's share of the 1M-read job
     "c4slice": dict(reads=60000, length=15000, hashes=512, seed=SEED ^ 4, repeats=None, filter=False,
                     label="60000 synthetic reads x 15000 bp: single-GPU slice of BASELINE configs[3] (1M x 15 kb over 8 GPUs)"),
+    # BASELINE configs[3] in full (its reference run is an 8-GPU job; the tables, the index and the scratch of the whole job fit one MI355X)
+    "c4": dict(reads=1000000, length=15000, hashes=512, seed=SEED ^ 4, repeats=None, filter=False,
+               label="1000000 synthetic reads x 15000 bp (BASELINE configs[3] in full, on one GPU)"),
     # BASELINE configs[4] read shape (12 kb) + planted repeat family + -f filter file + --filter-threshold
     "c5slice": dict(reads=40000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.01), filter=True,
                     label="40000 synthetic reads x 12000 bp with a planted 300-bp repeat family (one copy per 3 kb, 1% divergence), "
