@@ -214,6 +214,55 @@ int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t
 int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
                              int64_t m, int to_self, mhap_record_sink sink, void* user);
 
+/* ---- several GPUs: one sharded index, the exchange inside the library -------------------------------------
+ * The reference has one JVM, one index and a thread pool (AbstractMatchSearch.addData :67-117, findMatches() :121-199,
+ * J/impl/AbstractMatchSearch.java).  Over N GPUs the reads are dealt round-robin (read i of the data set -> rank i % N, which
+ * balances the id < id rule of J/impl/MinHashSearch.java:215-219), every rank sketches and indexes ITS reads only, and a search
+ * all-gathers the forward-strand query rows of all ranks (MinHash rows, meta and ids first; the 6x larger ordered rows behind
+ * the candidate stage) and runs every query against the rank's own index shard with the toSelf id rules — each unordered pair is
+ * reported exactly once, by the rank that stores its lower-id read.  No collective after the gather; records go to the sink.
+ *
+ * Two ways to form the ranks, same code underneath:
+ *  (a) one process per GPU (bench.py under torchrun, an MPI-style host): every process creates its handle; rank 0 calls
+ *      mhap_dist_unique_id and the host hands the 128 bytes to the other ranks (any channel); all call mhap_dist_init, which
+ *      creates an RCCL communicator over the handles' devices (ncclCommInitRank; collectives run over xGMI).
+ *  (b) one process, N devices (mhap-hip --gpus N, the JNI host of INTEGRATION.md): mhap_group_* below owns N handles and one
+ *      host thread per rank; the gather is direct peer-to-peer copies over xGMI (hipMemcpyPeerAsync: each rank pulls the other
+ *      ranks' rows), or RCCL (ncclCommInitAll) with MHAP_GROUP_TRANSPORT=rccl. */
+#define MHAP_DIST_ID_BYTES 128
+int mhap_dist_unique_id(void* id, size_t cap);                       /* ncclGetUniqueId; cap >= MHAP_DIST_ID_BYTES */
+int mhap_dist_init(mhap_handle* h, int32_t rank, int32_t nranks, const void* id);   /* collective over the nranks handles */
+int mhap_dist_finalize(mhap_handle* h);
+/* Collective: self-overlap of the union of the ranks' indexes (every rank calls it; each gets the records of the pairs whose
+ * lower-id read it stores).  The index must consist of sketched reads (mhap_index_add_reads / _staged): forward and reverse
+ * entries in pairs.  Replaces AbstractMatchSearch.findMatches() for the sharded index. */
+int mhap_dist_find_matches_self(mhap_handle* h, mhap_record_sink sink, void* user);
+/* Collective, -q mode (AbstractMatchSearch.findMatches(streamer), toSelf = false): this rank sketches the n query reads it was
+ * dealt (forward strands only), the query rows of all ranks are gathered, and every rank searches them against its shard. */
+int mhap_dist_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths,
+                                 const int64_t* ids, int64_t n, mhap_record_sink sink, void* user);
+/* wall-clock split of the last collective search on this rank, milliseconds: {pack + small gathers, index + candidate stage wait
+ * on the ordered rows, whole call} */
+int mhap_dist_last_timing(mhap_handle* h, double* out3);
+
+typedef struct mhap_group mhap_group;
+/* N handles on the given devices (NULL: devices 0..n-1; repeats allowed — several ranks may share a device, which is how a
+ * one-GPU box tests the N > 1 path). */
+int mhap_group_create(const mhap_params* params, const int32_t* devices, int32_t n, mhap_group** out, char* err, size_t errcap);
+void mhap_group_destroy(mhap_group* g);
+int32_t mhap_group_size(const mhap_group* g);
+mhap_handle* mhap_group_rank(mhap_group* g, int32_t rank);         /* for per-rank set-up (filters) and counters */
+const char* mhap_group_last_error(const mhap_group* g);
+/* AbstractMatchSearch.addData over N GPUs: read i of this call goes to rank (reads added so far + i) % N; the ranks sketch and
+ * index their shares concurrently.  May be called repeatedly (batches of one file, several files). */
+int mhap_group_add_reads(mhap_group* g, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n);
+int mhap_group_clear(mhap_group* g);
+/* findMatches() / findMatches(streamer) over the sharded index; the sink is called from the ranks' threads, one call at a time. */
+int mhap_group_find_matches_self(mhap_group* g, mhap_record_sink sink, void* user);
+int mhap_group_find_matches_reads(mhap_group* g, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids,
+                                  int64_t n, mhap_record_sink sink, void* user);
+int mhap_group_get_stats(mhap_group* g, mhap_stats* sum);           /* counters summed over the ranks */
+
 int mhap_get_stats(mhap_handle* h, mhap_stats* out);
 int mhap_get_kernel_times(mhap_handle* h, mhap_kernel_times* out);
 int mhap_reset_kernel_times(mhap_handle* h);

@@ -9,6 +9,7 @@ from .api import (  # noqa: F401
     MhapError,
     MhapParams,
     MinHashSearch,
+    MinHashSearchGroup,
     FastaData,
     FrequencyCounts,
     MatchResult,

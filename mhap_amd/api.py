@@ -61,6 +61,9 @@ EXPORTED_SYMBOLS = [
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_find_matches_sketches",
     "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
+    "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing",
+    "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",
+    "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats",
 ]
 
 
@@ -90,6 +93,13 @@ def load_library(build_if_missing=True):
     lib.mhap_destroy.argtypes = [C.c_void_p]
     lib.mhap_fasta_free.restype = None
     lib.mhap_default_params.restype = None
+    lib.mhap_group_destroy.restype = None
+    lib.mhap_group_destroy.argtypes = [C.c_void_p]
+    lib.mhap_group_rank.restype = C.c_void_p
+    lib.mhap_group_rank.argtypes = [C.c_void_p, C.c_int32]
+    lib.mhap_group_last_error.restype = C.c_char_p
+    lib.mhap_group_last_error.argtypes = [C.c_void_p]
+    lib.mhap_group_size.argtypes = [C.c_void_p]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError here = header/library mismatch
     _lib = lib
@@ -470,6 +480,36 @@ class MinHashSearch:
                 if not done[0]:
                     before_second_stage()       # no candidates at all: the caller still expects the wait to have happened
 
+    # -- one process per GPU: this handle as rank `rank` of `nranks` (the exchange runs inside the library, RCCL over xGMI) ----
+    @staticmethod
+    def dist_unique_id():
+        """ncclGetUniqueId: 128 bytes that rank 0 hands to the other ranks (any channel) before dist_init."""
+        buf = C.create_string_buffer(128)
+        rc = load_library().mhap_dist_unique_id(buf, C.c_size_t(128))
+        if rc != 0:
+            raise MhapError(f"mhap_dist_unique_id failed ({rc}): RCCL is not loadable")
+        return buf.raw
+
+    def dist_init(self, rank, nranks, unique_id):
+        self._chk(self._lib.mhap_dist_init(self._h, C.c_int32(rank), C.c_int32(nranks), C.c_char_p(bytes(unique_id))))
+
+    def dist_finalize(self):
+        self._chk(self._lib.mhap_dist_finalize(self._h))
+
+    def dist_find_matches(self):
+        """Collective: self overlap of the union of the ranks' indexes; returns this rank's records."""
+        return self._collect(lambda cb: self._lib.mhap_dist_find_matches_self(self._h, cb, None))
+
+    def dist_find_matches_stream(self, fasta):
+        """Collective, -q mode: `fasta` = the query reads dealt to this rank."""
+        return self._collect(lambda cb: self._lib.mhap_dist_find_matches_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
+                                                                              _ptr(fasta.ids), C.c_int64(len(fasta)), cb, None))
+
+    def dist_last_timing(self):
+        t = (C.c_double * 3)()
+        self._chk(self._lib.mhap_dist_last_timing(self._h, t))
+        return {"gather_small_ms": t[0], "wait_ordered_ms": t[1], "total_ms": t[2]}
+
     # -- counters -------------------------------------------------------------------------------
     def stats(self):
         s = _Stats()
@@ -486,3 +526,88 @@ class MinHashSearch:
 
     def synchronize(self):
         self._chk(self._lib.mhap_synchronize(self._h))
+
+
+class MinHashSearchGroup:
+    """One process, N GPUs: N ranks of one sharded index (mhap_group_*: AbstractMatchSearch's drivers over several devices).
+    Reads are dealt round-robin; every rank sketches and indexes its share; a search gathers the forward query rows of all
+    ranks (peer-to-peer copies over xGMI, or RCCL with MHAP_GROUP_TRANSPORT=rccl) and each rank searches them against its shard."""
+
+    def __init__(self, params=None, n=1, devices=None, kmer_filter=None):
+        self._lib = load_library()
+        self.params = params or MhapParams()
+        self._g = C.c_void_p()
+        err = C.create_string_buffer(512)
+        p = self.params._c()
+        dev = (C.c_int32 * n)(*devices) if devices is not None else None
+        rc = self._lib.mhap_group_create(C.byref(p), dev, C.c_int32(n), C.byref(self._g), err, C.c_size_t(512))
+        if rc != 0:
+            self._g = C.c_void_p()
+            raise MhapError(err.value.decode() or f"mhap_group_create failed ({rc})")
+        self.n = n
+        if kmer_filter is not None:
+            for r in range(n):
+                self.rank(r).set_filter(kmer_filter)
+
+    def rank(self, r):
+        """A non-owning MinHashSearch view of rank r's handle (filters, counters)."""
+        v = MinHashSearch.__new__(MinHashSearch)
+        v._lib, v.params = self._lib, self.params
+        h = self._lib.mhap_group_rank(self._g, C.c_int32(r))
+        if not h:
+            raise MhapError("rank out of range")
+        v._h = C.c_void_p(h)
+        v.close = lambda: None
+        return v
+
+    def close(self):
+        if getattr(self, "_g", None) and self._g.value:
+            self._lib.mhap_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MhapError(f"{self._lib.mhap_group_last_error(self._g).decode()} (code {rc})")
+
+    def add_data(self, fasta):
+        self._chk(self._lib.mhap_group_add_reads(self._g, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths), _ptr(fasta.ids),
+                                                 C.c_int64(len(fasta))))
+
+    def clear(self):
+        self._chk(self._lib.mhap_group_clear(self._g))
+
+    def _collect(self, call):
+        chunks = []
+
+        def sink(recs, n, user):
+            a = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(n * RECORD_DTYPE.itemsize,))
+            chunks.append(a.view(RECORD_DTYPE).copy())
+            return 0
+
+        cb = _SINK(sink)
+        self._chk(call(cb))
+        return np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+
+    def find_matches(self):
+        return self._collect(lambda cb: self._lib.mhap_group_find_matches_self(self._g, cb, None))
+
+    def find_matches_stream(self, fasta):
+        return self._collect(lambda cb: self._lib.mhap_group_find_matches_reads(self._g, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
+                                                                               _ptr(fasta.ids), C.c_int64(len(fasta)), cb, None))
+
+    def stats(self):
+        s = _Stats()
+        self._chk(self._lib.mhap_group_get_stats(self._g, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}

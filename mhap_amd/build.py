@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmhaphip.so")
 CLI = os.path.join(LIBDIR, "mhap-hip")
-SOURCES = ["sketch_kernels.hip", "search_kernels.hip", "mhap_capi.hip", "host_util.cpp"]
-HEADERS = ["device_common.hpp", "kernels.hpp", "overlap_lane.hpp", os.path.join("..", "..", "include", "mhap_hip.h")]
+SOURCES = ["sketch_kernels.hip", "search_kernels.hip", "mhap_capi.hip", "mhap_dist.hip", "host_util.cpp"]
+HEADERS = ["device_common.hpp", "kernels.hpp", "mhap_internal.hpp", "overlap_lane.hpp", os.path.join("..", "..", "include", "mhap_hip.h")]
 ARCH = "gfx950"
 
 

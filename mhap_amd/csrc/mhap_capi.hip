@@ -18,33 +18,12 @@ static double hp_now() { return std::chrono::duration<double, std::milli>(std::c
 // MHAP_DEBUG_SYNC=1: wait for every sketch kernel and say so (which launch hangs or faults)
 #define DBGSYNC(h, tag) do { if (getenv("MHAP_DEBUG_SYNC")) { fprintf(stderr, "[dbg] %s launched\n", tag); hipError_t _e = hipStreamSynchronize((h)->stream); fprintf(stderr, "[dbg] %s done: %s\n", tag, hipGetErrorString(_e)); } } while (0)
 #include "kernels.hpp"
+#include "mhap_internal.hpp"
 #include "overlap_lane.hpp"
 
 using namespace mhap;
 
 namespace {
-
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  hipError_t ensure(size_t bytes, bool keep = false, hipStream_t st = nullptr) {
-    if (bytes <= cap) return hipSuccess;
-    size_t ncap = std::max(bytes, keep ? cap * 2 : cap);
-    void* np = nullptr;
-    hipError_t e = hipMalloc(&np, ncap);
-    if (e != hipSuccess) return e;
-    if (keep && p && cap) {
-      e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
-      if (e == hipSuccess) e = hipStreamSynchronize(st);
-      if (e != hipSuccess) { (void)hipFree(np); return e; }
-    }
-    if (p) (void)hipFree(p);
-    p = np; cap = ncap;
-    return hipSuccess;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-  template <class T> T* as() const { return (T*)p; }
-};
 
 struct TimedLaunch { hipEvent_t a, b; int kind; };
 
@@ -160,6 +139,7 @@ struct mhap_handle {
   DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_ovf, inv_big;
   InvIndex inv{};   // device view of the inverted index in inv_table / inv_ovf
   mhap_stage_gate gate = nullptr; void* gate_user = nullptr;   // mhap_set_second_stage_gate
+  void* dist = nullptr;   // multi-GPU state (mhap_dist.hip)
   std::vector<mhap_record> out_recs;
 
   // timing
@@ -766,6 +746,22 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
 
 }  // namespace
 
+namespace mhap {
+HandleView handle_view(mhap_handle* h) {
+  HandleView v;
+  v.device = h->device; v.stream = h->stream; v.Hrow = h->Hrow; v.S = h->P.ordered_sketch_size; v.n_entries = h->n_entries;
+  v.d_minhash = h->d_minhash; v.d_ordered = h->d_ordered; v.d_meta = h->d_meta;
+  v.h_ids = h->ids.data(); v.h_fwd = h->fwd.data(); v.err = &h->err; v.dist = &h->dist;
+  return v;
+}
+// -q mode of the sharded search: sketch n query reads (forward strands only, AbstractMatchSearch.java:225,236) into caller tables
+// laid out like an index's (row 2i = read i's forward strand)
+int internal_sketch_queries(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_mh, void* d_od, void* d_mt) {
+  for (int64_t i = 0; i < n; i++) if (lengths[i] < 0) return fail(h, MHAP_E_INVALID, "negative read length");
+  return sketch_into(h, bases, offsets, lengths, n, true, (int32_t*)d_mh, h->Hrow, (int32_t*)d_od, 2LL * h->P.ordered_sketch_size, (int32_t*)d_mt);
+}
+}  // namespace mhap
+
 // =================================================================================================
 extern "C" {
 
@@ -839,6 +835,7 @@ void mhap_destroy(mhap_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->dist) { mhap_dist_release(h->dist); h->dist = nullptr; }
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,

@@ -1,0 +1,557 @@
+// mhap_dist.hip — several GPUs, one sharded index: the exchange step of SURVEY.md §8(e) inside libmhaphip.so.
+//
+// The reference is one JVM with one index and a thread pool (J/impl/AbstractMatchSearch.java:67-117 addData, :121-199
+// findMatches()); its only data-parallel axis is the read.  Here rank r of N holds the sketches and the inverted index of the
+// reads it was dealt, and a search is: pack the forward-strand rows of the rank's tables -> all-gather them (MinHash rows, meta,
+// ids first; the ordered rows, 6x the bytes, behind the candidate stage) -> every rank searches all forward rows against its own
+// shard with the toSelf id rules (J/impl/MinHashSearch.java:200-225), so every unordered pair is reported once, by the rank
+// that stores its lower-id read.  Two transports carry the gather:
+//   * RCCL (one process per GPU, or MHAP_GROUP_TRANSPORT=rccl): ncclAllGather on a communicator over the ranks' devices.  The
+//     library is bound at run time (dlopen): a host that already loaded an RCCL (PyTorch-ROCm ships one) shares it.
+//   * peer copies (one process, N devices: mhap_group_*): every rank pulls the other ranks' rows with hipMemcpyPeerAsync —
+//     on a fully connected xGMI node the direct all-gather uses all 7 links of a GPU at once; ranks may also share a device.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kernels.hpp"
+#include "mhap_internal.hpp"
+
+using namespace mhap;
+
+namespace {
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string why;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  static std::once_flag once;
+  std::call_once(once, []() {
+    // an RCCL the process already loaded comes first (same HIP runtime as the rest of the process), then the ROCm one
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    if (const char* e = getenv("MHAP_RCCL_LIB")) api.lib = dlopen(e, RTLD_NOW | RTLD_LOCAL);
+    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* n : names) if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) { api.why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?"); return; }
+    auto sym = [&](const char* n) { void* p = dlsym(api.lib, n); if (!p && api.why.empty()) api.why = std::string("librccl lacks ") + n; return p; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!api.why.empty()) { api.lib = nullptr; }
+  });
+  return api;
+}
+
+// ---- transports ------------------------------------------------------------------------------------------------------------
+struct Transport {
+  int rank = 0, nranks = 1;
+  virtual ~Transport() {}
+  // device all-gather of `bytes` per rank, enqueued on st (of this rank's device); recv holds nranks * bytes
+  virtual int allgather(const void* send, void* recv, size_t bytes, hipStream_t st, std::string& err) = 0;
+  // small host-side all-gather (counts)
+  virtual int allgather_host(const void* in, void* out, size_t bytes, std::string& err) = 0;
+  // every rank has drained its streams: send buffers may be rewritten
+  virtual void quiesce() {}
+  // this rank gives up: ranks of the same process waiting for it must not wait for ever
+  virtual void abort() {}
+  virtual const char* name() const = 0;
+};
+
+struct RcclTransport : Transport {
+  ncclComm_t comm = nullptr;
+  bool owns = true;
+  DevBuf scratch;
+  int device = 0;
+  ~RcclTransport() override {
+    scratch.release();
+    if (comm && owns && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
+  }
+  int allgather(const void* send, void* recv, size_t bytes, hipStream_t st, std::string& err) override {
+    const ncclResult_t r = rccl().AllGather(send, recv, bytes, ncclChar, comm, st);
+    if (r != ncclSuccess) { err = std::string("ncclAllGather: ") + rccl().GetErrorString(r); return MHAP_E_HIP; }
+    return MHAP_OK;
+  }
+  int allgather_host(const void* in, void* out, size_t bytes, std::string& err) override {
+    if (scratch.ensure(bytes * (size_t)(nranks + 1)) != hipSuccess) { err = "out of device memory (exchange scratch)"; return MHAP_E_NOMEM; }
+    char* d = scratch.as<char>();
+    hipStream_t st = nullptr;   // the null stream: this is a rendezvous, not a hot path
+    if (hipMemcpy(d, in, bytes, hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy (exchange scratch)"; return MHAP_E_HIP; }
+    const int rc = allgather(d, d + bytes, bytes, st, err);
+    if (rc != MHAP_OK) return rc;
+    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(out, d + bytes, bytes * (size_t)nranks, hipMemcpyDeviceToHost) != hipSuccess) {
+      err = "exchange of the row counts failed"; return MHAP_E_HIP;
+    }
+    return MHAP_OK;
+  }
+  const char* name() const override { return "rccl"; }
+};
+
+// One process, N ranks on N host threads: a rank publishes its send buffer + an event recorded behind the writes, all ranks
+// meet at a host barrier, and every rank enqueues its own N copies (pull).  Ranks on one device degrade to plain device copies.
+struct PeerHub {
+  int n;
+  std::mutex mu; std::condition_variable cv; int arrived = 0; uint64_t gen = 0; bool failed = false;
+  std::vector<const void*> ptr; std::vector<hipEvent_t> ev; std::vector<int> dev;
+  std::vector<char> hostbuf; size_t host_bytes = 0;
+  explicit PeerHub(int n_) : n(n_), ptr((size_t)n_, nullptr), ev((size_t)n_, nullptr), dev((size_t)n_, 0) {}
+  // false: a rank failed and left (every later barrier returns false at once)
+  bool barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    if (failed) return false;
+    const uint64_t g = gen;
+    if (++arrived == n) { arrived = 0; gen++; cv.notify_all(); }
+    else cv.wait(lk, [&]() { return gen != g || failed; });
+    return !failed;
+  }
+  void abort() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+};
+struct PeerTransport : Transport {
+  PeerHub* hub = nullptr;
+  int allgather(const void* send, void* recv, size_t bytes, hipStream_t st, std::string& err) override {
+    hub->ptr[(size_t)rank] = send;
+    bool ok = hipEventRecord(hub->ev[(size_t)rank], st) == hipSuccess;
+    if (!hub->barrier()) { err = "another rank failed"; return MHAP_E_STATE; }
+    for (int r = 0; r < nranks && ok; r++) {
+      char* dst = (char*)recv + (size_t)r * bytes;
+      if (r != rank) ok = ok && hipStreamWaitEvent(st, hub->ev[(size_t)r], 0) == hipSuccess;
+      if (hub->dev[(size_t)r] == hub->dev[(size_t)rank]) ok = ok && hipMemcpyAsync(dst, hub->ptr[(size_t)r], bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+      else ok = ok && hipMemcpyPeerAsync(dst, hub->dev[(size_t)rank], hub->ptr[(size_t)r], hub->dev[(size_t)r], bytes, st) == hipSuccess;
+    }
+    // the events of this round are consumed (waits enqueued) before any rank records the next one
+    if (!hub->barrier()) { err = "another rank failed"; return MHAP_E_STATE; }
+    if (!ok) { err = "peer-to-peer gather failed"; return MHAP_E_HIP; }
+    return MHAP_OK;
+  }
+  int allgather_host(const void* in, void* out, size_t bytes, std::string& err) override {
+    {
+      std::lock_guard<std::mutex> lk(hub->mu);
+      if (hub->hostbuf.size() < bytes * (size_t)nranks) hub->hostbuf.resize(bytes * (size_t)nranks);
+      memcpy(hub->hostbuf.data() + (size_t)rank * bytes, in, bytes);
+    }
+    if (!hub->barrier()) { err = "another rank failed"; return MHAP_E_STATE; }
+    memcpy(out, hub->hostbuf.data(), bytes * (size_t)nranks);
+    if (!hub->barrier()) { err = "another rank failed"; return MHAP_E_STATE; }
+    return MHAP_OK;
+  }
+  void abort() override { hub->abort(); }
+  void quiesce() override { (void)hub->barrier(); }
+  const char* name() const override { return "peer"; }
+};
+
+// ---- per-rank exchange state -------------------------------------------------------------------------------------------------
+struct DistState {
+  Transport* tr = nullptr;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_pack = nullptr, ev_small = nullptr, ev_big = nullptr;
+  DevBuf s_mh, s_od, s_mt, s_ids;      // this rank's forward rows, packed
+  DevBuf g_mh, g_od, g_mt, g_ids;      // gathered rows of all ranks, rank after rank
+  DevBuf q_mh, q_od, q_mt;             // -q mode: this rank's query sketches (both strand slots, forward filled)
+  std::vector<int64_t> ids_all, ids_local;
+  double t_small = 0, t_wait_big = 0, t_total = 0;
+  bool gate_ran = false;
+  ~DistState() {
+    DevBuf* bufs[] = {&s_mh, &s_od, &s_mt, &s_ids, &g_mh, &g_od, &g_mt, &g_ids, &q_mh, &q_od, &q_mt};
+    for (DevBuf* b : bufs) b->release();
+    if (ev_pack) (void)hipEventDestroy(ev_pack);
+    if (ev_small) (void)hipEventDestroy(ev_small);
+    if (ev_big) (void)hipEventDestroy(ev_big);
+    if (comm_stream) (void)hipStreamDestroy(comm_stream);
+    delete tr;
+  }
+};
+
+int dfail(const HandleView& v, int code, const std::string& msg) { *v.err = msg; return code; }
+
+#define DCHK(v, expr)                                                                                 \
+  do {                                                                                                \
+    hipError_t _e = (expr);                                                                           \
+    if (_e != hipSuccess)                                                                             \
+      return dfail((v), _e == hipErrorOutOfMemory ? MHAP_E_NOMEM : MHAP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+int attach(mhap_handle* h, Transport* tr) {
+  HandleView v = handle_view(h);
+  (void)hipSetDevice(v.device);
+  if (*v.dist) { mhap_dist_release(*v.dist); *v.dist = nullptr; }
+  DistState* d = new DistState();
+  d->tr = tr;
+  if (hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->ev_pack, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&d->ev_small, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_big, hipEventDisableTiming) != hipSuccess) {
+    delete d;
+    return dfail(v, MHAP_E_HIP, "cannot create the exchange stream");
+  }
+  *v.dist = d;
+  return MHAP_OK;
+}
+
+int gate_cb(void* user) {
+  DistState* d = (DistState*)user;
+  const double t0 = now_ms();
+  const hipError_t e = hipEventSynchronize(d->ev_big);   // the ordered rows of every rank have arrived
+  d->t_wait_big += now_ms() - t0;
+  d->gate_ran = true;
+  return e == hipSuccess ? 0 : 1;
+}
+
+// Gather `rows` forward rows of this rank (row j at src + j * src_pitch_rows rows) from every rank and search them against this
+// rank's index.  d_* = tables holding the query rows of this rank at stride `stride` rows (2: forward entries of an index;
+// the -q tables use the same pairing), ids = one id per local row.
+int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const int32_t* d_od, const int32_t* d_mt, int stride, const int64_t* ids,
+                        int64_t rows, int to_self, mhap_record_sink sink, void* user) {
+  HandleView v = handle_view(h);
+  Transport* tr = d->tr;
+  const int N = tr->nranks;
+  const double t0 = now_ms();
+  int rc = MHAP_OK;
+  bool finished = false;
+  struct Guard { Transport* t; bool* ok; ~Guard() { if (!*ok) t->abort(); } } guard{tr, &finished};   // an error return must not strand the other ranks of this process
+  d->t_small = d->t_wait_big = 0; d->gate_ran = false;
+  // equal shard size for the gather: the largest row count of any rank (shorter shards are padded with skipped rows)
+  std::vector<int64_t> counts((size_t)N, 0);
+  rc = tr->allgather_host(&rows, counts.data(), sizeof(int64_t), *v.err);
+  if (rc != MHAP_OK) return rc;
+  int64_t n_pad = 0, total = 0;
+  for (int64_t c : counts) { n_pad = std::max(n_pad, c); total += c; }
+  if (total == 0) { finished = true; tr->quiesce(); return MHAP_OK; }
+  if ((int64_t)N * n_pad > (int64_t)INT32_MAX / 2) return dfail(v, MHAP_E_INVALID, "too many query rows for one gather");
+  const size_t mh_row = (size_t)v.Hrow * 4, od_row = (size_t)v.S * 8, mt_row = (size_t)META_W * 4;
+  const size_t np = (size_t)n_pad;
+  DCHK(v, d->s_mh.ensure(np * mh_row)); DCHK(v, d->s_od.ensure(np * od_row)); DCHK(v, d->s_mt.ensure(np * mt_row)); DCHK(v, d->s_ids.ensure(np * 8));
+  DCHK(v, d->g_mh.ensure((size_t)N * np * mh_row)); DCHK(v, d->g_od.ensure((size_t)N * np * od_row));
+  DCHK(v, d->g_mt.ensure((size_t)N * np * mt_row)); DCHK(v, d->g_ids.ensure((size_t)N * np * 8));
+  hipStream_t st = v.stream, cs = d->comm_stream;
+  // pack: every `stride`-th row of the tables; padding rows get status -1 (skipped as queries)
+  if (rows > 0) {
+    DCHK(v, hipMemcpy2DAsync(d->s_mh.p, mh_row, d_mh, mh_row * (size_t)stride, mh_row, (size_t)rows, hipMemcpyDeviceToDevice, st));
+    DCHK(v, hipMemcpy2DAsync(d->s_mt.p, mt_row, d_mt, mt_row * (size_t)stride, mt_row, (size_t)rows, hipMemcpyDeviceToDevice, st));
+    DCHK(v, hipMemcpy2DAsync(d->s_od.p, od_row, d_od, od_row * (size_t)stride, od_row, (size_t)rows, hipMemcpyDeviceToDevice, st));
+    DCHK(v, hipMemcpyAsync(d->s_ids.p, ids, (size_t)rows * 8, hipMemcpyHostToDevice, st));
+  }
+  if (n_pad > rows) {
+    DCHK(v, hipMemsetAsync(d->s_mt.as<char>() + (size_t)rows * mt_row, 0xFF, (size_t)(n_pad - rows) * mt_row, st));
+    DCHK(v, hipMemsetAsync(d->s_ids.as<char>() + (size_t)rows * 8, 0, (size_t)(n_pad - rows) * 8, st));
+    DCHK(v, hipMemsetAsync(d->s_mh.as<char>() + (size_t)rows * mh_row, 0, (size_t)(n_pad - rows) * mh_row, st));
+  }
+  DCHK(v, hipEventRecord(d->ev_pack, st));
+  DCHK(v, hipStreamWaitEvent(cs, d->ev_pack, 0));
+  // the small tables first (all the candidate stage needs), then the ordered rows: they travel while the candidates are counted
+  rc = tr->allgather(d->s_mh.p, d->g_mh.p, np * mh_row, cs, *v.err); if (rc != MHAP_OK) return rc;
+  rc = tr->allgather(d->s_mt.p, d->g_mt.p, np * mt_row, cs, *v.err); if (rc != MHAP_OK) return rc;
+  rc = tr->allgather(d->s_ids.p, d->g_ids.p, np * 8, cs, *v.err); if (rc != MHAP_OK) return rc;
+  DCHK(v, hipEventRecord(d->ev_small, cs));
+  rc = tr->allgather(d->s_od.p, d->g_od.p, np * od_row, cs, *v.err); if (rc != MHAP_OK) return rc;
+  DCHK(v, hipEventRecord(d->ev_big, cs));
+  // meanwhile: this rank's inverted index (a no-op when the add built it eagerly)
+  rc = mhap_index_prepare(h); if (rc != MHAP_OK) return rc;
+  DCHK(v, hipEventSynchronize(d->ev_small));
+  d->ids_all.resize((size_t)N * np);
+  DCHK(v, hipMemcpy(d->ids_all.data(), d->g_ids.p, (size_t)N * np * 8, hipMemcpyDeviceToHost));
+  d->t_small = now_ms() - t0;
+  rc = mhap_set_second_stage_gate(h, gate_cb, d); if (rc != MHAP_OK) return rc;
+  rc = mhap_find_matches_device(h, d->g_mh.p, d->g_od.p, d->g_mt.p, d->ids_all.data(), (int64_t)N * n_pad, to_self, sink, user);
+  (void)mhap_set_second_stage_gate(h, nullptr, nullptr);
+  if (!d->gate_ran) (void)hipEventSynchronize(d->ev_big);   // no candidates here: the gather still has to finish before the buffers are reused
+  finished = rc == MHAP_OK;
+  if (finished) tr->quiesce();
+  d->t_total = now_ms() - t0;
+  return rc;
+}
+
+}  // namespace
+
+namespace mhap {
+void mhap_dist_release(void* dist_state) { delete (DistState*)dist_state; }
+int internal_sketch_queries(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_mh, void* d_od, void* d_mt);
+}  // namespace mhap
+
+// ================================================================================================================================
+extern "C" {
+
+int mhap_dist_unique_id(void* id, size_t cap) {
+  if (!id || cap < MHAP_DIST_ID_BYTES) return MHAP_E_INVALID;
+  RcclApi& api = rccl();
+  if (!api.lib) { fprintf(stderr, "mhap_dist_unique_id: %s\n", api.why.c_str()); return MHAP_E_HIP; }
+  ncclUniqueId u;
+  if (api.GetUniqueId(&u) != ncclSuccess) return MHAP_E_HIP;
+  static_assert(sizeof(u) == MHAP_DIST_ID_BYTES, "ncclUniqueId size");
+  memcpy(id, &u, sizeof u);
+  return MHAP_OK;
+}
+
+int mhap_dist_init(mhap_handle* h, int32_t rank, int32_t nranks, const void* id) {
+  if (!h) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  if (nranks < 1 || rank < 0 || rank >= nranks || !id) return dfail(v, MHAP_E_INVALID, "bad rank / world size / id");
+  RcclApi& api = rccl();
+  if (!api.lib) return dfail(v, MHAP_E_HIP, api.why);
+  (void)hipSetDevice(v.device);
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  RcclTransport* tr = new RcclTransport();
+  tr->rank = rank; tr->nranks = nranks; tr->device = v.device;
+  const ncclResult_t r = api.CommInitRank(&tr->comm, nranks, u, rank);
+  if (r != ncclSuccess) { tr->comm = nullptr; delete tr; return dfail(v, MHAP_E_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)); }
+  const int rc = attach(h, tr);
+  if (rc != MHAP_OK) delete tr;
+  return rc;
+}
+
+int mhap_dist_finalize(mhap_handle* h) {
+  if (!h) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  (void)hipSetDevice(v.device);
+  if (*v.dist) { mhap_dist_release(*v.dist); *v.dist = nullptr; }
+  return MHAP_OK;
+}
+
+int mhap_dist_find_matches_self(mhap_handle* h, mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job (mhap_dist_init / mhap_group_create first)");
+  (void)hipSetDevice(v.device);
+  if (v.n_entries & 1) return dfail(v, MHAP_E_STATE, "the sharded search needs an index of sketched reads (forward + reverse entries in pairs)");
+  const int64_t rows = v.n_entries / 2;
+  for (int64_t j = 0; j < rows; j++)
+    if (!v.h_fwd[(size_t)(2 * j)] || v.h_fwd[(size_t)(2 * j + 1)] || v.h_ids[(size_t)(2 * j)] != v.h_ids[(size_t)(2 * j + 1)])
+      return dfail(v, MHAP_E_STATE, "the sharded search needs an index of sketched reads (forward + reverse entries in pairs)");
+  d->ids_local.resize((size_t)rows);
+  for (int64_t j = 0; j < rows; j++) d->ids_local[(size_t)j] = v.h_ids[(size_t)(2 * j)];
+  return exchange_and_search(h, d, v.d_minhash, v.d_ordered, v.d_meta, 2, d->ids_local.data(), rows, 1, sink, user);
+}
+
+int mhap_dist_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n,
+                                 mhap_record_sink sink, void* user) {
+  if (!h) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job (mhap_dist_init / mhap_group_create first)");
+  if (n < 0 || (n > 0 && (!bases || !offsets || !lengths || !ids))) return dfail(v, MHAP_E_INVALID, "null argument");
+  (void)hipSetDevice(v.device);
+  const size_t m = (size_t)std::max<int64_t>(2 * n, 2);
+  DCHK(v, d->q_mh.ensure(m * (size_t)v.Hrow * 4)); DCHK(v, d->q_od.ensure(m * (size_t)v.S * 8)); DCHK(v, d->q_mt.ensure(m * META_W * 4));
+  if (n > 0) {
+    const int rc = internal_sketch_queries(h, bases, offsets, lengths, n, d->q_mh.p, d->q_od.p, d->q_mt.p);
+    if (rc != MHAP_OK) return rc;
+  }
+  return exchange_and_search(h, d, d->q_mh.as<int32_t>(), d->q_od.as<int32_t>(), d->q_mt.as<int32_t>(), 2, ids, n, 0, sink, user);
+}
+
+int mhap_dist_last_timing(mhap_handle* h, double* out3) {
+  if (!h || !out3) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job");
+  out3[0] = d->t_small; out3[1] = d->t_wait_big; out3[2] = d->t_total;
+  return MHAP_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================================================
+// One process, N devices.
+struct mhap_group {
+  int n = 0;
+  std::vector<mhap_handle*> h;
+  std::vector<int> dev;
+  PeerHub* hub = nullptr;
+  int64_t reads_added = 0;
+  std::string err;
+  std::mutex sink_mu;
+};
+
+namespace {
+
+struct SinkFan { mhap_group* g; mhap_record_sink sink; void* user; };
+int fan_sink(const mhap_record* r, int64_t n, void* user) {
+  SinkFan* f = (SinkFan*)user;
+  if (!f->sink) return 0;
+  std::lock_guard<std::mutex> lk(f->g->sink_mu);   // one call at a time, as the reference's outputResults lock (AbstractMatchSearch.java:323)
+  return f->sink(r, n, f->user);
+}
+
+// run fn(rank) on one thread per rank; first error wins
+int on_ranks(mhap_group* g, const std::function<int(int)>& fn) {
+  std::vector<int> rcs((size_t)g->n, MHAP_OK);
+  std::vector<std::thread> th;
+  for (int r = 1; r < g->n; r++) th.emplace_back([&, r]() { rcs[(size_t)r] = fn(r); });
+  rcs[0] = fn(0);
+  for (auto& t : th) t.join();
+  for (int r = 0; r < g->n; r++)
+    if (rcs[(size_t)r] != MHAP_OK) { g->err = "rank " + std::to_string(r) + ": " + mhap_last_error(g->h[(size_t)r]); return rcs[(size_t)r]; }
+  return MHAP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mhap_group_create(const mhap_params* params, const int32_t* devices, int32_t n, mhap_group** out, char* err, size_t errcap) {
+  auto seterr = [&](const std::string& m) { if (err && errcap) snprintf(err, errcap, "%s", m.c_str()); };
+  if (!params || !out || n < 1 || n > 1024) { seterr("bad group arguments"); return MHAP_E_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { seterr("no HIP device available"); return MHAP_E_HIP; }
+  mhap_group* g = new mhap_group();
+  g->n = n;
+  for (int r = 0; r < n; r++) g->dev.push_back(devices ? devices[r] : r % ndev);
+  for (int r = 0; r < n; r++) if (g->dev[(size_t)r] < 0 || g->dev[(size_t)r] >= ndev) { seterr("device ordinal out of range"); delete g; return MHAP_E_INVALID; }
+  g->h.assign((size_t)n, nullptr);
+  // the handles come up concurrently (most of mhap_create is tables built on the host)
+  std::vector<int> rcs((size_t)n, MHAP_OK);
+  std::vector<std::string> errs((size_t)n);
+  {
+    std::vector<std::thread> th;
+    for (int r = 0; r < n; r++) th.emplace_back([&, r]() {
+      mhap_params p = *params; p.device = g->dev[(size_t)r];
+      char e[512] = {0};
+      rcs[(size_t)r] = mhap_create(&p, &g->h[(size_t)r], e, sizeof e);
+      errs[(size_t)r] = e;
+    });
+    for (auto& t : th) t.join();
+  }
+  for (int r = 0; r < n; r++) if (rcs[(size_t)r] != MHAP_OK) { seterr(errs[(size_t)r]); const int rc = rcs[(size_t)r]; mhap_group_destroy(g); return rc; }
+  const char* tenv = getenv("MHAP_GROUP_TRANSPORT");
+  bool distinct = true;
+  for (int a = 0; a < n; a++) for (int b = a + 1; b < n; b++) if (g->dev[(size_t)a] == g->dev[(size_t)b]) distinct = false;
+  const bool want_rccl = tenv && strcmp(tenv, "rccl") == 0;
+  if (want_rccl && !distinct) { seterr("MHAP_GROUP_TRANSPORT=rccl needs one device per rank"); mhap_group_destroy(g); return MHAP_E_INVALID; }
+  if (want_rccl) {
+    RcclApi& api = rccl();
+    if (!api.lib) { seterr(api.why); mhap_group_destroy(g); return MHAP_E_HIP; }
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    const ncclResult_t r = api.CommInitAll(comms.data(), n, g->dev.data());
+    if (r != ncclSuccess) { seterr(std::string("ncclCommInitAll: ") + api.GetErrorString(r)); mhap_group_destroy(g); return MHAP_E_HIP; }
+    for (int k = 0; k < n; k++) {
+      RcclTransport* tr = new RcclTransport();
+      tr->rank = k; tr->nranks = n; tr->comm = comms[(size_t)k]; tr->device = g->dev[(size_t)k];
+      if (attach(g->h[(size_t)k], tr) != MHAP_OK) { delete tr; seterr(mhap_last_error(g->h[(size_t)k])); mhap_group_destroy(g); return MHAP_E_HIP; }
+    }
+  } else {
+    g->hub = new PeerHub(n);
+    for (int a = 0; a < n; a++) {
+      g->hub->dev[(size_t)a] = g->dev[(size_t)a];
+      (void)hipSetDevice(g->dev[(size_t)a]);
+      if (hipEventCreateWithFlags(&g->hub->ev[(size_t)a], hipEventDisableTiming) != hipSuccess) { seterr("cannot create the exchange events"); mhap_group_destroy(g); return MHAP_E_HIP; }
+      for (int b = 0; b < n; b++) {
+        if (g->dev[(size_t)b] == g->dev[(size_t)a]) continue;
+        int can = 0;
+        (void)hipDeviceCanAccessPeer(&can, g->dev[(size_t)a], g->dev[(size_t)b]);
+        if (can) { const hipError_t e = hipDeviceEnablePeerAccess(g->dev[(size_t)b], 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(); }
+      }
+    }
+    (void)hipGetLastError();
+    for (int k = 0; k < n; k++) {
+      PeerTransport* tr = new PeerTransport();
+      tr->rank = k; tr->nranks = n; tr->hub = g->hub;
+      if (attach(g->h[(size_t)k], tr) != MHAP_OK) { delete tr; seterr(mhap_last_error(g->h[(size_t)k])); mhap_group_destroy(g); return MHAP_E_HIP; }
+    }
+  }
+  *out = g;
+  return MHAP_OK;
+}
+
+void mhap_group_destroy(mhap_group* g) {
+  if (!g) return;
+  for (mhap_handle* h : g->h) if (h) mhap_destroy(h);
+  if (g->hub) {
+    for (size_t a = 0; a < g->hub->ev.size(); a++) if (g->hub->ev[a]) { (void)hipSetDevice(g->hub->dev[a]); (void)hipEventDestroy(g->hub->ev[a]); }
+    delete g->hub;
+  }
+  delete g;
+}
+
+int32_t mhap_group_size(const mhap_group* g) { return g ? g->n : 0; }
+mhap_handle* mhap_group_rank(mhap_group* g, int32_t rank) { return (g && rank >= 0 && rank < g->n) ? g->h[(size_t)rank] : nullptr; }
+const char* mhap_group_last_error(const mhap_group* g) { return g ? g->err.c_str() : "null group"; }
+
+int mhap_group_add_reads(mhap_group* g, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n) {
+  if (!g) return MHAP_E_INVALID;
+  if (n <= 0) return MHAP_OK;
+  if (!bases || !offsets || !lengths || !ids) { g->err = "null argument"; return MHAP_E_INVALID; }
+  const int N = g->n;
+  const int64_t first = g->reads_added;
+  const int rc = on_ranks(g, [&](int r) {
+    // rank r takes the reads whose ordinal in the data set is congruent to r: its share of this call, as index arrays over the caller's bases
+    std::vector<int64_t> off, id; std::vector<int32_t> len;
+    const int64_t i0 = ((r - first) % N + N) % N;
+    for (int64_t i = i0; i < n; i += N) { off.push_back(offsets[i]); len.push_back(lengths[i]); id.push_back(ids[i]); }
+    if (off.empty()) return (int)MHAP_OK;
+    return mhap_index_add_reads(g->h[(size_t)r], bases, off.data(), len.data(), id.data(), (int64_t)off.size());
+  });
+  if (rc == MHAP_OK) g->reads_added += n;
+  return rc;
+}
+
+int mhap_group_clear(mhap_group* g) {
+  if (!g) return MHAP_E_INVALID;
+  for (mhap_handle* h : g->h) { const int rc = mhap_index_clear(h); if (rc != MHAP_OK) return rc; }
+  g->reads_added = 0;
+  return MHAP_OK;
+}
+
+int mhap_group_find_matches_self(mhap_group* g, mhap_record_sink sink, void* user) {
+  if (!g) return MHAP_E_INVALID;
+  SinkFan f{g, sink, user};
+  return on_ranks(g, [&](int r) { return mhap_dist_find_matches_self(g->h[(size_t)r], fan_sink, &f); });
+}
+
+int mhap_group_find_matches_reads(mhap_group* g, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n,
+                                  mhap_record_sink sink, void* user) {
+  if (!g) return MHAP_E_INVALID;
+  if (n > 0 && (!bases || !offsets || !lengths || !ids)) { g->err = "null argument"; return MHAP_E_INVALID; }
+  SinkFan f{g, sink, user};
+  const int N = g->n;
+  return on_ranks(g, [&](int r) {
+    std::vector<int64_t> off, id; std::vector<int32_t> len;
+    for (int64_t i = r; i < n; i += N) { off.push_back(offsets[i]); len.push_back(lengths[i]); id.push_back(ids[i]); }
+    return mhap_dist_find_matches_reads(g->h[(size_t)r], bases, off.data(), len.data(), id.data(), (int64_t)off.size(), fan_sink, &f);
+  });
+}
+
+int mhap_group_get_stats(mhap_group* g, mhap_stats* sum) {
+  if (!g || !sum) return MHAP_E_INVALID;
+  memset(sum, 0, sizeof *sum);
+  for (mhap_handle* h : g->h) {
+    mhap_stats s;
+    const int rc = mhap_get_stats(h, &s);
+    if (rc != MHAP_OK) return rc;
+    sum->strands_indexed += s.strands_indexed; sum->queries_searched += s.queries_searched; sum->candidates_compared += s.candidates_compared;
+    sum->matches_found += s.matches_found; sum->slot_compares += s.slot_compares; sum->table_elements += s.table_elements;
+    sum->slow_pairs += s.slow_pairs; sum->index_splits += s.index_splits;
+  }
+  // every rank probes every query: the reference's "sequences searched" counts a query once
+  sum->queries_searched /= g->n;
+  return MHAP_OK;
+}
+
+}  // extern "C"

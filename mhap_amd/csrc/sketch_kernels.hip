@@ -301,14 +301,21 @@ __device__ inline void weight_strand(uint32_t* tab, uint32_t ts, const int64_t* 
   }
 }
 
-// LDS fast path: the whole strand's probe state lives in registers (one dword per k-mer: fp16<<16 | slot), keys are
-// fetched 8 at a time (one HBM latency per chunk instead of one per k-mer), inserts go straight to ds_cmpst (no
-// read-before-CAS), and the post-barrier pass is ONE ds_read per k-mer: the remembered slot holds the smallest
+// LDS fast path: the whole strand's probe state lives in registers (one dword per k-mer: fp16<<16 | slot), inserts go straight
+// to ds_cmpst (no read-before-CAS), and the post-barrier pass is ONE ds_read per k-mer: the remembered slot holds the smallest
 // position of that key, so `entry == mine` <=> first occurrence.  Requires nk <= MAXIT*WEIGHT_THREADS, ts <= 32768.
-// FUSED (k = 16, k2 = 12, packed strand): the keys are not loaded but hashed here from the strand's base codes in LDS
-// (fz.codes, block-mix tables fz.lut).  Nothing is written for them: the MinHash and ordered-sketch kernels recompute
-// the hashes they need from the same 2-bit codes (12 B/k-mer of HBM writes and their read-back are gone).
+// FUSED (k = 16, k2 = 12, packed strand): nothing is read from memory but the strand's base codes staged in LDS (fz.codes), and
+// the table is keyed by the 32 bits of codes themselves (code_mix) — equal codes <=> equal k-mers, so no hash of the reference is
+// needed to find repeats (round 2 computed murmur3_x64_128 per k-mer here: the kernel was bound by its 64-bit multiplies).
+// Materialised strands (raw bytes, k != 16) are keyed by the 64-bit keys hash_kmers_kernel stored, fetched CH at a time.
 struct FusedHash { const uint64_t* lut; const uint32_t* codes; bool on; };
+// Dedupe key of a packed 16-mer: its 32 bits of base codes ARE the k-mer, so equal k-mers are found by comparing codes — no
+// murmur3 in this kernel unless a k-mer filter needs the hash.  Two multiplies mix the codes so that table slot (low bits),
+// probe stride (middle bits) and fingerprint (top 16 bits) are independent.
+__device__ __forceinline__ uint32_t code_mix(uint32_t cw) {
+  uint32_t h = cw * 0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+  return h;
+}
 template <int MAXIT, bool FUSED>
 __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64_t* __restrict__ kp, uint32_t* __restrict__ wp, int nk,
                                          unsigned int* s_heavy, const FusedHash& fz, bool may_skip) {
@@ -321,33 +328,36 @@ __device__ inline void weight_strand_lds(uint32_t* tab, uint32_t ts, const int64
   for (uint32_t j = (uint32_t)tx * 4; j < ts; j += WEIGHT_THREADS * 4) *(uint4*)&tab[j] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   uint32_t st[MAXIT];
+  const bool codekey = FUSED && fz.on;
   constexpr int CH = FUSED ? 2 : ((MAXIT >= 24) ? 8 : 4);   // keys in flight per lane (register budget: two workgroups per CU need <= 64 VGPRs)
 #pragma unroll
   for (int c = 0; c < MAXIT; c += CH) {
     if (c * WEIGHT_THREADS < nk) {
-      int64_t key[CH];
+      int64_t key[CH];     // materialised keys (!codekey)
+      uint32_t cw[CH];     // base codes of the 16-mer (codekey)
 #pragma unroll
       for (int u = 0; u < CH; u++) {
         const int i = tx + (c + u) * WEIGHT_THREADS;
-        if (FUSED && fz.on) key[u] = (i < nk) ? (int64_t)lut_key16(fz.lut, codes_at(fz.codes, i)) : 0;
-        else key[u] = (i < nk) ? kp[i] : 0;
+        if (codekey) { cw[u] = (i < nk) ? codes_at(fz.codes, i) : 0u; key[u] = 0; }
+        else { key[u] = (i < nk) ? kp[i] : 0; cw[u] = 0u; }
       }
 #pragma unroll
       for (int u = 0; u < CH; u++) {
         const int i = tx + (c + u) * WEIGHT_THREADS;
         st[c + u] = 0;
         if (i < nk) {
-          const uint32_t fp = ((uint32_t)((uint64_t)key[u] >> 32)) << 16;
+          const uint32_t hm = codekey ? code_mix(cw[u]) : 0u;
+          const uint32_t fp = codekey ? (hm & 0xFFFF0000u) : (((uint32_t)((uint64_t)key[u] >> 32)) << 16);
           const uint32_t mine = fp | (uint32_t)(i + 1);
-          uint32_t slot = (uint32_t)(uint64_t)key[u] & mask;
-          const uint32_t stride = ((uint32_t)((uint64_t)key[u] >> 20) | 1u) & mask;   // double hashing (odd stride, power-of-two table): no primary clustering
+          uint32_t slot = (codekey ? hm : (uint32_t)(uint64_t)key[u]) & mask;
+          const uint32_t stride = ((codekey ? (hm >> 7) : (uint32_t)((uint64_t)key[u] >> 20)) | 1u) & mask;   // double hashing (odd stride, power-of-two table): no primary clustering
           for (;;) {
             const uint32_t old = atomicCAS(&tab[slot], 0u, mine);
             if (old == 0) break;
-            if (((old ^ mine) >> 16) == 0) {   // fingerprint match: compare the full keys (re-hashed when the keys are not in memory yet)
+            if (((old ^ mine) >> 16) == 0) {   // fingerprint match: compare the k-mers themselves (their codes, or the stored keys)
               const int op = (int)((old & 0xFFFFu) - 1u);
-              const int64_t okey = (FUSED && fz.on) ? (int64_t)lut_key16(fz.lut, codes_at(fz.codes, op)) : kp[op];
-              if (okey == key[u]) { atomicMin(&tab[slot], mine); break; }
+              const bool same = codekey ? (codes_at(fz.codes, op) == cw[u]) : (kp[op] == key[u]);
+              if (same) { atomicMin(&tab[slot], mine); break; }
             }
             slot = (slot + stride) & mask;
           }
@@ -507,7 +517,7 @@ __device__ inline void class_list(const uint32_t* __restrict__ wp, uint32_t* __r
 
 constexpr int WEIGHT_SVARS = 32;   // LDS scalars of kmer_weight_kernel: [0..1] strand index, [2] valid / partition fill, [3] heavy, [4] min weight,
                                    // [5] max weight, [8..31] class_list scratch
-template <int MAXIT, int WAVES_PER_SIMD, bool FUSED>
+template <int MAXIT, int WAVES_PER_SIMD, bool FUSED, bool REWEIGH>
 __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                                      const int64_t* __restrict__ keys, uint32_t* __restrict__ wts,
                                                                      uint32_t* __restrict__ perms,
@@ -525,21 +535,39 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
   uint32_t* codes = (uint32_t*)(lut + HASH_LUT_WORDS);
   if (FUSED) for (int i = threadIdx.x; i < HASH_LUT_WORDS; i += WEIGHT_THREADS) lut[i] = luts[i];
   uint32_t* slab = slabs + (size_t)blockIdx.x * (size_t)slab_entries;
-  const bool reweigh = (repeat_weight < 0.0) || (ft.enabled && repeat_weight < 1.0) || (ft.enabled && ft.bloom_mode == 1);
+  // REWEIGH (decided by the host: v1.0 mode, tf-idf under -f, --supress-noise 1): weights are not plain multiplicities.  A template
+  // parameter, so that the common instantiation carries none of the filter's state in its (scarce, at 8 waves per SIMD) scalar registers
+  const bool reweigh = REWEIGH;
+  // Without a reweighing rule a k-mer's weight is its multiplicity, and a strand and its reverse complement repeat the same
+  // k-mers (reverse-complementing is a bijection on k-mers): the work item is then a READ — its forward strand is examined, and a
+  // packed read without a repeated k-mer (nearly all of them) settles both strands at once; only a read with repeats has its
+  // reverse strand examined too (its first occurrences are other positions).  With a filter the weights depend on each k-mer's
+  // own hash, so every strand is an item.
+  const bool pairs = !reweigh;
+  const int64_t nitems = pairs ? (nstrands >> 1) : nstrands;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned long long sx = atomicAdd(counter, 1ULL);
-      svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32); svars[2] = 0; svars[3] = 0; svars[4] = 0xFFFFFFFFu; svars[5] = 0;
+      svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32);
     }
+    __syncthreads();
+    // readfirstlane: the item — and with it the descriptor, every pointer and loop bound below — is provably uniform (scalar
+    // registers and scalar loads instead of a copy per lane)
+    const int64_t item = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)svars[1]) << 32) |
+                                   (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)svars[0]));
+    if (item >= nitems) break;
+    int64_t read = pairs ? item : (item >> 1);
+    if (order) read = order[read];   // longest reads first
+    const ReadDesc rd = descs[read];
+    const int nk = rd.length - k + 1;
+    const int rcs_first = pairs ? 0 : (int)(item & 1), rcs_last = pairs ? 1 : rcs_first;
+    for (int rcs = rcs_first; rcs <= rcs_last; rcs++) {
+    const int64_t strand = 2 * read + rcs;
+    __syncthreads();
+    if (threadIdx.x == 0) { svars[2] = 0; svars[3] = 0; svars[4] = 0xFFFFFFFFu; svars[5] = 0; }
     if (threadIdx.x >= 8 && threadIdx.x < WEIGHT_SVARS) svars[threadIdx.x] = 0;
     __syncthreads();
-    int64_t strand = (int64_t)(((unsigned long long)svars[1] << 32) | svars[0]);
-    if (strand >= nstrands) break;
-    if (order) strand = 2LL * order[strand >> 1] + (strand & 1);   // longest reads first
-    const ReadDesc rd = descs[strand >> 1];
-    const int rcs = (int)(strand & 1);
-    const int nk = rd.length - k + 1;
     if (strand_skipped(rd, rcs) || nk < 1) {
       if (threadIdx.x == 0) { info[strand].valid = 0; info[strand].mode = 1; slist[atomicAdd(counter + 4, 1ULL)] = (int32_t)strand; }
       continue;
@@ -626,10 +654,19 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
       class_list(wp, perm, nk, svars + 8, info[strand].cnt);
       wg_release();
     }
+    // a packed read whose forward strand repeats no k-mer: neither does its reverse complement
+    const bool settle_rc = pairs && rcs == 0 && mode == 1 && !(rd.flags & MHAP_RD_RAW);
     if (threadIdx.x == 0) {
       info[strand].valid = valid; info[strand].mode = mode;
       if (!valid || mode == 1) slist[atomicAdd(counter + 4, 1ULL)] = (int32_t)strand;
       else slist[nstrands + (int64_t)atomicAdd(counter + 5, 1ULL)] = (int32_t)strand;
+      if (settle_rc) {
+        const bool rc_skipped = strand_skipped(rd, 1);
+        info[strand + 1].valid = rc_skipped ? 0 : 1; info[strand + 1].mode = 1;
+        slist[atomicAdd(counter + 4, 1ULL)] = (int32_t)(strand + 1);
+      }
+    }
+    if (settle_rc) break;
     }
   }
 }
@@ -656,21 +693,18 @@ void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int
   }
   const int nblocks = weight_grid(num_cus, nstrands, max_len, k);
   const dim3 g(nblocks), b(WEIGHT_THREADS);
+  const bool reweigh = (repeat_weight < 0.0) || (ft.enabled && repeat_weight < 1.0) || (ft.enabled && ft.bloom_mode == 1);
+#define MHAP_LAUNCH_WEIGHT(MI, WPS, FU, RW)                                                                                              \
+  hipLaunchKernelGGL((kmer_weight_kernel<MI, WPS, FU, RW>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries, \
+                     counter, k, ft, repeat_weight, info, store, luts, order, slist)
   if (lds_entries <= 16384u) {   // reads up to 12288 k-mers: 64 KiB table, 12 k-mers per lane in registers, two workgroups per CU
-    if (fused)
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, true>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
-    else
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT / 2, 8, false>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
+    if (fused) { if (reweigh) MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT / 2, 8, true, true); else MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT / 2, 8, true, false); }
+    else { if (reweigh) MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT / 2, 8, false, true); else MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT / 2, 8, false, false); }
   } else {
-    if (fused)
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, true>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
-    else
-      hipLaunchKernelGGL((kmer_weight_kernel<WEIGHT_MAXIT, 4, false>), g, b, lds, st, descs, nstrands, keys, wts, perm, slabs, slab_entries, lds_entries,
-                         counter, k, ft, repeat_weight, info, store, luts, order, slist);
+    if (fused) { if (reweigh) MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT, 4, true, true); else MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT, 4, true, false); }
+    else { if (reweigh) MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT, 4, false, true); else MHAP_LAUNCH_WEIGHT(WEIGHT_MAXIT, 4, false, false); }
   }
+#undef MHAP_LAUNCH_WEIGHT
 }
 
 // number of persistent workgroups (= HBM slabs the caller must provide)
@@ -1085,8 +1119,11 @@ __device__ __forceinline__ void perchain_row(int64_t* best, int32_t* bpos, const
 // pays most for) — plus the strands without a sketch (their zero rows / status).  WEIGHTED = true: a second launch takes
 // the other strands (class lists, a common weight > 1).  kmer_weight_kernel sorts the strands into the two work lists.
 // (amdgpu_waves_per_eu: the weighted instantiation needs 129 VGPRs left alone — one over four waves per SIMD.)
+#ifndef MH_WAVES_EU
+#define MH_WAVES_EU 4
+#endif
 template <int U, bool BITSLICED, bool WEIGHTED, bool PROF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU, 8))) void minhash_kernel(const ReadDesc* __restrict__ descs, int64_t nstrands,
                                                       const int64_t* __restrict__ keys, const uint32_t* __restrict__ wts,
                                                       const uint32_t* __restrict__ perms, const StrandInfo* __restrict__ info,
                                                       const uint8_t* __restrict__ store, const uint64_t* __restrict__ luts,
