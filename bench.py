@@ -6,12 +6,13 @@ murmur hashes, tf / tf-idf weights, weighted MinHash, ordered bottom-S sketch), 
 candidate count, second-stage overlap scoring, accepted records delivered to the host.  The packed reads are
 resident in HBM before the timed region starts (mhap_stage_reads); record text formatting is outside it.
 
-  python bench.py --gpus 1 --steps K --warmup W [--config c1|c2|c4slice|c5slice|c3]
+  python bench.py --gpus 1 --steps K --warmup W [--config c1|c2|c3|c4|c4slice|c5slice]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-N > 1 (strong scaling, same data set): rank r sketches reads r, r+N, ... and indexes them — only them; the forward
-query sketches of all ranks are all-gathered (RCCL over xGMI; the ordered rows asynchronously, under the candidate stage) and every
-rank searches them against its own index (MHAP_BENCH_RING=1: the query bundles rotate round a ring instead, 2 bundles in HBM).
+N > 1 (strong scaling, same data set): rank r sketches reads r, r+N, ... and indexes them — only them; the exchange is inside
+the library (mhap_dist_find_matches_self: the forward query sketches of all ranks are all-gathered over an RCCL communicator the
+library creates — the ordered rows asynchronously, under the candidate stage — and every rank searches them against its own index).
+torch.distributed only carries rank 0's communicator id to the other ranks and does the barrier / max-over-ranks timing.
 Prints ONE JSON line on rank 0.  At N = 1 the line also carries
   parity_check : the GPU path and the CPU oracle run on the SAME sample reads, sorted-record SHA-256 compared;
   cpu_baseline : the oracle timed on this box's host cores on that sample (threads = the cgroup CPU quota);
@@ -94,17 +95,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    # MHAP_BENCH_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path without RCCL)
-    backend = os.environ.get("MHAP_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
+    backend = "nccl"
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or (os.environ.get("MHAP_BENCH_FORCE_DIST") and "RANK" in os.environ):   # (1 rank under torchrun: RCCL path on one GPU)
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     S, k, k2 = 1536, 16, 12
     flt = None
@@ -142,9 +138,7 @@ def main():
             flt = mhap_amd.FrequencyCounts.from_file(filter_path, filter_cutoff=1e-5, repeat_weight=0.9)
     p = MhapParams(kmer_size=k, num_hashes=H, ordered_kmer_size=k2, ordered_sketch_size=S, device=local_rank)
     n_local = len(fa)
-    n_pad = mdist.shard_size(n_total, world)    # equal shard size for the all-gather (pad = zero-length reads)
     fa_bench = fa
-    fa = mdist.pad_shard(fa, n_total, world)
     t_gen = time.time() - t_gen
 
     ms = MinHashSearch(p, kmer_filter=flt)
@@ -154,12 +148,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     force_dist = world > 1 or bool(os.environ.get("MHAP_BENCH_FORCE_DIST"))   # 1 rank through the N>1 code path (RCCL on one GPU)
     if force_dist:
-        loc_mh = torch.zeros((2 * n_pad, H), dtype=torch.int32, device=dev)
-        loc_od = torch.zeros((2 * n_pad, S, 2), dtype=torch.int32, device=dev)
-        loc_mt = torch.zeros((2 * n_pad, 4), dtype=torch.int32, device=dev)
-        lids, lfwd = mdist.local_entry_ids(n_total, world, rank)
-        all_ids = mdist.all_bundle_ids(n_total, world)
-    use_ring = bool(os.environ.get("MHAP_BENCH_RING"))     # rotate the query bundles round a ring (2 bundles in HBM) instead of gathering them
+        # the ranks form their communicator inside the library (ncclCommInitRank); the host only hands rank 0's id round
+        ms.dist_init(rank, world, mdist.broadcast_unique_id(dist, rank, MinHashSearch.dist_unique_id))
     phase = {"sketch": 0.0, "exchange": 0.0, "search": 0.0}
 
     def step(timed_phases=False):
@@ -175,58 +165,20 @@ def main():
             if timed_phases:
                 phase["search"] += time.perf_counter() - t0
             return recs
-        # N > 1: this rank's reads are sketched into its own tables, indexed here and nowhere else (1/N of the inverted-index
-        # build); the forward query sketches of all ranks are gathered (or rotate round a ring) and searched against it
-        ms.sketch_staged_device(loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-        if use_ring:
-            ms.set_device_index(lids, lfwd, loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-            ms.prepare_index()
+        # N > 1: this rank's reads are sketched into its own tables and indexed here and nowhere else (1/N of the inverted-index
+        # build, filled while the reads are sketched); the collective search gathers every rank's forward query rows inside the library
+        ms.add_staged()
         if timed_phases:
             ms.synchronize()
             phase["sketch"] += time.perf_counter() - t0
-        cur = (mdist.forward_rows(loc_mh), mdist.forward_rows(loc_od), mdist.forward_rows(loc_mt))
-        torch.cuda.current_stream().synchronize()
-        if not use_ring:
-            # default exchange: all-gather the forward query rows — MinHash + meta first (all the candidate stage needs), the ordered
-            # rows asynchronously; the index build and the candidate stage run meanwhile, the second stage waits for them (gate)
-            t1 = time.perf_counter()
-            g_mh, _ = mdist.gather_forward(cur[0], world, dist)
-            g_mt, _ = mdist.gather_forward(cur[2], world, dist)
-            g_od, work = mdist.gather_forward(cur[1], world, dist, async_op=True)
-            ms.set_device_index(lids, lfwd, loc_mh.data_ptr(), loc_od.data_ptr(), loc_mt.data_ptr())
-            ms.prepare_index()
-            if timed_phases:
-                phase["exchange"] += time.perf_counter() - t1
-
-            def wait_ordered():
-                if work is not None:
-                    work.wait()
-                torch.cuda.current_stream().synchronize()
-            t1 = time.perf_counter()
-            recs = ms.find_matches_device(g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr(), all_ids, to_self=True, before_second_stage=wait_ordered)
-            if timed_phases:
-                phase["search"] += time.perf_counter() - t1
-            step.keep = (g_mh, g_od, g_mt)
-            return recs
-        parts = []
-        for t in range(world):
-            pending = None
-            if t + 1 < world:      # pass the bundle on while it is searched here (it is only read)
-                pending = mdist.ring_post(cur, world, rank, dist)
-            t1 = time.perf_counter()
-            origin = (rank - t) % world
-            parts.append(ms.find_matches_device(cur[0].data_ptr(), cur[1].data_ptr(), cur[2].data_ptr(),
-                                                mdist.bundle_ids(n_total, world, origin), to_self=True))
-            if timed_phases:
-                phase["search"] += time.perf_counter() - t1
-            if pending is not None:
-                t1 = time.perf_counter()
-                nxt = mdist.ring_wait(*pending)
-                if timed_phases:
-                    phase["exchange"] += time.perf_counter() - t1      # what the transfer was NOT hidden behind the search
-                step.keep = cur
-                cur = nxt
-        return np.concatenate(parts) if len(parts) > 1 else parts[0]
+            t0 = time.perf_counter()
+        recs = ms.dist_find_matches()
+        if timed_phases:
+            tm = ms.dist_last_timing()
+            exch = (tm["gather_small_ms"] + tm["wait_ordered_ms"]) / 1e3    # what of the gather the compute did not hide
+            phase["exchange"] += exch
+            phase["search"] += time.perf_counter() - t0 - exch
+        return recs
 
     def fence():
         ms.synchronize()
@@ -335,7 +287,7 @@ def main():
             "config": {"workload": f"{cfg_label}, k={k}, --num-hashes {H}, ordered sketch k2={k2} S={S}, self-overlap"
                                    + (", -f k-mer filter, --filter-threshold 1e-5" if cfg.get("filter") else ""),
                        "name": args.config, "error_rate": args.error_rate,
-                       "parallelism": f"reads round-robin over {world} GPU(s); per-rank index of own reads, RCCL all-gather of the forward query sketches" if world > 1 else "1 GPU"},
+                       "parallelism": f"reads round-robin over {world} GPU(s); per-rank index of own reads; RCCL all-gather of the forward query sketches inside libmhaphip (mhap_dist_*)" if world > 1 else "1 GPU"},
             "records_per_step": total_records,
             "sketches_per_sec": round(strands / float(pht[0].item()), 1) if float(pht[0].item()) > 0 else None,
             "sketches_per_sec_note": "2N strands / wall time of the sketch phase (packed reads in HBM -> MinHash + ordered tables in HBM, host "

@@ -76,14 +76,16 @@ typedef struct mhap_stats {
 } mhap_stats;
 
 /* Per-kernel HIP-event timings accumulated on the handle's stream (for bench/roofline). */
-#define MHAP_K_HASH 0      /* k-mer murmur3_x64_128 + murmur3_x86_32            */
-#define MHAP_K_DEDUP 1     /* per-strand k-mer multiplicity (tf weight)          */
-#define MHAP_K_MINHASH 2   /* weighted xorshift MinHash                          */
-#define MHAP_K_ORDERED 3   /* bottom-S select + sort                             */
-#define MHAP_K_CANDIDATE 4 /* brute-force all-pairs slot-equality count (fallback / MHAP_CANDIDATES=bruteforce) */
-#define MHAP_K_OVERLAP 5   /* second-stage getOverlapInfo                        */
-#define MHAP_K_INDEX_BUILD 6 /* inverted index build (MinHashSearch.addSequence) */
-#define MHAP_K_INDEX_QUERY 7 /* inverted index lookups + per-query hit counting  */
+#define MHAP_K_HASH 0      /* hash_kmers_kernel: murmur3 of every k-mer / k2-mer into HBM — only for reads the kernels cannot hash from
+                              their 2-bit codes (raw bytes, k != 16 or k2 != 12, reads beyond 24 591 bases); 0 on the default path */
+#define MHAP_K_WEIGHT 1    /* kmer_weight_kernel: per-strand k-mer multiplicity / tf-idf weight, weight classes, MinHash work lists */
+#define MHAP_K_DEDUP MHAP_K_WEIGHT   /* (name of rounds 1-2) */
+#define MHAP_K_MINHASH 2   /* minhash_kernel: weighted xorshift MinHash (hashes its k-mers from the 2-bit codes)            */
+#define MHAP_K_ORDERED 3   /* ordered_kernel: 12-mer hashes + bottom-S select + sort                                     */
+#define MHAP_K_CANDIDATE 4 /* candidate_kernel: brute-force all-pairs slot-equality count (MHAP_CANDIDATES=bruteforce only) */
+#define MHAP_K_OVERLAP 5   /* overlap_join_kernel (+ overlap_kernel for the pairs it hands over): second-stage getOverlapInfo */
+#define MHAP_K_INDEX_BUILD 6 /* index_build + index_finalize: inverted index (MinHashSearch.addSequence) */
+#define MHAP_K_INDEX_QUERY 7 /* index_query_kernel: inverted index lookups + per-query hit counting  */
 #define MHAP_K_COUNT 8
 typedef struct mhap_kernel_times {
   double ms[MHAP_K_COUNT];      /* summed kernel time, milliseconds */
@@ -313,6 +315,7 @@ int mhap_selftest_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, co
                         int64_t* out2);
 int mhap_selftest_transpose32(uint32_t* a32);
 int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out);
+int mhap_selftest_xorshift_unjump(uint64_t x, int32_t nsteps, uint64_t* out);   /* the key nsteps steps before chain value x */
 /* out8 = {empty, valid(rawScore), a1, a2, b1, b2, inter, k} */
 int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const int32_t* B, int32_t nB, int32_t lenB,
                                double max_shift, int32_t stride, int32_t* out8);

@@ -158,6 +158,16 @@ __host__ __device__ inline uint64_t xorshift_step(uint64_t x) {
   return x;
 }
 
+// The step undone: (I + L^4)^-1 = (I + L^4)(I + L^8)(I + L^16)(I + L^32), (I + R^35)^-1 = I + R^35, (I + L^21)^-1 = (I + L^21)(I + L^42).
+// The step is a bijection, so the k-mer key behind a slot's minimal chain value x after n steps is unstep^n(x): the MinHash
+// kernel of the weight-1 strands keeps only the minima and recovers the winning keys at the end (inverse jump tables).
+__host__ __device__ inline uint64_t xorshift_unstep(uint64_t x) {
+  x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
+  x ^= x >> 35;
+  x ^= x << 21; x ^= x << 42;
+  return x;
+}
+
 // In-place transpose of a 32x32 bit matrix held as 32 dwords: afterwards bit j of a[b] == bit b of the old a[j].
 // Five butterfly stages with compile-time indices (registers on the device).  Used to turn 32 k-mer keys per lane
 // into 64 bit-planes for the bit-sliced xorshift rows of minhash_kernel.

@@ -106,7 +106,7 @@ struct mhap_handle {
   // filter
   DevBuf f_keys, f_vals, f_bloom;
   FilterTable ft{};
-  DevBuf score_tbl, jump_tbl, hash_luts;
+  DevBuf score_tbl, jump_tbl, unjump_tbl, hash_luts;
 
   // index (owned or external)
   bool external = false;
@@ -120,7 +120,7 @@ struct mhap_handle {
   std::vector<uint8_t> status;   // per entry status (host mirror)
 
   // sketch scratch
-  DevBuf store, descs, keys, wts, perm, h32, info, slist, slabs, counters, order;
+  DevBuf store, descs, keys, wts, perm, h32, info, slist, slabs, counters, order, mhq, mhmerge;
   int jump_na = 0;   // fine xorshift jump tables (coarse ones follow them in jump_tbl)
   std::vector<int32_t> h_order;
   uint8_t* pin_store = nullptr;   // pinned host staging buffer of stage_reads
@@ -436,15 +436,17 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       time_end(h);
       DBGSYNC(h, "hash_kmers");
     }
-    time_begin(h, MHAP_K_DEDUP);
+    time_begin(h, MHAP_K_WEIGHT);
     launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(),
                         h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused,
                         h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), d_order, h->slist.as<int32_t>());
     time_end(h);
     DBGSYNC(h, "kmer_weights");
-    int per_cu = 8;
+    int per_cu = minhash_wgs_per_cu(H);   // the launch is persistent: exactly the workgroups that can be resident
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
-    const int mblocks = (int)std::min<int64_t>((nstr + 3) / 4, (int64_t)h->num_cus * per_cu);
+    const int mblocks = h->num_cus * per_cu;   // (each launch is trimmed to the workgroups its work list can feed)
+    HIPCHK(h, h->mhq.ensure(minhash_queue_bytes(2 * std::max(mblocks, 1)) * 4));   // (x4: one wave per workgroup when --num-hashes is huge)
+    HIPCHK(h, h->mhmerge.ensure(minhash_merge_bytes(std::max(mblocks, 1), H)));
     // The strands with weighted k-mers are a second launch (own instantiation).  On the same stream a handful of such strands (C2:
     // under 1 %) hold the GPU for one strand's duration (3 ms) after the weight-1 launch has drained.  So the two list lengths are
     // read back (one 16-byte copy: the weight kernel has to be complete anyway), each launch gets only the workgroups its list
@@ -457,7 +459,8 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     time_begin(h, MHAP_K_MINHASH);
     launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
                    h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
-                   meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>());
+                   meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(),
+                   h->mhmerge.as<unsigned long long>(), std::max(0, B.max_len - k + 1));
     HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
     time_end(h);
@@ -819,6 +822,13 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
       seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
   }
+  {   // ... and their inverses (the weight-1 MinHash kernel turns a slot's minimal chain value back into the winning key)
+    std::vector<uint64_t> ut((size_t)h->jump_na * 2048);
+    build_xorshift_unjump_tables(h->jump_na, ut.data());
+    if (h->unjump_tbl.ensure(ut.size() * 8) != hipSuccess || hipMemcpy(h->unjump_tbl.p, ut.data(), ut.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
+    }
+  }
   HPROF("create: jump tables");
   {   // block-mix tables of the k-mer hash kernel's k = 16 / k2 = 12 path
     std::vector<uint64_t> lt(768);
@@ -839,7 +849,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
-                    &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
+                    &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_ovf, &h->inv_big};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
@@ -1321,6 +1331,21 @@ int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out) {
   }
   for (int t = 0; t < r; t++) x = xorshift_step(x);
   *out = x;
+  return MHAP_OK;
+}
+
+// the key behind chain value x after nsteps >= 1 steps, recovered the way the weight-1 MinHash kernel does it (inverse byte tables
+// for the next multiple of 4 steps, then up to 3 steps forward)
+int mhap_selftest_xorshift_unjump(uint64_t x, int32_t nsteps, uint64_t* out) {
+  if (!out || nsteps < 1 || nsteps > (1 << 15)) return MHAP_E_INVALID;
+  const int a = (nsteps + (1 << XS_JUMP_LOG2) - 1) >> XS_JUMP_LOG2, r = (a << XS_JUMP_LOG2) - nsteps;
+  std::vector<uint64_t> ut((size_t)a * 2048);
+  build_xorshift_unjump_tables(a, ut.data());
+  const uint64_t* T = ut.data() + (size_t)(a - 1) * 2048;
+  uint64_t y = 0;
+  for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+  for (int t = 0; t < r; t++) y = xorshift_step(y);
+  *out = y;
   return MHAP_OK;
 }
 

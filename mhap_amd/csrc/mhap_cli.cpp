@@ -77,6 +77,31 @@ std::vector<std::string> list_files(const std::string& path) {   // non-hidden e
 [[noreturn]] void die(const std::string& m) { fprintf(stderr, "Exception in mhap-hip: %s\n", m.c_str()); exit(1); }
 void chk(mhap_handle* h, int rc) { if (rc != MHAP_OK) die(std::string(mhap_last_error(h)) + " (code " + std::to_string(rc) + ")"); }
 
+// One GPU (a handle) or several (a group: one rank per device, reads dealt round-robin, the exchange inside the library).
+struct Engine {
+  mhap_handle* h = nullptr;
+  mhap_group* g = nullptr;
+  int n = 1;
+  mhap_handle* rank(int r) const { return g ? mhap_group_rank(g, r) : h; }
+  void check(int rc) const {
+    if (rc == MHAP_OK) return;
+    die(std::string(g ? mhap_group_last_error(g) : mhap_last_error(h)) + " (code " + std::to_string(rc) + ")");
+  }
+  void add_reads(const mhap_fasta& fa) const {
+    if (fa.n <= 0) return;
+    check(g ? mhap_group_add_reads(g, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n) : mhap_index_add_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n));
+  }
+  void find_self(mhap_record_sink sink, void* user) const { check(g ? mhap_group_find_matches_self(g, sink, user) : mhap_find_matches_self(h, 0, -1, sink, user)); }
+  void find_reads(const mhap_fasta& fa, mhap_record_sink sink, void* user) const {
+    if (fa.n <= 0) return;
+    check(g ? mhap_group_find_matches_reads(g, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n, sink, user)
+            : mhap_find_matches_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n, sink, user));
+  }
+  mhap_stats stats() const { mhap_stats st; check(g ? mhap_group_get_stats(g, &st) : mhap_get_stats(h, &st)); return st; }
+  void clear() const { check(g ? mhap_group_clear(g) : mhap_index_clear(h)); }
+  void destroy() { if (g) mhap_group_destroy(g); else if (h) mhap_destroy(h); g = nullptr; h = nullptr; }
+};
+
 // ---- big-endian `.dat` primitives (DataOutputStream / ByteBuffer) ----
 void put8(std::string& b, uint8_t v) { b.push_back((char)v); }
 void put32(std::string& b, int32_t v) { for (int s = 24; s >= 0; s -= 8) b.push_back((char)((uint32_t)v >> s)); }
@@ -130,15 +155,18 @@ int sink_cb(const mhap_record* r, int64_t n, void* user) {
 void sink_flush(Sink& s) { if (!s.buf.empty()) fwrite(s.buf.data(), 1, s.buf.size(), s.out); s.buf.clear(); fflush(s.out); }
 
 // FrequencyCounts file -> (hash, fraction) arrays (J/sketch/FrequencyCounts.java:63-229)
-void load_filter(mhap_handle* h, const Options& o) {
+void load_filter(const Engine& E, const Options& o) {
   const double rw = o.d("--repeat-weight");
   const double offset = (rw >= 0.0 && rw < 1.0) ? rw : 0.0;   // MhapMain.java:346-350
   char sizes[256];
-  const int rc = mhap_set_filter_file(h, o.s("-f").c_str(), o.d("--filter-threshold"), offset, o.i("--supress-noise"), o.b("--no-tf") ? 1 : 0,
-                                      o.d("--repeat-idf-scale"), o.b("--no-rc") ? 0 : 1, sizes, sizeof sizes);
-  if (rc == MHAP_E_IO) die("Could not parse k-mer filter file.");
-  if (rc == MHAP_E_INVALID && !*mhap_last_error(h)) die("K-mer filter file first line must contain estimated number of k-mers in the file (long).");
-  chk(h, rc);
+  for (int r = 0; r < E.n; r++) {   // every rank applies the filter to the reads it sketches
+    mhap_handle* h = E.rank(r);
+    const int rc = mhap_set_filter_file(h, o.s("-f").c_str(), o.d("--filter-threshold"), offset, o.i("--supress-noise"), o.b("--no-tf") ? 1 : 0,
+                                        o.d("--repeat-idf-scale"), o.b("--no-rc") ? 0 : 1, sizes, sizeof sizes);
+    if (rc == MHAP_E_IO) die("Could not parse k-mer filter file.");
+    if (rc == MHAP_E_INVALID && !*mhap_last_error(h)) die("K-mer filter file first line must contain estimated number of k-mers in the file (long).");
+    chk(h, rc);
+  }
   fprintf(stderr, "Read in k-mer filter for sizes: [%s]\n", sizes);
 }
 
@@ -195,9 +223,11 @@ void write_dat(mhap_handle* h, const std::string& path, int H, int S, int k2) {
   fclose(f);
 }
 
-int64_t add_file_to_index(mhap_handle* h, const std::string& path, int64_t id_offset, const Options& o, int64_t* strands) {
+int64_t add_file_to_index(const Engine& E, const std::string& path, int64_t id_offset, const Options& o, int64_t* strands) {
   const int H = o.i("--num-hashes"), S = o.i("--ordered-sketch-size");
   if (ends_with(path, ".dat")) {   // MhapMain.java:563-564
+    if (E.g) die("--gpus N takes FASTA input (precomputed .dat sketches are searched on one GPU)");
+    mhap_handle* h = E.h;
     DatEntries d; read_dat(path, id_offset, H, S, false, d);
     if (!d.ids.empty()) chk(h, mhap_index_add_sketches(h, d.ids.data(), d.fwd.data(), d.seqlen.data(), d.mh.data(), d.ord.data(), d.osz.data(), d.olen.data(), (int64_t)d.ids.size()));
     if (g_headers.full) for (size_t i = 0; i < d.ids.size(); i++) g_headers.byid[d.ids[i]] = d.hdr[i];
@@ -210,7 +240,7 @@ int64_t add_file_to_index(mhap_handle* h, const std::string& path, int64_t id_of
   else if (mhap_fasta_read(path.c_str(), id_offset, &fa, err, sizeof err) != MHAP_OK) die(err);
   if (g_headers.full) collect_headers(fa);
   const double t_add = now();
-  if (fa.n > 0) chk(h, mhap_index_add_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n));
+  E.add_reads(fa);
   if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[cli] fasta read %.3f s, add_reads %.3f s\n", t_add - t_read, now() - t_add);
   // The parsed reads (1 byte per base) are released after the search, not here: unmapping a gigabyte takes ~0.13 s, and doing it on
   // another thread only moves the stall (the unmap holds the address-space lock the search's allocations need).  Bounded: beyond
@@ -225,7 +255,7 @@ int64_t add_file_to_index(mhap_handle* h, const std::string& path, int64_t id_of
     mhap_fasta_free(&f);
     parked.erase(parked.begin());
   }
-  mhap_stats st; chk(h, mhap_get_stats(h, &st));
+  const mhap_stats st = E.stats();
   *strands = st.strands_indexed;
   // seqNumberProcessed += seqStreamer.getNumberProcessed()/2 (MhapMain.java:462): the streamer counts the sketches it
   // produced (SequenceSketchStreamer.java:145,155,268-271), so reads below --min-olap-length and reads without a valid
@@ -261,7 +291,9 @@ int main(int argc, char** argv) {
   o.add("--no-tf", "Do not perform the tf weighing, in the tf-idf weighing.", "false", true);
   o.add("--no-rc", "Do not store or do comparison of the reverse compliment strings (in this MHAP version it only changes how -f k-mers are hashed).", "false", true);
   o.add("--settings", "Set all unset parameters for the default settings. 0) None, 1) Default, 2) Fast, 3) Sensitive.", "0");
-  o.add("--device", "[int] HIP device ordinal.", "0");
+  o.add("--device", "[int] HIP device ordinal (the first one with --gpus N).", "0");
+  o.add("--gpus", "[int] Number of GPUs: the reads are dealt round-robin over devices --device .. --device+N-1, every GPU sketches and indexes its share, and a search gathers the forward query sketches of all GPUs (over xGMI) against every share.", "1");
+  o.add("--devices", "Comma-separated HIP device ordinals, one per rank (overrides --device/--gpus; an ordinal may repeat).", "");
   if (!o.parse(argc, argv)) return 0;
 
   auto bad = [&](const char* m) { printf("%s\n", m); exit(1); };
@@ -290,13 +322,29 @@ int main(int argc, char** argv) {
   P.ordered_sketch_size = o.i("--ordered-sketch-size"); P.num_min_matches = o.i("--num-min-matches");
   P.min_store_length = o.i("--min-store-length"); P.min_olap_length = o.i("--min-olap-length"); P.device = o.i("--device");
   P.threshold = o.d("--threshold"); P.max_shift = o.d("--max-shift"); P.repeat_weight = o.d("--repeat-weight");
-  mhap_handle* h = nullptr; char err[512] = {0};
+  // ranks: --devices a,b,c  |  --gpus N from --device on  |  one handle
+  std::vector<int32_t> devs;
+  if (!o.s("--devices").empty()) {
+    const std::string dl = o.s("--devices");
+    for (size_t i = 0; i < dl.size();) { size_t j = dl.find(',', i); if (j == std::string::npos) j = dl.size(); if (j > i) devs.push_back(atoi(dl.substr(i, j - i).c_str())); i = j + 1; }
+  } else {
+    if (o.i("--gpus") < 1) bad("The number of GPUs must be positive.");
+    for (int r = 0; r < o.i("--gpus"); r++) devs.push_back(o.i("--device") + r);
+  }
+  if (devs.empty()) bad("No device given.");
+  const bool precompute = !o.s("-p").empty();
+  if (precompute && devs.size() > 1) { fprintf(stderr, "Usage 2 (-p) writes its .dat files from one GPU: using device %d only.\n", devs[0]); devs.resize(1); }
+  Engine E; E.n = (int)devs.size();
+  char err[512] = {0};
   const double t_create = now();
   // mhap_create is mostly the HIP runtime coming up (~0.25 s): it runs on its own thread while this one reads and parses the
   // FASTA file the index is built from
   int rc_create = MHAP_OK;
-  std::thread creator([&]() { rc_create = mhap_create(&P, &h, err, sizeof err); });
-  if (o.s("-p").empty() && !is_dir(o.s("-s")) && !ends_with(o.s("-s"), ".dat")) {
+  std::thread creator([&]() {
+    if (devs.size() == 1) { P.device = devs[0]; rc_create = mhap_create(&P, &E.h, err, sizeof err); }
+    else rc_create = mhap_group_create(&P, devs.data(), (int32_t)devs.size(), &E.g, err, sizeof err);
+  });
+  if (!precompute && !is_dir(o.s("-s")) && !ends_with(o.s("-s"), ".dat")) {
     char perr[512] = {0};
     if (mhap_fasta_read(o.s("-s").c_str(), 0, &g_preload.fa, perr, sizeof perr) == MHAP_OK) { g_preload.path = o.s("-s"); g_preload.valid = true; }
     // (a failure is reported by the regular read below)
@@ -304,23 +352,25 @@ int main(int argc, char** argv) {
   creator.join();
   if (rc_create != MHAP_OK) die(err);
   if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[cli] mhap_create + first FASTA read %.3f s\n", now() - t_create);
+  if (E.g) fprintf(stderr, "Using %d GPU ranks (reads dealt round-robin; every rank indexes its share).\n", E.n);
 
   const double t_total = now();
   if (!o.s("-f").empty()) {
     const double t = now();
     fprintf(stderr, "Reading in filter file %s.\n", o.s("-f").c_str());
-    load_filter(h, o);
+    load_filter(E, o);
     fprintf(stderr, "Time (s) to read filter file: %g\n", now() - t);
   }
 
-  if (!o.s("-p").empty()) {   // Usage 2: precompute `.dat` (MhapMain.java:384-451)
+  if (precompute) {   // Usage 2: precompute `.dat` (MhapMain.java:384-451)
+    mhap_handle* h = E.h;
     fprintf(stderr, "Processing FASTA files for binary compression...\n");
     if (!is_dir(o.s("-q"))) die("Target directory doesn't exit.");
     for (const std::string& pf : list_files(o.s("-p"))) {
       const double t = now();
       chk(h, mhap_index_clear(h));
       int64_t strands = 0;
-      add_file_to_index(h, pf, 0, o, &strands);
+      add_file_to_index(E, pf, 0, o, &strands);
       std::string name = pf.substr(pf.find_last_of('/') + 1);
       size_t dot = name.find_last_of('.'); if (dot != std::string::npos && dot > 0) name = name.substr(0, dot);
       const std::string out = o.s("-q") + "/" + name + ".dat";
@@ -330,14 +380,14 @@ int main(int argc, char** argv) {
       fprintf(stderr, "Time (s): %g\n", now() - t);
     }
     fprintf(stderr, "Total time (s): %g\n", now() - t_total);
-    mhap_destroy(h);
+    E.destroy();
     return 0;
   }
 
   fprintf(stderr, "Processing files for storage in reverse index...\n");
   const double t_proc = now();
   int64_t strands = 0;
-  int64_t seq_processed = add_file_to_index(h, o.s("-s"), 0, o, &strands);
+  int64_t seq_processed = add_file_to_index(E, o.s("-s"), 0, o, &strands);
   fprintf(stderr, "Stored %lld sequences in the index.\n", (long long)strands);
   fprintf(stderr, "Processed %lld unique sequences (fwd and rev).\n", (long long)strands);
   fprintf(stderr, "Time (s) to read and hash from file: %g\n", now() - t_proc);
@@ -346,13 +396,13 @@ int main(int argc, char** argv) {
   const double t_score = now();
   if (o.s("-q").empty()) {
     const double t = now();
-    chk(h, mhap_find_matches_self(h, 0, -1, sink_cb, &sink));
+    E.find_self(sink_cb, &sink);
     sink_flush(sink);
     fprintf(stderr, "Time (s) to score and output to self: %g\n", now() - t);
   } else {
     double t = now();
     if (!o.b("--no-self")) {
-      chk(h, mhap_find_matches_self(h, 0, -1, sink_cb, &sink));
+      E.find_self(sink_cb, &sink);
       sink_flush(sink);
       fprintf(stderr, "Time (s) to score and output to self: %g\n", now() - t);
     }
@@ -361,6 +411,8 @@ int main(int argc, char** argv) {
       fprintf(stderr, "Opened fasta file %s.\n", cf.c_str());
       int64_t nq = 0;
       if (ends_with(cf, ".dat")) {   // precomputed query sketches: forward entries only (SequenceSketchStreamer.java:291-303)
+        if (E.g) die("--gpus N takes FASTA input (precomputed .dat sketches are searched on one GPU)");
+        mhap_handle* h = E.h;
         DatEntries d;
         read_dat(cf, seq_processed, P.num_hashes, P.ordered_sketch_size, true, d);
         if (g_headers.full) for (size_t i = 0; i < d.ids.size(); i++) g_headers.byid[d.ids[i]] = d.hdr[i];
@@ -376,9 +428,9 @@ int main(int argc, char** argv) {
       mhap_fasta fa;
       if (mhap_fasta_read(cf.c_str(), seq_processed, &fa, err, sizeof err) != MHAP_OK) die(err);   // id offset = reads so far (MhapMain.java:527)
       if (g_headers.full) collect_headers(fa);
-      mhap_stats s0; chk(h, mhap_get_stats(h, &s0));
-      if (fa.n > 0) chk(h, mhap_find_matches_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n, sink_cb, &sink));
-      mhap_stats s1; chk(h, mhap_get_stats(h, &s1));
+      const mhap_stats s0 = E.stats();
+      E.find_reads(fa, sink_cb, &sink);
+      const mhap_stats s1 = E.stats();
       nq = s1.queries_searched - s0.queries_searched;   // forward sketches produced = getNumberProcessed() (MhapMain.java:537)
       mhap_fasta_free(&fa);
       sink_flush(sink);
@@ -391,13 +443,19 @@ int main(int argc, char** argv) {
   fprintf(stderr, "Total scoring time (s): %g\n", now() - t_score);
   fprintf(stderr, "Total time (s): %g\n", now() - t_total);
   // outputFinalStat (MhapMain.java:572-590); the inverted-index counters have no brute-force analogue
-  mhap_stats st; chk(h, mhap_get_stats(h, &st));
-  mhap_kernel_times kt; chk(h, mhap_get_kernel_times(h, &kt));
-  fprintf(stderr, "MinHash search time (s): %g\n", kt.ms[MHAP_K_CANDIDATE] * 1e-3);
+  const mhap_stats st = E.stats();
+  mhap_kernel_times kt; memset(&kt, 0, sizeof kt);
+  for (int r = 0; r < E.n; r++) {   // kernel time summed over the ranks (they run concurrently)
+    mhap_kernel_times k1; chk(E.rank(r), mhap_get_kernel_times(E.rank(r), &k1));
+    for (int i = 0; i < MHAP_K_COUNT; i++) { kt.ms[i] += k1.ms[i]; kt.launches[i] += k1.launches[i]; }
+  }
+  fprintf(stderr, "MinHash search time (s): %g\n", (kt.ms[MHAP_K_CANDIDATE] + kt.ms[MHAP_K_INDEX_QUERY]) * 1e-3);
   fprintf(stderr, "Total matches found: %lld\n", (long long)st.matches_found);
   fprintf(stderr, "Average number of matches per lookup: %g\n", (double)st.matches_found / (double)std::max<int64_t>(1, st.queries_searched));
   fprintf(stderr, "Average %% of hashed sequences fully compared that are matches: %g\n", (double)st.matches_found / (double)std::max<int64_t>(1, st.candidates_compared) * 100.0);
-  fprintf(stderr, "GPU kernel time (ms): hash %.3f, weights %.3f, minhash %.3f, ordered %.3f, candidates %.3f, overlap %.3f\n", kt.ms[0], kt.ms[1], kt.ms[2], kt.ms[3], kt.ms[4], kt.ms[5]);
+  fprintf(stderr, "GPU kernel time (ms): hash %.3f, weights %.3f, minhash %.3f, ordered %.3f, index build %.3f, index query %.3f, candidates %.3f, overlap %.3f\n",
+          kt.ms[MHAP_K_HASH], kt.ms[MHAP_K_WEIGHT], kt.ms[MHAP_K_MINHASH], kt.ms[MHAP_K_ORDERED], kt.ms[MHAP_K_INDEX_BUILD], kt.ms[MHAP_K_INDEX_QUERY],
+          kt.ms[MHAP_K_CANDIDATE], kt.ms[MHAP_K_OVERLAP]);
   // everything is written: leave without tearing down gigabytes of device and host mappings one by one (the kernel does it faster)
   fflush(nullptr);
   _exit(0);

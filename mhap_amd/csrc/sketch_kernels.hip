@@ -791,9 +791,13 @@ constexpr int BS_MINREM = 512;   // remaining k-mers of a weight class needed to
 constexpr int BS_ZMAX = MH_ZMAX;   // filter depth cap.  Every plane costs one VALU op per step, every false candidate a queue entry: measured at C2 with
                                    // caps 10 / 12 / 13 / 16 / 24: 91.4 / 89.5 / 89.6 / 91.6 / 101.7 ms (2048 x 2^-13 = a quarter of the steps pass a false candidate at 12)
 #ifndef MH_QCAP
-#define MH_QCAP 640
+#define MH_QCAP 4096
 #endif
-constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wave (LDS, 4 bytes each; with the 4 KB key tables 4 workgroups per CU fit at H = 512)
+constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wave.  The queue lives in global memory (16 KB per resident wave, written
+                                     // once and read once: it stays in L2): a row's candidates (~1000 in a strand's first row, fewer later) always fit, so the
+                                     // queue is drained at the END of a row only — where the 64 plane registers are dead — and the slot loop carries no
+                                     // drain code.  Round 2 kept 640 entries in LDS and drained mid-row: the drain's state stayed live across the slot loop
+                                     // (122 VGPRs) and its LDS kept a fifth workgroup off the CU.
 constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash (the murmur3_x86_32 part of the tables is not needed here)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
@@ -890,69 +894,56 @@ __device__ __forceinline__ int bs_depth(int32_t bhs) {
   return z > BS_ZDEEP ? BS_ZDEEP : z;
 }
 
-// returns a mask with a 0 bit for every chain that may undercut the slot minimum of filter depth z: the chain must be
-// negative with planes 62 .. 63-z all zero.  Branch-free: z (wave-uniform, from the slot's minimum) becomes one scalar
-// enable word per plane (s_bfe_i32 of the depth mask) and every plane costs one v_and_or_b32 — BS_ZMAX + 1 VALU ops per
-// step whatever the depth, no scalar compare/branch ladder (which took ~25 SGPR pairs for its conditions and, with them,
-// the registers of everything else in the slot loop).
-// Once a slot has a minimum its depth is practically always >= BS_ZFIX (the minimum of >= 2048 chain values), so the first
-// BS_ZFIX planes are OR-ed unconditionally (two per v_or3_b32) and only the planes beyond get enable words; a slot whose
-// minimum is shallower than that (z < BS_ZFIX, incl. "no negative minimum yet") takes the generic masked form.
-#ifndef MH_ZFIX
-#define MH_ZFIX 8
-#endif
-constexpr int BS_ZFIX = MH_ZFIX;   // 0: every plane masked (no depth branch in the step)
-struct BsEnable { uint32_t w[BS_ZMAX + 1]; };
-__device__ __forceinline__ BsEnable bs_enable(int z) {
-  const uint32_t m = z < 0 ? 0u : ((2u << z) - 1u);                       // bit 0: sign plane, bits 1..z: magnitude planes 62 .. 63-z
-  BsEnable en;
-#pragma unroll
-  for (int b = 0; b <= BS_ZMAX; b++) {
-    en.w[b] = (uint32_t)((int)(m << (31 - b)) >> 31);
-    if (b > BS_ZFIX) asm volatile("" : "+s"(en.w[b]));   // keep it a scalar mask word (otherwise it is turned back into 64-bit select conditions)
-  }
-  return en;
+// The candidate filter of a step.  A slot's candidates are the chains that are negative with the magnitude planes 62 .. 63-z
+// all zero (z = the depth of the slot's minimum).  The depths of 64 slots are held one per lane as MASK words
+// m = (2 << z) - 1 (bit 0: sign plane, bit b: magnitude plane 63-b; 0 = no negative minimum yet); a slot's word comes out
+// with one v_readlane and its bits become scalar enable words (s_bfe_i32).
+//
+// Hot form (every step, bs_hot_filter): ten full-rate three-input ops and no branch —
+//   planes 1..8 OR-ed unconditionally (once a slot has a minimum of >= 2048 chain values its depth is practically always >= 8),
+//   planes 9..12 through their enable words ((plane & enable) | acc),
+//   and a slot whose depth is below 8 (incl. "no minimum yet") is routed THROUGH THE TRIGGER: its `keep` word is 0, every chain
+//   looks like a candidate, and the triggered path recomputes the exact masked filter for it.
+// Every op is v_bitop3_b32: v_or3_b32 / v_and_or_b32, which round 2 used here, issue at half rate on gfx950
+// (profiles/r01_valu_microbench.txt: 3.5e13 against 5.8e13 lane-ops/s), and so did the depth handling's ten scalar ops per slot
+// (tools/bs_loop_probe.hip: filter + depth cost 40 % of the 107-op step they guard; in this form 9 %).
+constexpr uint32_t BS_TT_OR3 = 0xFE, BS_TT_ANDOR = 0xEA /* (a & b) | c */, BS_TT_ORAND = 0xA8 /* (a | b) & c */;
+__device__ __forceinline__ uint32_t bs_mask_of(int32_t bhs) {
+  const int z = bs_depth(bhs);
+  return z < 0 ? 0u : ((2u << z) - 1u);
 }
-__device__ __forceinline__ uint32_t bs_filter(const uint32_t (&P)[64], uint32_t ACT, const BsEnable& en, int z) {
-  uint32_t n0, n1;
-  if (BS_ZFIX == 8 && z >= BS_ZFIX) {
-    // eight magnitude planes in three v_or3_b32 whose results land in fresh registers (no copy of a loop-invariant start value),
-    // the sign plane and the inactive chains folded into one three-input op: n1 = t1 | ~P[63] | ~ACT
-    uint32_t t1;
-    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(n0) : "v"(P[62]), "v"(P[61]), "v"(P[60]));
-    asm("v_or3_b32 %0, %1, %2, %3" : "=v"(t1) : "v"(P[59]), "v"(P[58]), "v"(P[57]));
-    asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n0) : "v"(P[56]), "v"(P[55]));
-    n1 = __builtin_amdgcn_bitop3_b32(t1, P[63], ~ACT, 0xFB);
-  } else if (BS_ZFIX > 0 && z >= BS_ZFIX) {
-    n0 = ~P[63]; n1 = ~ACT;
-#pragma unroll
-    for (int b = 1; b + 1 <= BS_ZFIX; b += 4) {
-      asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n0) : "v"(P[63 - b]), "v"(P[62 - b]));
-      asm("v_or3_b32 %0, %0, %1, %2" : "+v"(n1) : "v"(P[61 - b]), "v"(P[60 - b]));
-    }
-  } else {
-    n1 = ~ACT;
-    n0 = ~P[63] & en.w[0];                       // z < 0 (all words 0): every active chain is a candidate
-#pragma unroll
-    for (int b = 1; b <= BS_ZFIX; b++) n0 |= P[63 - b] & en.w[b];
-  }
-  // planes beyond BS_ZFIX: one v_and_or_b32 (d = (plane & enable) | d) each, two accumulators (asm: the compiler prefers v_and + v_or3)
-#pragma unroll
-  for (int b = BS_ZFIX + 1; b <= BS_ZMAX; b += 2) {
-    asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(n0) : "v"(P[63 - b]), "s"(en.w[b]));
-    if (b + 1 <= BS_ZMAX) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(n1) : "v"(P[62 - b]), "s"(en.w[b + 1]));
-  }
-  return n0 | n1;
+__device__ __forceinline__ uint32_t bs_sbit(uint32_t m, int b) {   // bit b of a wave-uniform word as a scalar mask word
+  uint32_t r = (uint32_t)((int)(m << (31 - b)) >> 31);
+  asm volatile("" : "+s"(r));   // keep it a scalar mask word (otherwise it is turned back into 64-bit select conditions)
+  return r;
 }
-
-// Second look at a step whose first BS_ZMAX planes let a candidate through (a quarter of the steps at depth 12): the planes down to
-// the slot's real depth (<= BS_ZDEEP) are checked before anything is queued, which removes nearly all false candidates — and with them
-// most of the queueing and draining — for 8 more masked ORs in the triggered steps only.
-__device__ __forceinline__ uint32_t bs_filter_deep(const uint32_t (&P)[64], uint32_t nacc, int z) {
-  if (z <= BS_ZMAX) return nacc;
-  const uint32_t m = (2u << z) - 1u;
+static_assert(BS_ZMAX == 12, "bs_hot_filter is written for a first look of 12 planes");
+__device__ __forceinline__ uint32_t bs_hot_filter(const uint32_t (&P)[64], uint32_t nACT, uint32_t sm) {
+  const uint32_t keep = bs_sbit(sm, 8), e9 = bs_sbit(sm, 9), e10 = bs_sbit(sm, 10), e11 = bs_sbit(sm, 11), e12 = bs_sbit(sm, 12);
+  uint32_t n0 = __builtin_amdgcn_bitop3_b32(P[62], P[61], P[60], BS_TT_OR3);
+  const uint32_t t1 = __builtin_amdgcn_bitop3_b32(P[59], P[58], P[57], BS_TT_OR3);
+  n0 = __builtin_amdgcn_bitop3_b32(n0, P[56], P[55], BS_TT_OR3);
+  uint32_t n1 = __builtin_amdgcn_bitop3_b32(t1, P[63], nACT, 0xFB);          // t1 | ~sign | inactive
+  n0 = __builtin_amdgcn_bitop3_b32(P[54], e9, n0, BS_TT_ANDOR);
+  n1 = __builtin_amdgcn_bitop3_b32(P[53], e10, n1, BS_TT_ANDOR);
+  n0 = __builtin_amdgcn_bitop3_b32(P[52], e11, n0, BS_TT_ANDOR);
+  n1 = __builtin_amdgcn_bitop3_b32(P[51], e12, n1, BS_TT_ANDOR);
+  return __builtin_amdgcn_bitop3_b32(n0, n1, keep, BS_TT_ORAND);
+}
+// Triggered steps only.  Exact first look for a shallow slot (every plane through its enable bit; sm = 0: every active chain
+// is a candidate), then the second look: the planes down to the slot's real depth (<= BS_ZDEEP) are checked before anything is
+// queued, which removes nearly all false candidates of the 12-plane first look — and with them most of the queueing and draining.
+__device__ __forceinline__ uint32_t bs_cold_filter(const uint32_t (&P)[64], uint32_t nacc, uint32_t nACT, uint32_t sm) {
+  // (every plane is folded in with ONE three-input op, (plane & enable) | acc, so that no temporaries pile up next to the 64 planes)
+  if (!(sm & 0x100u)) {
+    nacc = __builtin_amdgcn_bitop3_b32(P[63], bs_sbit(sm, 0), nACT, 0xBA);   // (~sign & enable) | inactive   (table index = 4a + 2b + c)
 #pragma unroll
-  for (int b = BS_ZMAX + 1; b <= BS_ZDEEP; b++) nacc |= P[63 - b] & (uint32_t)((int)(m << (31 - b)) >> 31);
+    for (int b = 1; b <= BS_ZMAX; b++) nacc = __builtin_amdgcn_bitop3_b32(P[63 - b], bs_sbit(sm, b), nacc, BS_TT_ANDOR);
+  }
+  if (sm >> (BS_ZMAX + 1)) {
+#pragma unroll
+    for (int b = BS_ZMAX + 1; b <= BS_ZDEEP; b++) nacc = __builtin_amdgcn_bitop3_b32(P[63 - b], bs_sbit(sm, b), nacc, BS_TT_ANDOR);
+  }
   return nacc;
 }
 
@@ -979,22 +970,21 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
 }
 
 // Deferred candidates: pulling a candidate's 64-bit value out of the planes would cost 64 v_readlane + ~250 scalar ops
-// (~1600 issue cycles).  Instead a trigger only appends (slot, sub-step, lane, chain) words to a wave-private LDS queue;
-// slots are independent within a row, so the queue can be drained later, 64 entries at a time, one per lane: each lane
-// re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 4 steps + <= 3 single steps),
-// then ds_min_rtn_i64 lowers the slot minimum and the lane that ends up owning the minimum records its k-mer position.
-// Queue entry (32 bits): bits 0-4 chain j of the lane, 5-10 lane, 11-16 sub-step c, 17-29 slot s.  Chain value = (s w + c + 1)
-// steps from the key.  With 4-byte entries the queue holds a whole row's candidates nearly always, so the drain runs at the
-// end of the row — where the 64 plane registers are free and its table loads can all be in flight — rather than inside the
-// slot loop.
+// (~1600 issue cycles).  Instead a trigger only appends (slot, sub-step, lane, chain) words to the wave's queue (global memory,
+// fire-and-forget stores); slots are independent within a row, so the queue is drained at the end of the row, 64 entries at a
+// time, one per lane: each lane re-derives its chain value from the key (GF(2) jump-ahead tables for the multiple of 4 steps
+// + <= 3 single steps), then ds_min_rtn_i64 lowers the slot minimum and the lane that ends up owning the minimum records its
+// k-mer position.  Queue entry (32 bits): bits 0-4 chain j of the lane, 5-10 lane, 11-16 sub-step c, 17-29 slot s.  Chain value
+// = (s w + c + 1) steps from the key.  A row that overflows the queue (qn > BS_QCAP at the drain; never seen) makes the strand
+// fall back to the per-chain rows.
 #define MHAP_TICK() (PROF ? (unsigned long long)clock64() : 0ULL)
 template <bool PROF = false>
 __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, int w, const KeySrc& ks,
                                          const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
   const unsigned long long t0 = MHAP_TICK();
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // queue stores of this wave are visible to its own loads
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores of this wave have left it (vmcnt(0)) before its lanes read each other's entries
   __builtin_amdgcn_wave_barrier();
-  const int qn = qn_ref;
+  const int qn = qn_ref < BS_QCAP ? qn_ref : BS_QCAP;
   for (int b0 = 0; b0 < qn; b0 += 64) {
     const bool valid = b0 + lane < qn;
     const uint32_t e = valid ? q[b0 + lane] : 0u;
@@ -1041,21 +1031,19 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
 
 // append this trigger's candidates: one entry per candidate chain (a lane's mask nearly always has a single bit; the loop
 // runs while any lane has bits left).  The fill count lives in a wave-uniform register and queue slots are handed out with
-// ballot + mbcnt (no LDS atomic, no read-back); the queue is drained whenever the next round might not fit.
-template <bool PROF = false>
-__device__ __forceinline__ void bs_defer(int64_t* best, int32_t* bpos, uint32_t* q, int& qn, int s, int c, uint32_t cand, int rb, int w,
-                                         const KeySrc& ks, const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
-  const uint32_t head = ((uint32_t)s << 17) | ((uint32_t)c << 11) | ((uint32_t)lane << 5);
+// ballot + mbcnt (no atomic, no read-back).  Entries beyond the capacity are dropped; the count keeps running, so the drain sees it.
+__device__ __forceinline__ void bs_defer(uint32_t* __restrict__ q, int& qn, int s, int c, uint32_t cand) {
+  // (the lane id is recomputed here — two ops — rather than kept alive, or spilled, across the slot loop for this cold path)
+  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(0xFFFFFFFFu, __builtin_amdgcn_mbcnt_lo(0xFFFFFFFFu, 0u));
+  const uint32_t head = ((uint32_t)s << 17) | ((uint32_t)c << 11) | (lane << 5);
   unsigned long long m = __ballot(cand != 0u);
   do {
-    const int n = __popcll(m);
-    if (qn + n > BS_QCAP) bs_flush<PROF>(best, bpos, q, qn, rb, w, ks, jump, na, lane, tf);   // at most 64 entries per round: fits afterwards
     if (cand) {
       const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      q[idx] = head | (uint32_t)__builtin_ctz(cand);
+      if (idx < BS_QCAP) q[idx] = head | (uint32_t)__builtin_ctz(cand);
       cand &= cand - 1u;
     }
-    qn += n;
+    qn += __popcll(m);
     m = __ballot(cand != 0u);
   } while (m);
 }
@@ -1132,20 +1120,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
                                                       const uint64_t* __restrict__ jump, int jump_na, const int32_t* __restrict__ slist,
                                                       const unsigned long long* __restrict__ slist_count,
-                                                      unsigned long long* __restrict__ prof = nullptr) {
+                                                      uint32_t* __restrict__ qbuf, unsigned long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar LDS / queue bases)
   // PROF: wave-clock attribution {strand total, first-row total, first-row argmin, first-row defer, later-row defer, key load+transpose,
   // flush (nested in the defers / row ends), flush batches, strands}
   unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tf[2] = {0, 0}, nst = 0;
   uint64_t* lut = (uint64_t*)smem;                                   // shared by the workgroup's waves
   for (int i = threadIdx.x; i < MH_LUT_WORDS; i += blockDim.x) lut[i] = luts[i];
   __syncthreads();
-  const size_t per_wave = (size_t)H * 12 + 8 + (BITSLICED ? (size_t)BS_QCAP * 4 : 0);
+  const size_t per_wave = (size_t)H * 12 + 8;
   char* wbase = smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * ((per_wave + 15) & ~(size_t)15);
   int64_t* best = (int64_t*)wbase;
   int32_t* bpos = (int32_t*)(best + H);
-  uint32_t* bsq = (uint32_t*)(wbase + (((size_t)H * 12 + 7) & ~(size_t)7));   // deferred-candidate queue
+  uint32_t* bsq = qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * BS_QCAP;   // this wave's deferred-candidate queue (global memory)
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
   for (;;) {
     unsigned long long tk = 0;
@@ -1184,6 +1172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
     const int ncls = listed ? BS_WCLASSES : 1;
     const int w_uniform = WEIGHTED ? si_mode : 1;
     // ---- bit-sliced rows: every weight class (or the whole strand at its common weight), 2048 chains per row ----
+    bool bs_ok = true;         // false: a row's candidates overflowed the queue -> the strand is redone on the per-chain rows
     if (BITSLICED) {
       int bsqn = 0;            // deferred-candidate queue fill (wave-uniform)
       bool first = true;       // no slot minimum exists yet
@@ -1210,34 +1199,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
           transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
           if (PROF) tp[5] += MHAP_TICK() - tr0;
-          int vz = 0;   // filter depths of 64 slots at a time, one per lane (a drain in between only makes them conservative)
-          for (int s = 0; s < H; s++) {
-            if ((s & 63) == 0) vz = bs_depth(besthi[2 * (s + lane < H ? s + lane : H - 1) + 1]);
-            const int zs = __builtin_amdgcn_readlane(vz, s & 63);
-            const BsEnable en = bs_enable(zs);
-            for (int c = 0; c < w; c++) {
-              bs_step(P);
-              if (first) {   // nothing seen yet: the row's exact arg-min becomes the slot's first entry
+          if (first) {
+            // nothing seen yet: every step's exact row arg-min becomes the slot's first entry
+            for (int s = 0; s < H; s++)
+              for (int c = 0; c < w; c++) {
+                bs_step(P);
                 const unsigned long long ta = MHAP_TICK();
                 const uint32_t cand = bs_argmin(P, ACT);
                 const unsigned long long tb = MHAP_TICK();
-                bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, cand, base, w, ks, jump, jump_na, lane, tf);
+                bs_defer(bsq, bsqn, s, c, cand);
                 if (PROF) { tp[2] += tb - ta; tp[3] += MHAP_TICK() - tb; }
-                continue;
               }
-              uint32_t nacc = bs_filter(P, ACT, en, zs);
-              if (__any(nacc != 0xFFFFFFFFu)) {
-                const unsigned long long ta = MHAP_TICK();
-                nacc = bs_filter_deep(P, nacc, zs);
-                if (__any(nacc != 0xFFFFFFFFu)) bs_defer<PROF>(best, bpos, bsq, bsqn, s, c, ~nacc, base, w, ks, jump, jump_na, lane, tf);
-                if (PROF) tp[4] += MHAP_TICK() - ta;
+          } else {
+            const uint32_t nACT = ~ACT;
+            for (int s0 = 0; s0 < H; s0 += 64) {
+              // depth masks of 64 slots, one per lane (a drain in between only makes them conservative)
+              const uint32_t vm = bs_mask_of(besthi[2 * (s0 + lane < H ? s0 + lane : H - 1) + 1]);
+              const int tn = H - s0 < 64 ? H - s0 : 64;
+              for (int t = 0; t < tn; t++) {
+                const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)vm, t);
+                for (int c = 0; c < (WEIGHTED ? w : 1); c++) {
+                  bs_step(P);
+                  uint32_t nacc = bs_hot_filter(P, nACT, sm);
+                  if (__builtin_expect(__any(nacc != 0xFFFFFFFFu), 0)) {
+                    const unsigned long long ta = MHAP_TICK();
+                    nacc = bs_cold_filter(P, nacc, nACT, sm);
+                    if (__any(nacc != 0xFFFFFFFFu)) bs_defer(bsq, bsqn, s0 + t, c, ~nacc);
+                    if (PROF) tp[4] += MHAP_TICK() - ta;
+                  }
+                }
               }
             }
           }
+          if (bsqn > BS_QCAP) bs_ok = false;
           bs_flush<PROF>(best, bpos, bsq, bsqn, base, w, ks, jump, jump_na, lane, tf);
           if (PROF && first) tp[1] += MHAP_TICK() - tr0;
           first = false;
         }
+      }
+      if (!bs_ok) {
+        for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
     }
     // ---- per-chain rows: what the bit-sliced rows left of every class + the weights above BS_WCLASSES, U k-mers per lane ----
@@ -1256,7 +1259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
         ks.perm = listed ? plist + off : nullptr;
         off += count;
         int e0 = 0;
-        if (BITSLICED && cl < ncls && w <= BS_WMAX) while (count - e0 >= BS_MINREM) e0 += 2048;   // done above
+        if (BITSLICED && bs_ok && cl < ncls && w <= BS_WMAX) while (count - e0 >= BS_MINREM) e0 += 2048;   // done above
         while (e0 < count) {
           const int take = (64 * U - pfill) < (count - e0) ? (64 * U - pfill) : (count - e0);
 #pragma unroll
@@ -1302,6 +1305,233 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
   }
 }
 
+// =============================================================================================
+// The weight-1 strands' own kernel (every strand of a run without -f whose k-mers do not repeat: all of C2).  Same rows, step
+// and filters as minhash_kernel above, built around what round 2's profile showed the slot loop losing: a wave-step cost the
+// SIMD 176 ns where the 107-op step alone costs 121-134 (tools/bs_loop_probe.hip).
+//   * Only the slot MINIMA are kept (8 B per slot in LDS, no winner positions): the step is a bijection, so the key behind a
+//     minimum after n steps is unstep^n(min) — recovered once per strand through inverse jump tables.  Half the LDS, and the
+//     minima of different waves merge with a plain 64-bit atomic min, which is what makes the next point possible.
+//   * Work items are whole strands while there are plenty, then single ROWS: the last n_tail strands of the list are cut into
+//     their 2048-k-mer rows, any wave takes any row (as a strand's first row: no thresholds, the row's arg-min per slot), and the
+//     rows' minima meet in a global table (atomic min of the sign-flipped value; minhash_w1_finish_kernel turns it into the
+//     output rows).  A persistent launch then ends within one row's time (0.35 ms) on every wave instead of one strand's
+//     (1.75 ms), and a launch with fewer strands than waves (one rank's share of a small job, a batch of -q reads) still fills the GPU.
+//   * The deferred-candidate queue is in global memory and drained at the end of a row only; nothing of the drain, the key
+//     hashing or the per-chain rows of the general kernel is alive in the slot loop.  (MH_W1_WAVES_EU: 5 or 6 waves per SIMD fit the
+//     LDS now, but at 96 / 80 registers the allocator spills around the key load and the chip clocks lower: 4 / 5 / 6 waves measured
+//     88.1 / 92.6 / 94.6 ms at C2 on one box, round 2's kernel 89.3.)
+// =============================================================================================
+#ifndef MH_W1_WAVES_EU
+#define MH_W1_WAVES_EU 4
+#endif
+struct W1Args {
+  const ReadDesc* descs; const int64_t* keys; const uint8_t* store; const uint64_t* luts; const StrandInfo* info;
+  const int32_t* slist;              // the launch's strands: [0, n_whole) whole, [n_whole, n_whole + n_tail) row by row
+  long long n_whole, n_tail; int rmax;   // rmax: rows of the longest strand (row items: n_tail x rmax, row-major)
+  int k, k2, H;
+  unsigned long long* counter;       // work counter
+  unsigned long long* stat;          // strands sketched (statistics)
+  int32_t* out_rows; long long out_stride; int32_t* out_status; long long status_stride;
+  const uint64_t* jump; const uint64_t* unjump; int jump_na;
+  uint32_t* qbuf;                    // BS_QCAP words per wave
+  unsigned long long* merge;         // n_tail x H words, filled with 0xFF: minima of the row items, sign bit flipped (unsigned order)
+  unsigned long long* prof;          // MHAP_MINHASH_PROF: wave-clock sums {key load + transpose, first-row slots, later-row slots, drains, rows, first rows, candidates}
+};
+
+// the key behind chain value x after n >= 1 steps: inverse table for the next multiple of 4, then up to 3 steps forward
+__device__ __forceinline__ uint64_t w1_key_of(uint64_t x, int n, const uint64_t* __restrict__ unjump) {
+  const int a = (n + (1 << XS_JUMP_LOG2) - 1) >> XS_JUMP_LOG2, r = (a << XS_JUMP_LOG2) - n;
+  const uint32_t tb = (uint32_t)(a - 1) * 2048u;
+  uint64_t y = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) y ^= unjump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+#pragma unroll
+  for (int t = 0; t < (1 << XS_JUMP_LOG2) - 1; t++) { const uint64_t ny = xorshift_step(y); y = (t < r) ? ny : y; }
+  return y;
+}
+
+// drain: every queue entry's chain value, recomputed from its key, lowers its slot's minimum (LDS atomic min; no winner bookkeeping)
+__device__ __forceinline__ void w1_flush(int64_t* best, const uint32_t* __restrict__ q, int qn, int rb, const KeySrc& ks,
+                                         const uint64_t* __restrict__ jump, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores have left the wave before its lanes read each other's entries
+  __builtin_amdgcn_wave_barrier();
+  if (qn > BS_QCAP) qn = BS_QCAP;
+  for (int b0 = 0; b0 < qn; b0 += 64) {
+    if (b0 + lane < qn) {
+      const uint32_t e = q[b0 + lane];
+      const int j = (int)(e & 31u), l = (int)((e >> 5) & 63u), s = (int)(e >> 17);
+      const int nsteps = s + 1;
+      const int a = nsteps >> XS_JUMP_LOG2, r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+      uint64_t x = ks_key(ks, rb + j * 64 + l);
+      if (a > 0) {
+        const uint32_t tb = (uint32_t)(a - 1) * 2048u;
+        uint64_t y = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+        x = y;
+      }
+#pragma unroll
+      for (int t = 0; t < (1 << XS_JUMP_LOG2) - 1; t++) { const uint64_t nx = xorshift_step(x); x = (t < r) ? nx : x; }
+      atomicMin((long long*)&best[s], (long long)x);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// one row: k-mers [rb, rb + 2048) of the strand (key order), all H slots.  first: no minima exist yet.
+template <bool PROF>
+__device__ __forceinline__ void w1_row(int64_t* best, uint32_t* __restrict__ q, int rb, int nk, bool first, int H, const KeySrc& ks,
+                                       const uint64_t* __restrict__ jump, int lane, bool& ok, unsigned long long* tp) {
+  const unsigned long long t0 = MHAP_TICK();
+  uint32_t P[64];
+  uint32_t ACT = 0;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    const int i = rb + j * 64 + lane;
+    uint64_t key = 0;
+    if (i < nk) { key = ks_key(ks, i); ACT |= 1u << j; }
+    P[j] = (uint32_t)key;
+    P[32 + j] = (uint32_t)(key >> 32);
+    if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 keys in flight at a time
+  }
+  transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
+  transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
+  int qn = 0;   // queue fill (wave-uniform)
+  const unsigned long long t1 = MHAP_TICK();
+  if (first) {
+    for (int s = 0; s < H; s++) {
+      bs_step(P);
+      bs_defer(q, qn, s, 0, bs_argmin(P, ACT));
+    }
+  } else {
+    const int32_t* besthi = (const int32_t*)best;
+    const uint32_t nACT = ~ACT;
+    for (int s0 = 0; s0 < H; s0 += 64) {
+      const uint32_t vm = bs_mask_of(besthi[2 * (s0 + lane < H ? s0 + lane : H - 1) + 1]);   // depth masks of 64 slots, one per lane
+      const int tn = H - s0 < 64 ? H - s0 : 64;
+      for (int t = 0; t < tn; t++) {
+        const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)vm, t);
+        bs_step(P);
+        uint32_t nacc = bs_hot_filter(P, nACT, sm);
+        if (__builtin_expect(__any(nacc != 0xFFFFFFFFu), 0)) {
+          nacc = bs_cold_filter(P, nacc, nACT, sm);
+          if (__any(nacc != 0xFFFFFFFFu)) bs_defer(q, qn, s0 + t, 0, ~nacc);
+        }
+      }
+    }
+  }
+  if (qn > BS_QCAP) ok = false;
+  const unsigned long long t2 = MHAP_TICK();
+  w1_flush(best, q, qn, rb, ks, jump, lane);
+  if (PROF) { tp[0] += t1 - t0; tp[first ? 1 : 2] += t2 - t1; tp[3] += MHAP_TICK() - t2; tp[4]++; tp[5] += first ? 1 : 0; tp[6] += (unsigned long long)qn; }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES_EU, 8))) void minhash_w1_kernel(W1Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int H = a.H;
+  uint64_t* lut = (uint64_t*)smem;                                   // shared by the workgroup's waves
+  for (int i = threadIdx.x; i < MH_LUT_WORDS; i += blockDim.x) lut[i] = a.luts[i];
+  __syncthreads();
+  int64_t* best = (int64_t*)(smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * (size_t)H * 8);
+  uint32_t* q = a.qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * BS_QCAP;
+  const long long nitems = a.n_whole + a.n_tail * (long long)a.rmax;
+  unsigned long long nst = 0;
+  unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long tk0 = MHAP_TICK();
+  for (;;) {
+    unsigned long long tk = 0;
+    if (lane == 0) tk = atomicAdd(a.counter, 1ULL);
+    const long long idx = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tk >> 32)) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tk));
+    if (idx >= nitems) break;
+    const bool whole = idx < a.n_whole;
+    long long ti = 0; int row = 0;
+    if (!whole) { const long long t = idx - a.n_whole; ti = t % a.n_tail; row = (int)(t / a.n_tail); }
+    const long long sidx = a.slist[whole ? idx : a.n_whole + ti];
+    const ReadDesc rd = a.descs[sidx >> 1];
+    const int rcs = (int)(sidx & 1);
+    const int nk = rd.length - a.k + 1;
+    int32_t* orow = a.out_rows + sidx * a.out_stride;
+    const bool nosketch = strand_skipped(rd, rcs) || nk < 1 || rd.length - a.k2 + 1 < 1 || !a.info[sidx].valid;
+    if (nosketch) {
+      // too short (status 2) or ZeroNGramsFoundException from either sketch (status 1)
+      if (whole || row == 0) {
+        for (int s = lane; s < H; s += 64) orow[s] = 0;
+        if (lane == 0) a.out_status[sidx * a.status_stride] = strand_skipped(rd, rcs) ? 2 : 1;
+      }
+    } else {
+      const int nrows = (nk + 2047) >> 11;
+      if (whole || row < nrows) {
+        KeySrc ks;
+        ks.kp = (rd.flags & MHAP_RD_MAT) ? a.keys + rd.key_off + (rcs ? rd.key_stride : 0) : nullptr;
+        ks.W = (const uint32_t*)(a.store + rd.base_off); ks.nd = (((rd.length + 3) >> 2) + 3) >> 2; ks.L = rd.length; ks.rcs = rcs;
+        ks.lut = lut; ks.perm = nullptr;
+        for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool ok = true;
+        const int r0 = whole ? 0 : row, r1 = whole ? nrows : row + 1;
+        for (int r = r0; r < r1; r++) w1_row<PROF>(best, q, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
+        // (a row whose candidates overflowed the queue — never seen — is redone one k-mer at a time: exact, slow)
+        if (!ok) {
+          for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const int i1 = (r1 << 11) < nk ? (r1 << 11) : nk;
+          for (int i = (r0 << 11) + lane; i < i1; i += 64) {
+            uint64_t x = ks_key(ks, i);
+            for (int s = 0; s < H; s++) { x = xorshift_step(x); atomicMin((long long*)&best[s], (long long)x); }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (whole) {
+          for (int s = lane; s < H; s += 64) {
+            const int64_t x = best[s];
+            int32_t v = 0;
+            if (x != INT64_MAX) {
+              const uint64_t key = w1_key_of((uint64_t)x, s + 1, a.unjump);
+              v = (s & 1) ? (int32_t)(uint32_t)(key >> 32) : (int32_t)(uint32_t)key;   // MinHashSketch.java:147-150
+            }
+            orow[s] = v;
+          }
+          if (lane == 0) a.out_status[sidx * a.status_stride] = 0;
+          nst++;
+        } else {
+          unsigned long long* g = a.merge + (size_t)ti * (size_t)H;
+          for (int s = lane; s < H; s += 64) {
+            const int64_t x = best[s];
+            if (x != INT64_MAX) atomicMin(&g[s], (unsigned long long)x ^ 0x8000000000000000ULL);
+          }
+          if (row == 0) { if (lane == 0) a.out_status[sidx * a.status_stride] = 0; nst++; }
+        }
+      }
+    }
+  }
+  if (lane == 0) atomicAdd(a.stat, nst);
+  if (PROF && lane == 0) { tp[7] = MHAP_TICK() - tk0; for (int i = 0; i < 8; i++) atomicAdd(&a.prof[i], tp[i]); }
+}
+
+// output rows of the strands that were sketched row by row: the merged minima back to keys
+__global__ __launch_bounds__(256) void minhash_w1_finish_kernel(W1Args a) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= a.n_tail * (long long)a.H) return;
+  const long long ti = t / a.H;
+  const int s = (int)(t % a.H);
+  const long long sidx = a.slist[a.n_whole + ti];
+  const unsigned long long g = a.merge[t];
+  int32_t v = 0;
+  if (g != ~0ULL) {
+    const uint64_t key = w1_key_of(g ^ 0x8000000000000000ULL, s + 1, a.unjump);
+    v = (s & 1) ? (int32_t)(uint32_t)(key >> 32) : (int32_t)(uint32_t)key;
+  }
+  a.out_rows[sidx * a.out_stride + s] = v;
+}
+
 // Jump-ahead tables for the xorshift64 chain: the step is linear over GF(2), so M^(g a) x (g = 2^XS_JUMP_LOG2) is the XOR of
 // eight byte-indexed table entries.  out[(a-1)*2048 + i*256 + v] = M^(g a) applied to (v << 8i), a = 1..na; then nq coarse
 // tables out[(na+q-1)*2048 + ...] = M^(g na q), q = 1..nq, for chains that run past g na steps (weighted k-mers).
@@ -1328,39 +1558,73 @@ void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
     for (int j = 0; j < 64; j++) col[j] = nxt[j];
   }
 }
+// the same for the inverse map: out[(a-1)*2048 + i*256 + v] = M^-(g a) applied to (v << 8i), a = 1..na
+void build_xorshift_unjump_tables(int na, uint64_t* out) {
+  uint64_t col[64], nxt[64], base[64];
+  auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
+  for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < (1 << XS_JUMP_LOG2); t++) x = xorshift_unstep(x); col[j] = base[j] = x; }
+  for (int a = 1; a <= na; a++) {
+    uint64_t* T = out + (size_t)(a - 1) * 2048;
+    for (int i = 0; i < 8; i++)
+      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(col, (uint64_t)v << (8 * i));
+    for (int j = 0; j < 64; j++) nxt[j] = apply(base, col[j]);
+    for (int j = 0; j < 64; j++) col[j] = nxt[j];
+  }
+}
 
-// MHAP_MINHASH=perchain selects the kernel without bit-sliced rows (A/B measurements)
+// Resident workgroups per CU of the MinHash launches (4 waves = 4 strands each) and the bytes of queue memory their waves need
+int minhash_wgs_per_cu(int H) {
+  // the weight-1 kernel keeps 8 B per slot and wave in LDS (the general kernel 12 B: its launch simply gets fewer workgroups resident)
+  const size_t lds = (size_t)H * 8 * 4 + (size_t)MH_LUT_WORDS * 8;
+  int n = (int)((160 * 1024) / lds);
+  const int by_regs = MH_W1_WAVES_EU > MH_WAVES_EU ? MH_W1_WAVES_EU : MH_WAVES_EU;   // waves per SIMD = workgroups of four waves per CU
+  if (n > by_regs) n = by_regs;
+  return n < 1 ? 1 : n;
+}
+size_t minhash_queue_bytes(int nblocks_total) { return (size_t)nblocks_total * 4 * (size_t)BS_QCAP * 4; }
+
+// Strands of a weight-1 launch that are cut into row items (the others are taken whole): one strand's worth of rows per resident
+// wave at the end of the list evens the waves' finish times out to one row; a list shorter than that is all rows.
+int64_t minhash_tail_strands(int nblocks, int64_t n_unweighted) {
+  const int64_t waves = (int64_t)nblocks * 4;
+  return n_unweighted < waves ? n_unweighted : waves;
+}
+size_t minhash_merge_bytes(int nblocks, int H) { return (size_t)nblocks * 4 * (size_t)H * 8; }
+
+// MHAP_MINHASH=perchain selects the kernel without bit-sliced rows, MHAP_MINHASH=classic round 2's kernel for the weight-1 strands too (A/B measurements)
 void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
-                    const uint64_t* jump, int jump_na, const int32_t* slist) {
+                    const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, unsigned long long* merge, int max_nk) {
   // counter: the sketch phase's counter block — [1] / [2] work counters of the two launches, [4] / [5] lengths of their strand lists
-  // (written by kmer_weight_kernel), [9] / [11] strands sketched
+  // (written by kmer_weight_kernel), [9] / [11] strands sketched.  qbuf: minhash_queue_bytes(2 * nblocks) (one half per launch);
+  // merge: minhash_merge_bytes(nblocks, H); max_nk: k-mers of the launch's longest strand
   if (nstrands <= 0) return;
-  static int perchain = -1;
-  if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; }
-  size_t per_wave = (((size_t)H * 12 + 8 + (perchain ? 0 : (size_t)BS_QCAP * 4)) + 15) & ~(size_t)15;
+  static int perchain = -1, classic = 0;
+  if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; classic = (e && strcmp(e, "classic") == 0) ? 1 : 0; }
+  size_t per_wave = (((size_t)H * 12 + 8) + 15) & ~(size_t)15;
   const size_t lut_bytes = (size_t)MH_LUT_WORDS * 8;
   int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
   while (waves > 1 && per_wave * waves + lut_bytes > 150 * 1024) waves >>= 1;
   const size_t lds = per_wave * waves + lut_bytes;
   const dim3 block(64 * waves);
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
+  uint32_t* qbuf_w = qbuf + (size_t)nblocks * (size_t)waves * BS_QCAP;
   static int profmode = -1;
   if (profmode < 0) { const char* e = getenv("MHAP_MINHASH_PROF"); profmode = (e && atoi(e)) ? 1 : 0; }
   unsigned long long* counter_u = counter + 1; unsigned long long* counter_w = counter + 2;
   const int32_t* slist_w = slist + nstrands;
-  if (profmode && !perchain) {   // wave-clock attribution of the bit-sliced kernels (diagnostics; printed per launch)
+  if (profmode && !perchain && classic) {   // wave-clock attribution of round 2's kernels (diagnostics; printed per launch)
     static unsigned long long* dprof = nullptr;
     if (!dprof) (void)hipMalloc(&dprof, 16 * sizeof(unsigned long long));
     for (int pass = 0; pass < 2; pass++) {
       (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
       if (pass == 0)
         hipLaunchKernelGGL((minhash_kernel<MH_U, true, false, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                           counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, dprof);
+                           counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, dprof);
       else
         hipLaunchKernelGGL((minhash_kernel<MH_U, true, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                           counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, dprof);
+                           counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, dprof);
       unsigned long long hp[16];
       (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
       (void)hipStreamSynchronize(st);
@@ -1375,9 +1639,9 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
   }
   if (perchain) {
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, true>), dim3(nblocks), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
+                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w);
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
+                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf);
   } else {
     // n_unweighted / n_weighted >= 0: the lengths of the two work lists (the caller read them back): each launch gets only the
     // workgroups its list can feed, the weighted one first, on its own stream — its few workgroups take their slots, the weight-1
@@ -1387,10 +1651,43 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
     const int nb_u = n_unweighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, (n_unweighted + waves_wg - 1) / waves_wg);
     if (nb_w > 0)
       hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nb_w), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5);
-    if (nb_u > 0)
+                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w);
+    if (nb_u > 0 && (classic || n_unweighted < 0 || waves_wg != 4)) {
       hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nb_u), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                         counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4);
+                         counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf);
+    } else if (nb_u > 0) {
+      // the weight-1 strands: whole strands first, the last minhash_tail_strands() of the list row by row (see minhash_w1_kernel)
+      W1Args a;
+      a.descs = descs; a.keys = keys; a.store = store; a.luts = luts; a.info = info; a.slist = slist;
+      a.n_tail = minhash_tail_strands(nblocks, n_unweighted); a.n_whole = n_unweighted - a.n_tail;
+      a.rmax = max_nk > 0 ? (max_nk + 2047) >> 11 : 1;
+      a.k = k; a.k2 = k2; a.H = H; a.counter = counter_u; a.stat = counter_u + 8;
+      a.out_rows = out_rows; a.out_stride = out_stride; a.out_status = out_status; a.status_stride = status_stride;
+      a.jump = jump; a.unjump = unjump; a.jump_na = jump_na; a.qbuf = qbuf; a.merge = merge;
+      const long long items = a.n_whole + a.n_tail * (long long)a.rmax;
+      const int nb = (int)std::min<long long>(nblocks, (items + 3) / 4);
+      const size_t lds1 = (size_t)H * 8 * 4 + lut_bytes;
+      if (a.n_tail > 0) (void)hipMemsetAsync(merge, 0xFF, (size_t)a.n_tail * (size_t)H * 8, st);
+      a.prof = nullptr;
+      if (profmode) {
+        static unsigned long long* dprof1 = nullptr;
+        if (!dprof1) (void)hipMalloc(&dprof1, 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dprof1, 0, 8 * sizeof(unsigned long long), st);
+        a.prof = dprof1;
+        hipLaunchKernelGGL(minhash_w1_kernel<true>, dim3(nb), dim3(256), lds1, st, a);
+        unsigned long long hp[8];
+        (void)hipMemcpyAsync(hp, dprof1, sizeof(hp), hipMemcpyDeviceToHost, st);
+        (void)hipStreamSynchronize(st);
+        const double tot = (double)hp[7];
+        fprintf(stderr, "[minhash w1 prof] rows %llu (first-type %llu)  wave-clocks: total %.3g  key load+transpose %.1f%%  first-row slots %.1f%% (%.0f clocks/step)  "
+                        "later-row slots %.1f%% (%.0f clocks/step)  drains %.1f%%  candidates/row %.0f\n", hp[4], hp[5], tot, 100.0 * hp[0] / tot, 100.0 * hp[1] / tot,
+                hp[5] ? (double)hp[1] / ((double)hp[5] * H) : 0.0, 100.0 * hp[2] / tot, hp[4] > hp[5] ? (double)hp[2] / ((double)(hp[4] - hp[5]) * H) : 0.0,
+                100.0 * hp[3] / tot, hp[4] ? (double)hp[6] / (double)hp[4] : 0.0);
+      } else
+        hipLaunchKernelGGL(minhash_w1_kernel<false>, dim3(nb), dim3(256), lds1, st, a);
+      if (a.n_tail > 0)
+        hipLaunchKernelGGL(minhash_w1_finish_kernel, dim3((unsigned)((a.n_tail * (long long)H + 255) / 256)), dim3(256), 0, st, a);
+    }
   }
 }
 

@@ -1,6 +1,9 @@
-"""N>1 path on CPU: two gloo processes deal reads round-robin, exchange their per-rank sketch tables with the same
-all-gather + global-order re-layout the GPU path uses (mhap_amd/distributed.py), and the result must equal the
-single-process table; the per-rank query shards must partition the reads."""
+"""The N > 1 path on CPU (world_size 2 and 3, gloo): the host-side helpers bench.py uses around the library's multi-GPU entry
+points (mhap_amd/distributed.py), and the sharded search itself restated with the oracle's primitives — every rank keeps the
+sketches of the reads it was dealt, the forward query rows of all ranks are all-gathered, every rank scores all queries against
+its own shard under the toSelf id rules — whose union of records must equal the single-process oracle run.  (The GPU
+implementation of the same scheme, mhap_dist_* / mhap_group_*, is checked on the device in tests/test_cli_gpu.py and
+tests/test_gpu_parity.py.)"""
 import os
 import sys
 
@@ -13,120 +16,107 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-N_TOTAL, LEN, H, WORLD = 11, 400, 16, 2   # odd read count: exercises the padded shard
+N_TOTAL, LEN, H, S, K2 = 23, 1500, 64, 256, 12   # odd read count: unequal shards
 
 
-def _oracle_rows(fa):
+def _sketch(fa, i):
+    """(minhash fwd, minhash rc, ordered fwd (padded to S), ordered rc, sizes, seqlens) of read i, from the oracle."""
     import oracle_lib as O
-    rows = np.zeros((2 * len(fa), H), dtype=np.int32)
-    for i in range(len(fa)):
-        if fa.lengths[i] == 0:
-            continue                                   # padding read: status 2, row stays zero
-        s = fa.sequence(i)
-        rows[2 * i] = O.minhash(s, 16, H)[1]
-        rows[2 * i + 1] = O.minhash(O.rc(s), 16, H)[1]
-    return rows
+    s = fa.sequence(i)
+    out = []
+    for strand in (s, O.rc(s)):
+        _, mh = O.minhash(strand, 16, H)
+        _, od, seqlen = O.ordered(strand, K2, S)
+        pad = np.zeros((S, 2), dtype=np.int32)
+        pad[:len(od)] = od
+        out.append((mh, pad, len(od), seqlen))
+    return out
 
 
-def _worker(rank, port, out):
+def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     import mhap_amd
+    import oracle_lib as O
     from mhap_amd import distributed as md
-    shard = mhap_amd.synth_reads(N_TOTAL, LEN, seed=9, shard=rank, nshards=WORLD)
-    assert shard.ids.tolist() == [r + 1 for r in range(rank, N_TOTAL, WORLD)]
-    shard = md.pad_shard(shard, N_TOTAL, WORLD)
-    assert len(shard) == md.shard_size(N_TOTAL, WORLD)
-    local = torch.from_numpy(_oracle_rows(shard))
-    g = md.gather_global_order(local, WORLD, dist)
-    g_rm = md.gather_rank_major(local, WORLD, dist)
-    mine = md.shard_query_reads(N_TOTAL, WORLD, rank)
-    allq = [torch.zeros(len(mine), dtype=torch.int64) for _ in range(WORLD)]
-    dist.all_gather(allq, torch.from_numpy(mine))
+    full = mhap_amd.synth_reads(N_TOTAL, LEN, seed=11, error_rate=0.08)
+    shard = mhap_amd.synth_reads(N_TOTAL, LEN, seed=11, error_rate=0.08, shard=rank, nshards=world)
+    # the deal: generator shards and shard_of agree, ids stay global
+    mine = md.shard_of(full, world, rank)
+    assert shard.ids.tolist() == mine.ids.tolist() == (md.shard_indices(N_TOTAL, world, rank) + 1).tolist()
+    assert np.array_equal(shard.bases, mine.bases)
+    # rank 0's communicator id reaches every rank unchanged
+    uid = md.broadcast_unique_id(dist, rank, mhap_amd.MinHashSearch.dist_unique_id)
+    assert len(uid) == 128
+    uids = [None] * world
+    dist.all_gather_object(uids, uid)
+    assert all(u == uids[0] for u in uids)
+    # this rank's tables (both strands of its reads)
+    n_loc = len(shard)
+    sk = [_sketch(shard, i) for i in range(n_loc)]
+    # the exchange: forward rows padded to the largest shard, all-gathered (what mhap_dist_find_matches_self does over RCCL)
+    n_pad = (N_TOTAL + world - 1) // world
+    send_mh = torch.zeros((n_pad, H), dtype=torch.int32)
+    send_od = torch.zeros((n_pad, S, 2), dtype=torch.int32)
+    send_meta = torch.full((n_pad, 3), -1, dtype=torch.int64)          # id, ordered size, ordered seqlen; -1 = padding row
+    for j in range(n_loc):
+        mh, od, size, seqlen = sk[j][0]
+        send_mh[j] = torch.from_numpy(mh); send_od[j] = torch.from_numpy(od)
+        send_meta[j] = torch.tensor([int(shard.ids[j]), size, seqlen])
+    g_mh = [torch.zeros_like(send_mh) for _ in range(world)]; dist.all_gather(g_mh, send_mh)
+    g_od = [torch.zeros_like(send_od) for _ in range(world)]; dist.all_gather(g_od, send_od)
+    g_meta = [torch.zeros_like(send_meta) for _ in range(world)]; dist.all_gather(g_meta, send_meta)
+    q_mh = torch.cat(g_mh).numpy(); q_od = torch.cat(g_od).numpy(); q_meta = torch.cat(g_meta).numpy()
+    # the search: every gathered forward query against this rank's stored strands, toSelf rules (MinHashSearch.java:200-225)
+    lines = []
+    for q in range(q_mh.shape[0]):
+        qid, qsize, qlen = (int(v) for v in q_meta[q])
+        if qid < 0:
+            continue
+        for j in range(n_loc):
+            mid = int(shard.ids[j])
+            if mid >= qid:                      # same read, or the pair belongs to the rank that stores the lower id
+                continue
+            assert md.pair_owner(qid, mid, world) == rank
+            for strand in (0, 1):
+                mh, od, size, seqlen = sk[j][strand]
+                if int((mh == q_mh[q]).sum()) < 3:
+                    continue
+                ov = O.overlap(q_od[q][:qsize], qlen, od[:size], seqlen, K2, 0.2)
+                if ov["empty"] or ov["score"] < 0.78:
+                    continue
+                b1, b2 = ov["b1"], ov["b2"]
+                if strand:
+                    b1, b2 = LEN - ov["b2"] - 1, LEN - ov["b1"] - 1
+                rec = {"from_id": qid, "to_id": mid, "score": ov["score"], "raw": ov["raw"], "a1": ov["a1"], "a2": ov["a2"], "alen": LEN,
+                       "b1": b1, "b2": b2, "blen": LEN, "to_rc": strand}
+                lines.append(O.format_record(rec))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, lines)
     if rank == 0:
-        torch.save({"table": g, "table_rm": g_rm, "queries": torch.stack(allq)}, out)
+        torch.save({"lines": gathered}, out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_equals_single_process(tmp_path):
+def _run(world, tmp_path, port_base):
     import mhap_amd
-    from mhap_amd import distributed as md
-    out = str(tmp_path / "g.pt")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(port, out), nprocs=WORLD, join=True)
-    got = torch.load(out)
-    full = mhap_amd.synth_reads(N_TOTAL, LEN, seed=9)
-    want = _oracle_rows(full)
-    n_pad = md.shard_size(N_TOTAL, WORLD)
-    table = got["table"].numpy()
-    assert table.shape == (2 * n_pad * WORLD, H)
-    assert np.array_equal(table[:2 * N_TOTAL], want)          # global read order, fwd/rc interleaved
-    assert not table[2 * N_TOTAL:].any()                       # padding entries
-    ids, fwd = md.global_entry_ids(N_TOTAL, WORLD)
-    assert ids[:2 * N_TOTAL].tolist() == np.repeat(full.ids, 2).tolist() and fwd[:4].tolist() == [1, 0, 1, 0]
-    q = got["queries"].numpy()
-    assert sorted(q.ravel().tolist()) == list(range(n_pad * WORLD))   # query shards partition the reads
-    assert all((q[r] % WORLD == r).all() for r in range(WORLD))
-    # rank-major layout (what bench.py uses: no re-layout copy): entry rank*2*n_pad + 2*slot + strand = read slot*WORLD + rank
-    rm = got["table_rm"].numpy()
-    ids_rm, fwd_rm = md.rank_major_entry_ids(N_TOTAL, WORLD)
-    assert rm.shape == table.shape and len(ids_rm) == rm.shape[0]
-    for e in range(rm.shape[0]):
-        r = int(ids_rm[e]) - 1
-        if r < N_TOTAL:
-            assert np.array_equal(rm[e], want[2 * r + (1 - int(fwd_rm[e]))]), e
-        else:
-            assert not rm[e].any()
-    firsts = [md.rank_major_query_range(N_TOTAL, WORLD, r) for r in range(WORLD)]
-    assert firsts == [(r * 2 * n_pad, 2 * n_pad) for r in range(WORLD)]
-    assert sorted(set(int(i) for i in ids_rm if i <= N_TOTAL)) == list(range(1, N_TOTAL + 1))
+    import oracle_lib as O
+    out = str(tmp_path / f"w{world}.pt")
+    port = port_base + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    got = torch.load(out, weights_only=False)["lines"]
+    full = mhap_amd.synth_reads(N_TOTAL, LEN, seed=11, error_rate=0.08)
+    want = O.record_lines(O.run_self(full, H=H, S=S, nthreads=2)["records"])
+    assert len(want) > 10
+    union = sorted(ln for part in got for ln in part)
+    assert union == want                                   # every pair reported exactly once, by exactly one rank
+    assert sum(1 for part in got if part) == world         # and every rank had work
 
 
-# ---- query rotation (what bench.py's N > 1 step does): ring helpers over gloo, 3 ranks --------------------------------------
-RING_WORLD = 3
+def test_sharded_search_two_ranks_equals_single_process(tmp_path):
+    _run(2, tmp_path, 29500)
 
 
-def _ring_worker(rank, port, out):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=RING_WORLD)
-    import mhap_amd
-    from mhap_amd import distributed as md
-    shard = md.pad_shard(mhap_amd.synth_reads(N_TOTAL, LEN, seed=9, shard=rank, nshards=RING_WORLD), N_TOTAL, RING_WORLD)
-    local = torch.from_numpy(_oracle_rows(shard))                    # [2*n_pad, H], fwd/rc interleaved
-    cur = (md.forward_rows(local), torch.full((md.shard_size(N_TOTAL, RING_WORLD), 4), rank, dtype=torch.int32))
-    seen = []
-    for t in range(RING_WORLD):
-        pending = md.ring_post(cur, RING_WORLD, rank, dist) if t + 1 < RING_WORLD else None
-        origin = (rank - t) % RING_WORLD
-        assert int(cur[1][0, 0]) == origin                             # the bundle visiting at step t comes from rank - t
-        seen.append((origin, cur[0].clone(), md.bundle_ids(N_TOTAL, RING_WORLD, origin)))
-        if pending is not None:
-            cur = md.ring_wait(*pending)
-    ids, fwd = md.local_entry_ids(N_TOTAL, RING_WORLD, rank)
-    torch.save({"seen": seen, "ids": ids, "fwd": fwd}, out + str(rank))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_query_bundles_visit_every_rank(tmp_path):
-    import mhap_amd
-    from mhap_amd import distributed as md
-    out = str(tmp_path / "ring")
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_ring_worker, args=(port, out), nprocs=RING_WORLD, join=True)
-    full = mhap_amd.synth_reads(N_TOTAL, LEN, seed=9)
-    want = _oracle_rows(full)
-    all_ids = []
-    for rank in range(RING_WORLD):
-        got = torch.load(out + str(rank), weights_only=False)
-        assert sorted(o for o, _, _ in got["seen"]) == list(range(RING_WORLD))      # every rank's queries came by exactly once
-        for origin, rows, qids in got["seen"]:
-            for j, qid in enumerate(qids):
-                if qid <= N_TOTAL:
-                    assert np.array_equal(rows[j].numpy(), want[2 * (int(qid) - 1)]), (rank, origin, j)   # forward row of read qid
-                else:
-                    assert not rows[j].any()
-        assert got["fwd"].tolist() == [1, 0] * md.shard_size(N_TOTAL, RING_WORLD)
-        all_ids += [int(i) for i in got["ids"][::2] if i <= N_TOTAL]
-    assert sorted(all_ids) == list(range(1, N_TOTAL + 1))                            # the per-rank indexes partition the reads
+def test_sharded_search_three_ranks_equals_single_process(tmp_path):
+    _run(3, tmp_path, 31500)

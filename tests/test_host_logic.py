@@ -90,6 +90,28 @@ def test_xorshift_jump_tables_match_stepping():
         assert out.value == x, n
 
 
+def test_xorshift_unjump_recovers_the_key():
+    """The weight-1 MinHash kernel keeps only a slot's minimal chain value and turns it back into the winning k-mer key
+    (inverse jump tables + up to 3 forward steps): unjump(step^n(key), n) == key for every slot count it can meet."""
+    lib = mhap_amd.load_library()
+    M = (1 << 64) - 1
+
+    def step(x):
+        x ^= (x << 21) & M
+        x ^= x >> 35
+        x ^= (x << 4) & M
+        return x
+    rnd = random.Random(6)
+    out = C.c_uint64()
+    for n in list(range(1, 14)) + [63, 64, 65, 255, 256, 257, 510, 511, 512, 513, 768, 1023, 8192]:
+        for key in (rnd.getrandbits(64), 1, M, 0):
+            x = key
+            for _ in range(n):
+                x = step(x)
+            assert lib.mhap_selftest_xorshift_unjump(C.c_uint64(x), C.c_int32(n), C.byref(out)) == 0
+            assert out.value == key, (n, key)
+
+
 def test_filter_kmer_hash_is_canonical_when_rc():
     lib = mhap_amd.load_library()
     out = C.c_int64()
