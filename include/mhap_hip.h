@@ -92,6 +92,13 @@ typedef struct mhap_kernel_times {
   int64_t launches[MHAP_K_COUNT];
 } mhap_kernel_times;
 
+/* Interface version of this header (bumped whenever a struct layout or a signature changes) and the sizes of its structs as the
+ * library was compiled: a binding built against another header — a stale libmhaphip.so shipped next to newer host code — finds
+ * out at load time instead of overrunning a buffer. */
+#define MHAP_ABI_VERSION 3
+int mhap_abi_version(void);
+int mhap_abi_sizes(int32_t* out4);   /* {sizeof mhap_params, mhap_record, mhap_stats, mhap_kernel_times} */
+
 typedef struct mhap_handle mhap_handle;
 
 /* Record sink: called from the calling thread, one batch at a time; `recs` is owned by

@@ -16,7 +16,7 @@
  * by
  *     HipMinHashSearch hashSearch = new HipMinHashSearch(new FastaData(this.inFile, seqNumberProcessed), this.kmerSize, this.numHashes,
  *         this.orderedKmerSize, this.orderedSketchSize, this.numMinMatches, this.numThreads, false, this.minStoreLength, this.minOlapLength,
- *         this.maxShift, this.acceptScore, this.repeatWeight, 0);
+ *         this.maxShift, this.acceptScore, this.repeatWeight, new int[] {0});     // one HIP device ordinal per GPU: {0,1,...,7} shards the index over a node
  *     if (this.filterFile != null) hashSearch.setFilterFile(this.filterFile, this.filterThreshold, offset, this.supressNoise, this.noTf,
  *         this.repeatIdfScale, this.doReverseCompliment);      // before the reads are added
  *     hashSearch.addData();
@@ -45,10 +45,12 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 		System.loadLibrary("mhapjni");
 	}
 
-	/** reads handed to the GPU per native call (bases are concatenated into one byte[]) */
+	/** reads handed to the GPUs per native call (bases are concatenated into one byte[], which the native side copies) */
 	private final static int READS_PER_BATCH = 65536;
-	private final static long BASES_PER_BATCH = 1L << 30;
+	private final static long BASES_PER_BATCH = 1L << 28;
 	private final static int RECORD_BYTES = 64;
+	/** overlap records taken out of the native side per call: the Java heap holds one such chunk (<= 64 MB) at a time */
+	private final static int RECORDS_PER_TAKE = 1 << 20;
 
 	private final long handle;
 	private final FastaData data;
@@ -62,7 +64,7 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 	private boolean closed;
 
 	private static native long nativeCreate(int kmerSize, int numHashes, int orderedKmerSize, int orderedSketchSize, int numMinMatches,
-			int minStoreLength, int minOlapLength, double acceptScore, double maxShift, double repeatWeight, int device);
+			int minStoreLength, int minOlapLength, double acceptScore, double maxShift, double repeatWeight, int[] devices);
 
 	private static native void nativeDestroy(long handle);
 
@@ -71,18 +73,21 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 
 	private static native void nativeAddReads(long handle, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n);
 
-	private static native byte[] nativeFindMatchesSelf(long handle);
+	/** the three searches park their records natively and return how many there are; nativeTakeRecords hands them out in chunks */
+	private static native long nativeFindMatchesSelf(long handle);
 
-	private static native byte[] nativeFindMatchesReads(long handle, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n);
+	private static native long nativeFindMatchesReads(long handle, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n);
 
-	private static native byte[] nativeFindMatchesSketches(long handle, long[] ids, int[] seqLength, int[] minHashes, int[] ordered,
+	private static native long nativeFindMatchesSketches(long handle, long[] ids, int[] seqLength, int[] minHashes, int[] ordered,
 			int[] orderedSize, int[] orderedSeqLength, int m);
+
+	private static native byte[] nativeTakeRecords(long handle, int maxRecords);
 
 	private static native long[] nativeStats(long handle);
 
 	public HipMinHashSearch(FastaData data, int kmerSize, int numHashes, int orderedKmerSize, int orderedSketchSize, int numMinMatches,
 			int numThreads, boolean storeResults, int minStoreLength, int minOlapLength, double maxShift, double acceptScore,
-			double repeatWeight, int device)
+			double repeatWeight, int[] devices)
 	{
 		super(numThreads, storeResults);
 		this.data = data;
@@ -92,7 +97,7 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 		this.fullIds = new HashMap<Long, String>();
 		this.storedForwardIds = new ArrayList<SequenceId>();
 		this.handle = nativeCreate(kmerSize, numHashes, orderedKmerSize, orderedSketchSize, numMinMatches, minStoreLength, minOlapLength,
-				acceptScore, maxShift, repeatWeight, device);
+				acceptScore, maxShift, repeatWeight, devices);
 	}
 
 	/** new FrequencyCounts(...) for the GPU path (sketch/FrequencyCounts.java:63-229); call before addData(). */
@@ -238,14 +243,29 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 		return out;
 	}
 
-	private void deliver(ArrayList<MatchResult> matches, ArrayList<MatchResult> combined)
+	/**
+	 * Takes the records a native search parked out in chunks of at most RECORDS_PER_TAKE and hands every chunk on the way the
+	 * reference's drivers do (impl/AbstractMatchSearch.java:155-170,316-338): printed through outputResults in pieces of
+	 * NUM_ELEMENTS_PER_OUTPUT, or collected when storeResults is set.
+	 */
+	private void deliver(long parked, ArrayList<MatchResult> combined)
 	{
-		this.matchesProcessed += matches.size();
-		if (this.storeResults)
-			combined.addAll(matches);
-		else
-			for (int from = 0; from < matches.size(); from += NUM_ELEMENTS_PER_OUTPUT)
-				outputResults(matches.subList(from, Math.min(matches.size(), from + NUM_ELEMENTS_PER_OUTPUT)));
+		long taken = 0;
+		byte[] chunk = nativeTakeRecords(this.handle, RECORDS_PER_TAKE);
+		while (chunk != null)
+		{
+			ArrayList<MatchResult> matches = decode(chunk);
+			taken += matches.size();
+			this.matchesProcessed += matches.size();
+			if (this.storeResults)
+				combined.addAll(matches);
+			else
+				for (int from = 0; from < matches.size(); from += NUM_ELEMENTS_PER_OUTPUT)
+					outputResults(matches.subList(from, Math.min(matches.size(), from + NUM_ELEMENTS_PER_OUTPUT)));
+			chunk = nativeTakeRecords(this.handle, RECORDS_PER_TAKE);
+		}
+		if (taken != parked)
+			throw new MhapRuntimeException("Overlap records lost between the library and Java: " + taken + " of " + parked + ".");
 	}
 
 	/** The self driver (impl/AbstractMatchSearch.java:121-199): every stored forward sequence against the index, toSelf = true. */
@@ -253,7 +273,7 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 	public ArrayList<MatchResult> findMatches()
 	{
 		ArrayList<MatchResult> combined = new ArrayList<MatchResult>();
-		deliver(decode(nativeFindMatchesSelf(this.handle)), combined);
+		deliver(nativeFindMatchesSelf(this.handle), combined);
 		this.sequencesSearched = nativeStats(this.handle)[1];
 		flushOutput();
 		return combined;
@@ -286,11 +306,12 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 		return combined;
 	}
 
-	private ArrayList<MatchResult> searchSketches(List<SequenceSketch> batch)
+	/** searches a batch of query sketches; returns the number of records parked natively */
+	private long searchSketches(List<SequenceSketch> batch)
 	{
 		int m = batch.size();
 		if (m == 0)
-			return new ArrayList<MatchResult>();
+			return 0;
 		int S = this.orderedSketchSize;
 		long[] ids = new long[m];
 		int[] seqLength = new int[m], orderedSize = new int[m], orderedSeqLength = new int[m];
@@ -322,7 +343,7 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 				ordered[i * S * 2 + j] = wire.getInt();
 		}
 		this.sequencesSearched += m;
-		return decode(nativeFindMatchesSketches(this.handle, ids, seqLength, minHashes, ordered, orderedSize, orderedSeqLength, m));
+		return nativeFindMatchesSketches(this.handle, ids, seqLength, minHashes, ordered, orderedSize, orderedSeqLength, m);
 	}
 
 	/** Query READS straight from a FASTA file: sketched (forward strand only) and searched on the GPU. */
@@ -346,15 +367,16 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 		return combined;
 	}
 
-	private ArrayList<MatchResult> searchReads(ReadBatch batch)
+	/** sketches and searches a batch of query reads on the GPUs; returns the number of records parked natively */
+	private long searchReads(ReadBatch batch)
 	{
 		if (batch.reads.isEmpty())
-			return new ArrayList<MatchResult>();
+			return 0;
 		rememberIds(batch, false);
 		long before = nativeStats(this.handle)[1];
-		byte[] packed = nativeFindMatchesReads(this.handle, batch.baseBytes(), batch.offsets(), batch.lengths(), batch.ids(), batch.reads.size());
+		long parked = nativeFindMatchesReads(this.handle, batch.baseBytes(), batch.offsets(), batch.lengths(), batch.ids(), batch.reads.size());
 		this.sequencesSearched += nativeStats(this.handle)[1] - before;
-		return decode(packed);
+		return parked;
 	}
 
 	/** per-query seam (impl/AbstractMatchSearch.java:201): one sketch against the index. */
@@ -365,7 +387,17 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 			throw new MhapRuntimeException("Self matches are computed for the whole index at once: call findMatches().");
 		ArrayList<SequenceSketch> one = new ArrayList<SequenceSketch>();
 		one.add(hashes);
-		return searchSketches(one);
+		long parked = searchSketches(one);
+		ArrayList<MatchResult> out = new ArrayList<MatchResult>();
+		byte[] chunk = nativeTakeRecords(this.handle, RECORDS_PER_TAKE);
+		while (chunk != null)
+		{
+			out.addAll(decode(chunk));
+			chunk = nativeTakeRecords(this.handle, RECORDS_PER_TAKE);
+		}
+		if (out.size() != parked)
+			throw new MhapRuntimeException("Overlap records lost between the library and Java.");
+		return out;
 	}
 
 	@Override

@@ -4,6 +4,11 @@
  * replacement of MinHashSearch behind the reference's only operator seam, AbstractMatchSearch
  * (src/main/java/edu/umd/marbl/mhap/impl/AbstractMatchSearch.java:47,67-117,121-199,203-285).
  *
+ * The engine behind a Java object is a GROUP of ranks (mhap_group_*): one rank per GPU the host names, a group of one for a
+ * single GPU.  The reads of every addData batch are dealt round-robin over the ranks, every rank sketches and indexes its share,
+ * and a search gathers the forward query sketches of all ranks over xGMI inside the library — the Java host never sees the
+ * sharding (J/impl/AbstractMatchSearch.java has one index and a thread pool).
+ *
  * Not compiled in this repository's image (no JDK: no jni.h).  Build where a JDK is present:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../include mhap_jni.c \
  *       -L../mhap_amd/lib -lmhaphip -Wl,-rpath,'$ORIGIN' -o libmhapjni.so
@@ -11,10 +16,15 @@
  * argument counts agree and that every mhap_* function called exists in the header; it also compiles this file against a
  * minimal stand-in jni.h for syntax.
  *
- * Conventions: no JNI global references are held across calls; arrays are pinned with Get/ReleasePrimitiveArrayCritical
- * only around the one library call that reads them; records come back as one byte[] of packed mhap_record (64 bytes each,
- * little-endian, the layout of include/mhap_hip.h) that the Java side decodes with a ByteBuffer; every library error
- * becomes an unchecked MhapRuntimeException carrying mhap_last_error().
+ * Conventions
+ *  - no JNI global references are held across calls;
+ *  - input arrays are COPIED out with Get<Type>ArrayRegion before the library is called (no GetPrimitiveArrayCritical region
+ *    is held across a multi-second GPU call: that would stall the JVM's collector);
+ *  - overlap records never cross as one array: a search parks them natively (64-byte mhap_record, little-endian, the layout of
+ *    include/mhap_hip.h) and returns their COUNT; the Java side then takes them out in bounded chunks (nativeTakeRecords,
+ *    at most 1 << 20 records = 64 MB per byte[]) and hands each chunk to AbstractMatchSearch.outputResults — no 2 GB array limit,
+ *    no silent truncation, the Java heap holds one chunk at a time;
+ *  - every library error becomes an unchecked MhapRuntimeException carrying mhap_last_error() / mhap_group_last_error().
  */
 #include <jni.h>
 #include <stdint.h>
@@ -24,183 +34,242 @@
 #include "mhap_hip.h"
 
 #define MHAP_EXC "edu/umd/marbl/mhap/impl/MhapRuntimeException"
+#define MAX_TAKE (1 << 20)
 
-static mhap_handle* H(jlong h) { return (mhap_handle*)(intptr_t)h; }
+/* parked records: a list of blocks the sink appends to (the library calls the sink one batch at a time, also with several ranks) */
+typedef struct rec_block { struct rec_block* next; int64_t n, taken; mhap_record recs[1]; } rec_block;
+typedef struct { mhap_group* g; rec_block *head, *tail; int64_t parked; int oom; } engine;
+
+static engine* E(jlong h) { return (engine*)(intptr_t)h; }
 
 static void throw_mhap(JNIEnv* env, const char* msg) {
   jclass c = (*env)->FindClass(env, MHAP_EXC);
   if (c) (*env)->ThrowNew(env, c, msg ? msg : "libmhaphip error");
 }
 
-static int check(JNIEnv* env, mhap_handle* h, int rc) {
+static int check(JNIEnv* env, engine* e, int rc) {
   if (rc == MHAP_OK) return 0;
-  throw_mhap(env, h ? mhap_last_error(h) : "libmhaphip error");
+  throw_mhap(env, e && e->g ? mhap_group_last_error(e->g) : "libmhaphip error");
   return 1;
 }
 
-/* growing buffer the record sink appends to (the library calls the sink from the calling thread, one batch at a time) */
-typedef struct { mhap_record* p; int64_t n, cap; int oom; } rec_buf;
+static void drop_records(engine* e) {
+  while (e->head) { rec_block* b = e->head; e->head = b->next; free(b); }
+  e->tail = NULL; e->parked = 0; e->oom = 0;
+}
 
-static int collect_sink(const mhap_record* recs, int64_t n, void* user) {
-  rec_buf* b = (rec_buf*)user;
-  if (b->n + n > b->cap) {
-    int64_t ncap = b->cap ? b->cap : 65536;
-    while (ncap < b->n + n) ncap *= 2;
-    mhap_record* np = (mhap_record*)realloc(b->p, (size_t)ncap * sizeof(mhap_record));
-    if (!np) { b->oom = 1; return 1; }
-    b->p = np; b->cap = ncap;
-  }
-  memcpy(b->p + b->n, recs, (size_t)n * sizeof(mhap_record));
-  b->n += n;
+static int park_sink(const mhap_record* recs, int64_t n, void* user) {
+  engine* e = (engine*)user;
+  rec_block* b;
+  if (n <= 0) return 0;
+  b = (rec_block*)malloc(sizeof(rec_block) + (size_t)(n - 1) * sizeof(mhap_record));
+  if (!b) { e->oom = 1; return 1; }
+  b->next = NULL; b->n = n; b->taken = 0;
+  memcpy(b->recs, recs, (size_t)n * sizeof(mhap_record));
+  if (e->tail) e->tail->next = b; else e->head = b;
+  e->tail = b;
+  e->parked += n;
   return 0;
 }
 
-static jbyteArray records_to_java(JNIEnv* env, rec_buf* b) {
-  jbyteArray out = NULL;
-  if (b->oom) throw_mhap(env, "out of memory while collecting overlap records");
-  else {
-    const jsize bytes = (jsize)(b->n * (int64_t)sizeof(mhap_record));
-    out = (*env)->NewByteArray(env, bytes);
-    if (out && bytes > 0) (*env)->SetByteArrayRegion(env, out, 0, bytes, (const jbyte*)b->p);
+/* a search finished with code rc: its records are parked; returns their count or throws */
+static jlong finish_search(JNIEnv* env, engine* e, int rc) {
+  if (e->oom) { drop_records(e); throw_mhap(env, "out of memory while collecting overlap records"); return -1; }
+  if (rc != MHAP_OK) { drop_records(e); check(env, e, rc); return -1; }
+  return (jlong)e->parked;
+}
+
+/* copies of the four arrays that describe a batch of reads */
+typedef struct { char* bases; int64_t* offsets; int32_t* lengths; int64_t* ids; } read_batch;
+static void free_batch(read_batch* b) { free(b->bases); free(b->offsets); free(b->lengths); free(b->ids); }
+static int copy_batch(JNIEnv* env, read_batch* b, jbyteArray bases, jlongArray offsets, jintArray lengths, jlongArray ids, jint n) {
+  const jsize nb = (*env)->GetArrayLength(env, bases);
+  memset(b, 0, sizeof *b);
+  if (n < 0 || (*env)->GetArrayLength(env, offsets) < n || (*env)->GetArrayLength(env, lengths) < n || (*env)->GetArrayLength(env, ids) < n) {
+    throw_mhap(env, "read batch arrays are shorter than the read count");
+    return 1;
   }
-  free(b->p);
-  return out;
+  b->bases = (char*)malloc((size_t)nb + 1);
+  b->offsets = (int64_t*)malloc(((size_t)n + 1) * sizeof(int64_t));
+  b->lengths = (int32_t*)malloc(((size_t)n + 1) * sizeof(int32_t));
+  b->ids = (int64_t*)malloc(((size_t)n + 1) * sizeof(int64_t));
+  if (!b->bases || !b->offsets || !b->lengths || !b->ids) { free_batch(b); throw_mhap(env, "out of memory while copying a read batch"); return 1; }
+  (*env)->GetByteArrayRegion(env, bases, 0, nb, (jbyte*)b->bases);
+  (*env)->GetLongArrayRegion(env, offsets, 0, n, (jlong*)b->offsets);
+  (*env)->GetIntArrayRegion(env, lengths, 0, n, (jint*)b->lengths);
+  (*env)->GetLongArrayRegion(env, ids, 0, n, (jlong*)b->ids);
+  return 0;
 }
 
 /* long nativeCreate(int kmerSize, int numHashes, int orderedKmerSize, int orderedSketchSize, int numMinMatches,
- *                   int minStoreLength, int minOlapLength, double acceptScore, double maxShift, double repeatWeight, int device)
- * <- new MinHashSearch(...) impl/MinHashSearch.java:63-98 (flag defaults: main/MhapMain.java:67-125) */
+ *                   int minStoreLength, int minOlapLength, double acceptScore, double maxShift, double repeatWeight, int[] devices)
+ * <- new MinHashSearch(...) impl/MinHashSearch.java:63-98 (flag defaults: main/MhapMain.java:67-125); devices: one HIP device
+ *    ordinal per rank (one entry = one GPU) */
 JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeCreate(
     JNIEnv* env, jclass cls, jint kmerSize, jint numHashes, jint orderedKmerSize, jint orderedSketchSize, jint numMinMatches,
-    jint minStoreLength, jint minOlapLength, jdouble acceptScore, jdouble maxShift, jdouble repeatWeight, jint device) {
+    jint minStoreLength, jint minOlapLength, jdouble acceptScore, jdouble maxShift, jdouble repeatWeight, jintArray devices) {
   mhap_params p;
-  mhap_handle* h = NULL;
+  engine* e;
   char err[512];
+  int32_t devs[64];
+  const jsize nd = (*env)->GetArrayLength(env, devices);
   (void)cls;
+  if (nd < 1 || nd > 64) { throw_mhap(env, "between 1 and 64 devices, please"); return 0; }
+  (*env)->GetIntArrayRegion(env, devices, 0, nd, (jint*)devs);
   mhap_default_params(&p);
   p.kmer_size = kmerSize; p.num_hashes = numHashes; p.ordered_kmer_size = orderedKmerSize; p.ordered_sketch_size = orderedSketchSize;
-  p.num_min_matches = numMinMatches; p.min_store_length = minStoreLength; p.min_olap_length = minOlapLength; p.device = device;
+  p.num_min_matches = numMinMatches; p.min_store_length = minStoreLength; p.min_olap_length = minOlapLength; p.device = devs[0];
   p.threshold = acceptScore; p.max_shift = maxShift; p.repeat_weight = repeatWeight;
+  e = (engine*)calloc(1, sizeof(engine));
+  if (!e) { throw_mhap(env, "out of memory"); return 0; }
   err[0] = 0;
-  if (mhap_create(&p, &h, err, sizeof err) != MHAP_OK) { throw_mhap(env, err); return 0; }
-  return (jlong)(intptr_t)h;
+  if (mhap_group_create(&p, devs, (int32_t)nd, &e->g, err, sizeof err) != MHAP_OK) { free(e); throw_mhap(env, err); return 0; }
+  return (jlong)(intptr_t)e;
 }
 
-/* void nativeDestroy(long handle) */
+/* void nativeDestroy(long engine) */
 JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeDestroy(JNIEnv* env, jclass cls, jlong handle) {
+  engine* e = E(handle);
   (void)env; (void)cls;
-  mhap_destroy(H(handle));
+  if (!e) return;
+  drop_records(e);
+  mhap_group_destroy(e->g);
+  free(e);
 }
 
-/* void nativeSetFilterFile(long handle, String path, double filterCutoff, double offset, int removeUnique, boolean noTf,
+/* void nativeSetFilterFile(long engine, String path, double filterCutoff, double offset, int removeUnique, boolean noTf,
  *                          double range, boolean doReverseCompliment)
- * <- new FrequencyCounts(reader, filterCutoff, offset, removeUnique, noTf, numThreads, range, doRC) sketch/FrequencyCounts.java:63-229 */
+ * <- new FrequencyCounts(reader, filterCutoff, offset, removeUnique, noTf, numThreads, range, doRC) sketch/FrequencyCounts.java:63-229;
+ *    every rank applies the filter to the reads it sketches */
 JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeSetFilterFile(
     JNIEnv* env, jclass cls, jlong handle, jstring path, jdouble filterCutoff, jdouble offset, jint removeUnique, jboolean noTf,
     jdouble range, jboolean doReverseCompliment) {
+  engine* e = E(handle);
   const char* cpath = (*env)->GetStringUTFChars(env, path, NULL);
-  int rc;
+  int rc = MHAP_OK, r;
+  mhap_handle* bad = NULL;
   (void)cls;
   if (!cpath) return;
-  rc = mhap_set_filter_file(H(handle), cpath, filterCutoff, offset, removeUnique, noTf ? 1 : 0, range, doReverseCompliment ? 1 : 0, NULL, 0);
+  for (r = 0; r < mhap_group_size(e->g) && rc == MHAP_OK; r++) {
+    bad = mhap_group_rank(e->g, r);
+    rc = mhap_set_filter_file(bad, cpath, filterCutoff, offset, removeUnique, noTf ? 1 : 0, range, doReverseCompliment ? 1 : 0, NULL, 0);
+  }
   (*env)->ReleaseStringUTFChars(env, path, cpath);
   if (rc == MHAP_E_IO) throw_mhap(env, "Could not parse k-mer filter file.");
-  else check(env, H(handle), rc);
+  else if (rc != MHAP_OK) throw_mhap(env, mhap_last_error(bad));
 }
 
-/* void nativeAddReads(long handle, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n)
+/* void nativeAddReads(long engine, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n)
  * <- AbstractMatchSearch.addData + MinHashSearch.addSequence for a batch of reads (both strands are sketched and indexed on
- *    the GPU): impl/AbstractMatchSearch.java:67-117, impl/MinHashSearch.java:100-147, impl/SequenceSketchStreamer.java:123-156.
+ *    the GPUs): impl/AbstractMatchSearch.java:67-117, impl/MinHashSearch.java:100-147, impl/SequenceSketchStreamer.java:123-156.
  *    bases: the upper-cased sequences back to back (FastaData.java:194), offsets/lengths per read, ids = SequenceId.getHeaderId(). */
 JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeAddReads(
     JNIEnv* env, jclass cls, jlong handle, jbyteArray bases, jlongArray offsets, jintArray lengths, jlongArray ids, jint n) {
-  jbyte* b = (jbyte*)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
-  jlong* o = (jlong*)(*env)->GetPrimitiveArrayCritical(env, offsets, NULL);
-  jint* l = (jint*)(*env)->GetPrimitiveArrayCritical(env, lengths, NULL);
-  jlong* i = (jlong*)(*env)->GetPrimitiveArrayCritical(env, ids, NULL);
-  int rc = MHAP_E_NOMEM;
+  engine* e = E(handle);
+  read_batch b;
   (void)cls;
-  if (b && o && l && i) rc = mhap_index_add_reads(H(handle), (const char*)b, (const int64_t*)o, (const int32_t*)l, (const int64_t*)i, (int64_t)n);
-  if (i) (*env)->ReleasePrimitiveArrayCritical(env, ids, i, JNI_ABORT);
-  if (l) (*env)->ReleasePrimitiveArrayCritical(env, lengths, l, JNI_ABORT);
-  if (o) (*env)->ReleasePrimitiveArrayCritical(env, offsets, o, JNI_ABORT);
-  if (b) (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
-  check(env, H(handle), rc);
+  if (copy_batch(env, &b, bases, offsets, lengths, ids, n)) return;
+  check(env, e, mhap_group_add_reads(e->g, b.bases, b.offsets, b.lengths, b.ids, (int64_t)n));
+  free_batch(&b);
 }
 
-/* byte[] nativeFindMatchesSelf(long handle)
+/* long nativeFindMatchesSelf(long engine) -> number of records parked (take them with nativeTakeRecords)
  * <- AbstractMatchSearch.findMatches() (every stored forward sequence against the index, toSelf = true):
- *    impl/AbstractMatchSearch.java:121-199, impl/MinHashSearch.java:150-251.  Returns packed mhap_record[]. */
-JNIEXPORT jbyteArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesSelf(JNIEnv* env, jclass cls, jlong handle) {
-  rec_buf buf = {NULL, 0, 0, 0};
-  const int rc = mhap_find_matches_self(H(handle), 0, -1, collect_sink, &buf);
+ *    impl/AbstractMatchSearch.java:121-199, impl/MinHashSearch.java:150-251 */
+JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesSelf(JNIEnv* env, jclass cls, jlong handle) {
+  engine* e = E(handle);
   (void)cls;
-  if (rc != MHAP_OK && !buf.oom) { free(buf.p); check(env, H(handle), rc); return NULL; }
-  return records_to_java(env, &buf);
+  return finish_search(env, e, mhap_group_find_matches_self(e->g, park_sink, e));
 }
 
-/* byte[] nativeFindMatchesReads(long handle, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n)
+/* long nativeFindMatchesReads(long engine, byte[] bases, long[] offsets, int[] lengths, long[] ids, int n) -> records parked
  * <- AbstractMatchSearch.findMatches(SequenceSketchStreamer) for a batch of query READS (forward strand only, toSelf = false):
- *    impl/AbstractMatchSearch.java:203-285.  The queries are sketched on the GPU. */
-JNIEXPORT jbyteArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesReads(
+ *    impl/AbstractMatchSearch.java:203-285.  The queries are sketched on the GPUs (dealt over the ranks like the stored reads). */
+JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesReads(
     JNIEnv* env, jclass cls, jlong handle, jbyteArray bases, jlongArray offsets, jintArray lengths, jlongArray ids, jint n) {
-  rec_buf buf = {NULL, 0, 0, 0};
-  jbyte* b = (jbyte*)(*env)->GetPrimitiveArrayCritical(env, bases, NULL);
-  jlong* o = (jlong*)(*env)->GetPrimitiveArrayCritical(env, offsets, NULL);
-  jint* l = (jint*)(*env)->GetPrimitiveArrayCritical(env, lengths, NULL);
-  jlong* i = (jlong*)(*env)->GetPrimitiveArrayCritical(env, ids, NULL);
-  int rc = MHAP_E_NOMEM;
+  engine* e = E(handle);
+  read_batch b;
+  int rc;
   (void)cls;
-  if (b && o && l && i)
-    rc = mhap_find_matches_reads(H(handle), (const char*)b, (const int64_t*)o, (const int32_t*)l, (const int64_t*)i, (int64_t)n, collect_sink, &buf);
-  if (i) (*env)->ReleasePrimitiveArrayCritical(env, ids, i, JNI_ABORT);
-  if (l) (*env)->ReleasePrimitiveArrayCritical(env, lengths, l, JNI_ABORT);
-  if (o) (*env)->ReleasePrimitiveArrayCritical(env, offsets, o, JNI_ABORT);
-  if (b) (*env)->ReleasePrimitiveArrayCritical(env, bases, b, JNI_ABORT);
-  if (rc != MHAP_OK && !buf.oom) { free(buf.p); check(env, H(handle), rc); return NULL; }
-  return records_to_java(env, &buf);
+  if (copy_batch(env, &b, bases, offsets, lengths, ids, n)) return -1;
+  rc = mhap_group_find_matches_reads(e->g, b.bases, b.offsets, b.lengths, b.ids, (int64_t)n, park_sink, e);
+  free_batch(&b);
+  return finish_search(env, e, rc);
 }
 
-/* byte[] nativeFindMatchesSketches(long handle, long[] ids, int[] seqLength, int[] minHashes, int[] ordered, int[] orderedSize,
- *                                  int[] orderedSeqLength, int m)
+/* long nativeFindMatchesSketches(long engine, long[] ids, int[] seqLength, int[] minHashes, int[] ordered, int[] orderedSize,
+ *                                int[] orderedSeqLength, int m) -> records parked
  * <- the same driver when the streamer hands out SequenceSketch objects Java computed or read from a .dat file
  *    (impl/SequenceSketchStreamer.java:158-172,278-320): minHashes = m rows of MinHashSketch.getMinHashArray()
  *    (sketch/MinHashSketch.java:232), ordered = m rows of --ordered-sketch-size (hash, pos) pairs
- *    (sketch/BottomOverlapSketch.java:568-576), zero padded. */
-JNIEXPORT jbyteArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesSketches(
+ *    (sketch/BottomOverlapSketch.java:568-576), zero padded.  toSelf = false has no id rule, so every rank simply searches the
+ *    sketches against its own shard: the union over the ranks is the whole index's answer. */
+JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesSketches(
     JNIEnv* env, jclass cls, jlong handle, jlongArray ids, jintArray seqLength, jintArray minHashes, jintArray ordered,
     jintArray orderedSize, jintArray orderedSeqLength, jint m) {
-  rec_buf buf = {NULL, 0, 0, 0};
-  jlong* i = (jlong*)(*env)->GetPrimitiveArrayCritical(env, ids, NULL);
-  jint* sl = (jint*)(*env)->GetPrimitiveArrayCritical(env, seqLength, NULL);
-  jint* mh = (jint*)(*env)->GetPrimitiveArrayCritical(env, minHashes, NULL);
-  jint* od = (jint*)(*env)->GetPrimitiveArrayCritical(env, ordered, NULL);
-  jint* os = (jint*)(*env)->GetPrimitiveArrayCritical(env, orderedSize, NULL);
-  jint* ol = (jint*)(*env)->GetPrimitiveArrayCritical(env, orderedSeqLength, NULL);
-  int rc = MHAP_E_NOMEM;
+  engine* e = E(handle);
+  const jsize nmh = (*env)->GetArrayLength(env, minHashes), nod = (*env)->GetArrayLength(env, ordered);
+  int64_t* i = (int64_t*)malloc(((size_t)m + 1) * 8);
+  int32_t* sl = (int32_t*)malloc(((size_t)m + 1) * 4);
+  int32_t* mh = (int32_t*)malloc(((size_t)nmh + 1) * 4);
+  int32_t* od = (int32_t*)malloc(((size_t)nod + 1) * 4);
+  int32_t* os = (int32_t*)malloc(((size_t)m + 1) * 4);
+  int32_t* ol = (int32_t*)malloc(((size_t)m + 1) * 4);
+  int rc = MHAP_E_NOMEM, r;
+  mhap_handle* bad = NULL;
   (void)cls;
-  if (i && sl && mh && od && os && ol)
-    rc = mhap_find_matches_sketches(H(handle), (const int64_t*)i, (const int32_t*)sl, (const int32_t*)mh, (const int32_t*)od, (const int32_t*)os,
-                                    (const int32_t*)ol, (int64_t)m, collect_sink, &buf);
-  if (ol) (*env)->ReleasePrimitiveArrayCritical(env, orderedSeqLength, ol, JNI_ABORT);
-  if (os) (*env)->ReleasePrimitiveArrayCritical(env, orderedSize, os, JNI_ABORT);
-  if (od) (*env)->ReleasePrimitiveArrayCritical(env, ordered, od, JNI_ABORT);
-  if (mh) (*env)->ReleasePrimitiveArrayCritical(env, minHashes, mh, JNI_ABORT);
-  if (sl) (*env)->ReleasePrimitiveArrayCritical(env, seqLength, sl, JNI_ABORT);
-  if (i) (*env)->ReleasePrimitiveArrayCritical(env, ids, i, JNI_ABORT);
-  if (rc != MHAP_OK && !buf.oom) { free(buf.p); check(env, H(handle), rc); return NULL; }
-  return records_to_java(env, &buf);
+  if (i && sl && mh && od && os && ol && m >= 0) {
+    (*env)->GetLongArrayRegion(env, ids, 0, m, (jlong*)i);
+    (*env)->GetIntArrayRegion(env, seqLength, 0, m, (jint*)sl);
+    (*env)->GetIntArrayRegion(env, minHashes, 0, nmh, (jint*)mh);
+    (*env)->GetIntArrayRegion(env, ordered, 0, nod, (jint*)od);
+    (*env)->GetIntArrayRegion(env, orderedSize, 0, m, (jint*)os);
+    (*env)->GetIntArrayRegion(env, orderedSeqLength, 0, m, (jint*)ol);
+    rc = MHAP_OK;
+    for (r = 0; r < mhap_group_size(e->g) && rc == MHAP_OK && !e->oom; r++) {
+      bad = mhap_group_rank(e->g, r);
+      rc = mhap_find_matches_sketches(bad, i, sl, mh, od, os, ol, (int64_t)m, park_sink, e);
+    }
+  }
+  free(i); free(sl); free(mh); free(od); free(os); free(ol);
+  if (rc != MHAP_OK && !e->oom) { drop_records(e); throw_mhap(env, bad ? mhap_last_error(bad) : "out of memory while copying query sketches"); return -1; }
+  return finish_search(env, e, MHAP_OK);
 }
 
-/* long[] nativeStats(long handle) -> {strandsIndexed, queriesSearched, candidatesCompared, matchesFound, tableElements}
+/* byte[] nativeTakeRecords(long engine, int maxRecords) -> the next chunk of parked records (packed mhap_record[], at most
+ * min(maxRecords, 1 << 20) of them), or null once none are left */
+JNIEXPORT jbyteArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeTakeRecords(JNIEnv* env, jclass cls, jlong handle, jint maxRecords) {
+  engine* e = E(handle);
+  int64_t want = maxRecords < 1 ? 1 : (maxRecords > MAX_TAKE ? MAX_TAKE : maxRecords), got = 0;
+  jbyteArray out;
+  (void)cls;
+  if (e->parked <= 0) { drop_records(e); return NULL; }
+  if (want > e->parked) want = e->parked;
+  out = (*env)->NewByteArray(env, (jsize)(want * (int64_t)sizeof(mhap_record)));   /* <= 64 MB: fits a jsize */
+  if (!out) return NULL;                                                           /* OutOfMemoryError is pending */
+  while (got < want && e->head) {
+    rec_block* b = e->head;
+    int64_t k = b->n - b->taken;
+    if (k > want - got) k = want - got;
+    (*env)->SetByteArrayRegion(env, out, (jsize)(got * (int64_t)sizeof(mhap_record)), (jsize)(k * (int64_t)sizeof(mhap_record)),
+                               (const jbyte*)(b->recs + b->taken));
+    b->taken += k; got += k;
+    if (b->taken == b->n) { e->head = b->next; if (!e->head) e->tail = NULL; free(b); }
+  }
+  e->parked -= got;
+  return out;
+}
+
+/* long[] nativeStats(long engine) -> {strandsIndexed, queriesSearched, candidatesCompared, matchesFound, tableElements}, summed over the ranks
  * <- size(), getNumberSequencesSearched(), getNumberSequencesFullyCompared(), getMatchesProcessed(), getNumberElementsProcessed()
  *    (impl/MinHashSearch.java:253-300, main/MhapMain.java:572-590) */
 JNIEXPORT jlongArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeStats(JNIEnv* env, jclass cls, jlong handle) {
+  engine* e = E(handle);
   mhap_stats st;
   jlong v[5];
   jlongArray out;
   (void)cls;
-  if (check(env, H(handle), mhap_get_stats(H(handle), &st))) return NULL;
+  if (check(env, e, mhap_group_get_stats(e->g, &st))) return NULL;
   v[0] = st.strands_indexed; v[1] = st.queries_searched; v[2] = st.candidates_compared; v[3] = st.matches_found; v[4] = st.table_elements;
   out = (*env)->NewLongArray(env, 5);
   if (out) (*env)->SetLongArrayRegion(env, out, 0, 5, v);

@@ -63,8 +63,9 @@ EXPORTED_SYMBOLS = [
     "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
     "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing",
     "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",
-    "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats",
+    "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats", "mhap_abi_version", "mhap_abi_sizes",
 ]
+ABI_VERSION = 3   # MHAP_ABI_VERSION of include/mhap_hip.h this binding was written against
 
 
 def load_library(build_if_missing=True):
@@ -102,6 +103,13 @@ def load_library(build_if_missing=True):
     lib.mhap_group_size.argtypes = [C.c_void_p]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError here = header/library mismatch
+    # a stale library next to newer host code (or the reverse) must not get as far as a struct copy
+    sizes = (C.c_int32 * 4)()
+    lib.mhap_abi_sizes(sizes)
+    want = [C.sizeof(_Params), RECORD_DTYPE.itemsize, C.sizeof(_Stats), C.sizeof(_KTimes)]
+    if lib.mhap_abi_version() != ABI_VERSION or list(sizes) != want:
+        raise MhapError(f"{_LIB_PATH} was built from another include/mhap_hip.h (ABI {lib.mhap_abi_version()}, struct sizes {list(sizes)}; "
+                        f"this binding: ABI {ABI_VERSION}, {want}): rebuild it with `python -m mhap_amd.build`")
     _lib = lib
     return lib
 
@@ -215,7 +223,7 @@ class FrequencyCounts:
     """Parsed `-f` filter file (J/sketch/FrequencyCounts.java:63-229): k-mer hash -> fraction (+ the --supress-noise whitelist)."""
 
     def __init__(self, hashes, fractions, filter_cutoff=1.0e-5, offset=0.0, repeat_idf_scale=3.0, no_tf=False, supress_noise=0,
-                 whitelist=None, size_bloom=0):
+                 whitelist=None, size_bloom=None):
         self.hashes = np.ascontiguousarray(hashes, dtype=np.int64)
         self.fractions = np.ascontiguousarray(fractions, dtype=np.float64)
         self.filter_cutoff = filter_cutoff
@@ -224,29 +232,43 @@ class FrequencyCounts:
         self.no_tf = no_tf
         self.supress_noise = supress_noise            # removeUnique: 1 drop k-mers absent from the file, 2 give them idf 1
         self.whitelist = np.ascontiguousarray(whitelist if whitelist is not None else self.hashes, dtype=np.int64)
-        self.size_bloom = size_bloom or max(1, len(self.whitelist))   # first number of the file's first line
+        # first number of the file's first line; only an object built WITHOUT a file falls back to the whitelist length
+        self.size_bloom = max(1, len(self.whitelist)) if size_bloom is None else (1 if size_bloom == 0 else int(size_bloom))
 
     @classmethod
     def from_file(cls, path, filter_cutoff=1.0e-5, repeat_weight=0.9, repeat_idf_scale=3.0, no_tf=False, do_rc=True,
                   supress_noise=0):
+        """The parser of mhap_set_filter_file (host_util.cpp), line for line: header "sizeBloom sizeRepeat" (both >= 0; a sizeBloom
+        of 0 counts as 1, FrequencyCounts.java:102-121), then `kmer [fraction [ignored]]`; a malformed fraction drops the whole line."""
         lib = load_library()
         offset = repeat_weight if 0.0 <= repeat_weight < 1.0 else 0.0   # MhapMain.java:346-350
         hs, fr, allh = [], [], []
         out = C.c_int64()
         with open(path, "r") as fh:
-            first = fh.readline().split()                  # "sizeBloom sizeRepeat" (FrequencyCounts.java:102-104)
-            size_bloom = int(first[0]) if first else 1
+            first = fh.readline().split()
+            try:
+                size_bloom, size_repeat = int(first[0]), int(first[1])
+            except (IndexError, ValueError):
+                raise MhapError("K-mer filter file first line must contain estimated number of k-mers in the file (long).")
+            if size_bloom < 0 or size_repeat < 0:
+                raise MhapError("K-mer filter file first line must contain estimated number of k-mers in the file (long).")
             for line in fh:
                 parts = line.split(None, 2)
                 if len(parts) < 1:
                     continue
                 kmer = parts[0].encode("latin-1")
                 if lib.mhap_hash_kmer(kmer, C.c_int32(len(kmer)), C.c_int32(1 if do_rc else 0), C.byref(out)) != 0:
-                    raise MhapError("cannot hash filter k-mer " + parts[0])
-                allh.append(out.value)
+                    continue
+                frac = None
                 if len(parts) >= 2:
+                    try:
+                        frac = float(parts[1])
+                    except ValueError:
+                        continue
+                allh.append(out.value)
+                if frac is not None:
                     hs.append(out.value)
-                    fr.append(float(parts[1]))
+                    fr.append(frac)
         return cls(np.array(hs, dtype=np.int64), np.array(fr, dtype=np.float64), filter_cutoff, offset,
                    repeat_idf_scale, no_tf, supress_noise, np.array(allh, dtype=np.int64), size_bloom)
 
@@ -334,7 +356,10 @@ class MinHashSearch:
 
     # -- configuration --------------------------------------------------------------------------
     def set_filter(self, fc):
-        self._chk(self._lib.mhap_set_filter(self._h, _ptr(fc.hashes), _ptr(fc.fractions), C.c_int64(len(fc.hashes)),
+        hashes, fractions = fc.hashes, fc.fractions
+        if len(hashes) == 0:      # a filter whose table is empty is still a filter (every k-mer gets idf = range): non-NULL pointers say so
+            hashes, fractions = np.zeros(1, np.int64), np.zeros(1, np.float64)
+        self._chk(self._lib.mhap_set_filter(self._h, _ptr(hashes), _ptr(fractions), C.c_int64(len(fc.hashes)),
                                             C.c_double(fc.filter_cutoff), C.c_double(fc.offset), C.c_double(fc.range),
                                             C.c_int(1 if fc.no_tf else 0)))
         if getattr(fc, "supress_noise", 0):

@@ -58,7 +58,12 @@ def build(force=False, verbose=False):
     try:
         hipcc = _hipcc()
     except RuntimeError:
-        if os.path.exists(LIB) and not force:   # GPU box without a compiler on PATH: the shipped artefact is all there is
+        if os.path.exists(LIB) and not force:   # a box without a compiler: the shipped artefact is all there is — but say so if it is stale
+            cmd = ["hipcc", f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+                   "-Wno-pass-failed", *srcs, "-o", LIB, "-lz", "-ldl"]
+            if _stale(LIB, _digest(deps, cmd[1:])):
+                print(f"warning: {LIB} does not match the sources next to it (no hipcc here to rebuild it); "
+                      "mhap_amd.load_library() checks its ABI version and struct sizes", file=sys.stderr)
             return LIB
         raise
     cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",

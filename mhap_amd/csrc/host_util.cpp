@@ -33,7 +33,7 @@ int fmt6(double v, char* out, size_t cap) {
   // Fast path (every record pays for two of these): unless the value sits within 10^-9 of a HALF_UP tie at the sixth decimal, the
   // shortest round-trip digits (which differ from the exact value by < 1 ulp) round like the exact value, so a multiply and a floor
   // decide.  Ties and huge values take the digit-string path below.
-  if (a < 1e9) {
+  if (a < 4e6) {   // (beyond 2^22 the product's rounding error approaches the 1e-3 tie margin: those take the digit-string path)
     const double x = a * 1e6, fl = std::floor(x), frac = x - fl;
     if (std::fabs(frac - 0.5) > 1e-3) {
       unsigned long long q = (unsigned long long)fl + (frac > 0.5 ? 1ULL : 0ULL);
@@ -99,6 +99,13 @@ struct Xoshiro256ss {
 }  // namespace
 
 extern "C" {
+
+int mhap_abi_version(void) { return MHAP_ABI_VERSION; }
+int mhap_abi_sizes(int32_t* out4) {
+  if (!out4) return MHAP_E_INVALID;
+  out4[0] = (int32_t)sizeof(mhap_params); out4[1] = (int32_t)sizeof(mhap_record); out4[2] = (int32_t)sizeof(mhap_stats); out4[3] = (int32_t)sizeof(mhap_kernel_times);
+  return MHAP_OK;
+}
 
 int mhap_format_record(const mhap_record* r, char* out, size_t cap) {
   if (!r || !out || cap == 0) return -1;
@@ -369,18 +376,29 @@ int mhap_set_filter_file(mhap_handle* h, const char* path, double filter_cutoff,
       size_bloom = a == 0 ? 1 : a;
       continue;
     }
-    char kmer[4096]; double frac = 0.0;
-    const int got = sscanf(line, "%4095s %lf", kmer, &frac);
+    // String.split("\\s+", 3): k-mer, optional fraction, rest ignored (:158-173)
+    char kmer[4096], ftok[256];
+    const int got = sscanf(line, "%4095s %255s", kmer, ftok);
     if (got < 1) continue;
     int64_t hv; const int kl = (int)strlen(kmer);
     if (mhap_hash_kmer(kmer, kl, do_rc, &hv) != MHAP_OK) continue;
-    if (std::find(sizes.begin(), sizes.end(), kl) == sizes.end()) sizes.push_back(kl);
+    if (std::find(sizes.begin(), sizes.end(), kl) == sizes.end()) sizes.push_back(kl);   // kmerSizes.add comes before the parse (:163-166)
+    double frac = 0.0;
+    if (got >= 2) {
+      // Double.parseDouble throws on a malformed number and the exception handler drops the WHOLE line — it never reaches the
+      // whitelist either (:173,190-198)
+      char* end = nullptr;
+      frac = strtod(ftok, &end);
+      if (end == ftok || *end != 0) continue;
+    }
     if (remove_unique > 0) all.push_back(hv);
     if (got >= 2) { hs.push_back(hv); fr.push_back(frac); }
   }
   free(line); fclose(f);
   if (rc != MHAP_OK) return rc;
-  rc = mhap_set_filter(h, hs.data(), fr.data(), (int64_t)hs.size(), filter_cutoff, offset, range, no_tf);
+  // a file without a single (k-mer, fraction) line still installs the filter, with an empty table (see mhap_set_filter)
+  static const int64_t none_h = 0; static const double none_f = 0.0;
+  rc = mhap_set_filter(h, hs.empty() ? &none_h : hs.data(), hs.empty() ? &none_f : fr.data(), (int64_t)hs.size(), filter_cutoff, offset, range, no_tf);
   if (rc == MHAP_OK && remove_unique > 0) rc = mhap_set_filter_whitelist(h, all.data(), (int64_t)all.size(), size_bloom, remove_unique);
   if (kmer_sizes && kmer_sizes_cap) {
     std::sort(sizes.begin(), sizes.end());

@@ -870,6 +870,8 @@ int mhap_set_filter(mhap_handle* h, const int64_t* hashes, const double* fractio
                     double range, int no_tf) {
   if (!h) return MHAP_E_INVALID;
   (void)hipSetDevice(h->device);
+  // n == 0 with a NULL table clears the filter; n == 0 with a non-NULL pointer is a filter file that yielded no entry (header only, or
+  // k-mer-only lines): the reference still has kmerFilter != null then, and every k-mer gets idf = range (FrequencyCounts.java:295-300)
   if (n <= 0 && !hashes) { h->ft = FilterTable{nullptr, nullptr, 0, 0, 0, 0, range}; return MHAP_OK; }
   if (offset < 0.0 || offset >= 1.0) return fail(h, MHAP_E_INVALID, "Offset can only be between 0 and 1.0.");   // FrequencyCounts.java:74-75
   // FrequencyCounts.java:176-184 keep fraction >= cutoff; maxValue = max kept fraction

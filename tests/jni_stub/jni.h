@@ -21,6 +21,10 @@ struct JNINativeInterface_ {
   void (*ReleasePrimitiveArrayCritical)(JNIEnv*, jarray, void*, jint);
   jbyteArray (*NewByteArray)(JNIEnv*, jsize);
   void (*SetByteArrayRegion)(JNIEnv*, jbyteArray, jsize, jsize, const jbyte*);
+  jsize (*GetArrayLength)(JNIEnv*, jarray);
+  void (*GetByteArrayRegion)(JNIEnv*, jbyteArray, jsize, jsize, jbyte*);
+  void (*GetIntArrayRegion)(JNIEnv*, jintArray, jsize, jsize, jint*);
+  void (*GetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, jlong*);
   jlongArray (*NewLongArray)(JNIEnv*, jsize);
   void (*SetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, const jlong*);
 };

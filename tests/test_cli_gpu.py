@@ -10,6 +10,7 @@ import pytest
 import oracle_lib as O
 import mhap_amd
 from mhap_amd import FastaData, MhapParams, MinHashSearch
+from mhap_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -189,28 +190,90 @@ def test_cli_filter_file_and_presets(tmp_path):
     assert bad.returncode == 1 and "0<=threshold<=1.0" in bad.stdout
 
 
-def test_bench_two_ranks_on_one_gpu_matches_one_rank():
-    """Functional check of bench.py's N>1 path (round-robin shards, table gather in global read order, sharded
-    queries) with 2 gloo ranks sharing this GPU: record count and record checksum must equal the single-rank run's."""
+def test_cli_filter_files_without_fractions(tmp_path):
+    """Legal but unusual -f files (J/sketch/FrequencyCounts.java:150-200): k-mer-only lines (no fraction: they only feed the
+    --supress-noise whitelist), a header-only file (the filter is still installed: every k-mer gets idf = --repeat-idf-scale), and a
+    line whose fraction does not parse (Double.parseDouble throws: the whole line is dropped, whitelist included).  The native
+    parser (mhap_set_filter_file) and the Python mirror (FrequencyCounts.from_file) must agree with the oracle on all of them."""
+    fa = mhap_amd.synth_reads(120, 2500, seed=41, error_rate=0.05)
+    fasta = tmp_path / "reads.fasta"
+    W.write_fasta(fa, str(fasta))
+    flags = ["--num-hashes", "128", "--ordered-sketch-size", "512"]
+    u, cnt, total = W.count_kmers(fa, 16, True, None)
+    order = np.argsort(-cnt)[:300]
+    lines = [W.kmer_string(u[i], 16) for i in order]
+    reads = FastaData.from_file(str(fasta))
+
+    def check(name, body, mode, expect_bloom):
+        f = tmp_path / name
+        f.write_text(body)
+        got, _ = _run(["-s", str(fasta), "-f", str(f)] + (["--supress-noise", str(mode)] if mode else []) + flags)
+        fc = mhap_amd.FrequencyCounts.from_file(str(f), filter_cutoff=1e-5, repeat_weight=0.9, supress_noise=mode)
+        assert fc.size_bloom == expect_bloom
+        oflt = O.Filter(fc.hashes, fc.fractions, 1e-5, 0.9, 3.0, False, remove_unique=mode, whitelist=fc.whitelist, size_bloom=fc.size_bloom)
+        want = O.record_lines(O.run_self(reads, H=128, S=512, nthreads=8, flt=oflt)["records"])
+        assert got == want and len(want) > 20, name
+        with MinHashSearch(MhapParams(num_hashes=128, ordered_sketch_size=512), kmer_filter=fc) as ms:     # the Python path installs the same filter
+            ms.add_data(reads)
+            assert sorted(mhap_amd.records_to_lines(ms.find_matches())) == want, name
+        return fc
+
+    plain, _ = _run(["-s", str(fasta)] + flags)
+    # whitelist only: no line carries a fraction
+    fc = check("white.txt", "300 300\n" + "".join(k + "\n" for k in lines), 1, 300)
+    assert len(fc.hashes) == 0 and len(fc.whitelist) == 300
+    check("white2.txt", "300 300\n" + "".join(k + "\n" for k in lines), 2, 300)
+    # header only, sizeBloom 0 (counts as 1): idf = range for every k-mer, so the weights are round(3 tf), not tf
+    fc = check("header.txt", "0 0\n", 0, 1)
+    assert len(fc.hashes) == 0
+    # a malformed fraction drops its line from the table AND from the whitelist
+    body = "300 300\n" + "".join(f"{k}\t{'oops' if i % 7 == 3 else '%.6e' % (cnt[order[i]] / total)}\n" for i, k in enumerate(lines))
+    fc = check("bad.txt", body, 1, 300)
+    assert len(fc.whitelist) == 300 - len([i for i in range(300) if i % 7 == 3])
+    assert plain   # (sanity: the unfiltered run has records too)
+
+
+def test_bench_distributed_path_through_the_library_one_rccl_rank():
+    """bench.py's N > 1 code path on the one GPU this box has: torchrun with one rank, RCCL communicator created inside the library
+    from the id torch.distributed broadcasts (mhap_dist_init), collective search (mhap_dist_find_matches_self).  Record count and
+    record checksum must equal the plain single-GPU run's."""
     import sys
     args = ["--reads", "3000", "--length", "3000", "--steps", "1", "--warmup", "0", "--error-rate", "0.05", "--no-cpu-baseline"]
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads(one.stdout.strip().split("\n")[-1])
-    env = dict(os.environ, MHAP_BENCH_BACKEND="gloo")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
-                         capture_output=True, text=True, timeout=900, env=env)
-    assert two.returncode == 0, two.stderr[-3000:]
-    r2 = json.loads([l for l in two.stdout.strip().split("\n") if l.startswith("{")][-1])
-    assert r2["n_gpus"] == 2 and r1["n_gpus"] == 1
+    dist = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                           "--master-port", "29611", os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args,
+                          capture_output=True, text=True, timeout=900, env=dict(os.environ, MHAP_BENCH_FORCE_DIST="1"))
+    assert dist.returncode == 0, dist.stderr[-3000:]
+    r2 = json.loads([l for l in dist.stdout.strip().split("\n") if l.startswith("{")][-1])
     assert r2["records_per_step"] == r1["records_per_step"] and r1["records_per_step"] > 1000
-    # order- and shard-independent fingerprint of the record lines: the sharded run emits exactly the single-rank records
     assert r2["records_checksum"] == r1["records_checksum"] and r1["records_sha256_sorted_lines"]
-    # the ring variant of the exchange (query bundles rotate, two in memory) gives the same records
-    ring = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                           "--master-port", "29613", os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args,
-                          capture_output=True, text=True, timeout=900, env=dict(env, MHAP_BENCH_RING="1"))
-    assert ring.returncode == 0, ring.stderr[-3000:]
-    r3 = json.loads([l for l in ring.stdout.strip().split("\n") if l.startswith("{")][-1])
-    assert r3["records_checksum"] == r1["records_checksum"] and r3["records_per_step"] == r1["records_per_step"]
+    assert r2["phase_wall_ms"]["exchange"] >= 0.0
+
+
+def test_cli_gpus_flag_shards_the_index_and_keeps_the_records(tmp_path):
+    """mhap-hip --devices 0,0[,0]: two and three ranks (sharing this box's one GPU) — reads dealt round-robin, one index shard
+    per rank, the forward query rows gathered inside the library — print exactly the records of the one-GPU run, in self mode
+    and with -q (toSelf = false); --gpus N with a device that does not exist fails loudly."""
+    fa = mhap_amd.synth_reads(1200, 2500, seed=31, error_rate=0.06)
+    fasta = tmp_path / "reads.fasta"
+    W.write_fasta(fa, str(fasta))
+    q = mhap_amd.synth_reads(1200, 2500, seed=31, error_rate=0.06, shard=5, nshards=12)     # reads of the same genome as queries
+    qf = tmp_path / "queries.fasta"
+    W.write_fasta(q, str(qf))
+    flags = ["--num-hashes", "128", "--ordered-sketch-size", "512"]
+    one, _ = _run(["-s", str(fasta), "-q", str(qf)] + flags)
+    assert len(one) > 500
+    for devs in ("0,0", "0,0,0"):
+        many, err = _run(["-s", str(fasta), "-q", str(qf), "--devices", devs] + flags)
+        assert many == one, devs
+        assert f"Using {len(devs.split(','))} GPU ranks" in err
+    ndev = 1
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except Exception:
+        pass
+    bad = subprocess.run([CLI, "-s", str(fasta), "--gpus", str(ndev + 1)] + flags, capture_output=True, text=True)
+    assert bad.returncode != 0 and "device ordinal out of range" in bad.stderr

@@ -245,6 +245,69 @@ def test_index_export_roundtrip_and_query_sharding():
     assert kt["index_build"]["launches"] in (1, 2) and kt["index_query"]["launches"] == 3   # (2: + the overflow-segment layout pass)
 
 
+def test_group_of_ranks_on_one_device_matches_the_oracle():
+    """The multi-GPU path inside the library (mhap_group_*: reads dealt round-robin, one index shard per rank, forward query rows
+    gathered by peer copies, every rank scoring all queries against its shard under the toSelf id rules) with 2, 3 and 4 ranks
+    sharing this box's one GPU: self overlap, -q mode (toSelf = false), a ragged data set (short and unsketchable reads, fewer
+    reads than ranks) and incremental adds all give the oracle's records."""
+    from mhap_amd import MinHashSearchGroup
+    fa = mhap_amd.synth_reads(700, 3000, seed=202, error_rate=0.07)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=512, device=0)
+    want = O.record_lines(O.run_self(fa, H=128, S=512, nthreads=8)["records"])
+    assert len(want) > 300
+    q = mhap_amd.synth_reads(700, 3000, seed=202, error_rate=0.07, shard=3, nshards=10)
+    q = mhap_amd.FastaData(q.bases, q.offsets, q.lengths, np.arange(len(q), dtype=np.int64) + 701)
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        want_q = sorted(mhap_amd.records_to_lines(ms.find_matches_stream(q)))
+    assert len(want_q) > 50
+    for n in (2, 3, 4):
+        with MinHashSearchGroup(p, n=n, devices=[0] * n) as g:
+            g.add_data(fa)
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want, n
+            assert sorted(mhap_amd.records_to_lines(g.find_matches_stream(q))) == want_q, n
+            st = g.stats()
+            assert st["strands_indexed"] == 2 * len(fa) and st["matches_found"] == len(want) + len(want_q)
+            # the same data set again through the cleared group, in three uneven batches (the deal continues across calls)
+            g.clear()
+            for lo, hi in ((0, 5), (5, 333), (333, len(fa))):
+                g.add_data(fa.subset(np.arange(lo, hi)))
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want, n
+    # ragged: reads below --min-olap-length, reads shorter than k, and fewer sketchable reads than ranks
+    seqs = [fa.sequence(i) for i in range(6)] + ["ACGT" * 20, "ACGTACGTAC", fa.sequence(6)[:130]]
+    small = mhap_amd.FastaData.from_strings(seqs)
+    want_s = O.record_lines(O.run_self(small, H=128, S=512, nthreads=2)["records"])
+    with MinHashSearchGroup(p, n=4, devices=[0, 0, 0, 0]) as g:
+        g.add_data(small)
+        assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want_s
+    one = mhap_amd.FastaData.from_strings([fa.sequence(0)])
+    with MinHashSearchGroup(p, n=3, devices=[0, 0, 0]) as g:      # two ranks hold nothing at all
+        g.add_data(one)
+        assert len(g.find_matches()) == 0
+
+
+def test_rccl_rank_of_one_and_errors_of_the_sharded_search():
+    """mhap_dist_init over RCCL with a world of one rank (all a one-GPU box can form) runs the same pack / gather / search code as
+    N ranks; the collective entry points fail loudly on a handle that is no rank, and on an index that is not made of sketched reads."""
+    fa = mhap_amd.synth_reads(400, 2500, seed=203, error_rate=0.06)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=256, device=0)
+    want = O.record_lines(O.run_self(fa, H=64, S=256, nthreads=8)["records"])
+    with MinHashSearch(p) as ms:
+        with pytest.raises(mhap_amd.MhapError, match="not a rank"):
+            ms.dist_find_matches()
+        ms.dist_init(0, 1, MinHashSearch.dist_unique_id())
+        ms.add_data(fa)
+        assert sorted(mhap_amd.records_to_lines(ms.dist_find_matches())) == want and len(want) > 100
+        tm = ms.dist_last_timing()
+        assert tm["total_ms"] > 0 and tm["gather_small_ms"] >= 0
+        tables = ms.export()
+        ms.clear()
+        keep = np.arange(len(tables["ids"])) % 2 == 0       # forward entries only: not pairs any more
+        ms.add_sketches({k: v[keep] for k, v in tables.items() if k != "status"})
+        with pytest.raises(mhap_amd.MhapError, match="pairs"):
+            ms.dist_find_matches()
+
+
 def test_batching_and_chunking_do_not_change_results(monkeypatch):
     fa = mhap_amd.synth_reads(300, 2000, seed=8, error_rate=0.05)
     p = MhapParams(num_hashes=64, ordered_sketch_size=300)

@@ -389,9 +389,13 @@ def test_jni_shim_and_java_class_agree():
     declared = set(re.findall(r"\b(mhap_[a-z_0-9]+)\s*\(", header))
     assert called and called <= declared, called - declared
     assert called <= set(api.EXPORTED_SYMBOLS)
-    for needed in ("mhap_create", "mhap_index_add_reads", "mhap_find_matches_self", "mhap_find_matches_reads", "mhap_find_matches_sketches",
-                   "mhap_set_filter_file", "mhap_get_stats", "mhap_destroy"):
+    # the engine behind the Java object is a group of ranks (one per GPU, a group of one for a single GPU)
+    for needed in ("mhap_group_create", "mhap_group_add_reads", "mhap_group_find_matches_self", "mhap_group_find_matches_reads",
+                   "mhap_find_matches_sketches", "mhap_set_filter_file", "mhap_group_get_stats", "mhap_group_destroy", "mhap_group_rank"):
         assert needed in called, needed
+    # records cross in bounded chunks, and no critical region is held across a library call
+    assert "nativeTakeRecords" in natives and "GetPrimitiveArrayCritical(" not in csrc.split("*/", 1)[1]
+    assert "RECORDS_PER_TAKE" in java and "int[] devices" in java
     # the reference's seams (AbstractMatchSearch.java:119,121,201,203,312,314,340) are all overridden
     assert "extends AbstractMatchSearch" in java
     body = java.split("public final class HipMinHashSearch", 1)[1]
