@@ -154,6 +154,30 @@ int mhap_stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, 
                      const int64_t* ids, int64_t n);
 int mhap_index_add_staged(mhap_handle* h);
 
+/* The reads an EMPTY index is about to receive over the coming mhap_index_add_* calls (a file added in batches, as
+ * AbstractMatchSearch.addData does, J/impl/AbstractMatchSearch.java:67-117): the sketch tables and the inverted index are sized
+ * once for all of them and every batch's postings go into the index while the batch is sketched.  Without the hint a second
+ * batch makes the first search rebuild the inverted index (correct, slower). */
+int mhap_index_reserve(mhap_handle* h, int64_t total_reads);
+
+/* Streamed FASTA ingest (FastaData + SequenceSketchStreamer.enqueueFullFile, J/impl/FastaData.java:101-204,
+ * J/impl/SequenceSketchStreamer.java:179-222: the reference reads and sketches through a queue with T threads).
+ * mhap_fasta_scan_open maps the file (plain text; gz / bz2 are inflated into memory first) and finds its records on all host
+ * threads: ids (1-based count of non-empty records + id_offset), lengths, whether a read is pure ACGT — no copy of the bases.
+ * mhap_index_add_scan then feeds the index in groups of <= 256 Mbase: host threads pack group g+1 from the text straight into
+ * pinned 2-bit staging while the GPU sketches and indexes group g (two staging buffers), so parsing, packing, the upload and the
+ * kernels overlap and the 1-byte-per-base copy of the reads never exists. */
+typedef struct mhap_fasta_scan mhap_fasta_scan;
+int mhap_fasta_scan_open(const char* path, int64_t id_offset, mhap_fasta_scan** out, char* err, size_t errcap);
+void mhap_fasta_scan_free(mhap_fasta_scan* s);
+int64_t mhap_fasta_scan_reads(const mhap_fasta_scan* s);          /* non-empty records */
+int64_t mhap_fasta_scan_bases(const mhap_fasta_scan* s);
+/* ids[n], lengths[n] (either may be NULL); headers: the n NUL-terminated names back to back (mhap_fasta.headers), valid until the scan is freed */
+int mhap_fasta_scan_info(mhap_fasta_scan* s, int64_t* ids, int32_t* lengths, const char** headers, int64_t* headers_bytes);
+int mhap_index_add_scan(mhap_handle* h, const mhap_fasta_scan* s);
+/* the reads of the scan as query reads against the index (-q mode, mhap_find_matches_reads), in groups */
+int mhap_find_matches_scan(mhap_handle* h, const mhap_fasta_scan* s, mhap_record_sink sink, void* user);
+
 /* Sketch only (no index change); outputs to caller-allocated HOST arrays, any may be NULL:
  * minhash[2n][max(1,H)], ordered[2n][S][2] (hash,pos), ordered_size[2n], status[2n].
  * Strand order: 2*i = forward, 2*i+1 = reverse complement.  Used by parity tests and the
@@ -266,6 +290,9 @@ const char* mhap_group_last_error(const mhap_group* g);
  * index their shares concurrently.  May be called repeatedly (batches of one file, several files). */
 int mhap_group_add_reads(mhap_group* g, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n);
 int mhap_group_clear(mhap_group* g);
+/* mhap_index_add_scan over the ranks: record i of the scan goes to rank (reads added so far + i) % N; every rank runs its own
+ * pack / upload / sketch pipeline over its share of the mapped text */
+int mhap_group_add_scan(mhap_group* g, const mhap_fasta_scan* s);
 /* findMatches() / findMatches(streamer) over the sharded index; the sink is called from the ranks' threads, one call at a time. */
 int mhap_group_find_matches_self(mhap_group* g, mhap_record_sink sink, void* user);
 int mhap_group_find_matches_reads(mhap_group* g, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids,

@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     MinHashSearch,
     MinHashSearchGroup,
     FastaData,
+    FastaScan,
     FrequencyCounts,
     MatchResult,
     format_record,

@@ -64,6 +64,8 @@ EXPORTED_SYMBOLS = [
     "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing",
     "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",
     "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats", "mhap_abi_version", "mhap_abi_sizes",
+    "mhap_index_reserve", "mhap_fasta_scan_open", "mhap_fasta_scan_free", "mhap_fasta_scan_reads", "mhap_fasta_scan_bases", "mhap_fasta_scan_info",
+    "mhap_index_add_scan", "mhap_find_matches_scan", "mhap_group_add_scan",
 ]
 ABI_VERSION = 3   # MHAP_ABI_VERSION of include/mhap_hip.h this binding was written against
 
@@ -101,6 +103,12 @@ def load_library(build_if_missing=True):
     lib.mhap_group_last_error.restype = C.c_char_p
     lib.mhap_group_last_error.argtypes = [C.c_void_p]
     lib.mhap_group_size.argtypes = [C.c_void_p]
+    lib.mhap_fasta_scan_free.restype = None
+    lib.mhap_fasta_scan_free.argtypes = [C.c_void_p]
+    lib.mhap_fasta_scan_reads.restype = C.c_int64
+    lib.mhap_fasta_scan_reads.argtypes = [C.c_void_p]
+    lib.mhap_fasta_scan_bases.restype = C.c_int64
+    lib.mhap_fasta_scan_bases.argtypes = [C.c_void_p]
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)  # AttributeError here = header/library mismatch
     # a stale library next to newer host code (or the reverse) must not get as far as a struct copy
@@ -273,6 +281,56 @@ class FrequencyCounts:
                    repeat_idf_scale, no_tf, supress_noise, np.array(allh, dtype=np.int64), size_bloom)
 
 
+class FastaScan:
+    """A FASTA file mapped and scanned, not copied (mhap_fasta_scan_*): ids, lengths and names of its records; the index is fed from
+    the mapped text in groups, host threads packing one group while the GPU sketches the previous one (MinHashSearch.add_scan)."""
+
+    def __init__(self, path, id_offset=0):
+        self._lib = load_library()
+        self._s = C.c_void_p()
+        err = C.create_string_buffer(512)
+        rc = self._lib.mhap_fasta_scan_open(path.encode(), C.c_int64(id_offset), C.byref(self._s), err, C.c_size_t(512))
+        if rc != 0:
+            self._s = C.c_void_p()
+            raise MhapError(err.value.decode() or f"mhap_fasta_scan_open failed ({rc})")
+        self._lib.mhap_fasta_scan_reads.restype = C.c_int64
+        self._lib.mhap_fasta_scan_bases.restype = C.c_int64
+        self.n = self._lib.mhap_fasta_scan_reads(self._s)
+        self.total_bases = self._lib.mhap_fasta_scan_bases(self._s)
+
+    def __len__(self):
+        return int(self.n)
+
+    def info(self):
+        """(ids, lengths, names)"""
+        ids = np.zeros(max(self.n, 1), np.int64)
+        lens = np.zeros(max(self.n, 1), np.int32)
+        hp, hb = C.c_char_p(), C.c_int64()
+        rc = self._lib.mhap_fasta_scan_info(self._s, _ptr(ids), _ptr(lens), C.byref(hp), C.byref(hb))
+        if rc != 0:
+            raise MhapError(f"mhap_fasta_scan_info failed ({rc})")
+        raw = C.string_at(hp, hb.value) if hb.value else b""
+        names = [x.decode("latin-1") for x in raw.split(b"\0")[:self.n]]
+        return ids[:self.n], lens[:self.n], names
+
+    def close(self):
+        if getattr(self, "_s", None) and self._s.value:
+            self._lib.mhap_fasta_scan_free(self._s)
+            self._s = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class MatchResult:
     """One overlap record (J/impl/MatchResult.java)."""
     __slots__ = ("from_id", "to_id", "score", "raw", "a1", "a2", "alen", "b1", "b2", "blen", "to_rc")
@@ -373,6 +431,18 @@ class MinHashSearch:
     def add_data(self, fasta):
         self._chk(self._lib.mhap_index_add_reads(self._h, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths),
                                                  _ptr(fasta.ids), C.c_int64(len(fasta))))
+
+    def add_scan(self, scan):
+        """Streamed ingest of a scanned FASTA file (mhap_index_add_scan): parse, pack, upload and sketch overlap."""
+        self._chk(self._lib.mhap_index_add_scan(self._h, scan._s))
+
+    def reserve(self, total_reads):
+        """The reads an empty index is about to receive over several add_data calls (mhap_index_reserve)."""
+        self._chk(self._lib.mhap_index_reserve(self._h, C.c_int64(total_reads)))
+
+    def find_matches_scan(self, scan):
+        """-q mode with the query reads of a scanned file."""
+        return self._collect(lambda cb: self._lib.mhap_find_matches_scan(self._h, scan._s, cb, None))
 
     def stage(self, fasta):
         """Pack + upload reads so that they are resident in HBM (bench: outside the timed region)."""
@@ -609,6 +679,9 @@ class MinHashSearchGroup:
     def add_data(self, fasta):
         self._chk(self._lib.mhap_group_add_reads(self._g, _ptr(fasta.bases), _ptr(fasta.offsets), _ptr(fasta.lengths), _ptr(fasta.ids),
                                                  C.c_int64(len(fasta))))
+
+    def add_scan(self, scan):
+        self._chk(self._lib.mhap_group_add_scan(self._g, scan._s))
 
     def clear(self):
         self._chk(self._lib.mhap_group_clear(self._g))

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmhaphip.so")
 CLI = os.path.join(LIBDIR, "mhap-hip")
-SOURCES = ["sketch_kernels.hip", "search_kernels.hip", "mhap_capi.hip", "mhap_dist.hip", "host_util.cpp"]
+SOURCES = ["sketch_kernels.hip", "search_kernels.hip", "mhap_capi.hip", "mhap_dist.hip", "mhap_ingest.hip", "host_util.cpp"]
 HEADERS = ["device_common.hpp", "kernels.hpp", "mhap_internal.hpp", "overlap_lane.hpp", os.path.join("..", "..", "include", "mhap_hip.h")]
 ARCH = "gfx950"
 

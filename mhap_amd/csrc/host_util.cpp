@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/mhap_hip.h"
+#include "mhap_internal.hpp"
 
 namespace {
 
@@ -205,9 +206,8 @@ int mhap_fasta_read(const char* path, int64_t id_offset, mhap_fasta* out, char* 
   const int64_t nrec = (int64_t)hdr.size();
   std::vector<size_t> body((size_t)nrec), bend((size_t)nrec);
   std::vector<int64_t> rlen((size_t)nrec);
-  unsigned hw = std::thread::hardware_concurrency();
-  if (const char* e = getenv("MHAP_HOST_THREADS")) { if (atoi(e) > 0) hw = (unsigned)atoi(e); }
-  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)(hw ? hw : 1), (int64_t)(N >> 22) + 1));   // >= 4 MB of text per thread
+  const int hw = mhap::usable_host_threads(64);
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)hw, (int64_t)(N >> 22) + 1));   // >= 4 MB of text per thread
   auto par = [&](const std::function<void(int64_t, int64_t)>& fn) {
     if (nthreads == 1 || nrec < 2) { fn(0, nrec); return; }
     std::vector<std::thread> th;
@@ -324,8 +324,7 @@ int mhap_synth_reads_repeats(uint64_t seed, int64_t n, int32_t len, double cover
   // ins:del:sub = 0.1188:0.0183:0.0129 (J/utils/RandomSequenceGenerator.java:93-96), scaled to error_rate
   const double p_ins = error_rate * (0.1188 / 0.15), p_del = error_rate * (0.0183 / 0.15), p_sub = error_rate * (0.0129 / 0.15);
   static const char ALPHA[4] = {'A', 'C', 'G', 'T'};
-  unsigned hc = std::thread::hardware_concurrency();
-  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(hc ? hc : 1u, 32u), n));
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(mhap::usable_host_threads(32), n));
   std::vector<std::thread> th;
   for (int t = 0; t < nthreads; t++) {
     th.emplace_back([&, t]() {

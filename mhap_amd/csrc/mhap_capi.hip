@@ -48,12 +48,7 @@ void parallel_for(int64_t n, int nthreads, const std::function<void(int64_t, int
 // size is bumped to 1, :117-121)
 void build_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, std::vector<unsigned long long>& out, uint64_t& bit_size, int& k);
 
-int host_threads() {
-  const char* e = getenv("MHAP_HOST_THREADS");
-  if (e && atoi(e) > 0) return atoi(e);
-  unsigned hc = std::thread::hardware_concurrency();
-  return (int)std::max(1u, std::min(hc, 32u));
-}
+int host_threads() { return usable_host_threads(32); }
 
 }  // namespace
 
@@ -99,6 +94,8 @@ struct mhap_handle {
   bool inv_ready = false; int64_t inv_ne = 0; uint32_t inv_cmask = 0;
   bool inv_finalized = false;   // the overflow postings of the table in place have been laid out (launch_index_finalize)
   bool eager = false; int64_t eager_first = 0; uint32_t eager_cmask = 0;   // set by mhap_index_add_staged around sketch_staged
+  int64_t inv_cap_entries = 0;     // entries the table in place was sized for (>= inv_ne: mhap_index_reserve sizes it for reads still to come)
+  int64_t reserve_reads = 0;       // mhap_index_reserve: reads the empty index is about to receive, over one or more adds
   std::string err;
   int Hrow = 1;      // minhash row stride (ints)
   int ord_cap = 0;   // ordered-kernel sort capacity
@@ -330,6 +327,7 @@ static int inv_reset(mhap_handle* h, int64_t ne, hipStream_t st) {
   h->inv.tmp_cap = (uint32_t)tmp_cap;
   h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
   h->inv_finalized = false;
+  h->inv_cap_entries = ne;
   return MHAP_OK;
 }
 
@@ -546,10 +544,9 @@ struct QuerySide {
 // (re)build the inverted index for the current entries unless the table in place already covers them
 int ensure_inverted_index(mhap_handle* h) {
   const int ne = (int)h->n_entries, H = h->P.num_hashes;
-  const uint64_t cap = inv_capacity(ne);
-  const uint32_t cmask = (uint32_t)(cap - 1);
-  if (!(h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cmask == cmask)) {
+  if (!(h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cap_entries >= (int64_t)ne)) {   // (a table sized for more entries than it holds is fine)
     { const int rr = inv_reset(h, ne, h->stream); if (rr != MHAP_OK) return rr; }
+    const uint32_t cmask = h->inv.cmask;
     HPROF("index build launch");
     time_begin(h, MHAP_K_INDEX_BUILD);
     launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv);
@@ -601,11 +598,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
   const char* cmode = getenv("MHAP_CANDIDATES");
   const bool use_index = !(cmode && strcmp(cmode, "bruteforce") == 0);
-  uint32_t cmask = 0;
   if (use_index) {
     int rcb = ensure_inverted_index(h);
     if (rcb != MHAP_OK) return rcb;
-    cmask = h->inv_cmask;
   }
 
   for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
@@ -752,11 +747,25 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
 namespace mhap {
 HandleView handle_view(mhap_handle* h) {
   HandleView v;
-  v.device = h->device; v.stream = h->stream; v.Hrow = h->Hrow; v.S = h->P.ordered_sketch_size; v.n_entries = h->n_entries;
+  v.device = h->device; v.stream = h->stream; v.Hrow = h->Hrow; v.S = h->P.ordered_sketch_size; v.k = h->P.kmer_size; v.min_olap_length = h->P.min_olap_length;
+  v.n_entries = h->n_entries;
   v.d_minhash = h->d_minhash; v.d_ordered = h->d_ordered; v.d_meta = h->d_meta;
   v.h_ids = h->ids.data(); v.h_fwd = h->fwd.data(); v.err = &h->err; v.dist = &h->dist;
   return v;
 }
+int internal_stage_packed(mhap_handle* h, const ReadDesc* descs, const int64_t* ids, int64_t n, const void* packed, size_t bytes) {
+  (void)hipSetDevice(h->device);
+  h->st_descs.assign(descs, descs + n);
+  h->st_ids.assign(ids, ids + n);
+  h->st_n = n;
+  const size_t need = std::max<size_t>(bytes, 4);
+  HIPCHK(h, h->store.ensure(need));
+  if (bytes) HIPCHK(h, hipMemcpyAsync(h->store.p, packed, bytes, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // the caller reuses its staging buffer
+  h->st_bytes = (int64_t)need;
+  return MHAP_OK;
+}
+
 // -q mode of the sharded search: sketch n query reads (forward strands only, AbstractMatchSearch.java:225,236) into caller tables
 // laid out like an index's (row 2i = read i's forward strand)
 int internal_sketch_queries(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_mh, void* d_od, void* d_mt) {
@@ -968,22 +977,37 @@ int mhap_stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, 
   return stage_reads(h, bases, offsets, lengths, n, false);
 }
 
+int mhap_index_reserve(mhap_handle* h, int64_t total_reads) {
+  if (!h || total_reads < 0) return h ? fail(h, MHAP_E_INVALID, "negative read count") : MHAP_E_INVALID;
+  if (h->n_entries != 0) return fail(h, MHAP_E_STATE, "mhap_index_reserve applies to an empty index");
+  if (2 * total_reads > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
+  h->reserve_reads = total_reads;
+  return MHAP_OK;
+}
+
 int mhap_index_add_staged(mhap_handle* h) {
   if (!h) return MHAP_E_INVALID;
   (void)hipSetDevice(h->device);
   const int64_t n = h->st_n;
   if (n <= 0 || (int64_t)h->st_ids.size() != n) return fail(h, MHAP_E_STATE, "no staged reads (call mhap_stage_reads first)");
   if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
-  int rc = ensure_index_capacity(h, h->n_entries + 2 * n);
-  if (rc != MHAP_OK) return rc;
   const int64_t first = h->n_entries;
+  // mhap_index_reserve: the tables (and the inverted index below) are sized once for every read that is still to come
+  const int64_t want_entries = std::max<int64_t>(first + 2 * n, first == 0 ? 2 * h->reserve_reads : 0);
+  int rc = ensure_index_capacity(h, want_entries);
+  if (rc != MHAP_OK) return rc;
   const int S = h->P.ordered_sketch_size;
-  // a fresh index is filled while its reads are being sketched: the inverted-index inserts of a launch group run on a
-  // second stream next to the group's ordered-sketch kernel (an index that grows by a later add is rebuilt at search time)
-  h->inv_ready = false;
+  // the index is filled while its reads are being sketched: the inverted-index inserts of a launch group run on a second stream next
+  // to the group's ordered-sketch kernel.  A fresh index starts a table (sized for the reserved reads); a later add extends the table
+  // in place when it was sized for it and no search has laid its overflow postings out yet; otherwise the table is rebuilt at search time
   const char* cmode = getenv("MHAP_CANDIDATES");
-  if (first == 0 && !(cmode && strcmp(cmode, "bruteforce") == 0) && !getenv("MHAP_NO_EAGER_INDEX")) {
-    { const int rr = inv_reset(h, 2 * n, h->side_stream); if (rr != MHAP_OK) return rr; }
+  const bool eager_ok = !(cmode && strcmp(cmode, "bruteforce") == 0) && !getenv("MHAP_NO_EAGER_INDEX");
+  const bool extend = eager_ok && first > 0 && h->inv_ready && h->inv_ne == first && !h->inv_finalized && h->inv_cap_entries >= first + 2 * n;
+  h->inv_ready = false;
+  if (eager_ok && first == 0) {
+    { const int rr = inv_reset(h, want_entries, h->side_stream); if (rr != MHAP_OK) return rr; }
+    h->eager = true; h->eager_first = first; h->eager_cmask = h->inv.cmask;
+  } else if (extend) {
     h->eager = true; h->eager_first = first; h->eager_cmask = h->inv.cmask;
   }
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
@@ -1096,7 +1120,7 @@ int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids
 
 int mhap_index_clear(mhap_handle* h) {
   if (!h) return MHAP_E_INVALID;
-  h->n_entries = 0; h->external = false; h->inv_ready = false;
+  h->n_entries = 0; h->external = false; h->inv_ready = false; h->reserve_reads = 0;
   h->ids.clear(); h->fwd.clear(); h->seqlen.clear(); h->status.clear();
   h->d_minhash = h->own_minhash.as<int32_t>(); h->d_ordered = h->own_ordered.as<int32_t>(); h->d_meta = h->own_meta.as<int32_t>();
   h->stats = mhap_stats{};

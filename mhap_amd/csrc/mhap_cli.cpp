@@ -91,6 +91,7 @@ struct Engine {
     if (fa.n <= 0) return;
     check(g ? mhap_group_add_reads(g, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n) : mhap_index_add_reads(h, fa.bases, fa.offsets, fa.lengths, fa.ids, fa.n));
   }
+  void add_scan(const mhap_fasta_scan* sc) const { check(g ? mhap_group_add_scan(g, sc) : mhap_index_add_scan(h, sc)); }
   void find_self(mhap_record_sink sink, void* user) const { check(g ? mhap_group_find_matches_self(g, sink, user) : mhap_find_matches_self(h, 0, -1, sink, user)); }
   void find_reads(const mhap_fasta& fa, mhap_record_sink sink, void* user) const {
     if (fa.n <= 0) return;
@@ -133,7 +134,18 @@ void collect_headers(const mhap_fasta& fa) {
   }
 }
 
-struct Preload { std::string path; mhap_fasta fa; bool valid = false; } g_preload;
+// --store-full-id: the names of a scanned file, keyed by the ids its records were given
+void collect_headers(mhap_fasta_scan* sc) {
+  const int64_t n = mhap_fasta_scan_reads(sc);
+  std::vector<int64_t> ids((size_t)std::max<int64_t>(n, 1));
+  const char* p = nullptr; int64_t bytes = 0;
+  if (mhap_fasta_scan_info(sc, ids.data(), nullptr, &p, &bytes) != MHAP_OK) return;
+  const char* e = p + bytes;
+  for (int64_t i = 0; i < n && p && p < e; i++) { g_headers.byid[ids[(size_t)i]] = std::string(p); p += strlen(p) + 1; }
+}
+
+// the file the index is built from is mapped and scanned while the HIP runtime comes up
+struct Preload { std::string path; mhap_fasta_scan* scan = nullptr; } g_preload;
 struct Sink { FILE* out; std::string buf; int64_t n = 0; };
 int sink_cb(const mhap_record* r, int64_t n, void* user) {
   Sink* s = (Sink*)user;
@@ -234,27 +246,17 @@ int64_t add_file_to_index(const Engine& E, const std::string& path, int64_t id_o
     *strands = (int64_t)d.ids.size();
     return (int64_t)d.ids.size() / 2;
   }
-  mhap_fasta fa; char err[512];
+  // FASTA: the file is mapped and scanned (record boundaries, lengths, on all host threads), then fed to the index in groups — host
+  // threads pack the next group from the text while the GPU sketches the previous one (mhap_index_add_scan)
+  mhap_fasta_scan* sc = nullptr; char err[512];
   const double t_read = now();
-  if (g_preload.valid && g_preload.path == path && id_offset == 0) { fa = g_preload.fa; g_preload.valid = false; }   // read while the runtime came up
-  else if (mhap_fasta_read(path.c_str(), id_offset, &fa, err, sizeof err) != MHAP_OK) die(err);
-  if (g_headers.full) collect_headers(fa);
+  if (g_preload.scan && g_preload.path == path && id_offset == 0) { sc = g_preload.scan; g_preload.scan = nullptr; }   // scanned while the runtime came up
+  else if (mhap_fasta_scan_open(path.c_str(), id_offset, &sc, err, sizeof err) != MHAP_OK) die(err);
+  if (g_headers.full) collect_headers(sc);
   const double t_add = now();
-  E.add_reads(fa);
-  if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[cli] fasta read %.3f s, add_reads %.3f s\n", t_add - t_read, now() - t_add);
-  // The parsed reads (1 byte per base) are released after the search, not here: unmapping a gigabyte takes ~0.13 s, and doing it on
-  // another thread only moves the stall (the unmap holds the address-space lock the search's allocations need).  Bounded: beyond
-  // 8 GB of parked reads the oldest are released right away.
-  static std::vector<mhap_fasta> parked;
-  static int64_t parked_bytes = 0;
-  parked.push_back(fa);
-  parked_bytes += fa.n > 0 ? fa.offsets[fa.n - 1] + fa.lengths[fa.n - 1] : 0;
-  while (parked_bytes > (8LL << 30) && parked.size() > 1) {
-    mhap_fasta& f = parked.front();
-    parked_bytes -= f.n > 0 ? f.offsets[f.n - 1] + f.lengths[f.n - 1] : 0;
-    mhap_fasta_free(&f);
-    parked.erase(parked.begin());
-  }
+  E.add_scan(sc);
+  if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[cli] fasta scan %.3f s, add (pack + upload + sketch + index, pipelined) %.3f s\n", t_add - t_read, now() - t_add);
+  // (the mapping is released at exit: unmapping gigabytes holds the address-space lock the search's allocations need)
   const mhap_stats st = E.stats();
   *strands = st.strands_indexed;
   // seqNumberProcessed += seqStreamer.getNumberProcessed()/2 (MhapMain.java:462): the streamer counts the sketches it
@@ -267,7 +269,13 @@ int64_t add_file_to_index(const Engine& E, const std::string& path, int64_t id_o
 
 int main(int argc, char** argv) {
   Options o;
-  const unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+  // --num-threads defaults to the CPUs the process may use: the hardware threads, capped by the container's CPU quota (cgroup v2)
+  unsigned hc = std::max(1u, std::thread::hardware_concurrency());
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0}; long long per = 0;
+    if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) { const long long c = (atoll(q) + per - 1) / per; if (c > 0 && (unsigned long long)c < hc) hc = (unsigned)c; }
+    fclose(f);
+  }
   o.add("-s", "Usage 1 only. The FASTA or binary dat file (see Usage 2) of reads that will be stored in a box, and that all subsequent reads will be compared to.", "");
   o.add("-q", "Usage 1: The FASTA file of reads, or a directory of files, that will be compared to the set of reads in the box (see -s). Usage 2: The output directory for the binary formatted dat files.", "");
   o.add("-p", "Usage 2 only. The directory containing FASTA files that should be converted to binary format for storage.", "");
@@ -346,12 +354,13 @@ int main(int argc, char** argv) {
   });
   if (!precompute && !is_dir(o.s("-s")) && !ends_with(o.s("-s"), ".dat")) {
     char perr[512] = {0};
-    if (mhap_fasta_read(o.s("-s").c_str(), 0, &g_preload.fa, perr, sizeof perr) == MHAP_OK) { g_preload.path = o.s("-s"); g_preload.valid = true; }
-    // (a failure is reported by the regular read below)
+    if (mhap_fasta_scan_open(o.s("-s").c_str(), 0, &g_preload.scan, perr, sizeof perr) == MHAP_OK) g_preload.path = o.s("-s");
+    else g_preload.scan = nullptr;
+    // (a failure is reported by the regular scan below)
   }
   creator.join();
   if (rc_create != MHAP_OK) die(err);
-  if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[cli] mhap_create + first FASTA read %.3f s\n", now() - t_create);
+  if (getenv("MHAP_HOST_PROF")) fprintf(stderr, "[cli] mhap_create + first FASTA scan %.3f s\n", now() - t_create);
   if (E.g) fprintf(stderr, "Using %d GPU ranks (reads dealt round-robin; every rank indexes its share).\n", E.n);
 
   const double t_total = now();

@@ -512,6 +512,24 @@ int mhap_group_add_reads(mhap_group* g, const char* bases, const int64_t* offset
   return rc;
 }
 
+int mhap_group_add_scan(mhap_group* g, const mhap_fasta_scan* s) {
+  if (!g || !s) return MHAP_E_INVALID;
+  const int64_t n = mhap_fasta_scan_reads(s);
+  if (n <= 0) return MHAP_OK;
+  const int N = g->n;
+  const int64_t first = g->reads_added;
+  const int rc = on_ranks(g, [&](int r) {
+    const int64_t i0 = ((r - first) % N + N) % N;          // rank r takes the records whose ordinal in the data set is congruent to r
+    if (i0 >= n) return (int)MHAP_OK;
+    int64_t entries = 0;
+    (void)mhap_index_size(g->h[(size_t)r], &entries);
+    if (entries == 0) { const int rr = mhap_index_reserve(g->h[(size_t)r], (n - i0 + N - 1) / N); if (rr != MHAP_OK) return rr; }
+    return ingest_add_subset(g->h[(size_t)r], scan_impl(s), i0, N);
+  });
+  if (rc == MHAP_OK) g->reads_added += n;
+  return rc;
+}
+
 int mhap_group_clear(mhap_group* g) {
   if (!g) return MHAP_E_INVALID;
   for (mhap_handle* h : g->h) { const int rc = mhap_index_clear(h); if (rc != MHAP_OK) return rc; }

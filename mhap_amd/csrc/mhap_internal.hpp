@@ -5,11 +5,32 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <thread>
 
 #include "../../include/mhap_hip.h"
 
 namespace mhap {
+
+// Host threads worth starting: the hardware threads, capped by the container's CPU quota when there is one (cgroup v2 cpu.max) —
+// more runnable threads than quota only buy CFS throttling (stalls of up to a period, 100 ms) — and by MHAP_HOST_THREADS.
+inline int usable_host_threads(int hard_cap = 64) {
+  if (const char* e = getenv("MHAP_HOST_THREADS")) { if (atoi(e) > 0) return atoi(e); }
+  unsigned hc = std::thread::hardware_concurrency();
+  if (hc == 0) hc = 1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64] = {0}; long long per = 0;
+    if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) {
+      const long long c = (atoll(q) + per - 1) / per;
+      if (c > 0 && (unsigned long long)c < hc) hc = (unsigned)c;
+    }
+    fclose(f);
+  }
+  return (int)std::max(1u, std::min(hc, (unsigned)hard_cap));
+}
 
 struct DevBuf {
   void* p = nullptr;
@@ -39,7 +60,7 @@ struct DevBuf {
 // through mhap_dist_release).
 struct HandleView {
   int device; hipStream_t stream;
-  int Hrow, S;
+  int Hrow, S, k, min_olap_length;
   int64_t n_entries;
   const int32_t *d_minhash, *d_ordered, *d_meta;
   const int64_t* h_ids; const uint8_t* h_fwd;
@@ -48,6 +69,15 @@ struct HandleView {
 };
 HandleView handle_view(mhap_handle* h);
 void mhap_dist_release(void* dist_state);
+// install a group of reads that the caller packed itself (2 bits per base / raw bytes, laid out like stage_reads does) as the handle's
+// staged reads: descs[i] = {base_off, length, flags (MHAP_RD_SKIP / MHAP_RD_RAW)}, packed = `bytes` bytes of host memory (pinned: the
+// upload then runs at PCIe speed)
+struct ReadDesc;
+int internal_stage_packed(mhap_handle* h, const ReadDesc* descs, const int64_t* ids, int64_t n, const void* packed, size_t bytes);
+// records start, start + stride, ... of a scanned FASTA file into the handle's index (mhap_ingest.hip)
+struct FastaScanImpl;
+int ingest_add_subset(mhap_handle* h, const FastaScanImpl* scan, int64_t start, int64_t stride);
+const FastaScanImpl* scan_impl(const mhap_fasta_scan* s);
 int internal_sketch_queries(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_mh, void* d_od, void* d_mt);
 
 }  // namespace mhap

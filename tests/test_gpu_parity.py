@@ -308,6 +308,85 @@ def test_rccl_rank_of_one_and_errors_of_the_sharded_search():
             ms.dist_find_matches()
 
 
+def _awkward_fasta(path, fa, width=70):
+    """The reads of `fa` as a FASTA file that exercises the parser: wrapped lines, lower case, CRLF, an IUPAC read, reads below
+    --min-olap-length and below k, empty records, names with white space and commas (ids count non-empty records only)."""
+    import random
+    rnd = random.Random(4)
+    with open(path, "w", newline="") as fh:
+        for i in range(len(fa)):
+            s = fa.sequence(i)
+            if i % 11 == 3:
+                s = s.lower()
+            if i % 17 == 5:
+                s = s[:300] + "NRYKM" + s[305:]               # raw-byte read (IUPAC codes survive, FastaData.java:194)
+            eol = "\r\n" if i % 5 == 2 else "\n"
+            fh.write(f">read{i},extra words{eol}")
+            if i % 3 == 0:
+                fh.write(s + eol)
+            else:
+                w = width + rnd.randrange(20)
+                fh.write(eol.join(s[j:j + w] for j in range(0, len(s), w)) + eol)
+            if i % 13 == 7:
+                fh.write(">empty_record" + eol)                # no sequence: skipped, takes no id
+            if i % 19 == 9:
+                fh.write(">tiny" + eol + "ACGTAC" + eol)       # shorter than k: takes an id, is never sketched
+            if i % 23 == 11:
+                fh.write(">short" + eol + s[:100] + eol)       # below --min-olap-length 116
+
+
+def test_streamed_ingest_matches_the_copying_path_and_the_oracle(tmp_path, monkeypatch):
+    """mhap_index_add_scan (mapped file -> groups packed by host threads while the GPU sketches the previous group, inverted index
+    extended in place group after group) must give what FastaData.from_file + add_data gives, and both the oracle's records: wrapped
+    and one-line records, lower case, CRLF, IUPAC reads, short and empty records; also with the file gzipped, as -q queries, and
+    over a group of ranks."""
+    import gzip
+    from mhap_amd import FastaScan, MinHashSearchGroup
+    fa = mhap_amd.synth_reads(360, 3000, seed=77, error_rate=0.06)
+    path = str(tmp_path / "awkward.fasta")
+    _awkward_fasta(path, fa)
+    whole = FastaData.from_file(path)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=512)
+    want = O.record_lines(O.run_self(whole, H=128, S=512, nthreads=8)["records"])
+    assert len(want) > 100
+    with FastaScan(path) as sc:
+        ids, lens, names = sc.info()
+        assert ids.tolist() == whole.ids.tolist() and lens.tolist() == whole.lengths.tolist()
+        assert names[0] == "read0" and "empty_record" not in names and names.count("tiny") > 3
+        for group_bases in ("150000", "40000000"):             # many small groups / one group
+            monkeypatch.setenv("MHAP_INGEST_GROUP_BASES", group_bases)
+            with MinHashSearch(p) as ms:
+                ms.add_scan(sc)
+                assert ms.size() == 2 * len(whole)
+                got = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+                kt = ms.kernel_times()
+                assert got == want, group_bases
+                # the inverted index was filled group by group while the reads were sketched: the search did not rebuild it
+                assert kt["index_build"]["launches"] <= (len(whole) * 3000) // int(group_bases) + 6
+                again = sorted(mhap_amd.records_to_lines(ms.find_matches_scan(sc)))      # the same file as -q queries (toSelf = false)
+            with MinHashSearch(p) as ms2:
+                ms2.add_data(whole)
+                assert sorted(mhap_amd.records_to_lines(ms2.find_matches_stream(whole))) == again
+        monkeypatch.setenv("MHAP_INGEST_GROUP_BASES", "300000")
+        with MinHashSearchGroup(p, n=3, devices=[0, 0, 0]) as g:
+            g.add_scan(sc)
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want
+    gz = str(tmp_path / "awkward.fasta.gz")
+    with open(path, "rb") as src, gzip.open(gz, "wb") as dst:
+        dst.write(src.read())
+    with FastaScan(gz) as sc, MinHashSearch(p) as ms:
+        ms.add_scan(sc)
+        assert sorted(mhap_amd.records_to_lines(ms.find_matches())) == want
+    # adds in batches: with mhap_index_reserve the eagerly built index is extended in place, without it the first search rebuilds it
+    for reserve in (True, False):
+        with MinHashSearch(p) as ms:
+            if reserve:
+                ms.reserve(len(whole))
+            for lo in range(0, len(whole), 97):
+                ms.add_data(whole.subset(np.arange(lo, min(len(whole), lo + 97))))
+            assert sorted(mhap_amd.records_to_lines(ms.find_matches())) == want, reserve
+
+
 def test_batching_and_chunking_do_not_change_results(monkeypatch):
     fa = mhap_amd.synth_reads(300, 2000, seed=8, error_rate=0.05)
     p = MhapParams(num_hashes=64, ordered_sketch_size=300)
