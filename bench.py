@@ -320,16 +320,20 @@ def main():
 
 
 def pmc_traffic(kernel, config, n_total, L, world):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (tools/pmc_summary.py).  The counters
-    were collected on the default workload (c2: 100k x 10kb, 1 GPU); for any other shape the field stays null."""
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (tools/pmc_summary.py).  The counters were
+    collected on the default workload (c2: 100k x 10kb, 1 GPU) with the kernels of ONE build: the summary carries the digest of the
+    library's sources (mhap_amd.build.source_digest) and the field stays null when the sources have changed since, or for any other
+    shape — a stale byte count must not be divided by a live kernel time."""
     if not (config == "c2" and n_total == 100000 and L == 10000 and world == 1):
         return None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(path):
-            continue
+    from mhap_amd import build as mbuild
+    here = mbuild.source_digest()
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")), reverse=True):
         try:
-            d = json.load(open(path))["kernels"].get(kernel)
+            doc = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if doc.get("source_digest") != here:
+                continue
+            d = doc["kernels"].get(kernel)
             if d:
                 return int(d["hbm_bytes_per_launch"]), "profiles/" + name + " (" + d["fetch_rule"] + ")"
         except Exception:

@@ -38,6 +38,13 @@ def _digest(deps, cmd):
     return h.hexdigest()
 
 
+def source_digest():
+    """SHA-256 over the kernel / library sources and headers (no build command): what a profile of the kernels is stamped with
+    (tools/pmc_summary.py) and what bench.py compares before it quotes that profile's byte counts."""
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in HEADERS]
+    return _digest(deps, ["sources"])
+
+
 def _stale(target, digest):
     stamp = target + ".sha256"
     if not (os.path.exists(target) and os.path.exists(stamp)):

@@ -122,11 +122,14 @@ void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const un
                     DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared);
 // Second stage: one wavefront per candidate (equal-hash join); pairs it cannot decide exactly are appended to `slow`.
 constexpr int OJ_MAX_S = 8192;   // largest ordered sketch the join path stages in LDS
-size_t overlap_join_lds_bytes(int S);
-int overlap_join_blocks_per_cu(int S);
-void launch_overlap_join(hipStream_t st, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
-                         const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
-                         const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs, unsigned long long* rec_count,
-                         unsigned long long rec_cap, unsigned long long* compared, Candidate* slow, unsigned long long* slow_count, unsigned long long* work);
+size_t overlap_join_lds_bytes(int S, bool shared);
+int overlap_join_blocks_per_cu(int S, bool shared);
+int overlap_join_waves_per_block();
+int overlap_join_table_slots(int S);
+void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
+                         unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
+                         int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
+                         unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,
+                         unsigned long long* slow_count, unsigned long long* work);
 
 }  // namespace mhap

@@ -87,7 +87,8 @@ struct mhap_handle {
   hipStream_t own_stream = nullptr;
   hipStream_t side_stream = nullptr;      // eager inverted-index build next to the ordered-sketch kernel
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  int oj_per_cu = 0, oj_per_cu_S = -1;    // resident join-kernel workgroups per CU at ordered sketch size oj_per_cu_S
+  int oj_per_cu[2] = {0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (wave / shared shape) at ordered sketch size oj_per_cu_S
+  int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = shared, 2 = wave
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
   // inverted index state: the table in inv_table covers entries [0, inv_ne) with mask inv_cmask when inv_ready
@@ -594,6 +595,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const int64_t per_lane = 3LL * (2LL * S + 2);
   const char* omode = getenv("MHAP_OVERLAP");
   const bool lane_only = omode && strcmp(omode, "lane") == 0;
+  { const char* jm = getenv("MHAP_JOIN_MODE"); h->join_mode = jm && strcmp(jm, "shared") == 0 ? 1 : (jm && strcmp(jm, "wave") == 0 ? 2 : 0); }
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
   // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
   const char* cmode = getenv("MHAP_CANDIDATES");
@@ -679,16 +681,30 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
     // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
     if (h->gate && h->gate(h->gate_user) != 0) return fail(h, MHAP_E_STATE, "second-stage gate aborted the search");
-    const bool use_join = !lane_only && S <= OJ_MAX_S && overlap_join_lds_bytes(S) <= 64 * 1024;
+    // the join kernel's two shapes (search_kernels.hip): a workgroup shares one staged query — for runs of many candidates per query —
+    // or every wave stages its own.  MHAP_JOIN_MODE=shared|wave pins one.
+    const bool fits_wave = overlap_join_lds_bytes(S, false) <= 64 * 1024, fits_shared = overlap_join_lds_bytes(S, true) <= 64 * 1024;
+    const bool use_join = !lane_only && S <= OJ_MAX_S && (fits_wave || fits_shared);
     unsigned long long nslow = use_join ? 0 : ncand;
     if (use_join) {
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
-      const int chunk = 8;
-      const int64_t want = ((int64_t)ncand + 2LL * chunk - 1) / (2LL * chunk);
-      if (h->oj_per_cu_S != S) { h->oj_per_cu = overlap_join_blocks_per_cu(S); h->oj_per_cu_S = S; }
-      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * h->oj_per_cu, want));
+      bool shared = !fits_wave || (fits_shared && (int64_t)ncand >= 4LL * nq);
+      if (h->join_mode == 1 && fits_shared) shared = true;
+      if (h->join_mode == 2 && fits_wave) shared = false;
+      if (h->oj_per_cu_S != S) {
+        h->oj_per_cu[0] = fits_wave ? overlap_join_blocks_per_cu(S, false) : 0;
+        h->oj_per_cu[1] = fits_shared ? overlap_join_blocks_per_cu(S, true) : 0;
+        h->oj_per_cu_S = S;
+      }
+      // candidates per pull of a wave: 8 amortise the counter and keep a query's hashes staged across its candidates — unless the
+      // candidates are few (a small batch of -q reads, one rank's share of a small job): then every resident wave should get some
+      const int per_cu = h->oj_per_cu[shared ? 1 : 0], wpb = overlap_join_waves_per_block();
+      const int64_t resident_waves = (int64_t)h->num_cus * per_cu * wpb;
+      const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)ncand / std::max<int64_t>(resident_waves, 1)));
+      const int64_t want = ((int64_t)ncand + (int64_t)wpb * chunk - 1) / ((int64_t)wpb * chunk);
+      const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * per_cu, want));
       time_begin(h, MHAP_K_OVERLAP);
-      launch_overlap_join(h->stream, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
+      launch_overlap_join(h->stream, shared, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                           qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,
                           (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7);
       time_end(h);

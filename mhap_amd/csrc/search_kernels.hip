@@ -603,7 +603,7 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
 // beyond the caps below (joined k-mers, groups, group length) are appended to `slow` for overlap_kernel's literal merge.
 // =============================================================================================
 #ifndef MH_OJ_WAVES
-#define MH_OJ_WAVES 2
+#define MH_OJ_WAVES 4
 #endif
 constexpr int OJ_WAVES = MH_OJ_WAVES;
 constexpr int OJ_JCAP = 128;           // joined k-mers + group records kept per pair
@@ -776,6 +776,30 @@ __device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t
   return med;
 }
 
+// Lookup table over the query's hashes, in LDS: 16-bit entries, entry = index + 1 of the FIRST of the query's entries with that
+// hash (0 = empty), open addressing with linear probing at a load factor <= 0.5; a probe that lands on an entry checks the hash
+// itself in `ah`.  Round 2 found every entry of the other sketch by binary search in the sorted hashes: eleven DEPENDENT LDS round
+// trips per entry, 36 % of this kernel at the C5 slice and 24 % at C2 (-DMH_OJ_JOIN_ONLY / -DMH_OJ_NO_SEARCH timing builds);
+// a probe is one round trip for most misses and two for a hit.
+__device__ __forceinline__ uint32_t oj_slot_of(int h, int tshift) { return ((uint32_t)h * 0x9E3779B1u) >> tshift; }   // the product's top bits
+__device__ __forceinline__ void oj_table_insert(uint16_t* ht, uint32_t tmask, int tshift, int h, int i) {
+  uint32_t slot = oj_slot_of(h, tshift);
+  for (;;) {
+    uint32_t* w = (uint32_t*)ht + (slot >> 1);
+    const int sb = (int)(slot & 1u) * 16;
+    const uint32_t old = __atomic_load_n(w, __ATOMIC_RELAXED);
+    if ((old >> sb) & 0xFFFFu) { slot = (slot + 1u) & tmask; continue; }
+    if (atomicCAS(w, old, old | ((uint32_t)(i + 1) << sb)) == old) break;   // (lost against the word's other half: same slot again)
+  }
+}
+int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; return t; }
+
+// SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its OJ_WAVES waves stage the
+//                 query's hashes and build the table together (one copy in LDS), then take the run's candidates one by one from an
+//                 LDS counter.  For repeat-rich inputs, where one query has tens to thousands of candidates.
+// SHARED = false: every wave works alone — pulls its own chunks, keeps its own hashes and table.  For inputs with a few candidates
+//                 per query, where the waves of a workgroup would wait for each other at every run.
+template <bool SHARED>
 __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                                      unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                                      int64_t ord_stride, const int32_t* __restrict__ meta,
@@ -785,43 +809,31 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
                                                                      unsigned long long* __restrict__ rec_count, unsigned long long rec_cap,
                                                                      unsigned long long* __restrict__ compared, Candidate* __restrict__ slow,
                                                                      unsigned long long* __restrict__ slow_count, int chunk,
-                                                                     unsigned long long* __restrict__ work) {
+                                                                     unsigned long long* __restrict__ work, int ts) {
   extern __shared__ int32_t oj_lds[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int32_t* ah = oj_lds + (size_t)wv * ((size_t)sp.S + OJ_LDS_EXTRA);   // the query sketch's hashes
-  int32_t* jp1 = ah + sp.S;                                            // join: position in the query / in the other sketch,
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int spad = (sp.S + 3) & ~3, own = spad + ts / 2;               // ints of the hashes + the table
+  int32_t* ah = SHARED ? oj_lds : oj_lds + (size_t)wv * (own + OJ_LDS_EXTRA);   // the query sketch's hashes,
+  uint16_t* ht = (uint16_t*)(ah + spad);                               // ... the table over them,
+  int32_t* svar = oj_lds + own;                                        // (SHARED) {run length, next candidate of the run, chunk start lo, hi}
+  int32_t* jp1 = SHARED ? svar + 4 + (size_t)wv * OJ_LDS_EXTRA : ah + own;   // per wave — join: position in the query / in the other sketch,
   int32_t* jp2 = jp1 + OJ_JCAP;
   uint32_t* jij = (uint32_t*)(jp2 + OJ_JCAP);                          // ... entry indices (i | j << 16)
   int32_t* sh = (int32_t*)jij;                                         // (later) shifts of the current records, median selection
-  int32_t* gi = (int32_t*)(jij + OJ_JCAP);                                        // groups: {first i, first j, m, n, first record, records}
+  int32_t* gi = (int32_t*)(jij + OJ_JCAP);                             // groups: {first i, first j, m, n, first record, records}
   int32_t* gpa = gi + OJ_GCAP * 6;                                     // ... positions of the group's entries in the query
   int32_t* gpb = gpa + OJ_GCAP * OJ_GLEN;                              // ... and in the other sketch
+  const uint32_t tmask = (uint32_t)ts - 1u;
+  const int tshift = 32 - (31 - __builtin_clz((unsigned)ts));
   unsigned long long n = *cand_count;
   if (n > cand_cap) n = cand_cap;
   int curq = -1, nA = 0, len1 = 0;
   const int32_t* qrow = nullptr;
   unsigned long long mine = 0;
-  // chunks of consecutive candidates (one query's candidates are contiguous) are pulled from a counter: a static split makes the
-  // launch's duration depend on every workgroup of the grid being resident at once (one more per CU than fit = a second round)
-  for (;;) {
-    unsigned long long c0 = 0;
-    if (lane == 0) c0 = atomicAdd(work, (unsigned long long)chunk);
-    c0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c0 >> 32)) << 32) |
-         (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c0);
-    if (c0 >= n) break;
-    const unsigned long long c1 = c0 + (unsigned long long)chunk < n ? c0 + (unsigned long long)chunk : n;
-    for (unsigned long long c = c0; c < c1; c++) {
-      Candidate cd = cand[c];   // wave-uniform values are pinned to SGPRs: loop bounds and branches below become scalar
-      cd.q = __builtin_amdgcn_readfirstlane(cd.q); cd.m = __builtin_amdgcn_readfirstlane(cd.m);
-      if (cd.q != curq) {   // candidates of one query are contiguous: its hashes are staged once per run
-        curq = cd.q;
-        const int32_t* qm = qmeta + (int64_t)cd.q * META_W;
-        nA = __builtin_amdgcn_readfirstlane(qm[0]); len1 = __builtin_amdgcn_readfirstlane(qm[1]);
-        qrow = qordered + (int64_t)cd.q * qord_stride;
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < nA; i += 64) ah[i] = qrow[2 * i];
-        oj_lds_sync();
-      }
+  constexpr int NT = SHARED ? 64 * OJ_WAVES : 64;                      // threads that stage one query
+  const int tid = SHARED ? (int)threadIdx.x : lane;
+  // one candidate pair, by the wave
+  auto one_candidate = [&](const Candidate cd) {
       const int32_t* mm = meta + (int64_t)cd.m * META_W;
       const int nB = __builtin_amdgcn_readfirstlane(mm[0]), len2 = __builtin_amdgcn_readfirstlane(mm[1]);
       const uint2* brow = (const uint2*)(ordered + (int64_t)cd.m * ord_stride);
@@ -829,12 +841,21 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
       int nj = 0, ng = 0;
       bool bad = false;
       if (nA > 0 && nB > 0) {
-        const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
         int carry = 0;   // hash of the last entry of the previous OJ_U blocks (run detection across blocks)
         uint2 en[OJ_U];
 #pragma unroll
         for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = make_uint2(0u, 0u); if (j < nB) en[u] = brow[j]; }
+#ifdef MH_OJ_NO_SEARCH
+        for (int j0 = 0; j0 < nB && !bad; j0 += 64 * OJ_U) {   // (timing experiment: the rows are streamed, nothing is looked up)
+          int acc = 0;
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) { acc += (int)en[u].x; const int jn = j0 + (u + OJ_U) * 64 + lane; en[u] = make_uint2(0u, 0u); if (jn < nB) en[u] = brow[jn]; }
+          if (acc == 0x7fffffff) bad = true;
+        }
+        for (int j0 = nB; j0 < nB && !bad; j0 += 64 * OJ_U) {
+#else
         for (int j0 = 0; j0 < nB && !bad; j0 += 64 * OJ_U) {
+#endif
           // OJ_U blocks of 64 entries at a time: their binary searches (dependent LDS reads) overlap each other and the loads
           // of the next OJ_U blocks
           uint2 e[OJ_U];
@@ -846,21 +867,24 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
             en[u] = make_uint2(0u, 0u);
             if (jn < nB) en[u] = brow[jn];
           }
-          // lower bound of every hash among the query's: l = last index whose hash is smaller (-1: none).  Fixed probe
-          // sequence for a sorted array of any length (first probe splits [0,nA) into two overlapping halves of p2 entries)
-#pragma unroll
-          for (int u = 0; u < OJ_U; u++) l[u] = (ah[p2 - 1] < (int)e[u].x) ? nA - p2 : -1;
-          for (int q = p2 >> 1; q > 0; q >>= 1) {
-#pragma unroll
-            for (int u = 0; u < OJ_U; u++) l[u] = (ah[l[u] + q] < (int)e[u].x) ? l[u] + q : l[u];
-          }
+          // table probe: the first slot of every entry's hash for all OJ_U entries at once (independent LDS reads), then the lanes
+          // whose slot is taken check the hash and, on another one, walk on; l = index of the query's first entry with that hash
           bool found[OJ_U];
           bool anyf = false;
+          uint32_t slotv[OJ_U], ev[OJ_U];
+#pragma unroll
+          for (int u = 0; u < OJ_U; u++) { slotv[u] = oj_slot_of((int)e[u].x, tshift); ev[u] = ht[slotv[u]]; }
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
             const int j = j0 + u * 64 + lane;
-            l[u] += 1;
-            found[u] = j < nB && l[u] < nA && ah[l[u] < nA ? l[u] : 0] == (int)e[u].x;
+            l[u] = -1;
+            uint32_t v = j < nB ? ev[u] : 0u, slot = slotv[u];
+            while (v != 0u) {
+              if (ah[v - 1u] == (int)e[u].x) { l[u] = (int)v - 1; break; }
+              slot = (slot + 1u) & tmask;
+              v = ht[slot];
+            }
+            found[u] = l[u] >= 0;
             anyf |= found[u];
           }
           if (__any(anyf)) {
@@ -917,13 +941,16 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
       if (nj + gtot > OJ_JCAP) bad = true;
       if (bad) {
         if (lane == 0) { const unsigned long long slot = atomicAdd(slow_count, 1ULL); slow[slot] = cd; }
-        continue;
+        return;
       }
       mine++;
       // OverlapInfo.EMPTY (score 0, all zero) unless the pair gets through every stage below
       double score = 0.0;
       int valid = 0, a1 = 0, a2 = 0, b1 = 0, b2 = 0;
       do {
+#ifdef MH_OJ_JOIN_ONLY
+        if (nj >= 0) break;   // (timing experiment: everything after the join skipped; results are wrong)
+#endif
         if (ng == 0 && nj < 3) break;   // computeEdges needs three valid records (:126): fewer joined k-mers can only end EMPTY
         int iA[OJ_R], jB[OJ_R];   // the joined k-mers' entry indices move to registers, their LDS words become `sh`
 #pragma unroll
@@ -1113,27 +1140,105 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
           recs[slot] = d;
         }
       }
+  };
+  // chunks of consecutive candidates (one query's candidates are contiguous) are pulled from a counter: a static split makes the
+  // launch's duration depend on every workgroup of the grid being resident at once (one more per CU than fit = a second round)
+  const unsigned long long step = SHARED ? (unsigned long long)chunk * OJ_WAVES : (unsigned long long)chunk;
+  for (;;) {
+    unsigned long long c0 = 0;
+    if (SHARED) {
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        const unsigned long long v = atomicAdd(work, step);
+        svar[2] = (int32_t)(uint32_t)v; svar[3] = (int32_t)(uint32_t)(v >> 32);
+      }
+      __syncthreads();
+      c0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(svar[3]) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(svar[2]);
+    } else {
+      if (lane == 0) c0 = atomicAdd(work, step);
+      c0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(c0 >> 32)) << 32) |
+           (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c0);
+    }
+    if (c0 >= n) break;
+    const unsigned long long c1 = c0 + step < n ? c0 + step : n;
+    unsigned long long c = c0;
+    while (c < c1) {
+      Candidate cd = cand[c];   // wave-uniform values are pinned to SGPRs: loop bounds and branches below become scalar
+      cd.q = __builtin_amdgcn_readfirstlane(cd.q); cd.m = __builtin_amdgcn_readfirstlane(cd.m);
+      if (SHARED || cd.q != curq) {   // candidates of one query are contiguous: its hashes are staged once per run
+        curq = cd.q;
+        const int32_t* qm = qmeta + (int64_t)cd.q * META_W;
+        nA = __builtin_amdgcn_readfirstlane(qm[0]); len1 = __builtin_amdgcn_readfirstlane(qm[1]);
+        qrow = qordered + (int64_t)cd.q * qord_stride;
+        if (SHARED) {
+          __syncthreads();               // the previous run's waves are done with the hashes and the table
+          if (threadIdx.x == 0) { svar[0] = (int32_t)(c1 - c); svar[1] = 0; }
+        } else __builtin_amdgcn_wave_barrier();
+        for (int i = tid * 8; i < ts; i += NT * 8) *(uint4*)&ht[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (SHARED) __syncthreads(); else oj_lds_sync();
+        if (SHARED)                      // the run ends at the chunk's first candidate of another query
+          for (unsigned long long t = c + 1 + threadIdx.x; t < c1; t += NT)
+            if (cand[t].q != curq) { atomicMin(&svar[0], (int32_t)(t - c)); break; }
+        for (int i = tid; i < nA; i += NT) {
+          const int h = qrow[2 * i];
+          ah[i] = h;
+          if (i == 0 || qrow[2 * (i - 1)] != h) oj_table_insert(ht, tmask, tshift, h, i);   // the first entry of a run of equal hashes speaks for it
+        }
+        if (SHARED) __syncthreads(); else oj_lds_sync();
+      }
+      if (SHARED) {                      // this wave's next candidate of the run
+        const unsigned long long rend = c + (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(svar[0]);
+        int ci = 0;
+        if (lane == 0) ci = atomicAdd(&svar[1], 1);
+        ci = __builtin_amdgcn_readfirstlane(ci);
+        // (the loop below keeps `c` at the run's start and walks `cw`; it leaves with c = the run's end)
+        for (unsigned long long cw = c + (unsigned long long)(uint32_t)ci; cw < rend;) {
+          Candidate cx = cand[cw];
+          cx.q = __builtin_amdgcn_readfirstlane(cx.q); cx.m = __builtin_amdgcn_readfirstlane(cx.m);
+          one_candidate(cx);
+          int cn = 0;
+          if (lane == 0) cn = atomicAdd(&svar[1], 1);
+          cw = c + (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(cn);
+        }
+        c = rend;
+      } else {
+        one_candidate(cd);
+        c++;
+      }
     }
   }
   if (mine && lane == 0) atomicAdd(compared, mine);
 }
 
-size_t overlap_join_lds_bytes(int S) { return (size_t)OJ_WAVES * ((size_t)S + OJ_LDS_EXTRA) * 4; }
-// workgroups of the join kernel one CU holds at this sketch size (the launch is a persistent grid with a static split of the
-// candidates: one workgroup more per CU than fit would run as a second round)
-int overlap_join_blocks_per_cu(int S) {
+// LDS bytes of one workgroup: the hashes and the table once (shared) or per wave, the join scratch per wave
+size_t overlap_join_lds_bytes(int S, bool shared) {
+  const size_t own = (size_t)((S + 3) & ~3) + (size_t)overlap_join_table_slots(S) / 2;
+  return (shared ? own + 4 + (size_t)OJ_WAVES * OJ_LDS_EXTRA : (size_t)OJ_WAVES * (own + OJ_LDS_EXTRA)) * 4;
+}
+// workgroups of the join kernel one CU holds at this sketch size
+int overlap_join_blocks_per_cu(int S, bool shared) {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel, 64 * OJ_WAVES, overlap_join_lds_bytes(S)) != hipSuccess || n < 1) n = 1;
+  const hipError_t e = shared ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<true>, 64 * OJ_WAVES, overlap_join_lds_bytes(S, true))
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<false>, 64 * OJ_WAVES, overlap_join_lds_bytes(S, false));
+  if (e != hipSuccess || n < 1) n = 1;
   return n;
 }
+int overlap_join_waves_per_block() { return OJ_WAVES; }
 
-void launch_overlap_join(hipStream_t st, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
-                         const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
-                         const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs, unsigned long long* rec_count,
-                         unsigned long long rec_cap, unsigned long long* compared, Candidate* slow, unsigned long long* slow_count,
-                         unsigned long long* work) {
-  hipLaunchKernelGGL(overlap_join_kernel, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S), st, cand, cand_count, cand_cap, ordered,
-                     ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk, work);
+void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
+                         unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
+                         int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
+                         unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,
+                         unsigned long long* slow_count, unsigned long long* work) {
+  const int ts = overlap_join_table_slots(sp.S);
+  if (shared)
+    hipLaunchKernelGGL(overlap_join_kernel<true>, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S, true), st, cand, cand_count, cand_cap,
+                       ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count,
+                       chunk, work, ts);
+  else
+    hipLaunchKernelGGL(overlap_join_kernel<false>, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S, false), st, cand, cand_count, cand_cap,
+                       ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count,
+                       chunk, work, ts);
 }
 
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,

@@ -2,6 +2,9 @@
 # Re-derives the golden records with a real MHAP jar when a JVM is available and diffs them against the
 # committed oracle-derived fixture: the self overlap, the -q index-vs-stream run (queries below --min-olap-length included:
 # id offsets), the -f filter run and both --supress-noise modes.
+# Then (needs javac too) compiles tools/jvm/ScoreTableDump.java against the jar's Guava and diffs, bit for bit, the three pieces of
+# JDK / Guava arithmetic the restatement depends on with tools/jvm/native_dump.py: the (inter, k) identity table (Math.log / Math.exp
+# against glibc), String.format("%.6f") on 20 000 doubles incl. ties, and BloomFilter sizing + membership.
 # Usage: MHAP_JAR=/path/mhap-2.1.3.jar sh tests/golden/verify_against_jar.sh
 set -e
 cd "$(dirname "$0")"
@@ -29,3 +32,17 @@ for name, key in (("self", "sorted_records"), ("query", "query_records_no_self")
 assert bad == 0, "MISMATCH between mhap.jar and the oracle-derived fixture"
 print("fixture matches mhap.jar")
 PY
+if command -v javac >/dev/null 2>&1; then
+  ROOT=$(cd ../.. && pwd)
+  javac -cp "$MHAP_JAR" -d "$T" "$ROOT/tools/jvm/ScoreTableDump.java"
+  for what in "score 12 1536" "fmt6" "bloom"; do
+    name=$(echo $what | cut -d' ' -f1)
+    java -cp "$MHAP_JAR:$T" ScoreTableDump $what > "$T/$name.jvm"
+    python3 "$ROOT/tools/jvm/native_dump.py" $what > "$T/$name.native"
+    if cmp -s "$T/$name.jvm" "$T/$name.native"; then echo "ok       $name: $(wc -l < "$T/$name.jvm") lines identical to the JVM's"
+    else echo "MISMATCH $name: first differing lines:"; diff "$T/$name.jvm" "$T/$name.native" | head -6; exit 1; fi
+  done
+  echo "JDK / Guava arithmetic matches the restatement"
+else
+  echo "no javac on PATH: the arithmetic dumps (tools/jvm) were not compared"
+fi

@@ -699,6 +699,41 @@ def test_full_config2_against_oracle():
     assert len(got) == 41915 and sha.startswith("8f75366010aaae7d")      # the fingerprint of the round-1 and round-2 bench lines
 
 
+@pytest.mark.timeout(2400)
+def test_full_config4_on_one_gpu_properties_and_subset_parity():
+    """BASELINE configs[3] at FULL size — 1 000 000 reads x 15 kb, 2 M strands, H = 512, S = 1536 (quoted as an 8-GPU job; the
+    tables, the index and the scratch of the whole job fit one MI355X) — through the streaming-free C ABI path: the size-independent
+    properties of every record, the record count and checksum the benchmark prints for this configuration, and full parity with
+    the CPU oracle on the pairs among a 3 000-read subset (without -f a pair's record depends on its two reads only)."""
+    import hashlib
+    from mhap_amd import workloads as W
+    fa = W.config_reads("c4")
+    assert len(fa) == 1000000
+    with MinHashSearch(MhapParams()) as ms:
+        ms.add_data(fa)
+        recs = ms.find_matches()
+        st = ms.stats()
+    assert st["strands_indexed"] == 2000000 and st["queries_searched"] == 1000000
+    assert len(recs) == 313605                                              # profiles/r02_bench_c4.json, profiles/r03_e2e_probe.txt
+    assert np.all(recs["to_id"] < recs["from_id"]) and np.all((recs["from_id"] <= 1000000) & (recs["to_id"] >= 1))
+    assert np.all((recs["score"] >= 0.78) & (recs["score"] <= 1.0) & (recs["raw"] >= 3))
+    assert np.all((recs["a1"] >= 0) & (recs["a1"] <= recs["a2"]) & (recs["a2"] <= 15000 - 11) & (recs["alen"] == 15000) & (recs["blen"] == 15000))
+    assert np.all((recs["b1"] >= -1) & (recs["b2"] <= 15000) & (recs["b1"] <= recs["b2"]))
+    pairs = np.unique(np.stack([recs["from_id"], recs["to_id"], recs["to_rc"].astype(np.int64)], 1), axis=0)
+    assert len(pairs) == len(recs)                                          # one record per (query, stored strand)
+    lines = mhap_amd.records_to_lines(recs)
+    csum = 0
+    for ln in lines:
+        csum = (csum + int.from_bytes(hashlib.sha256(ln.encode()).digest()[:8], "little")) & ((1 << 64) - 1)
+    assert len(set(lines)) == len(lines)
+    # pairs among reads 1..3000 exactly as the oracle scores them
+    nsub = 3000
+    want = O.record_lines(O.run_self(fa.subset(np.arange(nsub)), nthreads=16, cap=1 << 20)["records"])
+    m = (recs["from_id"] <= nsub) & (recs["to_id"] <= nsub)
+    assert sorted(mhap_amd.records_to_lines(recs[m])) == want and len(want) >= 1
+    print(f"c4 full: {len(recs)} records, checksum {csum:016x}, {len(want)} of them among the first {nsub} reads")
+
+
 def test_config4_read_shape_slice():
     """BASELINE configs[3]/[4] read shapes (15 kb and 12 kb reads, H=512, S=1536: more than 12288 k-mers per strand takes the
     24-k-mers-per-lane weight kernel, 8 bit-sliced MinHash rows) on a slice of reads: full record parity with the oracle."""
