@@ -124,7 +124,7 @@ void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const un
 constexpr int OJ_MAX_S = 8192;   // largest ordered sketch the join path stages in LDS
 size_t overlap_join_lds_bytes(int S, bool shared);
 int overlap_join_blocks_per_cu(int S, bool shared);
-int overlap_join_waves_per_block();
+int overlap_join_waves_per_block(bool shared);
 int overlap_join_table_slots(int S);
 void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
                          unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,

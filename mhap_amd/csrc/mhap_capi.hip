@@ -688,7 +688,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     unsigned long long nslow = use_join ? 0 : ncand;
     if (use_join) {
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
-      bool shared = !fits_wave || (fits_shared && (int64_t)ncand >= 4LL * nq);
+      bool shared = !fits_wave || (fits_shared && (int64_t)ncand >= 16LL * nq);   // (C2: 4.5 candidates per query, 4.7 ms alone / 5.0 shared; C5 slice: 79, 169 / 67)
       if (h->join_mode == 1 && fits_shared) shared = true;
       if (h->join_mode == 2 && fits_wave) shared = false;
       if (h->oj_per_cu_S != S) {
@@ -698,7 +698,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       }
       // candidates per pull of a wave: 8 amortise the counter and keep a query's hashes staged across its candidates — unless the
       // candidates are few (a small batch of -q reads, one rank's share of a small job): then every resident wave should get some
-      const int per_cu = h->oj_per_cu[shared ? 1 : 0], wpb = overlap_join_waves_per_block();
+      const int per_cu = h->oj_per_cu[shared ? 1 : 0], wpb = overlap_join_waves_per_block(shared);
       const int64_t resident_waves = (int64_t)h->num_cus * per_cu * wpb;
       const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)ncand / std::max<int64_t>(resident_waves, 1)));
       const int64_t want = ((int64_t)ncand + (int64_t)wpb * chunk - 1) / ((int64_t)wpb * chunk);

@@ -776,22 +776,25 @@ __device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t
   return med;
 }
 
-// Lookup table over the query's hashes, in LDS: 16-bit entries, entry = index + 1 of the FIRST of the query's entries with that
-// hash (0 = empty), open addressing with linear probing at a load factor <= 0.5; a probe that lands on an entry checks the hash
-// itself in `ah`.  Round 2 found every entry of the other sketch by binary search in the sorted hashes: eleven DEPENDENT LDS round
-// trips per entry, 36 % of this kernel at the C5 slice and 24 % at C2 (-DMH_OJ_JOIN_ONLY / -DMH_OJ_NO_SEARCH timing builds);
-// a probe is one round trip for most misses and two for a hit.
-__device__ __forceinline__ uint32_t oj_slot_of(int h, int tshift) { return ((uint32_t)h * 0x9E3779B1u) >> tshift; }   // the product's top bits
-__device__ __forceinline__ void oj_table_insert(uint16_t* ht, uint32_t tmask, int tshift, int h, int i) {
-  uint32_t slot = oj_slot_of(h, tshift);
-  for (;;) {
-    uint32_t* w = (uint32_t*)ht + (slot >> 1);
-    const int sb = (int)(slot & 1u) * 16;
-    const uint32_t old = __atomic_load_n(w, __ATOMIC_RELAXED);
-    if ((old >> sb) & 0xFFFFu) { slot = (slot + 1u) & tmask; continue; }
-    if (atomicCAS(w, old, old | ((uint32_t)(i + 1) << sb)) == old) break;   // (lost against the word's other half: same slot again)
-  }
+// Lookup of a hash among the query's sorted hashes, in LDS.  The hashes of a bottom-S sketch are uniform order statistics of
+// [first, last], so  bucket(h) = (h - first) * NB / (last - first + 1)  spreads them evenly; st[b] = index of the first entry
+// whose bucket is >= b (NB + 1 16-bit words, NB >= 2 S: 0.375 entries per bucket at the defaults).  A lookup reads st[b] and
+// st[b + 1], then the bucket's first two hashes — two dependent LDS round trips, the same for every lane — and only a bucket of
+// three or more entries (0.7 % of them) costs a lane more.  Equal hashes share a bucket and the scan ascends, so a hit is the
+// FIRST entry with that hash, as the lower bound was.  Round 2 found every entry of the other sketch by binary search: eleven
+// dependent round trips per entry, 36 % of this kernel at the C5 slice and 24 % at C2 (-DMH_OJ_JOIN_ONLY / -DMH_OJ_NO_SEARCH
+// timing builds).  (An open-addressing hash table was tried first: the probe chains' MAXIMUM over the 64 lanes, not their mean,
+// sets a wave's time — 8.0 ms at C2 against the binary search's 4.7.)
+struct OjBuckets { int first, last; uint32_t mult; };
+__device__ __forceinline__ OjBuckets oj_buckets(int first, int last, int nb) {
+  OjBuckets k;
+  k.first = first; k.last = last;
+  unsigned long long range = (unsigned long long)(uint32_t)(last - first) + 1ULL;
+  if (range < 2ULL * (unsigned long long)nb) range = 2ULL * (unsigned long long)nb;   // (keeps mult below 2^32; a degenerate sketch uses fewer buckets)
+  k.mult = (uint32_t)(((unsigned long long)nb << 32) / range);
+  return k;
 }
+__device__ __forceinline__ int oj_bucket_of(const OjBuckets& k, int h) { return (int)__umulhi((uint32_t)(h - k.first), k.mult); }
 int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; return t; }
 
 // SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its OJ_WAVES waves stage the
@@ -799,8 +802,8 @@ int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; r
 //                 LDS counter.  For repeat-rich inputs, where one query has tens to thousands of candidates.
 // SHARED = false: every wave works alone — pulls its own chunks, keeps its own hashes and table.  For inputs with a few candidates
 //                 per query, where the waves of a workgroup would wait for each other at every run.
-template <bool SHARED>
-__global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
+template <bool SHARED, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                                      unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                                      int64_t ord_stride, const int32_t* __restrict__ meta,
                                                                      const int32_t* __restrict__ qordered, int64_t qord_stride,
@@ -812,10 +815,10 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
                                                                      unsigned long long* __restrict__ work, int ts) {
   extern __shared__ int32_t oj_lds[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int spad = (sp.S + 3) & ~3, own = spad + ts / 2;               // ints of the hashes + the table
+  const int spad = (sp.S + 3) & ~3, own = SHARED ? spad + ts / 2 + 2 : spad;   // ints of the hashes (+ the table: ts + 1 shorts, padded)
   int32_t* ah = SHARED ? oj_lds : oj_lds + (size_t)wv * (own + OJ_LDS_EXTRA);   // the query sketch's hashes,
-  uint16_t* ht = (uint16_t*)(ah + spad);                               // ... the table over them,
-  int32_t* svar = oj_lds + own;                                        // (SHARED) {run length, next candidate of the run, chunk start lo, hi}
+  uint16_t* st = (uint16_t*)(ah + spad);                               // ... the bucket starts over them,
+  int32_t* svar = oj_lds + own;                                        // (SHARED) {-, next candidate of the run, chunk start lo, hi}
   int32_t* jp1 = SHARED ? svar + 4 + (size_t)wv * OJ_LDS_EXTRA : ah + own;   // per wave — join: position in the query / in the other sketch,
   int32_t* jp2 = jp1 + OJ_JCAP;
   uint32_t* jij = (uint32_t*)(jp2 + OJ_JCAP);                          // ... entry indices (i | j << 16)
@@ -823,14 +826,13 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
   int32_t* gi = (int32_t*)(jij + OJ_JCAP);                             // groups: {first i, first j, m, n, first record, records}
   int32_t* gpa = gi + OJ_GCAP * 6;                                     // ... positions of the group's entries in the query
   int32_t* gpb = gpa + OJ_GCAP * OJ_GLEN;                              // ... and in the other sketch
-  const uint32_t tmask = (uint32_t)ts - 1u;
-  const int tshift = 32 - (31 - __builtin_clz((unsigned)ts));
+  OjBuckets bk = {0, 0, 0u};
   unsigned long long n = *cand_count;
   if (n > cand_cap) n = cand_cap;
   int curq = -1, nA = 0, len1 = 0;
   const int32_t* qrow = nullptr;
   unsigned long long mine = 0;
-  constexpr int NT = SHARED ? 64 * OJ_WAVES : 64;                      // threads that stage one query
+  constexpr int NT = SHARED ? 64 * WAVES : 64;                      // threads that stage one query
   const int tid = SHARED ? (int)threadIdx.x : lane;
   // one candidate pair, by the wave
   auto one_candidate = [&](const Candidate cd) {
@@ -867,25 +869,52 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
             en[u] = make_uint2(0u, 0u);
             if (jn < nB) en[u] = brow[jn];
           }
-          // table probe: the first slot of every entry's hash for all OJ_U entries at once (independent LDS reads), then the lanes
-          // whose slot is taken check the hash and, on another one, walk on; l = index of the query's first entry with that hash
           bool found[OJ_U];
           bool anyf = false;
-          uint32_t slotv[OJ_U], ev[OJ_U];
+          if constexpr (SHARED) {
+            // bucket lookup (above): st[b], st[b + 1], then the bucket's first two hashes — the OJ_U entries' reads are independent
+            int i0[OJ_U], i1[OJ_U], x0[OJ_U], x1[OJ_U];
 #pragma unroll
-          for (int u = 0; u < OJ_U; u++) { slotv[u] = oj_slot_of((int)e[u].x, tshift); ev[u] = ht[slotv[u]]; }
-#pragma unroll
-          for (int u = 0; u < OJ_U; u++) {
-            const int j = j0 + u * 64 + lane;
-            l[u] = -1;
-            uint32_t v = j < nB ? ev[u] : 0u, slot = slotv[u];
-            while (v != 0u) {
-              if (ah[v - 1u] == (int)e[u].x) { l[u] = (int)v - 1; break; }
-              slot = (slot + 1u) & tmask;
-              v = ht[slot];
+            for (int u = 0; u < OJ_U; u++) {
+              const int hb = (int)e[u].x;
+              const int b = (hb >= bk.first && hb <= bk.last) ? oj_bucket_of(bk, hb) : 0;
+              i0[u] = st[b]; i1[u] = st[b + 1];
             }
-            found[u] = l[u] >= 0;
-            anyf |= found[u];
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) { x0[u] = ah[i0[u]]; x1[u] = ah[i0[u] + 1]; }   // (past the bucket / the sketch: read, never used)
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              const int j = j0 + u * 64 + lane;
+              const int hb = (int)e[u].x;
+              l[u] = -1;
+              if (j < nB && hb >= bk.first && hb <= bk.last && i0[u] < i1[u]) {
+                if (x0[u] == hb) l[u] = i0[u];
+                else if (i0[u] + 1 < i1[u]) {
+                  if (x1[u] == hb) l[u] = i0[u] + 1;
+                  else for (int i = i0[u] + 2; i < i1[u]; i++) if (ah[i] == hb) { l[u] = i; break; }
+                }
+              }
+              found[u] = l[u] >= 0;
+              anyf |= found[u];
+            }
+          } else {
+            // no room for a table per wave: lower bound of every hash among the query's by binary search, l = last index whose hash
+            // is smaller (-1: none).  Fixed probe sequence for a sorted array of any length (the first probe splits [0, nA) into two
+            // overlapping halves of p2 entries); the OJ_U searches' dependent LDS reads overlap each other
+            const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) l[u] = (ah[p2 - 1] < (int)e[u].x) ? nA - p2 : -1;
+            for (int q = p2 >> 1; q > 0; q >>= 1) {
+#pragma unroll
+              for (int u = 0; u < OJ_U; u++) l[u] = (ah[l[u] + q] < (int)e[u].x) ? l[u] + q : l[u];
+            }
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              const int j = j0 + u * 64 + lane;
+              l[u] += 1;
+              found[u] = j < nB && l[u] < nA && ah[l[u] < nA ? l[u] : 0] == (int)e[u].x;
+              anyf |= found[u];
+            }
           }
           if (__any(anyf)) {
 #pragma unroll
@@ -1143,7 +1172,7 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
   };
   // chunks of consecutive candidates (one query's candidates are contiguous) are pulled from a counter: a static split makes the
   // launch's duration depend on every workgroup of the grid being resident at once (one more per CU than fit = a second round)
-  const unsigned long long step = SHARED ? (unsigned long long)chunk * OJ_WAVES : (unsigned long long)chunk;
+  const unsigned long long step = SHARED ? (unsigned long long)chunk * WAVES : (unsigned long long)chunk;
   for (;;) {
     unsigned long long c0 = 0;
     if (SHARED) {
@@ -1161,7 +1190,7 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
     }
     if (c0 >= n) break;
     const unsigned long long c1 = c0 + step < n ? c0 + step : n;
-    unsigned long long c = c0;
+    unsigned long long c = c0, rend = c0;
     while (c < c1) {
       Candidate cd = cand[c];   // wave-uniform values are pinned to SGPRs: loop bounds and branches below become scalar
       cd.q = __builtin_amdgcn_readfirstlane(cd.q); cd.m = __builtin_amdgcn_readfirstlane(cd.m);
@@ -1172,22 +1201,28 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
         qrow = qordered + (int64_t)cd.q * qord_stride;
         if (SHARED) {
           __syncthreads();               // the previous run's waves are done with the hashes and the table
-          if (threadIdx.x == 0) { svar[0] = (int32_t)(c1 - c); svar[1] = 0; }
+          if (threadIdx.x == 0) svar[1] = 0;
+          rend = c1;                     // the run ends at the chunk's first candidate of another query (every wave finds it for itself)
+          for (unsigned long long t0 = c + 1; t0 < c1; t0 += 64) {
+            const unsigned long long bal = __ballot(t0 + lane < c1 && cand[t0 + lane].q != curq);
+            if (bal) { rend = t0 + (unsigned long long)__builtin_ctzll(bal); break; }
+          }
         } else __builtin_amdgcn_wave_barrier();
-        for (int i = tid * 8; i < ts; i += NT * 8) *(uint4*)&ht[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (SHARED) __syncthreads(); else oj_lds_sync();
-        if (SHARED)                      // the run ends at the chunk's first candidate of another query
-          for (unsigned long long t = c + 1 + threadIdx.x; t < c1; t += NT)
-            if (cand[t].q != curq) { atomicMin(&svar[0], (int32_t)(t - c)); break; }
-        for (int i = tid; i < nA; i += NT) {
-          const int h = qrow[2 * i];
-          ah[i] = h;
-          if (i == 0 || qrow[2 * (i - 1)] != h) oj_table_insert(ht, tmask, tshift, h, i);   // the first entry of a run of equal hashes speaks for it
+        if (!SHARED) {
+          for (int i = lane; i < nA; i += 64) ah[i] = qrow[2 * i];
+        } else if (nA > 0) {
+          bk = oj_buckets(__builtin_amdgcn_readfirstlane(qrow[0]), __builtin_amdgcn_readfirstlane(qrow[2 * (nA - 1)]), ts);
+          for (int i = tid; i < nA; i += NT) {   // entry i starts every bucket after its predecessor's up to its own
+            const int h = qrow[2 * i];
+            ah[i] = h;
+            const int b1 = oj_bucket_of(bk, h), b0 = i ? oj_bucket_of(bk, qrow[2 * (i - 1)]) + 1 : 0;
+            for (int b = b0; b <= b1; b++) st[b] = (uint16_t)i;
+            if (i == nA - 1) for (int b = b1 + 1; b <= ts; b++) st[b] = (uint16_t)nA;
+          }
         }
         if (SHARED) __syncthreads(); else oj_lds_sync();
       }
       if (SHARED) {                      // this wave's next candidate of the run
-        const unsigned long long rend = c + (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane(svar[0]);
         int ci = 0;
         if (lane == 0) ci = atomicAdd(&svar[1], 1);
         ci = __builtin_amdgcn_readfirstlane(ci);
@@ -1210,20 +1245,25 @@ __global__ __launch_bounds__(64 * OJ_WAVES) void overlap_join_kernel(const Candi
   if (mine && lane == 0) atomicAdd(compared, mine);
 }
 
+// waves of one workgroup: the shared shape wants many takers per staged query, the per-wave shape small workgroups (LDS per wave
+// is what bounds the resident waves there)
+constexpr int OJ_WAVES_SHARED = OJ_WAVES, OJ_WAVES_ALONE = 2;
+int overlap_join_waves_per_block(bool shared) { return shared ? OJ_WAVES_SHARED : OJ_WAVES_ALONE; }
 // LDS bytes of one workgroup: the hashes and the table once (shared) or per wave, the join scratch per wave
 size_t overlap_join_lds_bytes(int S, bool shared) {
-  const size_t own = (size_t)((S + 3) & ~3) + (size_t)overlap_join_table_slots(S) / 2;
-  return (shared ? own + 4 + (size_t)OJ_WAVES * OJ_LDS_EXTRA : (size_t)OJ_WAVES * (own + OJ_LDS_EXTRA)) * 4;
+  const size_t sp = (size_t)((S + 3) & ~3);
+  return (shared ? sp + (size_t)overlap_join_table_slots(S) / 2 + 2 + 4 + (size_t)OJ_WAVES_SHARED * OJ_LDS_EXTRA : (size_t)OJ_WAVES_ALONE * (sp + OJ_LDS_EXTRA)) * 4;
 }
 // workgroups of the join kernel one CU holds at this sketch size
 int overlap_join_blocks_per_cu(int S, bool shared) {
   int n = 0;
-  const hipError_t e = shared ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<true>, 64 * OJ_WAVES, overlap_join_lds_bytes(S, true))
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<false>, 64 * OJ_WAVES, overlap_join_lds_bytes(S, false));
+  const hipError_t e = shared ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<true, OJ_WAVES_SHARED>, 64 * OJ_WAVES_SHARED,
+                                                                             overlap_join_lds_bytes(S, true))
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<false, OJ_WAVES_ALONE>, 64 * OJ_WAVES_ALONE,
+                                                                             overlap_join_lds_bytes(S, false));
   if (e != hipSuccess || n < 1) n = 1;
   return n;
 }
-int overlap_join_waves_per_block() { return OJ_WAVES; }
 
 void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
                          unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
@@ -1232,13 +1272,13 @@ void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, co
                          unsigned long long* slow_count, unsigned long long* work) {
   const int ts = overlap_join_table_slots(sp.S);
   if (shared)
-    hipLaunchKernelGGL(overlap_join_kernel<true>, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S, true), st, cand, cand_count, cand_cap,
-                       ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count,
-                       chunk, work, ts);
+    hipLaunchKernelGGL((overlap_join_kernel<true, OJ_WAVES_SHARED>), dim3(nblocks), dim3(64 * OJ_WAVES_SHARED), overlap_join_lds_bytes(sp.S, true), st, cand,
+                       cand_count, cand_cap, ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared,
+                       slow, slow_count, chunk, work, ts);
   else
-    hipLaunchKernelGGL(overlap_join_kernel<false>, dim3(nblocks), dim3(64 * OJ_WAVES), overlap_join_lds_bytes(sp.S, false), st, cand, cand_count, cand_cap,
-                       ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count,
-                       chunk, work, ts);
+    hipLaunchKernelGGL((overlap_join_kernel<false, OJ_WAVES_ALONE>), dim3(nblocks), dim3(64 * OJ_WAVES_ALONE), overlap_join_lds_bytes(sp.S, false), st, cand,
+                       cand_count, cand_cap, ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared,
+                       slow, slow_count, chunk, work, ts);
 }
 
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
