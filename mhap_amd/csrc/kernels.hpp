@@ -100,14 +100,20 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // are stored contiguously in the overflow pool (CSR: per-(slot, value) start / count in a second hash table).  During the build
 // they are appended to `tmp` and counted; launch_index_finalize lays them out once all entries are in.
 struct InvIndex {
-  unsigned long long* table; uint32_t cmask;
-  unsigned long long* ovf_keys; uint32_t* ovf_cnt; uint32_t* ovf_start; uint32_t* ovf_fill; uint32_t ovf_mask;
-  uint2* tmp; uint32_t* pool; unsigned long long* counters;   // counters[0]: tmp items, counters[1]: pool words allocated
-  uint32_t ne;   // entries the tables were sized for (an upper bound of any query's distinct hits)
-  uint32_t tmp_cap;
+  uint32_t* ends;        // [H][nb + 1]: postings of bucket b of slot s are items[s][ends[s][b] .. ends[s][b + 1]), ends[s][0] = 0
+  uint2* items;          // [H][slot_stride]: (mix of the value, entry), grouped by bucket
+  uint32_t nb, shift;    // buckets per slot (a power of two, 1024 .. 2^21), bucket = mix >> shift
+  uint64_t slot_stride;  // postings one slot has room for
+  uint32_t ne;           // entries the index was sized for (an upper bound of any query's distinct hits)
+  // scratch of the build
+  uint2* staged;         // [H][slot_stride]: the postings grouped by coarse bin
+  uint32_t* tile_counts; // [H][tiles][512]
+  uint32_t* bin_start;   // [H][513]
 };
-void launch_index_finalize(hipStream_t st, const InvIndex& ix, unsigned long long n_tmp);
-void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H, const InvIndex& ix);
+int index_tiles(int ne);
+void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,
+                         unsigned long long* missing);   // self-check: postings that are not where a lookup would find them
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix);
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,

@@ -85,17 +85,12 @@ struct mhap_handle {
   int num_cus = 256;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
-  hipStream_t side_stream = nullptr;      // eager inverted-index build next to the ordered-sketch kernel
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int oj_per_cu[2] = {0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (wave / shared shape) at ordered sketch size oj_per_cu_S
   int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = shared, 2 = wave
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
-  // inverted index state: the table in inv_table covers entries [0, inv_ne) with mask inv_cmask when inv_ready
-  bool inv_ready = false; int64_t inv_ne = 0; uint32_t inv_cmask = 0;
-  bool inv_finalized = false;   // the overflow postings of the table in place have been laid out (launch_index_finalize)
-  bool eager = false; int64_t eager_first = 0; uint32_t eager_cmask = 0;   // set by mhap_index_add_staged around sketch_staged
-  int64_t inv_cap_entries = 0;     // entries the table in place was sized for (>= inv_ne: mhap_index_reserve sizes it for reads still to come)
+  // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
+  bool inv_ready = false; int64_t inv_ne = 0;
   int64_t reserve_reads = 0;       // mhap_index_reserve: reads the empty index is about to receive, over one or more adds
   std::string err;
   int Hrow = 1;      // minhash row stride (ints)
@@ -134,15 +129,14 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_table, inv_ovf, inv_big;
-  InvIndex inv{};   // device view of the inverted index in inv_table / inv_ovf
+  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big;
+  InvIndex inv{};   // device view of the inverted index in inv_ends / inv_items
   mhap_stage_gate gate = nullptr; void* gate_user = nullptr;   // mhap_set_second_stage_gate
   void* dist = nullptr;   // multi-GPU state (mhap_dist.hip)
   std::vector<mhap_record> out_recs;
 
   // timing
   std::vector<TimedLaunch> pending;
-  std::vector<TimedLaunch> pending_side;   // launches on side_stream: collected once the main stream has joined it
   std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
   mhap_kernel_times ktimes{};
   mhap_stats stats{};
@@ -290,45 +284,22 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
 // Batches run back to back on the handle's stream.  (A two-stream variant that overlapped hash/weight/ordered of
 // batch b+1 with MinHash of batch b was measured at 358 -> 355..365 ms/step: the kernels compete for the same VALU
 // issue slots and LDS, so it was removed.)
-static uint64_t inv_capacity(int64_t ne) {
-  uint64_t cap = 1024;
-#ifndef MH_INV_SLOTS_PER_ENTRY
-#define MH_INV_SLOTS_PER_ENTRY 4
-#endif
-  while (cap < (uint64_t)MH_INV_SLOTS_PER_ENTRY * (uint64_t)ne) cap <<= 1;   // load factor <= 0.25: short probe chains (a wave walks the longest chain of its 64 lanes)
-  return cap;
-}
-
-// (Re)allocate and zero the inverted index for `ne` entries on stream st: H slot tables of inv_capacity(ne) words, the per-value
-// overflow table (one slot per 8 postings: key, count, segment start, fill), the temporary overflow list and the overflow pool
-// (one item per 4 postings; beyond that inserts stay in their runs).
-static int inv_reset(mhap_handle* h, int64_t ne, hipStream_t st) {
+// (Re)allocate the inverted index for `ne` entries: per MinHash slot an ends table of one bucket per entry (rounded up to a power
+// of two: 0.5-1 postings per bucket), room for ne postings of 8 bytes, and the sort's scratch (as much again + the tile counts).
+static int inv_alloc(mhap_handle* h, int64_t ne) {
   const int H = h->P.num_hashes;
-  const uint64_t cap = inv_capacity(ne);
-  const size_t tbytes = (size_t)H * (size_t)cap * 8;
-  const uint64_t postings = (uint64_t)ne * (uint64_t)H;
-  uint64_t oslots = 1024;
-  while (oslots < postings / 8) oslots <<= 1;
-  const uint64_t tmp_cap = std::min<uint64_t>(std::max<uint64_t>(postings / 4, 1u << 16), 0xFFFFFFF0ull);
-  const size_t obytes = 64 + (size_t)oslots * 20 + (size_t)tmp_cap * 12;
-  HIPCHK(h, h->inv_table.ensure(tbytes));
-  HIPCHK(h, h->inv_ovf.ensure(obytes));
-  HIPCHK(h, hipMemsetAsync(h->inv_table.p, 0, tbytes, st));
-  HIPCHK(h, hipMemsetAsync(h->inv_ovf.p, 0, 64 + (size_t)oslots * 12, st));      // counters, keys, counts
-  char* o = h->inv_ovf.as<char>();
-  h->inv.table = h->inv_table.as<unsigned long long>(); h->inv.cmask = (uint32_t)(cap - 1);
-  h->inv.counters = (unsigned long long*)o;
-  h->inv.ovf_keys = (unsigned long long*)(o + 64);
-  h->inv.ovf_cnt = (uint32_t*)(o + 64 + (size_t)oslots * 8);
-  h->inv.ovf_start = (uint32_t*)(o + 64 + (size_t)oslots * 12);
-  h->inv.ovf_fill = (uint32_t*)(o + 64 + (size_t)oslots * 16);
-  h->inv.ovf_mask = (uint32_t)(oslots - 1);
-  h->inv.tmp = (uint2*)(o + 64 + (size_t)oslots * 20);
-  h->inv.pool = (uint32_t*)(o + 64 + (size_t)oslots * 20 + (size_t)tmp_cap * 8);
-  h->inv.tmp_cap = (uint32_t)tmp_cap;
+  uint32_t lg = 10;
+  while (lg < 21 && (1ULL << lg) < (uint64_t)ne) lg++;
+  const size_t nb = (size_t)1 << lg, stride = (size_t)std::max<int64_t>(ne, 1), tiles = (size_t)index_tiles((int)ne);
+  HIPCHK(h, h->inv_ends.ensure((size_t)H * (nb + 1) * 4));
+  HIPCHK(h, h->inv_items.ensure((size_t)H * stride * 8));
+  HIPCHK(h, h->inv_staged.ensure((size_t)H * stride * 8));
+  HIPCHK(h, h->inv_scratch.ensure((size_t)H * (tiles * 512 + 513) * 4));
+  h->inv.ends = h->inv_ends.as<uint32_t>(); h->inv.items = h->inv_items.as<uint2>(); h->inv.staged = h->inv_staged.as<uint2>();
+  h->inv.tile_counts = h->inv_scratch.as<uint32_t>(); h->inv.bin_start = h->inv.tile_counts + (size_t)H * tiles * 512;
+  h->inv.nb = (uint32_t)nb; h->inv.shift = 32 - lg;
+  h->inv.slot_stride = (uint64_t)stride;
   h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
-  h->inv_finalized = false;
-  h->inv_cap_entries = ne;
   return MHAP_OK;
 }
 
@@ -465,17 +436,6 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     time_end(h);
     DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
-    if (h->eager) {
-      // the postings of this launch group go into the inverted index on a second stream while the ordered-sketch kernel runs
-      HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
-      HIPCHK(h, hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-      time_begin(h, MHAP_K_INDEX_BUILD, h->side_stream);
-      launch_index_build(h->side_stream, d_minhash - h->eager_first * mh_stride, mh_stride, d_meta - h->eager_first * META_W,
-                         (int)(h->eager_first + 2 * B.r0), (int)nstr, H, h->inv);
-      time_end(h, h->side_stream);
-      h->pending_side.push_back(h->pending.back()); h->pending.pop_back();
-      HIPCHK(h, hipEventRecord(h->ev_join, h->side_stream));
-    }
     time_begin(h, MHAP_K_ORDERED);
     launch_ordered(h->stream, dd, nstr, max_len_codes, B.max_len, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
                    ord_rows, ord_stride, meta_rows, META_W);
@@ -545,30 +505,24 @@ struct QuerySide {
 // (re)build the inverted index for the current entries unless the table in place already covers them
 int ensure_inverted_index(mhap_handle* h) {
   const int ne = (int)h->n_entries, H = h->P.num_hashes;
-  if (!(h->inv_ready && h->inv_ne == (int64_t)ne && h->inv_cap_entries >= (int64_t)ne)) {   // (a table sized for more entries than it holds is fine)
-    { const int rr = inv_reset(h, ne, h->stream); if (rr != MHAP_OK) return rr; }
-    const uint32_t cmask = h->inv.cmask;
-    HPROF("index build launch");
-    time_begin(h, MHAP_K_INDEX_BUILD);
-    launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, 0, ne, H, h->inv);
-    time_end(h);
-    HIPCHK(h, hipGetLastError());
-    h->inv_ready = true; h->inv_ne = ne; h->inv_cmask = cmask;
-  }
-  if (!h->inv_finalized) {
-    // every entry is in: lay the overflow postings (values shared by more than a run's cap of entries) out per value
-    unsigned long long ntmp = 0;
-    HIPCHK(h, hipMemcpyAsync(&ntmp, h->inv.counters, 8, hipMemcpyDeviceToHost, h->stream));
+  if (h->inv_ready && h->inv_ne == (int64_t)ne) return MHAP_OK;
+  { const int rr = inv_alloc(h, ne); if (rr != MHAP_OK) return rr; }
+  HPROF("index build launch");
+  time_begin(h, MHAP_K_INDEX_BUILD);
+  launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, H, h->inv);
+  time_end(h);
+  HIPCHK(h, hipGetLastError());
+  if (getenv("MHAP_DEBUG_INDEX")) {   // self-check: every stored (entry, slot) must find its own posting
+    unsigned long long* ctr = h->counters.as<unsigned long long>();
+    unsigned long long missing = 0;
+    HIPCHK(h, hipMemsetAsync(ctr + 15, 0, 8, h->stream));
+    launch_index_verify(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, H, h->inv, ctr + 15);
+    HIPCHK(h, hipMemcpyAsync(&missing, ctr + 15, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (ntmp > 0) {
-      if (ntmp > h->inv.tmp_cap) ntmp = h->inv.tmp_cap;
-      time_begin(h, MHAP_K_INDEX_BUILD);
-      launch_index_finalize(h->stream, h->inv, ntmp);
-      time_end(h);
-      HIPCHK(h, hipGetLastError());
-    }
-    h->inv_finalized = true;
+    fprintf(stderr, "[index] self-check: %llu of %lld postings missing\n", missing, (long long)ne * H);
+    if (missing) return fail(h, MHAP_E_STATE, "inverted index self-check failed");
   }
+  h->inv_ready = true; h->inv_ne = ne;
   return MHAP_OK;
 }
 
@@ -826,9 +780,7 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = std::max(1, prop.multiProcessorCount);
   if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { seterr(hipGetErrorString(e)); delete h; return MHAP_E_HIP; }
   h->stream = h->own_stream;
-  if (hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->mh_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_mh_fork, hipEventDisableTiming) != hipSuccess ||
+  if (hipStreamCreateWithFlags(&h->mh_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_mh_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_mh_join, hipEventDisableTiming) != hipSuccess) { seterr("cannot create the side streams"); mhap_destroy(h); return MHAP_E_HIP; }
   h->Hrow = std::max(1, P.num_hashes);
   int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
@@ -875,13 +827,10 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_table, &h->inv_ovf, &h->inv_big};
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->pin_io) (void)hipHostFree(h->pin_io);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
-  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   if (h->ev_mh_fork) (void)hipEventDestroy(h->ev_mh_fork);
   if (h->ev_mh_join) (void)hipEventDestroy(h->ev_mh_join);
   if (h->mh_stream) (void)hipStreamDestroy(h->mh_stream);
@@ -966,7 +915,7 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   HPROF("finish_add begin");
-  h->inv_ready = false;   // the entry set changes (mhap_index_add_staged re-validates an eagerly built table afterwards)
+  h->inv_ready = false;   // the entry set changes
   h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
   for (int64_t i = 0; i < n; i++) {
     h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
@@ -1008,38 +957,15 @@ int mhap_index_add_staged(mhap_handle* h) {
   if (n <= 0 || (int64_t)h->st_ids.size() != n) return fail(h, MHAP_E_STATE, "no staged reads (call mhap_stage_reads first)");
   if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
   const int64_t first = h->n_entries;
-  // mhap_index_reserve: the tables (and the inverted index below) are sized once for every read that is still to come
+  // mhap_index_reserve: the tables are sized once for every read that is still to come
   const int64_t want_entries = std::max<int64_t>(first + 2 * n, first == 0 ? 2 * h->reserve_reads : 0);
   int rc = ensure_index_capacity(h, want_entries);
   if (rc != MHAP_OK) return rc;
   const int S = h->P.ordered_sketch_size;
-  // the index is filled while its reads are being sketched: the inverted-index inserts of a launch group run on a second stream next
-  // to the group's ordered-sketch kernel.  A fresh index starts a table (sized for the reserved reads); a later add extends the table
-  // in place when it was sized for it and no search has laid its overflow postings out yet; otherwise the table is rebuilt at search time
-  const char* cmode = getenv("MHAP_CANDIDATES");
-  const bool eager_ok = !(cmode && strcmp(cmode, "bruteforce") == 0) && !getenv("MHAP_NO_EAGER_INDEX");
-  const bool extend = eager_ok && first > 0 && h->inv_ready && h->inv_ne == first && !h->inv_finalized && h->inv_cap_entries >= first + 2 * n;
-  h->inv_ready = false;
-  if (eager_ok && first == 0) {
-    { const int rr = inv_reset(h, want_entries, h->side_stream); if (rr != MHAP_OK) return rr; }
-    h->eager = true; h->eager_first = first; h->eager_cmask = h->inv.cmask;
-  } else if (extend) {
-    h->eager = true; h->eager_first = first; h->eager_cmask = h->inv.cmask;
-  }
+  h->inv_ready = false;   // (the inverted index is built by the first search: a sort of all postings, 2 ms per 100 M)
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
-  const bool built = h->eager && rc == MHAP_OK;
-  if (h->eager && rc != MHAP_OK) { (void)hipStreamSynchronize(h->side_stream); for (auto& t : h->pending_side) h->free_events.emplace_back(t.a, t.b); h->pending_side.clear(); }
-  h->eager = false;
   if (rc != MHAP_OK) return rc;
   rc = finish_add(h, first, h->st_ids.data(), n);
-  if (built) {   // join the second stream (its last inserts overlapped the host work above)
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    for (auto& t : h->pending_side) h->pending.push_back(t);
-    h->pending_side.clear();
-    const int rs = sync_stream(h);
-    if (rs != MHAP_OK) return rs;
-    if (rc == MHAP_OK) { h->inv_ready = true; h->inv_ne = h->n_entries; h->inv_cmask = h->eager_cmask; }
-  }
   return rc;
 }
 

@@ -177,116 +177,174 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 }
 
 // =============================================================================================
-// Inverted index on the GPU (the reference's own structure, J/impl/MinHashSearch.java:100-147,161-181):
-// one open-addressing table per MinHash slot holding (value, entry+1) words; entries with equal values sit in
-// one probe run.  A query does H probes and counts hits per stored entry in an LDS count table; the hit count
-// of a pair equals the number of slots with equal values, so the candidate set is identical to the brute-force count.
-// Work ~ N*H probes + hits instead of N*2N*H/2 compares.
+// Inverted index on the GPU (the reference's structure, J/impl/MinHashSearch.java:100-147,161-181: per MinHash slot a map
+// value -> list of stored sequences).  Here: per slot, the postings (mix(value), entry) of all stored entries GROUPED BY BUCKET,
+// bucket = top bits of mix(value) (fmix32, a bijection: equal values <=> equal mixes, and the mixes are uniform whatever the
+// distribution of the minima), plus a table of bucket ends.  One bucket per stored entry (rounded up to a power of two), so a
+// bucket holds 0.5-1 postings on average and a lookup is two dependent loads: the bucket's bounds, then its postings — the ones
+// whose mix equals the query's are the hits.  A query counts hits per stored entry in an LDS count table; the hit count of a pair
+// equals the number of slots with equal values, so the candidate set is identical to the brute-force count.
 //
-// Repeats (the reference keeps value -> ArrayList, :123-141): a value shared by n entries would cost n^2/2 CAS probes to
-// insert into one run, so a run holds at most ~INV_RUN_CAP (16) entries of one value; further entries of that value are counted
-// per (slot, value) in a second hash table and appended to a temporary list — O(1) per insert however popular the value —
-// and index_finalize lays them out contiguously per value (segment from a bump allocator, fill with one atomic each): the
-// reference's value -> postings list as CSR.  A query that finds INV_RUN_CAP entries of its value in the run has its whole
-// wavefront stream the value's segment (coalesced loads, 64 postings per step) instead of one lane chasing pointers.  A query whose distinct hits outgrow the LDS count table is not handed to
-// the brute-force kernel any more: it is re-run in passes over hash-partitions of the stored entries (split in two until
-// every part fits), which bounds its cost by its own postings.
+// Built by a two-level counting sort whose only atomics are in LDS (a global atomic costs this chip ~50 ps of its memory side:
+// 102 M of them at C2 are 4-5 ms per pass, measured with the one-level counting sort that was tried first, 11.2 ms in all):
+//   1. index_hist_kernel     per tile of IB_TE entries x IB_S slots, LDS histogram over the 512 coarse bins (top 9 bits of the mix)
+//   2. index_offsets_kernel  per slot: exclusive scan over (bin, tile) -> where each tile's share of each bin starts
+//   3. index_scatter_kernel  same tiles: postings to their bin (LDS cursors), 64 contiguous bytes per (tile, slot, bin) on average
+//   4. index_bins_kernel     per (slot, bin): the bin's ~ne/512 postings grouped by bucket through an LDS histogram, ends written
+// A value shared by many entries (a repeat) simply makes its bucket long: the postings are contiguous and a workgroup streams them
+// with coalesced loads.  Rounds 1-2 kept an open-addressing table of (value, entry) words per slot with runs of equal values, an
+// overflow pool and a per-value overflow table: 4.3 GB at C2 and 34 GB at C4 against 1.4 / 12.5 GB here (+ the sort's scratch),
+// every insert a CAS chain into a random line, and — what cost the C5 slice 40 of its 54 ms of index_query — a lookup had to walk
+// to the end of its CLUSTER, which the 16-entry runs of popular values made hundreds of words long for some lane of nearly every
+// workgroup (670 loads per wave in the second tier: r03 PMC pass).
 // =============================================================================================
-__device__ inline uint32_t inv_hash(uint32_t v) { return fmix32(v); }
-#ifndef MH_INV_RUN_CAP
-#define MH_INV_RUN_CAP 16
-#endif
-constexpr int INV_RUN_CAP = MH_INV_RUN_CAP;   // a run absorbs the values ordinary coverage shares (30x with 15 % errors: a handful of entries); beyond that a value is a repeat.
-                                               // Measured with 64 / 32 / 16 / 8: C2 and the C4 slice unchanged, C5 slice query 89.7 / 82.1 / 78.2 / 77.3 ms and build 14.3 / 11.0 / 8.8 / 8.6 ms
-                                               // (long runs are walked by ONE lane, and they grow the clusters every other probe has to cross)
+__device__ __forceinline__ uint32_t inv_mix(uint32_t v) { return fmix32(v); }
 
-__device__ inline uint32_t inv_ovf_slot(const InvIndex& ix, unsigned long long key, bool claim) {
-  uint32_t hp = (uint32_t)fmix64(key) & ix.ovf_mask;
-  for (;;) {
-    const unsigned long long old = claim ? atomicCAS(&ix.ovf_keys[hp], 0ULL, key) : ix.ovf_keys[hp];
-    if (old == key || (claim && old == 0ULL)) return hp;
-    if (!claim && old == 0ULL) return 0xFFFFFFFFu;
-    hp = (hp + 1) & ix.ovf_mask;
-  }
-}
-
-__device__ inline void inv_overflow_push(const InvIndex& ix, int s, uint32_t v, int e, unsigned long long* T, uint32_t pos, unsigned long long word) {
-  const unsigned long long t = atomicAdd(&ix.counters[0], 1ULL);
-  if (t >= (unsigned long long)ix.tmp_cap) {
-    // temporary list exhausted (pathological input): keep probing the run uncapped — slower, still exact
-    for (;;) { pos = (pos + 1) & ix.cmask; if (atomicCAS(&T[pos], 0ULL, word) == 0ULL) return; }
-  }
-  const uint32_t hp = inv_ovf_slot(ix, (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL, true);
-  atomicAdd(&ix.ovf_cnt[hp], 1u);
-  ix.tmp[t] = make_uint2(hp, (uint32_t)e);
-}
-
-// Finalize, pass 1: every (slot, value) with overflow postings gets a contiguous segment of the pool.
-__global__ void index_segments_kernel(InvIndex ix) {
-  const uint32_t hp = blockIdx.x * blockDim.x + threadIdx.x;
-  if (hp > ix.ovf_mask) return;
-  const uint32_t c = ix.ovf_cnt[hp];
-  if (c) { ix.ovf_start[hp] = (uint32_t)atomicAdd(&ix.counters[1], (unsigned long long)c); ix.ovf_fill[hp] = 0; }
-}
-// Finalize, pass 2: the temporary (value slot, entry) items go to their segments.
-__global__ void index_fill_kernel(InvIndex ix, unsigned long long n_tmp) {
-  const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_tmp) return;
-  const uint2 it = ix.tmp[t];
-  ix.pool[ix.ovf_start[it.x] + atomicAdd(&ix.ovf_fill[it.x], 1u)] = it.y;
-}
-void launch_index_finalize(hipStream_t st, const InvIndex& ix, unsigned long long n_tmp) {
-  if (n_tmp == 0) return;
-  (void)hipMemsetAsync(&ix.counters[1], 0, 8, st);
-  hipLaunchKernelGGL(index_segments_kernel, dim3((ix.ovf_mask + 256) / 256), dim3(256), 0, st, ix);
-  hipLaunchKernelGGL(index_fill_kernel, dim3((unsigned)((n_tmp + 255) / 256)), dim3(256), 0, st, ix, n_tmp);
-}
-
-constexpr int IB_S = 4, IB_E = 256 / IB_S;   // slots x entries of one workgroup (1x256 / 4x64 / 8x32 / 16x16: 6.2 / 6.1 / 6.3 / 6.5 ms at C2)
-__global__ __launch_bounds__(256) void index_build_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta,
-                                                          int e0, int ne, int H, InvIndex ix) {
-  // slot-group-major order: a workgroup inserts IB_E entries x IB_S slots, and consecutive workgroups walk the entries of one
-  // group of IB_S slots, so only those few tables (8 MB each at C2) are written at a time — they stay in the memory-side cache
-  // instead of every CAS going to a random line of the whole 2.1 GB
-  const int tiles = (ne + IB_E - 1) / IB_E;
+constexpr int IB_BINS_LOG = 9, IB_BINS = 1 << IB_BINS_LOG;   // coarse bins per slot
+constexpr int IB_S = 8;                                      // slots of one workgroup (32 bytes of every MinHash row it reads)
+constexpr int IB_TE = 4096;                                  // entries of one tile
+constexpr int IB_THREADS = 256;
+// Steps 1 and 3.  Slot-group-major grid: consecutive workgroups are the tiles of one group of IB_S slots.
+template <bool SCATTER>
+__global__ __launch_bounds__(IB_THREADS) void index_tile_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta,
+                                                                int ne, int H, int tiles, InvIndex ix) {
+  __shared__ uint32_t bins[IB_S][IB_BINS];
   const int g = (int)(blockIdx.x / (unsigned)tiles), tile = (int)(blockIdx.x % (unsigned)tiles);
-  const int e = e0 + tile * IB_E + (int)(threadIdx.x / IB_S), s = g * IB_S + (int)(threadIdx.x % IB_S);   // entries [e0, e0 + ne) of the tables
-  if (e >= e0 + ne || s >= H) return;
-  if (meta[(int64_t)e * META_W + 3] != 0) return;                       // skipped strands are not stored (addSequence never sees them)
-  const uint32_t v = (uint32_t)minhash[(int64_t)e * row_stride + s];
-  unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
-  const unsigned long long word = ((unsigned long long)v << 32) | (unsigned long long)(uint32_t)(e + 1);
-  uint32_t pos = inv_hash(v) & ix.cmask;
-  int same = 0;
-  for (;;) {
-    const unsigned long long old = atomicCAS(&T[pos], 0ULL, word);
-    if (old == 0ULL) break;
-    if ((uint32_t)(old >> 32) == v && ++same >= INV_RUN_CAP) { inv_overflow_push(ix, s, v, e, T, pos, word); break; }
-    pos = (pos + 1) & ix.cmask;
+  const int sl = (int)(threadIdx.x % IB_S), s = g * IB_S + sl;
+  for (int i = threadIdx.x; i < IB_S * IB_BINS; i += IB_THREADS) {
+    const int ss = g * IB_S + i / IB_BINS;
+    (&bins[0][0])[i] = (SCATTER && ss < H) ? ix.tile_counts[((size_t)ss * tiles + tile) * IB_BINS + (i % IB_BINS)] : 0u;
+  }
+  __syncthreads();
+  if (s < H) {
+    const int e1 = min(ne, (tile + 1) * IB_TE);
+    for (int e = tile * IB_TE + (int)(threadIdx.x / IB_S); e < e1; e += IB_THREADS / IB_S) {
+      if (meta[(int64_t)e * META_W + 3] != 0) continue;                  // skipped strands are not stored (addSequence never sees them)
+      const uint32_t hv = inv_mix((uint32_t)minhash[(int64_t)e * row_stride + s]);
+      const uint32_t at = atomicAdd(&bins[sl][hv >> (32 - IB_BINS_LOG)], 1u);
+      if (SCATTER) ix.staged[(size_t)s * ix.slot_stride + at] = make_uint2(hv, (uint32_t)e);
+    }
+  }
+  if (!SCATTER) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < IB_S * IB_BINS; i += IB_THREADS) {
+      const int ss = g * IB_S + i / IB_BINS;
+      if (ss < H) ix.tile_counts[((size_t)ss * tiles + tile) * IB_BINS + (i % IB_BINS)] = (&bins[0][0])[i];
+    }
   }
 }
 
-void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int e0, int ne, int H, const InvIndex& ix) {
-  const int64_t total = (int64_t)ne * H;
+// Step 2, one workgroup per slot, one thread per bin: tile_counts[s][t][bin] becomes the first posting (within the slot) of tile t's
+// share of the bin; bin_start[s][bin] (IB_BINS + 1 words) the bins' bounds.
+__global__ __launch_bounds__(IB_BINS) void index_offsets_kernel(InvIndex ix, int tiles) {
+  __shared__ uint32_t wsum[IB_BINS / 64];
+  const int s = blockIdx.x, bin = threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t* c = ix.tile_counts + (size_t)s * tiles * IB_BINS + bin;
+  uint32_t total = 0;
+  for (int t = 0; t < tiles; t++) total += c[(size_t)t * IB_BINS];
+  uint32_t incl = total;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  uint32_t run = incl - total;
+  for (int w = 0; w < wv; w++) run += wsum[w];
+  uint32_t* bs = ix.bin_start + (size_t)s * (IB_BINS + 1);
+  bs[bin] = run;
+  if (bin == IB_BINS - 1) bs[IB_BINS] = run + total;
+  for (int t = 0; t < tiles; t++) { const uint32_t v = c[(size_t)t * IB_BINS]; c[(size_t)t * IB_BINS] = run; run += v; }
+}
+
+// Step 4, one workgroup per (slot, bin): the bin's postings move from `staged` to `items` grouped by bucket; the buckets' ends are
+// written (ends[s][0] = 0 by bin 0).  sub = buckets per bin (a power of two, <= IB_SUB_MAX).
+constexpr int IB_SUB_MAX = 4096, IB_FIN_THREADS = 128;
+__global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix) {
+  __shared__ uint32_t cnt[IB_SUB_MAX];
+  __shared__ uint32_t wsum[IB_FIN_THREADS / 64];
+  __shared__ uint32_t s_carry;
+  const int s = blockIdx.x >> IB_BINS_LOG, bin = blockIdx.x & (IB_BINS - 1);
+  const int sub = (int)(ix.nb >> IB_BINS_LOG), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t* bs = ix.bin_start + (size_t)s * (IB_BINS + 1) + bin;
+  const uint32_t lo = bs[0], n = bs[1] - lo;
+  const uint2* in = ix.staged + (size_t)s * ix.slot_stride + lo;
+  uint2* out = ix.items + (size_t)s * ix.slot_stride + lo;
+  uint32_t* ends = ix.ends + (size_t)s * ((size_t)ix.nb + 1) + (size_t)bin * sub + 1;
+  for (int i = threadIdx.x; i < sub; i += IB_FIN_THREADS) cnt[i] = 0;
+  if (threadIdx.x == 0) { s_carry = 0; if (bin == 0) ends[-1] = 0; }
+  __syncthreads();
+  const uint32_t smask = (uint32_t)sub - 1u;
+  for (uint32_t i = threadIdx.x; i < n; i += IB_FIN_THREADS) atomicAdd(&cnt[(in[i].x >> ix.shift) & smask], 1u);
+  __syncthreads();
+  for (int base = 0; base < sub; base += IB_FIN_THREADS) {      // exclusive scan of the counts; ends = inclusive
+    const int i = base + (int)threadIdx.x;
+    const uint32_t v = i < sub ? cnt[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t before = s_carry, total = 0;
+    for (int w = 0; w < IB_FIN_THREADS / 64; w++) { const uint32_t t = wsum[w]; if (w < wv) before += t; total += t; }
+    if (i < sub) { cnt[i] = before + incl - v; ends[i] = lo + before + incl; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry += total;
+    __syncthreads();
+  }
+  for (uint32_t i = threadIdx.x; i < n; i += IB_FIN_THREADS) {
+    const uint2 x = in[i];
+    out[atomicAdd(&cnt[(x.x >> ix.shift) & smask], 1u)] = x;
+  }
+}
+
+// Self-check (MHAP_DEBUG_INDEX=1, tests): every stored (entry, slot) finds its posting in its bucket; counts the ones that do not.
+__global__ void index_verify_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta, int ne, int H, InvIndex ix,
+                                    unsigned long long* __restrict__ missing) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)ne * H) return;
+  const int e = (int)(t / H), s = (int)(t % H);
+  if (meta[(int64_t)e * META_W + 3] != 0) return;
+  const uint32_t hv = inv_mix((uint32_t)minhash[(int64_t)e * row_stride + s]);
+  const uint32_t* E = ix.ends + (size_t)s * ((size_t)ix.nb + 1) + (hv >> ix.shift);
+  const uint2* P = ix.items + (size_t)s * ix.slot_stride;
+  for (uint32_t i = E[0]; i < E[1]; i++) if (P[i].x == hv && P[i].y == (uint32_t)e) return;
+  atomicAdd(missing, 1ULL);
+}
+void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,
+                         unsigned long long* missing) {
+  const long long total = (long long)ne * H;
   if (total <= 0) return;
-  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)(((ne + IB_E - 1) / IB_E) * ((H + IB_S - 1) / IB_S))), dim3(256), 0, st, minhash, row_stride, meta, e0, ne, H, ix);
+  hipLaunchKernelGGL(index_verify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, minhash, row_stride, meta, ne, H, ix, missing);
+}
+
+int index_tiles(int ne) { return (ne + IB_TE - 1) / IB_TE; }
+// (re)build the index for entries [0, ne): ix.ends / items / staged / tile_counts / bin_start sized by the caller (index_tiles)
+void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix) {
+  if ((int64_t)ne * H <= 0) return;
+  const int tiles = index_tiles(ne);
+  const unsigned grid = (unsigned)tiles * (unsigned)((H + IB_S - 1) / IB_S);
+  hipLaunchKernelGGL(index_tile_kernel<false>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
+  hipLaunchKernelGGL(index_offsets_kernel, dim3((unsigned)H), dim3(IB_BINS), 0, st, ix, tiles);
+  hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
+  hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
 }
 
 // One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].
 constexpr int IQ_THREADS = 128;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
-                                  // CU by LDS either way: more probe chains in flight per CU only thrash the memory side)
+                                  // CU by LDS either way: more lookups in flight per CU only thrash the memory side)
 constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
+constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lane that looked it up; longer ones are streamed by the workgroup
 #ifndef MH_IQ_BIG_CT
 #define MH_IQ_BIG_CT 16384
 #endif
 #ifndef MH_IQ_BIG_THREADS
-#define MH_IQ_BIG_THREADS 1024   // 512 / 1024 lanes: 79.0 / 62.8 ms on the C5 slice (one workgroup per CU: more wavefronts hide more of the pool-load and LDS-probe latency)
+#define MH_IQ_BIG_THREADS 1024
 #endif
 constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = MH_IQ_BIG_THREADS;   // second tier: 128 KB count table, one workgroup per CU
-// Two tiers.  <INV_CT, IQ_THREADS> (32 KB of LDS, four workgroups per CU) takes every query; one whose distinct hits outgrow its
-// table (repeats: thousands of stored entries share a MinHash value with the query) is appended to `big` and re-run by
-// <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in one pass; only beyond that a hit set is split into
-// hash-partition passes.  big == nullptr: split right away.
+// Two tiers.  <INV_CT, IQ_THREADS> (32 KB of LDS, four workgroups per CU) takes every query; one whose buckets hold more than four
+// tables' worth of postings (repeats: thousands of stored entries share a MinHash value with the query), or whose distinct hits
+// outgrow the table, is appended to `big` and re-run by <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in
+// one pass; only beyond that a hit set is split into hash-partition passes over the stored entries (split in two until every
+// part fits), which bounds a query's cost by its own postings.  big == nullptr: split right away.
 template <int INV_CT, int IQ_THREADS>
 __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
@@ -301,7 +359,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   __shared__ uint32_t s_distinct, s_over, s_top, s_prefix, s_bits;
   __shared__ uint32_t stack[2 * IQ_STACK];
   __shared__ uint32_t s_nseg[2];
-  __shared__ uint2 seglist[IQ_THREADS];
+  __shared__ uint2 seglist[IQ_THREADS];   // queued long buckets: (first posting within the slot, length),
+  __shared__ uint2 segkey[IQ_THREADS];    // ... (slot, the query's mix there)
   __shared__ unsigned long long segpre[IQ_THREADS + 1];
   __shared__ unsigned long long wsum[IQ_THREADS / 64];
   __shared__ unsigned long long s_base;
@@ -311,6 +370,27 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   const int32_t* qm = qmeta + (int64_t)qe * META_W;
   const int64_t qid = qids[qe];
   const int qlen = qm[2];
+  const int32_t* qrow = qminhash + (int64_t)qe * qrow_stride;
+  const size_t eper = (size_t)ix.nb + 1;
+  if (big != nullptr) {
+    // first tier: the buckets' lengths alone say whether this table can hold the hits — a repeat-rich query is handed over after
+    // H loads instead of after counting until the table overflows
+    unsigned long long tot = 0;
+    for (int s = threadIdx.x; s < sp.H; s += IQ_THREADS) {
+      const uint32_t* E = ix.ends + (size_t)s * eper + (inv_mix((uint32_t)qrow[s]) >> ix.shift);
+      tot += E[1] - E[0];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    tot = 0;
+    for (unsigned w = 0; w < IQ_THREADS / 64; w++) tot += wsum[w];
+    if (tot > 4ULL * INV_CT) {
+      if (threadIdx.x == 0) big[atomicAdd(big_count, 1ULL)] = qe;
+      return;
+    }
+  }
   if (threadIdx.x == 0) { stack[0] = 0; stack[1] = 0; s_top = 1; }
   __syncthreads();
   for (;;) {
@@ -328,9 +408,9 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     const uint32_t pmask = bits >= (uint32_t)MAX_BITS ? (0xFFFFFFFFu >> CT_LOG) : ((1u << bits) - 1u);
     unsigned long long mine = 0;
     // count one hit of stored entry `me` (the id/length rules do not depend on the count: they are applied to the few entries that
-    // reach numMinMatches, below, so that the probe loop's only global loads are the index words)
+    // reach numMinMatches, below, so that the lookup loop's only global loads are the index words)
     auto count_hit = [&](int me) {
-      const uint32_t hm = inv_hash((uint32_t)me);
+      const uint32_t hm = inv_mix((uint32_t)me);
       if (((hm >> CT_LOG) & pmask) != prefix) return;
       uint32_t slot = hm & (INV_CT - 1);
       for (int tries = 0; tries < INV_CT; tries++) {
@@ -348,49 +428,25 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     for (int s0 = 0, it = 0; s0 < sp.H; s0 += IQ_THREADS, it++) {   // workgroup-uniform trip count (barriers inside)
       const int s = s0 + (int)threadIdx.x;
       if (s < sp.H) {
-        const uint32_t v = (uint32_t)qminhash[(int64_t)qe * qrow_stride + s];
-        const unsigned long long* T = ix.table + (size_t)s * ((size_t)ix.cmask + 1);
-        uint32_t pos = inv_hash(v) & ix.cmask;
-        int same = 0;
-        bool open = true;
-        {
-          unsigned long long w[4];                                              // four probe words per round trip to memory
+        const uint32_t hv = inv_mix((uint32_t)qrow[s]);
+        const uint32_t* E = ix.ends + (size_t)s * eper + (hv >> ix.shift);
+        const uint32_t lo = E[0], n = E[1] - lo;
+        if (n > (uint32_t)IQ_INLINE) {
+          // a long bucket (a value many entries share): queued for the whole workgroup (a repeat's bucket holds tens of thousands
+          // of postings: one lane would stream it alone)
+          const uint32_t at = atomicAdd(&s_nseg[it & 1], 1u);
+          seglist[at] = make_uint2(lo, n); segkey[at] = make_uint2((uint32_t)s, hv);
+        } else if (n) {
+          const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
+          uint2 w[4];                                                             // the usual bucket in one round trip
 #pragma unroll
-          for (int u = 0; u < 4; u++) w[u] = T[(pos + (uint32_t)u) & ix.cmask];
-          pos = (pos + 4) & ix.cmask;
+          for (int u = 0; u < 4; u++) w[u] = (uint32_t)u < n ? P[u] : make_uint2(~hv, 0u);
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (!open) break;
-            if (w[u] == 0ULL) { open = false; break; }
-            if ((uint32_t)(w[u] >> 32) != v) continue;
-            same++;
-            if (bits == 0) mine++;                                             // "table elements processed" (:173), counted once
-            count_hit((int)(uint32_t)w[u] - 1);
-          }
-        }
-        while (open) {                                                          // a run that goes on (a value many entries share): 16 words per trip
-          if (big != nullptr && *(volatile uint32_t*)&s_over) break;            // first tier, table already overflowed: the query starts over in the second
-          unsigned long long w[16];
-#pragma unroll
-          for (int u = 0; u < 16; u++) w[u] = T[(pos + (uint32_t)u) & ix.cmask];
-          pos = (pos + 16) & ix.cmask;
-#pragma unroll
-          for (int u = 0; u < 16; u++) {
-            if (!open) break;
-            if (w[u] == 0ULL) { open = false; break; }
-            if ((uint32_t)(w[u] >> 32) != v) continue;
-            same++;
-            if (bits == 0) mine++;
-            count_hit((int)(uint32_t)w[u] - 1);
-          }
-        }
-        if (same >= INV_RUN_CAP) {
-          // the run holds its cap of this value: the rest of the value's entries are a contiguous segment of the overflow pool,
-          // queued for the whole workgroup (a repeat's segment holds tens of thousands of entries: one wave would stream it alone)
-          const uint32_t hp = inv_ovf_slot(ix, (((unsigned long long)(uint32_t)s << 32) | v) + 1ULL, false);
-          if (hp != 0xFFFFFFFFu) {
-            const uint32_t ln = ix.ovf_cnt[hp];
-            if (ln) { seglist[atomicAdd(&s_nseg[it & 1], 1u)] = make_uint2(ix.ovf_start[hp], ln); if (bits == 0) mine += ln; }
+          for (int u = 0; u < 4; u++)
+            if (w[u].x == hv) { if (bits == 0) mine++; count_hit((int)w[u].y); }   // "table elements processed" (:173), counted once
+          for (uint32_t u = 4; u < n; u++) {
+            const uint2 x = P[u];
+            if (x.x == hv) { if (bits == 0) mine++; count_hit((int)x.y); }
           }
         }
       }
@@ -401,10 +457,10 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       __syncthreads();                       // every lane holds the same (nseg, over_now) before anyone counts again
       if (big != nullptr && over_now) { handed_over = true; break; }            // first tier: the query is handed over, stop counting
       if (nseg) {
-        // all queued segments as ONE index space (exclusive prefix of their lengths in segpre): a trip of the loop below has
-        // 8 x IQ_THREADS pool loads in flight whatever the segments' lengths — one segment per trip cost a memory round trip per
-        // segment, and repeat-rich queries queue a hundred short ones
-        // (64-bit sums: a thousand segments of a huge index can hold more than 2^32 postings between them)
+        // all queued buckets as ONE index space (exclusive prefix of their lengths in segpre): a trip of the loop below has
+        // 8 x IQ_THREADS loads in flight whatever the buckets' lengths — one bucket per trip cost a memory round trip per
+        // bucket, and repeat-rich queries queue a hundred short ones
+        // (64-bit sums: a thousand buckets of a huge index can hold more than 2^32 postings between them)
         unsigned long long len = threadIdx.x < nseg ? seglist[threadIdx.x].y : 0u, incl = len;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const unsigned long long v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
@@ -415,29 +471,32 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
         if (threadIdx.x == 0) segpre[nseg] = total;
         __syncthreads();
-        // first tier: segments that hold more than four tables' worth of postings between them (a repeat) will outgrow this table —
-        // hand the query over before streaming them
-        if (big != nullptr && total > 4ULL * INV_CT) { if (threadIdx.x == 0) s_over = 1; handed_over = true; break; }
-        // second tier, whole index, every slot probed: segments with more than twice the table's capacity between them (and an
+        // second tier, whole index, every slot looked up: buckets with more than twice the table's capacity between them (and an
         // index with that many entries) are split before they are streamed: the pass would overflow after streaming everything
-        // (its elements are already counted)
-        if (big == nullptr && bits == 0 && s0 + IQ_THREADS >= sp.H && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; break; }
-        uint32_t g = 0;   // segment of this lane's current element (its elements come in ascending order)
+        // (the postings are still streamed, to count the ones that match — "table elements processed" — but no hit is counted)
+        bool count_only = false;
+        if (big == nullptr && bits == 0 && s0 + IQ_THREADS >= sp.H && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; count_only = true; }
+        uint32_t g = 0;   // bucket of this lane's current posting (its postings come in ascending order)
         for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
-          uint32_t e[8];
+          uint2 e[8];
+          uint32_t want[8];
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             const unsigned long long i = i0 + (unsigned long long)IQ_THREADS * u;
-            e[u] = 0xFFFFFFFFu;
+            e[u] = make_uint2(0u, 0u); want[u] = 1u;                               // (never equal)
             if (i < total) {
               while (i >= segpre[g + 1]) g++;
-              e[u] = ix.pool[(size_t)seglist[g].x + (size_t)(i - segpre[g])];
+              const uint2 key = segkey[g];
+              e[u] = ix.items[(size_t)key.x * ix.slot_stride + (size_t)seglist[g].x + (size_t)(i - segpre[g])];
+              want[u] = key.y;
             }
           }
 #pragma unroll
           for (int u = 0; u < 8; u++)
-            if (e[u] != 0xFFFFFFFFu) count_hit((int)e[u]);
+            if (e[u].x == want[u]) { if (bits == 0) mine++; if (!count_only) count_hit((int)e[u].y); }
         }
+        if (count_only) break;
+        __syncthreads();         // the queue is reused by the next trip's lookups
       }
     }
     (void)handed_over;
