@@ -102,15 +102,17 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 struct InvIndex {
   uint32_t* ends;        // [H][nb + 1]: postings of bucket b of slot s are items[s][ends[s][b] .. ends[s][b + 1]), ends[s][0] = 0
   uint2* items;          // [H][slot_stride]: (mix of the value, entry), grouped by bucket
-  uint32_t nb, shift;    // buckets per slot (a power of two, 1024 .. 2^21), bucket = mix >> shift
+  uint32_t nb, shift;    // buckets per slot (a power of two, 1024 .. 2^20), bucket = mix >> shift
   uint64_t slot_stride;  // postings one slot has room for
   uint32_t ne;           // entries the index was sized for (an upper bound of any query's distinct hits)
   // scratch of the build
   uint2* staged;         // [H][slot_stride]: the postings grouped by coarse bin
-  uint32_t* tile_counts; // [H][tiles][512]
-  uint32_t* bin_start;   // [H][513]
+  uint32_t* tile_counts; // [H][tiles][coarse bins]
+  uint32_t* bin_start;   // [H][coarse bins + 1]
 };
 int index_tiles(int ne);
+int index_coarse_bins();
+int index_max_buckets_log();
 void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,
                          unsigned long long* missing);   // self-check: postings that are not where a lookup would find them
 void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix);

@@ -289,14 +289,14 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
 static int inv_alloc(mhap_handle* h, int64_t ne) {
   const int H = h->P.num_hashes;
   uint32_t lg = 10;
-  while (lg < 21 && (1ULL << lg) < (uint64_t)ne) lg++;
-  const size_t nb = (size_t)1 << lg, stride = (size_t)std::max<int64_t>(ne, 1), tiles = (size_t)index_tiles((int)ne);
+  while (lg < (uint32_t)index_max_buckets_log() && (1ULL << lg) < (uint64_t)ne) lg++;
+  const size_t nb = (size_t)1 << lg, stride = (size_t)std::max<int64_t>(ne, 1), tiles = (size_t)index_tiles((int)ne), cb = (size_t)index_coarse_bins();
   HIPCHK(h, h->inv_ends.ensure((size_t)H * (nb + 1) * 4));
   HIPCHK(h, h->inv_items.ensure((size_t)H * stride * 8));
   HIPCHK(h, h->inv_staged.ensure((size_t)H * stride * 8));
-  HIPCHK(h, h->inv_scratch.ensure((size_t)H * (tiles * 512 + 513) * 4));
+  HIPCHK(h, h->inv_scratch.ensure((size_t)H * (tiles * cb + cb + 1) * 4));
   h->inv.ends = h->inv_ends.as<uint32_t>(); h->inv.items = h->inv_items.as<uint2>(); h->inv.staged = h->inv_staged.as<uint2>();
-  h->inv.tile_counts = h->inv_scratch.as<uint32_t>(); h->inv.bin_start = h->inv.tile_counts + (size_t)H * tiles * 512;
+  h->inv.tile_counts = h->inv_scratch.as<uint32_t>(); h->inv.bin_start = h->inv.tile_counts + (size_t)H * tiles * cb;
   h->inv.nb = (uint32_t)nb; h->inv.shift = 32 - lg;
   h->inv.slot_stride = (uint64_t)stride;
   h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
@@ -513,6 +513,7 @@ int ensure_inverted_index(mhap_handle* h) {
   time_end(h);
   HIPCHK(h, hipGetLastError());
   if (getenv("MHAP_DEBUG_INDEX")) {   // self-check: every stored (entry, slot) must find its own posting
+    HIPCHK(h, h->counters.ensure(256));
     unsigned long long* ctr = h->counters.as<unsigned long long>();
     unsigned long long missing = 0;
     HIPCHK(h, hipMemsetAsync(ctr + 15, 0, 8, h->stream));

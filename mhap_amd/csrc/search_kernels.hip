@@ -187,10 +187,10 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 //
 // Built by a two-level counting sort whose only atomics are in LDS (a global atomic costs this chip ~50 ps of its memory side:
 // 102 M of them at C2 are 4-5 ms per pass, measured with the one-level counting sort that was tried first, 11.2 ms in all):
-//   1. index_hist_kernel     per tile of IB_TE entries x IB_S slots, LDS histogram over the 512 coarse bins (top 9 bits of the mix)
+//   1. index_tile_kernel<0>  per tile of IB_TE entries x IB_S slots, LDS histogram over the 128 coarse bins (top 7 bits of the mix)
 //   2. index_offsets_kernel  per slot: exclusive scan over (bin, tile) -> where each tile's share of each bin starts
-//   3. index_scatter_kernel  same tiles: postings to their bin (LDS cursors), 64 contiguous bytes per (tile, slot, bin) on average
-//   4. index_bins_kernel     per (slot, bin): the bin's ~ne/512 postings grouped by bucket through an LDS histogram, ends written
+//   3. index_tile_kernel<1>  same tiles: postings to their bin (LDS cursors), 256 contiguous bytes per (tile, slot, bin) on average
+//   4. index_bins_kernel     per (slot, bin): the bin's ~ne/128 postings grouped by bucket through an LDS histogram, ends written
 // A value shared by many entries (a repeat) simply makes its bucket long: the postings are contiguous and a workgroup streams them
 // with coalesced loads.  Rounds 1-2 kept an open-addressing table of (value, entry) words per slot with runs of equal values, an
 // overflow pool and a per-value overflow table: 4.3 GB at C2 and 34 GB at C4 against 1.4 / 12.5 GB here (+ the sort's scratch),
@@ -200,7 +200,12 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // =============================================================================================
 __device__ __forceinline__ uint32_t inv_mix(uint32_t v) { return fmix32(v); }
 
-constexpr int IB_BINS_LOG = 9, IB_BINS = 1 << IB_BINS_LOG;   // coarse bins per slot
+#ifndef MH_IB_BINS_LOG
+#define MH_IB_BINS_LOG 7
+#endif
+constexpr int IB_BINS_LOG = MH_IB_BINS_LOG, IB_BINS = 1 << IB_BINS_LOG;   // coarse bins per slot: a tile's share of a bin is IB_TE / IB_BINS postings = 256
+                                                                          // contiguous bytes (512 bins, 64-byte shares: the scatter took 2.6 ms at C2, its
+                                                                          // half-written lines leaving the L2 before their neighbours arrived)
 constexpr int IB_S = 8;                                      // slots of one workgroup (32 bytes of every MinHash row it reads)
 constexpr int IB_TE = 4096;                                  // entries of one tile
 constexpr int IB_THREADS = 256;
@@ -257,7 +262,7 @@ __global__ __launch_bounds__(IB_BINS) void index_offsets_kernel(InvIndex ix, int
 
 // Step 4, one workgroup per (slot, bin): the bin's postings move from `staged` to `items` grouped by bucket; the buckets' ends are
 // written (ends[s][0] = 0 by bin 0).  sub = buckets per bin (a power of two, <= IB_SUB_MAX).
-constexpr int IB_SUB_MAX = 4096, IB_FIN_THREADS = 128;
+constexpr int IB_SUB_MAX = 8192, IB_FIN_THREADS = 256;
 __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix) {
   __shared__ uint32_t cnt[IB_SUB_MAX];
   __shared__ uint32_t wsum[IB_FIN_THREADS / 64];
@@ -317,6 +322,8 @@ void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_str
 }
 
 int index_tiles(int ne) { return (ne + IB_TE - 1) / IB_TE; }
+int index_coarse_bins() { return IB_BINS; }
+int index_max_buckets_log() { return IB_BINS_LOG + 13; }   // IB_SUB_MAX buckets per coarse bin
 // (re)build the index for entries [0, ne): ix.ends / items / staged / tile_counts / bin_start sized by the caller (index_tiles)
 void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix) {
   if ((int64_t)ne * H <= 0) return;
@@ -332,6 +339,10 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 constexpr int IQ_THREADS = 128;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
                                   // CU by LDS either way: more lookups in flight per CU only thrash the memory side)
 constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
+#ifndef MH_IQ_SPT
+#define MH_IQ_SPT 1   // 1 / 2 / 4 at C2: 4.7 / 4.7 / 5.7 ms (4 costs a workgroup per CU its LDS queue; the memory side, not the latency, bounds the lookups)
+#endif
+constexpr int IQ_SPT = MH_IQ_SPT;   // slots a lane of the first tier looks up per trip (their loads are in flight together)
 constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lane that looked it up; longer ones are streamed by the workgroup
 #ifndef MH_IQ_BIG_CT
 #define MH_IQ_BIG_CT 16384
@@ -345,7 +356,7 @@ constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = 
 // outgrow the table, is appended to `big` and re-run by <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in
 // one pass; only beyond that a hit set is split into hash-partition passes over the stored entries (split in two until every
 // part fits), which bounds a query's cost by its own postings.  big == nullptr: split right away.
-template <int INV_CT, int IQ_THREADS>
+template <int INV_CT, int IQ_THREADS, int SPT>
 __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
@@ -359,9 +370,10 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   __shared__ uint32_t s_distinct, s_over, s_top, s_prefix, s_bits;
   __shared__ uint32_t stack[2 * IQ_STACK];
   __shared__ uint32_t s_nseg[2];
-  __shared__ uint2 seglist[IQ_THREADS];   // queued long buckets: (first posting within the slot, length),
-  __shared__ uint2 segkey[IQ_THREADS];    // ... (slot, the query's mix there)
-  __shared__ unsigned long long segpre[IQ_THREADS + 1];
+  constexpr int QCAP = IQ_THREADS * SPT;   // a trip looks SPT slots per lane up (their loads in flight together) and may queue as many buckets
+  __shared__ uint2 seglist[QCAP];         // queued long buckets: (first posting within the slot, length),
+  __shared__ uint2 segkey[QCAP];          // ... (slot, the query's mix there)
+  __shared__ unsigned long long segpre[QCAP + 1];
   __shared__ unsigned long long wsum[IQ_THREADS / 64];
   __shared__ unsigned long long s_base;
   const int qi = blockIdx.x;
@@ -425,28 +437,42 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       }
     };
     bool handed_over = false;
-    for (int s0 = 0, it = 0; s0 < sp.H; s0 += IQ_THREADS, it++) {   // workgroup-uniform trip count (barriers inside)
-      const int s = s0 + (int)threadIdx.x;
-      if (s < sp.H) {
-        const uint32_t hv = inv_mix((uint32_t)qrow[s]);
-        const uint32_t* E = ix.ends + (size_t)s * eper + (hv >> ix.shift);
-        const uint32_t lo = E[0], n = E[1] - lo;
-        if (n > (uint32_t)IQ_INLINE) {
+    for (int s0 = 0, it = 0; s0 < sp.H; s0 += QCAP, it++) {   // workgroup-uniform trip count (barriers inside)
+      uint32_t hv[SPT], lo[SPT], n[SPT];
+#pragma unroll
+      for (int u = 0; u < SPT; u++) {
+        const int s = s0 + u * IQ_THREADS + (int)threadIdx.x;
+        hv[u] = 0; lo[u] = 0; n[u] = 0;
+        if (s < sp.H) {
+          hv[u] = inv_mix((uint32_t)qrow[s]);
+          const uint32_t* E = ix.ends + (size_t)s * eper + (hv[u] >> ix.shift);
+          lo[u] = E[0]; n[u] = E[1] - lo[u];
+        }
+      }
+      uint2 w[SPT][4];                                                           // the usual bucket in one round trip
+#pragma unroll
+      for (int u = 0; u < SPT; u++) {
+        const uint2* P = ix.items + (size_t)(s0 + u * IQ_THREADS + (int)threadIdx.x) * ix.slot_stride + lo[u];
+        const uint32_t m = n[u] <= (uint32_t)IQ_INLINE ? n[u] : 0u;
+#pragma unroll
+        for (int x = 0; x < 4; x++) w[u][x] = (uint32_t)x < m ? P[x] : make_uint2(~hv[u], 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < SPT; u++) {
+        const int s = s0 + u * IQ_THREADS + (int)threadIdx.x;
+        if (n[u] > (uint32_t)IQ_INLINE) {
           // a long bucket (a value many entries share): queued for the whole workgroup (a repeat's bucket holds tens of thousands
           // of postings: one lane would stream it alone)
           const uint32_t at = atomicAdd(&s_nseg[it & 1], 1u);
-          seglist[at] = make_uint2(lo, n); segkey[at] = make_uint2((uint32_t)s, hv);
-        } else if (n) {
-          const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
-          uint2 w[4];                                                             // the usual bucket in one round trip
+          seglist[at] = make_uint2(lo[u], n[u]); segkey[at] = make_uint2((uint32_t)s, hv[u]);
+        } else if (n[u]) {
 #pragma unroll
-          for (int u = 0; u < 4; u++) w[u] = (uint32_t)u < n ? P[u] : make_uint2(~hv, 0u);
-#pragma unroll
-          for (int u = 0; u < 4; u++)
-            if (w[u].x == hv) { if (bits == 0) mine++; count_hit((int)w[u].y); }   // "table elements processed" (:173), counted once
-          for (uint32_t u = 4; u < n; u++) {
-            const uint2 x = P[u];
-            if (x.x == hv) { if (bits == 0) mine++; count_hit((int)x.y); }
+          for (int x = 0; x < 4; x++)
+            if (w[u][x].x == hv[u]) { if (bits == 0) mine++; count_hit((int)w[u][x].y); }   // "table elements processed" (:173), counted once
+          const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo[u];
+          for (uint32_t x = 4; x < n[u]; x++) {
+            const uint2 y = P[x];
+            if (y.x == hv[u]) { if (bits == 0) mine++; count_hit((int)y.y); }
           }
         }
       }
@@ -461,21 +487,26 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         // 8 x IQ_THREADS loads in flight whatever the buckets' lengths — one bucket per trip cost a memory round trip per
         // bucket, and repeat-rich queries queue a hundred short ones
         // (64-bit sums: a thousand buckets of a huge index can hold more than 2^32 postings between them)
-        unsigned long long len = threadIdx.x < nseg ? seglist[threadIdx.x].y : 0u, incl = len;
+        unsigned long long lens[SPT], len = 0;                                    // lane t holds buckets t * SPT .. t * SPT + SPT - 1
+#pragma unroll
+        for (int u = 0; u < SPT; u++) { const uint32_t q = threadIdx.x * SPT + u; lens[u] = q < nseg ? seglist[q].y : 0u; len += lens[u]; }
+        unsigned long long incl = len;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { const unsigned long long v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
         if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
         __syncthreads();
         unsigned long long wbase = 0, total = 0;
         for (unsigned w = 0; w < IQ_THREADS / 64; w++) { const unsigned long long t = wsum[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
-        if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
+        unsigned long long run = wbase + incl - len;
+#pragma unroll
+        for (int u = 0; u < SPT; u++) { const uint32_t q = threadIdx.x * SPT + u; if (q < nseg) segpre[q] = run; run += lens[u]; }
         if (threadIdx.x == 0) segpre[nseg] = total;
         __syncthreads();
         // second tier, whole index, every slot looked up: buckets with more than twice the table's capacity between them (and an
         // index with that many entries) are split before they are streamed: the pass would overflow after streaming everything
         // (the postings are still streamed, to count the ones that match — "table elements processed" — but no hit is counted)
         bool count_only = false;
-        if (big == nullptr && bits == 0 && s0 + IQ_THREADS >= sp.H && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; count_only = true; }
+        if (big == nullptr && bits == 0 && s0 + QCAP >= sp.H && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; count_only = true; }
         uint32_t g = 0;   // bucket of this lane's current posting (its postings come in ascending order)
         for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
           uint2 e[8];
@@ -552,6 +583,144 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   }
 }
 
+// Second tier: DENSE counts.  A query the first tier hands over has thousands of distinct hits — on repeat-rich reads most of the
+// index — and a hash table of them in LDS (rounds 1-2: 12 288 entries, beyond that hash-partition passes that each stream all of
+// the query's postings again; 21 190 splits per step on the C5 slice) is the wrong structure: 128 KB of LDS hold a saturating
+// 16-bit counter for each of 65 536 stored entries, indexed by the entry itself — no keys, no probing, no overflow.  An index
+// with more entries is covered in passes over entry ranges of 65 536; the first pass notes which ranges the query's postings
+// fall into and the others are skipped.
+constexpr int DQ_THREADS = 1024, DQ_RANGE_LOG = 16, DQ_MAX_RANGES = 4096;   // (an index of more than 4096 ranges = 2^28 entries runs every pass)
+__global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
+                                                                       const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
+                                                                       const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
+                                                                       const int32_t* __restrict__ qmeta, SearchParams sp, Candidate* __restrict__ cand,
+                                                                       unsigned long long* __restrict__ cand_count, unsigned long long cand_cap,
+                                                                       unsigned long long* __restrict__ split_count, unsigned long long* __restrict__ elements) {
+  __shared__ uint32_t cnt[1 << (DQ_RANGE_LOG - 1)];     // two counters per word
+  __shared__ uint2 seglist[DQ_THREADS];                 // queued long buckets: (first posting within the slot, length),
+  __shared__ uint2 segkey[DQ_THREADS];                  // ... (slot, the query's mix there)
+  __shared__ unsigned long long segpre[DQ_THREADS + 1];
+  __shared__ unsigned long long wsum[DQ_THREADS / 64];
+  __shared__ uint32_t rmask[DQ_MAX_RANGES / 32];        // ranges of stored entries the query's postings fall into
+  __shared__ uint32_t s_nseg[2], s_emit;
+  __shared__ unsigned long long s_base;
+  const int qi = blockIdx.x;
+  if (qi >= nq) return;
+  const int qe = qlist[qi];
+  const int32_t* qm = qmeta + (int64_t)qe * META_W;
+  const int64_t qid = qids[qe];
+  const int qlen = qm[2];
+  const int32_t* qrow = qminhash + (int64_t)qe * qrow_stride;
+  const size_t eper = (size_t)ix.nb + 1;
+  const uint32_t npass = (ix.ne + (1u << DQ_RANGE_LOG) - 1) >> DQ_RANGE_LOG;
+  const uint32_t sat = (uint32_t)(sp.num_min_matches < 0xF000 ? (sp.num_min_matches > 0 ? sp.num_min_matches : 1) : 0xF000);   // counts stop here
+  for (int j = threadIdx.x; j < DQ_MAX_RANGES / 32; j += DQ_THREADS) rmask[j] = 0;
+  unsigned long long mine = 0;
+  for (uint32_t pass = 0; pass < npass; pass++) {
+    __syncthreads();
+    if (pass > 0 && !((rmask[(pass >> 5) & (DQ_MAX_RANGES / 32 - 1)] >> (pass & 31)) & 1u) && npass <= (uint32_t)DQ_MAX_RANGES) continue;   // (uniform)
+    for (int j = threadIdx.x; j < (1 << (DQ_RANGE_LOG - 1)); j += DQ_THREADS) cnt[j] = 0;
+    if (threadIdx.x == 0) { s_nseg[0] = 0; s_nseg[1] = 0; s_emit = 0; }
+    __syncthreads();
+    // one hit of stored entry `me`: the counter is read first and left alone once it has reached numMinMatches, so it can pass
+    // that by no more than the adds in flight (8 x 1024) and never carries into its neighbour
+#define DQ_COUNT_HIT(me_)                                                                                             \
+    do {                                                                                                              \
+      const uint32_t me = (me_);                                                                                      \
+      if (pass == 0) { mine++; const uint32_t r = me >> DQ_RANGE_LOG; if (r) atomicOr(&rmask[(r >> 5) & (DQ_MAX_RANGES / 32 - 1)], 1u << (r & 31)); }   \
+      if ((me >> DQ_RANGE_LOG) == pass) {                                                                             \
+        const uint32_t wi = (me & ((1u << DQ_RANGE_LOG) - 1)) >> 1;                                                   \
+        const int sh = (int)(me & 1u) * 16;                                                                           \
+        if (((__hip_atomic_load(&cnt[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> sh) & 0xFFFFu) < sat) atomicAdd(&cnt[wi], 1u << sh);   \
+      }                                                                                                               \
+    } while (0)
+    for (int s0 = 0, it = 0; s0 < sp.H; s0 += DQ_THREADS, it++) {   // workgroup-uniform trip count (barriers inside)
+      const int s = s0 + (int)threadIdx.x;
+      if (s < sp.H) {
+        const uint32_t hv = inv_mix((uint32_t)qrow[s]);
+        const uint32_t* E = ix.ends + (size_t)s * eper + (hv >> ix.shift);
+        const uint32_t lo = E[0], n = E[1] - lo;
+        if (n > (uint32_t)IQ_INLINE) {
+          const uint32_t at = atomicAdd(&s_nseg[it & 1], 1u);
+          seglist[at] = make_uint2(lo, n); segkey[at] = make_uint2((uint32_t)s, hv);
+        } else {
+          const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
+          for (uint32_t u = 0; u < n; u++) { const uint2 x = P[u]; if (x.x == hv) DQ_COUNT_HIT(x.y); }
+        }
+      }
+      __syncthreads();
+      const uint32_t nseg = s_nseg[it & 1];
+      if (threadIdx.x == 0) s_nseg[(it + 1) & 1] = 0;
+      __syncthreads();
+      if (nseg) {
+        // all queued buckets as ONE index space (exclusive prefix of their lengths in segpre): a trip of the loop below has
+        // 8 x 1024 loads in flight whatever the buckets' lengths
+        unsigned long long len = threadIdx.x < nseg ? seglist[threadIdx.x].y : 0u, incl = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned long long v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned long long wbase = 0, total = 0;
+        for (unsigned w = 0; w < DQ_THREADS / 64; w++) { const unsigned long long t = wsum[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
+        if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
+        if (threadIdx.x == 0) segpre[nseg] = total;
+        __syncthreads();
+        uint32_t g = 0;   // bucket of this lane's current posting (its postings come in ascending order)
+        for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += DQ_THREADS * 8) {
+          uint2 e[8];
+          uint32_t want[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const unsigned long long i = i0 + (unsigned long long)DQ_THREADS * u;
+            e[u] = make_uint2(0u, 0u); want[u] = 1u;                               // (never equal)
+            if (i < total) {
+              while (i >= segpre[g + 1]) g++;
+              const uint2 key = segkey[g];
+              e[u] = ix.items[(size_t)key.x * ix.slot_stride + (size_t)seglist[g].x + (size_t)(i - segpre[g])];
+              want[u] = key.y;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++)
+            if (e[u].x == want[u]) DQ_COUNT_HIT(e[u].y);
+        }
+        __syncthreads();         // the queue is reused by the next trip's lookups
+      }
+    }
+#undef DQ_COUNT_HIT
+    __syncthreads();
+    if (pass == 0 && mine) atomicAdd(elements, mine);           // "table elements processed" (:173), counted once
+    if (pass > 0 && threadIdx.x == 0) atomicAdd(split_count, 1ULL);   // a pass beyond the first = the hit set was split
+    // emit this range's candidates as ONE contiguous block (one global atomic)
+    constexpr int PER = (1 << DQ_RANGE_LOG) / DQ_THREADS;      // 64 entries per lane: lane t owns entries t * 64 .. t * 64 + 63 of the range
+    unsigned long long mymask = 0;
+    int mycount = 0;
+#pragma unroll 4
+    for (int j = 0; j < PER / 2; j++) {
+      const uint32_t w = cnt[threadIdx.x * (PER / 2) + j];
+#pragma unroll
+      for (int hf = 0; hf < 2; hf++) {
+        if ((int)((w >> (16 * hf)) & 0xFFFFu) >= sp.num_min_matches) {                             // MinHashSearch.java:204
+          const uint32_t me = (pass << DQ_RANGE_LOG) + threadIdx.x * PER + 2 * j + hf;
+          if (me < ix.ne && pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1ULL << (2 * j + hf); mycount++; }   // :200-225
+        }
+      }
+    }
+    uint32_t local = 0;
+    if (mycount) local = atomicAdd(&s_emit, (uint32_t)mycount);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(cand_count, (unsigned long long)s_emit) : 0ULL;
+    __syncthreads();
+    unsigned long long slot = s_base + local;
+    while (mymask) {
+      const int b = __builtin_ctzll(mymask);
+      mymask &= mymask - 1;
+      if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)((pass << DQ_RANGE_LOG) + threadIdx.x * PER + b); }
+      slot++;
+    }
+  }
+}
+
 bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
 
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
@@ -560,11 +729,11 @@ void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminh
                         unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, bool big_tier) {
   if (nq <= 0) return;
   if (!big_tier)
-    hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
+    hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
                        meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
   else
-    hipLaunchKernelGGL((index_query_kernel<INV_CT_BIG, IQ_THREADS_BIG>), dim3((unsigned)nq), dim3(IQ_THREADS_BIG), 0, st, ix, qminhash, qrow_stride, qlist, nq,
-                       ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, nullptr, nullptr);
+    hipLaunchKernelGGL(index_query_dense_kernel, dim3((unsigned)nq), dim3(DQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids, meta, qmeta, sp,
+                       cand, cand_count, cand_cap, split_count, elements);
 }
 
 // =============================================================================================

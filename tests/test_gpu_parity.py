@@ -242,7 +242,7 @@ def test_index_export_roundtrip_and_query_sharding():
         again2 = sorted(mhap_amd.records_to_lines(ms2.find_matches(0, 60))) + sorted(mhap_amd.records_to_lines(ms2.find_matches(60, -1)))
         kt = ms2.kernel_times()
     assert again == full and len(full) > 50 and sorted(again2) == full
-    assert kt["index_build"]["launches"] in (1, 2) and kt["index_query"]["launches"] == 3   # (2: + the overflow-segment layout pass)
+    assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 3
 
 
 def test_group_of_ranks_on_one_device_matches_the_oracle():
@@ -467,11 +467,12 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     assert sa["candidates_compared"] == sb["candidates_compared"]
 
 
-def test_index_query_second_tier_splits_huge_hit_sets(monkeypatch):
+def test_index_query_tiers_on_huge_hit_sets(monkeypatch):
     """14 000 crafted entries that all share the values of two MinHash slots (2 hits < numMinMatches: counted, never a candidate)
-    plus 40 identical entries: every query's hit set holds 14 000 distinct entries — over the second tier's 16384-entry table at
-    its 3/4 fill limit — so it is split into hash-partition passes there; candidates and records equal the all-pairs path's and
-    the processed-elements statistic equals its closed form."""
+    plus 40 identical entries: every query's hit set holds 14 000 distinct entries.  The first tier hands such a query to the
+    second, whose dense counters (one per stored entry) take it in one pass; with the second tier switched off
+    (MHAP_INDEX_TIERS=1) the first splits the hit set into hash-partition passes.  Candidates and records equal the all-pairs
+    path's either way and the processed-elements statistic equals its closed form."""
     fa = mhap_amd.synth_reads(1, 1500, seed=3, error_rate=0.0)
     p = MhapParams(num_hashes=16, ordered_sketch_size=32, min_olap_length=50)
     with MinHashSearch(p) as ms:
@@ -489,18 +490,61 @@ def test_index_query_second_tier_splits_huge_hit_sets(monkeypatch):
           "minhash": mh, "ordered": np.repeat(base["ordered"][:1], n, axis=0), "ordered_size": np.repeat(base["ordered_size"][:1], n),
           "ordered_seqlen": np.repeat(base["ordered_seqlen"][:1], n)}
     out = {}
-    for mode in ("index", "bruteforce"):
+    for mode in ("index", "first-tier-only", "bruteforce"):
         if mode == "bruteforce":
             monkeypatch.setenv("MHAP_CANDIDATES", "bruteforce")
+        if mode == "first-tier-only":
+            monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
         with MinHashSearch(p) as ms:
             ms.add_sketches(sk)
             out[mode] = (_sorted_records(ms.find_matches()), ms.stats())
+        monkeypatch.delenv("MHAP_INDEX_TIERS", raising=False)
     monkeypatch.delenv("MHAP_CANDIDATES")
-    (ri, si), (rb, sb) = out["index"], out["bruteforce"]
-    assert np.array_equal(ri, rb) and len(ri) == ncopy * (ncopy - 1) // 2
-    assert si["index_splits"] > 0 and si["slot_compares"] == 0 and sb["slot_compares"] > 0
-    assert si["candidates_compared"] == sb["candidates_compared"] == ncopy * (ncopy - 1) // 2
-    assert si["table_elements"] == 2 * n * n + 14 * (ncopy * ncopy + (n - ncopy))
+    (ri, si), (r1, s1), (rb, sb) = out["index"], out["first-tier-only"], out["bruteforce"]
+    assert np.array_equal(ri, rb) and np.array_equal(r1, rb) and len(ri) == ncopy * (ncopy - 1) // 2
+    assert si["index_splits"] == 0 and s1["index_splits"] > 0 and si["slot_compares"] == 0 and sb["slot_compares"] > 0
+    assert si["candidates_compared"] == s1["candidates_compared"] == sb["candidates_compared"] == ncopy * (ncopy - 1) // 2
+    want_elements = 2 * n * n + 14 * (ncopy * ncopy + (n - ncopy))
+    assert si["table_elements"] == want_elements and s1["table_elements"] == want_elements
+
+
+def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
+    """A repeat-rich sample (the C5 slice's generator: a 300-bp repeat family planted every 3 kb) with more than 65 536 stored
+    entries: the second tier's dense counters cover the index in two entry ranges.  Records equal the first-tier-only path's
+    (hash-partition passes), the index finds every posting where a lookup expects it (MHAP_DEBUG_INDEX self-check), and the
+    processed-elements statistic equals an independent count from the exported MinHash rows."""
+    from mhap_amd import workloads as W
+    import tempfile, os
+    n = 34000
+    fa = W.config_reads("c5slice", shard=0, nshards=1, reads=n, length=2000, error_rate=0.15)
+    path = os.path.join(tempfile.mkdtemp(), "kmers.txt")
+    W.write_filter_file(fa, path, max_reads=2000)
+    flt = mhap_amd.FrequencyCounts.from_file(path, filter_cutoff=1e-5, repeat_weight=0.9)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=256)
+    monkeypatch.setenv("MHAP_DEBUG_INDEX", "1")
+    out = {}
+    for mode in ("tiers", "first-tier-only"):
+        if mode == "first-tier-only":
+            monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
+        with MinHashSearch(p, kmer_filter=flt) as ms:
+            ms.add_data(fa)
+            recs = _sorted_records(ms.find_matches())
+            st = ms.stats()
+            if mode == "tiers":
+                assert ms.size() == 2 * n > 65536
+                sk = ms.export()
+        out[mode] = (recs, st)
+    monkeypatch.delenv("MHAP_INDEX_TIERS")
+    stored = sk["status"] == 0
+    query = stored & (sk["is_fwd"] != 0)
+    want = 0
+    for s in range(sk["minhash"].shape[1]):
+        vals, cnt = np.unique(sk["minhash"][stored, s], return_counts=True)
+        want += int(cnt[np.searchsorted(vals, sk["minhash"][query, s])].sum())
+    (ra, sa), (rb, sb) = out["tiers"], out["first-tier-only"]
+    assert np.array_equal(ra, rb) and len(ra) > 1000
+    assert sa["table_elements"] == want == sb["table_elements"]
+    assert sa["index_splits"] > 0          # a second entry range was needed for some query
 
 
 def test_inverted_index_with_a_shared_repeat():
