@@ -273,11 +273,30 @@ def main():
                 "ceiling_spec_steps_per_s": round(ceil_spec, 1), "frac_of_spec_ceiling": round(xs_rate / ceil_spec, 4),
                 "ceiling_measured_clock_steps_per_s": round(ceil_meas, 1), "frac_of_measured_ceiling": round(xs_rate / ceil_meas, 4),
                 "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes): one step of 32 chains is 107 full-rate ops "
-                                "(43 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32) + 9 ops of depth filter + ~4 of compare/loop = 120.  Spec "
+                                "(43 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32) + 10 v_bitop3_b32 of depth filter + 3 of compare/loop = 120 (the compiled slot loop has exactly 120 VALU instructions).  Spec "
                                 "ceiling = 32 x (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 7.86e13 lane-ops/s) / 120; the measured one uses the "
                                 "6.5e13 lane-ops/s an all-VALU probe sustains (tools/valu_ops.hip).  Per-chain formulation: 4.79e12 steps/s",
                 "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4),
                 "weight_factor_assumed": wfac}
+
+        # second stage: the stage whose honest bound IS HBM/L2 bandwidth — 8 S' bytes of the stored row per candidate
+        # pair + 8 S' of the query row once per query; the time is the `overlap` slot (join kernel + the per-lane kernel of the
+        # pairs the join hands over).  The candidate stage beside it: random lookups into the inverted index, 2 lines per lookup.
+        Sp = min(S, L - k2 + 1)
+        ov_s, iq_s = kernel_ms_per_step["overlap"] / 1e3, kernel_ms_per_step["index_query"] / 1e3
+        alg2 = (int(st["candidates_compared"]) + n_total) * 8 * Sp
+        tr2, tr2_src = pmc_traffic("overlap_join_kernel", args.config, n_total, L, world)
+        ach2 = alg2 / ov_s / 1e9 if ov_s > 0 else 0.0
+        roofline_stage2 = {"bound": "hbm", "kernel": "overlap_join_kernel (+ overlap_kernel for the pairs it hands over)",
+                           "achieved": round(ach2, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBS, 4),
+                           "traffic": tr2, "traffic_source": tr2_src, "alg_bytes_per_step": int(alg2), "ms_per_step": round(ov_s * 1e3, 3),
+                           "pairs_per_s": round(int(st["candidates_compared"]) / ov_s, 1) if ov_s > 0 else None,
+                           "candidate_stage": {"kernel": "index_query_kernel (+ index_query_dense_kernel)", "ms_per_step": round(iq_s * 1e3, 3),
+                                               "lookups_per_s": round(n_total * H / iq_s, 1) if iq_s > 0 else None,
+                                               "postings_per_s": round(int(st["table_elements"]) / iq_s, 1) if iq_s > 0 else None,
+                                               "index_build_ms_per_step": round(kernel_ms_per_step["index_build"], 3)},
+                           "note": "algorithmic bytes = (candidate pairs + queries) x 8 S' (SURVEY §8(d): the stored row per pair, the query "
+                                   "row once per query) over the summed time of the second-stage kernels"}
 
         strands = 2 * n_total
         out = {
@@ -302,7 +321,7 @@ def main():
             "overlap_slow_pairs_per_step": int(st["slow_pairs"]),
             "records_sha256_sorted_lines": sha, "records_checksum": "%016x" % records_checksum,
             "hbm_traffic_by_kernel": hbm_by_kernel,
-            "roofline": roofline, "valu": valu,
+            "roofline": roofline, "valu": valu, "roofline_stage2": roofline_stage2,
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),
             "value_incl_host_pack_and_pcie": round(total_records / (sec_per_step + t_stage), 2),

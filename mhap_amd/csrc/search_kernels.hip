@@ -619,7 +619,8 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
   for (uint32_t pass = 0; pass < npass; pass++) {
     __syncthreads();
     if (pass > 0 && !((rmask[(pass >> 5) & (DQ_MAX_RANGES / 32 - 1)] >> (pass & 31)) & 1u) && npass <= (uint32_t)DQ_MAX_RANGES) continue;   // (uniform)
-    for (int j = threadIdx.x; j < (1 << (DQ_RANGE_LOG - 1)); j += DQ_THREADS) cnt[j] = 0;
+    const uint32_t span = min(1u << DQ_RANGE_LOG, ix.ne - (pass << DQ_RANGE_LOG));   // stored entries of this range (the last one is partial)
+    for (uint32_t j = threadIdx.x; j < (span + 1) / 2; j += DQ_THREADS) cnt[j] = 0;
     if (threadIdx.x == 0) { s_nseg[0] = 0; s_nseg[1] = 0; s_emit = 0; }
     __syncthreads();
     // one hit of stored entry `me`: the counter is read first and left alone once it has reached numMinMatches, so it can pass
@@ -695,8 +696,8 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
     constexpr int PER = (1 << DQ_RANGE_LOG) / DQ_THREADS;      // 64 entries per lane: lane t owns entries t * 64 .. t * 64 + 63 of the range
     unsigned long long mymask = 0;
     int mycount = 0;
-#pragma unroll 4
-    for (int j = 0; j < PER / 2; j++) {
+    const int jmax = threadIdx.x * PER >= span ? 0 : (int)min((uint32_t)PER, span - threadIdx.x * PER + 1) / 2;
+    for (int j = 0; j < jmax; j++) {
       const uint32_t w = cnt[threadIdx.x * (PER / 2) + j];
 #pragma unroll
       for (int hf = 0; hf < 2; hf++) {

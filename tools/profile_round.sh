@@ -1,6 +1,6 @@
-# final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload (run on the GPU box); ROUND=r02 bash tools/profile_round.sh
+# final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload (run on the GPU box); ROUND=r03 bash tools/profile_round.sh
 export TMPDIR=/tmp
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o prof --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_final/bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -17,4 +17,13 @@ timeout 600 python bench.py > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/
 tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
 MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
 for c in c1 c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_out/$R/${R}_bench_$c.json 2>/dev/null; done
+ls -la gpurun_out/$R
+# round 3 additions: the whole of configs[3] on one GPU, one rank of an N-GPU job, the native driver end to end, the C5 slice's kernels
+timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c4.json 2>/dev/null
+for n in 2 4 8; do python tools/emulate_rank.py $n 2>/dev/null | tail -1; done > gpurun_out/$R/${R}_emulate_rank.txt
+(bash tools/e2e_probe.sh c2; bash tools/e2e_probe.sh c4) > gpurun_out/$R/${R}_e2e_probe.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 --config c5slice > /dev/null 2>&1
+cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats_c5slice.csv
+[ -x tools/bin/vgpr_bank ] && tools/bin/vgpr_bank > gpurun_out/$R/${R}_vgpr_bank_probe.txt
+timeout 400 python tools/check_elements.py c5slice 2>/dev/null | tail -1 > gpurun_out/$R/${R}_check_elements_c5slice.txt
 ls -la gpurun_out/$R
