@@ -155,9 +155,9 @@ int mhap_stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, 
 int mhap_index_add_staged(mhap_handle* h);
 
 /* The reads an EMPTY index is about to receive over the coming mhap_index_add_* calls (a file added in batches, as
- * AbstractMatchSearch.addData does, J/impl/AbstractMatchSearch.java:67-117): the sketch tables and the inverted index are sized
- * once for all of them and every batch's postings go into the index while the batch is sketched.  Without the hint a second
- * batch makes the first search rebuild the inverted index (correct, slower). */
+ * AbstractMatchSearch.addData does, J/impl/AbstractMatchSearch.java:67-117): the sketch tables are sized once for all of
+ * them, so that no batch makes them grow (a reallocation + copy of every row sketched so far).  The inverted index is built
+ * from all rows by the first search after the last add (a counting sort of the postings: 3 ms per 10^8). */
 int mhap_index_reserve(mhap_handle* h, int64_t total_reads);
 
 /* Streamed FASTA ingest (FastaData + SequenceSketchStreamer.enqueueFullFile, J/impl/FastaData.java:101-204,
