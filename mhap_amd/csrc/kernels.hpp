@@ -14,7 +14,10 @@ constexpr int CAND_TQ = 128;         // queries per candidate tile
 constexpr int CAND_TM = 128;         // index entries per candidate tile
 constexpr int CAND_KS = 32;          // slots staged per LDS chunk
 constexpr int OVL_THREADS = 128;
-constexpr int INV_CT = 4096;         // LDS hit-count table entries per query (inverted-index path)     // lanes per second-stage workgroup
+#ifndef MH_INV_CT
+#define MH_INV_CT 2048   // 4096 / 2048 / 1024: C2 4.73 / 4.31 / 4.39 ms, C5 slice 20.3 / 12.8 / 12.2 (a smaller table = more workgroups per CU, less to zero and to scan, and an earlier hand-over to the dense tier)
+#endif
+constexpr int INV_CT = MH_INV_CT;    // LDS hit-count table entries per query (first tier of the inverted-index path)
 
 // Weight classes of a strand's distinct k-mers (MinHashSketch.java:98-128).  mode > 0: every k-mer position carries the
 // weight `mode` (no repeated k-mer, one tf-idf weight) and neither wts[] nor the class list is read.  mode == 0: the class
@@ -120,7 +123,8 @@ void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminh
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
                         unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, bool big_tier);
-bool index_query_tiers();   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
+bool index_query_tiers();
+bool index_query_first_tier_ok(int64_t entries, int num_min_matches);   // false: every query goes to the dense tier   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
 // (two tiers: the first launch appends the queries whose hit set outgrows its 4096-entry LDS table to `big`; a second launch with
 //  big_tier = true re-runs those with a 16384-entry table, one workgroup per CU)
 // Second stage: one lane per candidate.

@@ -289,7 +289,10 @@ int stage_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const
 static int inv_alloc(mhap_handle* h, int64_t ne) {
   const int H = h->P.num_hashes;
   uint32_t lg = 10;
-  while (lg < (uint32_t)index_max_buckets_log() && (1ULL << lg) < (uint64_t)ne) lg++;
+#ifndef MH_INV_BUCKETS_PER_ENTRY
+#define MH_INV_BUCKETS_PER_ENTRY 1
+#endif
+  while (lg < (uint32_t)index_max_buckets_log() && (1ULL << lg) < (uint64_t)MH_INV_BUCKETS_PER_ENTRY * (uint64_t)ne) lg++;
   const size_t nb = (size_t)1 << lg, stride = (size_t)std::max<int64_t>(ne, 1), tiles = (size_t)index_tiles((int)ne), cb = (size_t)index_coarse_bins();
   HIPCHK(h, h->inv_ends.ensure((size_t)H * (nb + 1) * 4));
   HIPCHK(h, h->inv_items.ensure((size_t)H * stride * 8));
@@ -588,10 +591,12 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         HIPCHK(h, h->inv_big.ensure((size_t)nq * 4));
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
         const bool tiers = index_query_tiers() && !(tv && tv[0] == '1');
+        // (an index of 2^24 entries or more, or numMinMatches beyond the first tier's 8-bit counters: every query takes the dense tier)
+        const bool first_ok = index_query_first_tier_ok(h->n_entries, sp.num_min_matches);
         time_begin(h, MHAP_K_INDEX_QUERY);
         launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers ? h->inv_big.as<int32_t>() : nullptr, ctr + 6, false);
+                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && first_ok ? h->inv_big.as<int32_t>() : nullptr, ctr + 6, !first_ok);
         time_end(h);
         HIPCHK(h, hipGetLastError());
         unsigned long long c5[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -599,7 +604,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return rc;
         if (c5[6] > 0 && c5[0] <= cand_cap) {
-          // queries whose distinct hits outgrew the small LDS table (repeats): second tier with the 16384-entry table
+          // queries whose hits outgrow the first tier's LDS table (repeats): second tier, dense counters
           time_begin(h, MHAP_K_INDEX_QUERY);
           launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->inv_big.as<int32_t>(), (int)c5[6],
                              h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,

@@ -335,9 +335,14 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
   hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
 }
 
-// One workgroup per query.  LDS: keys[CT] (entry+1), cnts[CT].
-constexpr int IQ_THREADS = 128;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
+// One workgroup (one wavefront) per query.  LDS: tbl[CT], a hit-count table of packed words: entry + 1 in the low 24 bits, its
+// (saturating) hit count in the high 8.
+#ifndef MH_IQ_THREADS
+#define MH_IQ_THREADS 64
+#endif
+constexpr int IQ_THREADS = MH_IQ_THREADS;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
                                   // CU by LDS either way: more lookups in flight per CU only thrash the memory side)
+constexpr int IQ_SAT = 180;       // hit counts of the first tier saturate here (8-bit counters)
 constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
 #ifndef MH_IQ_SPT
 #define MH_IQ_SPT 1   // 1 / 2 / 4 at C2: 4.7 / 4.7 / 5.7 ms (4 costs a workgroup per CU its LDS queue; the memory side, not the latency, bounds the lookups)
@@ -351,7 +356,7 @@ constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lan
 #define MH_IQ_BIG_THREADS 1024
 #endif
 constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = MH_IQ_BIG_THREADS;   // second tier: 128 KB count table, one workgroup per CU
-// Two tiers.  <INV_CT, IQ_THREADS> (32 KB of LDS, four workgroups per CU) takes every query; one whose buckets hold more than four
+// Two tiers.  <INV_CT, IQ_THREADS> (16 KB of LDS for the table) takes every query; one whose buckets hold more than four
 // tables' worth of postings (repeats: thousands of stored entries share a MinHash value with the query), or whose distinct hits
 // outgrow the table, is appended to `big` and re-run by <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in
 // one pass; only beyond that a hit set is split into hash-partition passes over the stored entries (split in two until every
@@ -365,8 +370,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
                                                           unsigned long long cand_cap, unsigned long long* __restrict__ split_count,
                                                           unsigned long long* __restrict__ elements, int32_t* __restrict__ big,
                                                           unsigned long long* __restrict__ big_count) {
-  __shared__ uint32_t keys[INV_CT];
-  __shared__ uint32_t cnts[INV_CT];
+  __shared__ uint32_t tbl[INV_CT];
+  static_assert(INV_CT <= 32 * IQ_THREADS, "the emit mask holds 32 table slots per lane");
   __shared__ uint32_t s_distinct, s_over, s_top, s_prefix, s_bits;
   __shared__ uint32_t stack[2 * IQ_STACK];
   __shared__ uint32_t s_nseg[2];
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       else { s_top--; s_prefix = stack[2 * s_top]; s_bits = stack[2 * s_top + 1]; }
       s_distinct = 0; s_over = 0; s_nseg[0] = 0; s_nseg[1] = 0;
     }
-    for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) { keys[j] = 0; cnts[j] = 0; }
+    for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) tbl[j] = 0;
     __syncthreads();
     const uint32_t bits = s_bits, prefix = s_prefix;
     if (bits == 0xFFFFFFFFu) break;
@@ -421,18 +426,22 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     unsigned long long mine = 0;
     // count one hit of stored entry `me` (the id/length rules do not depend on the count: they are applied to the few entries that
     // reach numMinMatches, below, so that the lookup loop's only global loads are the index words)
+    // (the count is read before it is raised and left alone from `sat` on, so it passes `sat` by at most the adds in flight — one
+    // per lane — and never wraps; the host keeps queries out of this tier when numMinMatches > IQ_SAT or entries do not fit 24 bits)
+    const uint32_t sat = (uint32_t)(sp.num_min_matches < IQ_SAT ? sp.num_min_matches : IQ_SAT);
     auto count_hit = [&](int me) {
       const uint32_t hm = inv_mix((uint32_t)me);
       if (((hm >> CT_LOG) & pmask) != prefix) return;
+      const uint32_t id = (uint32_t)me + 1u;
       uint32_t slot = hm & (INV_CT - 1);
       for (int tries = 0; tries < INV_CT; tries++) {
-        uint32_t k = *(volatile uint32_t*)&keys[slot];
-        if (k == 0) {
-          if (*(volatile uint32_t*)&s_distinct >= (INV_CT * 3) / 4) { s_over = 1; break; }
-          const uint32_t old = atomicCAS(&keys[slot], 0u, (uint32_t)me + 1u);
-          if (old == 0) { atomicAdd(&s_distinct, 1u); k = (uint32_t)me + 1u; } else k = old;
+        uint32_t w = __hip_atomic_load(&tbl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((w & 0xFFFFFFu) == 0) {
+          if (__hip_atomic_load(&s_distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (INV_CT * 3) / 4) { s_over = 1; break; }
+          const uint32_t old = atomicCAS(&tbl[slot], 0u, id);
+          if (old == 0) { atomicAdd(&s_distinct, 1u); w = id; } else w = old;
         }
-        if (k == (uint32_t)me + 1u) { atomicAdd(&cnts[slot], 1u); break; }
+        if ((w & 0xFFFFFFu) == id) { if ((w >> 24) < sat) atomicAdd(&tbl[slot], 1u << 24); break; }
         slot = (slot + 1) & (INV_CT - 1);
       }
     };
@@ -558,8 +567,9 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
 #pragma unroll
     for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
       const int j = threadIdx.x + IQ_THREADS * t;
-      if (keys[j] != 0 && (int)cnts[j] >= sp.num_min_matches) {                                    // MinHashSearch.java:204
-        const int me = (int)keys[j] - 1;
+      const uint32_t w = tbl[j];
+      if ((w & 0xFFFFFFu) != 0 && (int)(w >> 24) >= sp.num_min_matches) {                          // MinHashSearch.java:204
+        const int me = (int)(w & 0xFFFFFFu) - 1;
         if (pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1u << t; mycount++; }   // :200-225
       }
     }
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
 #pragma unroll
     for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
       if (mymask & (1u << t)) {
-        if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)keys[threadIdx.x + IQ_THREADS * t] - 1; }
+        if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)(tbl[threadIdx.x + IQ_THREADS * t] & 0xFFFFFFu) - 1; }
         slot++;
       }
     }
@@ -723,6 +733,8 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
 }
 
 bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
+// the first tier's packed table holds entry indices below 2^24 - 1 and counts up to IQ_SAT
+bool index_query_first_tier_ok(int64_t entries, int num_min_matches) { return entries < (1 << 24) - 1 && num_min_matches <= IQ_SAT; }
 
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,

@@ -508,6 +508,31 @@ def test_index_query_tiers_on_huge_hit_sets(monkeypatch):
     assert si["table_elements"] == want_elements and s1["table_elements"] == want_elements
 
 
+def test_large_num_min_matches_takes_the_dense_tier():
+    """--num-min-matches beyond what the first tier's 8-bit hit counters can tell apart (180): every query is counted by the dense
+    tier.  Near-identical copies of one read share most of their 512 MinHash values; records, compared pairs and processed elements
+    equal the oracle's at numMinMatches = 3 (first tier), 150 (first tier, close to its limit) and 250 (dense tier)."""
+    rnd = random.Random(9)
+    base = _rand_seq(rnd, 3000)
+    seqs = [_rand_seq(rnd, 3000) for _ in range(40)]
+    for c in range(12):
+        s = list(base)
+        for _ in range(c):                         # copy c differs from the original in c bases
+            s[rnd.randrange(3000)] = rnd.choice("ACGT")
+        seqs.append("".join(s))
+    fa = FastaData.from_strings(seqs)
+    for nmm in (3, 150, 250):
+        p = MhapParams(num_hashes=512, ordered_sketch_size=512, num_min_matches=nmm)
+        want = O.run_self(fa, H=512, S=512, num_min_matches=nmm, nthreads=8)
+        with MinHashSearch(p) as ms:
+            ms.add_data(fa)
+            got = ms.find_matches()
+            st = ms.stats()
+        assert np.array_equal(_sorted_records(got), _sorted_records(want["records"])), nmm
+        assert st["table_elements"] == want["elements"] and st["candidates_compared"] == want["compared"], nmm
+        assert len(got) >= 30 if nmm < 250 else len(got) > 0, (nmm, len(got))
+
+
 def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
     """A repeat-rich sample (the C5 slice's generator: a 300-bp repeat family planted every 3 kb) with more than 65 536 stored
     entries: the second tier's dense counters cover the index in two entry ranges.  Records equal the first-tier-only path's
