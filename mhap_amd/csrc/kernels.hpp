@@ -134,11 +134,11 @@ void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const un
                     DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared);
 // Second stage: one wavefront per candidate (equal-hash join); pairs it cannot decide exactly are appended to `slow`.
 constexpr int OJ_MAX_S = 8192;   // largest ordered sketch the join path stages in LDS
-size_t overlap_join_lds_bytes(int S, bool shared);
-int overlap_join_blocks_per_cu(int S, bool shared);
-int overlap_join_waves_per_block(bool shared);
+size_t overlap_join_lds_bytes(int S, int shape);     // shape: 0 every wave alone, 1 pairs of waves share a query, 2 teams of four + bucket table
+int overlap_join_blocks_per_cu(int S, int shape);
+int overlap_join_waves_per_block(int shape);
 int overlap_join_table_slots(int S);
-void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
+void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
                          unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
                          int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
                          unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,

@@ -85,8 +85,8 @@ struct mhap_handle {
   int num_cus = 256;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
-  int oj_per_cu[2] = {0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (wave / shared shape) at ordered sketch size oj_per_cu_S
-  int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = shared, 2 = wave
+  int oj_per_cu[3] = {0, 0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (per shape) at ordered sketch size oj_per_cu_S
+  int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = alone, 2 = pair, 3 = team
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
@@ -553,7 +553,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const int64_t per_lane = 3LL * (2LL * S + 2);
   const char* omode = getenv("MHAP_OVERLAP");
   const bool lane_only = omode && strcmp(omode, "lane") == 0;
-  { const char* jm = getenv("MHAP_JOIN_MODE"); h->join_mode = jm && strcmp(jm, "shared") == 0 ? 1 : (jm && strcmp(jm, "wave") == 0 ? 2 : 0); }
+  { const char* jm = getenv("MHAP_JOIN_MODE"); h->join_mode = !jm ? 0 : (strcmp(jm, "alone") == 0 ? 1 : (strcmp(jm, "pair") == 0 ? 2 : (strcmp(jm, "team") == 0 ? 3 : 0))); }
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
   // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
   const char* cmode = getenv("MHAP_CANDIDATES");
@@ -641,30 +641,32 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
     // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
     if (h->gate && h->gate(h->gate_user) != 0) return fail(h, MHAP_E_STATE, "second-stage gate aborted the search");
-    // the join kernel's two shapes (search_kernels.hip): a workgroup shares one staged query — for runs of many candidates per query —
-    // or every wave stages its own.  MHAP_JOIN_MODE=shared|wave pins one.
-    const bool fits_wave = overlap_join_lds_bytes(S, false) <= 64 * 1024, fits_shared = overlap_join_lds_bytes(S, true) <= 64 * 1024;
-    const bool use_join = !lane_only && S <= OJ_MAX_S && (fits_wave || fits_shared);
+    // the join kernel's three shapes (search_kernels.hip): every wave alone, pairs of waves sharing a staged query, teams of four with
+    // a bucket table — by the candidates per query.  MHAP_JOIN_MODE=alone|pair|team pins one.
+    bool fits[3];
+    for (int i = 0; i < 3; i++) fits[i] = overlap_join_lds_bytes(S, i) <= 64 * 1024;
+    const bool use_join = !lane_only && S <= OJ_MAX_S && (fits[0] || fits[1] || fits[2]);
     unsigned long long nslow = use_join ? 0 : ncand;
     if (use_join) {
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
-      bool shared = !fits_wave || (fits_shared && (int64_t)ncand >= 16LL * nq);   // (C2: 4.5 candidates per query, 4.7 ms alone / 5.0 shared; C5 slice: 79, 169 / 67)
-      if (h->join_mode == 1 && fits_shared) shared = true;
-      if (h->join_mode == 2 && fits_wave) shared = false;
+      // (C2: 4.5 candidates per query — alone 4.94, pair 4.83, team 5.03 ms; C5 slice: 79 — alone 93, pair 87, team 77; a rank of eight,
+      //  0.56 per query: alone 0.86, pair 1.24)
+      int shape = (int64_t)ncand >= 16LL * nq ? 2 : ((int64_t)ncand >= 2LL * nq ? 1 : 0);
+      if (h->join_mode > 0) shape = h->join_mode - 1;
+      while (!fits[shape]) shape = (shape + 1) % 3;
       if (h->oj_per_cu_S != S) {
-        h->oj_per_cu[0] = fits_wave ? overlap_join_blocks_per_cu(S, false) : 0;
-        h->oj_per_cu[1] = fits_shared ? overlap_join_blocks_per_cu(S, true) : 0;
+        for (int i = 0; i < 3; i++) h->oj_per_cu[i] = fits[i] ? overlap_join_blocks_per_cu(S, i) : 0;
         h->oj_per_cu_S = S;
       }
       // candidates per pull of a wave: 8 amortise the counter and keep a query's hashes staged across its candidates — unless the
       // candidates are few (a small batch of -q reads, one rank's share of a small job): then every resident wave should get some
-      const int per_cu = h->oj_per_cu[shared ? 1 : 0], wpb = overlap_join_waves_per_block(shared);
+      const int per_cu = h->oj_per_cu[shape], wpb = overlap_join_waves_per_block(shape);
       const int64_t resident_waves = (int64_t)h->num_cus * per_cu * wpb;
       const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)ncand / std::max<int64_t>(resident_waves, 1)));
       const int64_t want = ((int64_t)ncand + (int64_t)wpb * chunk - 1) / ((int64_t)wpb * chunk);
       const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * per_cu, want));
       time_begin(h, MHAP_K_OVERLAP);
-      launch_overlap_join(h->stream, shared, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
+      launch_overlap_join(h->stream, shape, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                           qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,
                           (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7);
       time_end(h);

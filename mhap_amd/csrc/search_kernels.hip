@@ -858,7 +858,10 @@ constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
 #define MH_OJ_U 3
 #endif
 constexpr int OJ_U = MH_OJ_U;          // 64-entry blocks of the other sketch in flight per wave
-constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN);   // ints per wave besides the query hashes
+#ifndef MH_OJ_PAD
+#define MH_OJ_PAD 0   // (experiment: unused ints per wave, to see what the resident waves per CU are worth)
+#endif
+constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN) + MH_OJ_PAD;   // ints per wave besides the query hashes
 
 __device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1038,12 +1041,12 @@ __device__ __forceinline__ OjBuckets oj_buckets(int first, int last, int nb) {
 __device__ __forceinline__ int oj_bucket_of(const OjBuckets& k, int h) { return (int)__umulhi((uint32_t)(h - k.first), k.mult); }
 int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; return t; }
 
-// SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its OJ_WAVES waves stage the
-//                 query's hashes and build the table together (one copy in LDS), then take the run's candidates one by one from an
-//                 LDS counter.  For repeat-rich inputs, where one query has tens to thousands of candidates.
-// SHARED = false: every wave works alone — pulls its own chunks, keeps its own hashes and table.  For inputs with a few candidates
-//                 per query, where the waves of a workgroup would wait for each other at every run.
-template <bool SHARED, int WAVES>
+// SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its WAVES waves stage the
+//                 query's hashes (and, TABLE, build the bucket table) together — one copy in LDS — then take the run's candidates one
+//                 by one from an LDS counter.
+// SHARED = false: every wave works alone — pulls its own chunks, keeps its own hashes.
+// (the shapes in use and what each is for: OJ_ALONE / OJ_PAIR / OJ_TEAM below)
+template <bool SHARED, int WAVES, bool TABLE>
 __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                                      unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                                      int64_t ord_stride, const int32_t* __restrict__ meta,
@@ -1056,7 +1059,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
                                                                      unsigned long long* __restrict__ work, int ts) {
   extern __shared__ int32_t oj_lds[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int spad = (sp.S + 3) & ~3, own = SHARED ? spad + ts / 2 + 2 : spad;   // ints of the hashes (+ the table: ts + 1 shorts, padded)
+  const int spad = (sp.S + 3) & ~3, own = TABLE ? spad + ts / 2 + 2 : spad;   // ints of the hashes (+ the table: ts + 1 shorts, padded)
   int32_t* ah = SHARED ? oj_lds : oj_lds + (size_t)wv * (own + OJ_LDS_EXTRA);   // the query sketch's hashes,
   uint16_t* st = (uint16_t*)(ah + spad);                               // ... the bucket starts over them,
   int32_t* svar = oj_lds + own;                                        // (SHARED) {-, next candidate of the run, chunk start lo, hi}
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
           }
           bool found[OJ_U];
           bool anyf = false;
-          if constexpr (SHARED) {
+          if constexpr (TABLE) {
             // bucket lookup (above): st[b], st[b + 1], then the bucket's first two hashes — the OJ_U entries' reads are independent
             int i0[OJ_U], i1[OJ_U], x0[OJ_U], x1[OJ_U];
 #pragma unroll
@@ -1139,7 +1142,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
               anyf |= found[u];
             }
           } else {
-            // no room for a table per wave: lower bound of every hash among the query's by binary search, l = last index whose hash
+            // no table (its 8 KB would cost resident waves, and this kernel's time is inversely proportional to them): lower bound of every hash among the query's by binary search, l = last index whose hash
             // is smaller (-1: none).  Fixed probe sequence for a sorted array of any length (the first probe splits [0, nA) into two
             // overlapping halves of p2 entries); the OJ_U searches' dependent LDS reads overlap each other
             const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
@@ -1449,8 +1452,8 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
             if (bal) { rend = t0 + (unsigned long long)__builtin_ctzll(bal); break; }
           }
         } else __builtin_amdgcn_wave_barrier();
-        if (!SHARED) {
-          for (int i = lane; i < nA; i += 64) ah[i] = qrow[2 * i];
+        if (!TABLE) {
+          for (int i = tid; i < nA; i += NT) ah[i] = qrow[2 * i];
         } else if (nA > 0) {
           bk = oj_buckets(__builtin_amdgcn_readfirstlane(qrow[0]), __builtin_amdgcn_readfirstlane(qrow[2 * (nA - 1)]), ts);
           for (int i = tid; i < nA; i += NT) {   // entry i starts every bucket after its predecessor's up to its own
@@ -1486,40 +1489,48 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
   if (mine && lane == 0) atomicAdd(compared, mine);
 }
 
-// waves of one workgroup: the shared shape wants many takers per staged query, the per-wave shape small workgroups (LDS per wave
-// is what bounds the resident waves there)
-constexpr int OJ_WAVES_SHARED = OJ_WAVES, OJ_WAVES_ALONE = 2;
-int overlap_join_waves_per_block(bool shared) { return shared ? OJ_WAVES_SHARED : OJ_WAVES_ALONE; }
-// LDS bytes of one workgroup: the hashes and the table once (shared) or per wave, the join scratch per wave
-size_t overlap_join_lds_bytes(int S, bool shared) {
-  const size_t sp = (size_t)((S + 3) & ~3);
-  return (shared ? sp + (size_t)overlap_join_table_slots(S) / 2 + 2 + 4 + (size_t)OJ_WAVES_SHARED * OJ_LDS_EXTRA : (size_t)OJ_WAVES_ALONE * (sp + OJ_LDS_EXTRA)) * 4;
+// The three shapes of the join kernel.  Its time is inversely proportional to the waves a CU holds (padding the LDS of the ALONE
+// shape by 4 / 12 KB per wave: 4.97 -> 6.66 / 12.5 ms at C2, i.e. 18 -> 12 / 7 waves per CU), and what bounds those is LDS:
+//   ALONE  every wave stages its own query (6 KB of hashes at S = 1536) and searches them by bisection: 8.7 KB per wave, 18 waves per CU.
+//          For a candidate or fewer per query (a rank of a multi-GPU job: every query against an eighth of the reads).
+//   PAIR   two waves share one staged query and take its candidates in turn: 5.6 KB per wave, 28 waves per CU (the VGPR limit) —
+//          but a wave now waits for its partner at every run's end, which takes most of that back (C2, 4.5 candidates per query:
+//          4.83 ms against 4.94 alone).  For a few candidates per query.
+//   TEAM   four waves share the query and a bucket table over its hashes (two LDS round trips per lookup instead of eleven).
+//          For tens of candidates per query (repeat-rich reads).
+enum { OJ_ALONE = 0, OJ_PAIR = 1, OJ_TEAM = 2 };
+constexpr int OJ_SHAPE_WAVES[3] = {2, 2, OJ_WAVES};
+int overlap_join_waves_per_block(int shape) { return OJ_SHAPE_WAVES[shape]; }
+// LDS bytes of one workgroup: the hashes (and the table) once or per wave, the join scratch per wave
+size_t overlap_join_lds_bytes(int S, int shape) {
+  const size_t sp = (size_t)((S + 3) & ~3), w = (size_t)OJ_SHAPE_WAVES[shape];
+  if (shape == OJ_ALONE) return w * (sp + OJ_LDS_EXTRA) * 4;
+  return (sp + (shape == OJ_TEAM ? (size_t)overlap_join_table_slots(S) / 2 + 2 : 0) + 4 + w * OJ_LDS_EXTRA) * 4;
+}
+template <class F> static auto oj_dispatch(int shape, F f) {
+  if (shape == OJ_TEAM) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_TEAM], true>);
+  if (shape == OJ_PAIR) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_PAIR], false>);
+  return f(overlap_join_kernel<false, OJ_SHAPE_WAVES[OJ_ALONE], false>);
 }
 // workgroups of the join kernel one CU holds at this sketch size
-int overlap_join_blocks_per_cu(int S, bool shared) {
+int overlap_join_blocks_per_cu(int S, int shape) {
   int n = 0;
-  const hipError_t e = shared ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<true, OJ_WAVES_SHARED>, 64 * OJ_WAVES_SHARED,
-                                                                             overlap_join_lds_bytes(S, true))
-                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, overlap_join_kernel<false, OJ_WAVES_ALONE>, 64 * OJ_WAVES_ALONE,
-                                                                             overlap_join_lds_bytes(S, false));
+  const hipError_t e = oj_dispatch(shape, [&](auto kern) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 64 * OJ_SHAPE_WAVES[shape], overlap_join_lds_bytes(S, shape)); });
   if (e != hipSuccess || n < 1) n = 1;
   return n;
 }
 
-void launch_overlap_join(hipStream_t st, bool shared, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
+void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, const Candidate* cand, const unsigned long long* cand_count,
                          unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
                          int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
                          unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,
                          unsigned long long* slow_count, unsigned long long* work) {
   const int ts = overlap_join_table_slots(sp.S);
-  if (shared)
-    hipLaunchKernelGGL((overlap_join_kernel<true, OJ_WAVES_SHARED>), dim3(nblocks), dim3(64 * OJ_WAVES_SHARED), overlap_join_lds_bytes(sp.S, true), st, cand,
-                       cand_count, cand_cap, ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared,
-                       slow, slow_count, chunk, work, ts);
-  else
-    hipLaunchKernelGGL((overlap_join_kernel<false, OJ_WAVES_ALONE>), dim3(nblocks), dim3(64 * OJ_WAVES_ALONE), overlap_join_lds_bytes(sp.S, false), st, cand,
-                       cand_count, cand_cap, ordered, ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared,
-                       slow, slow_count, chunk, work, ts);
+  oj_dispatch(shape, [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * OJ_SHAPE_WAVES[shape]), overlap_join_lds_bytes(sp.S, shape), st, cand, cand_count, cand_cap, ordered,
+                       ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk, work, ts);
+    return 0;
+  });
 }
 
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
