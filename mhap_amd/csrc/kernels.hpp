@@ -122,11 +122,11 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, bool big_tier);
+                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, int tier);
+int index_query_dense_ranges(int64_t entries);   // passes the dense tier makes over an index of this size
 bool index_query_tiers();
 bool index_query_first_tier_ok(int64_t entries, int num_min_matches);   // false: every query goes to the dense tier   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
-// (two tiers: the first launch appends the queries whose hit set outgrows its 4096-entry LDS table to `big`; a second launch with
-//  big_tier = true re-runs those with a 16384-entry table, one workgroup per CU)
+// (tiers: 0 the first, 1 the same kernel with a large table, 2 dense counters — launch_index_query in search_kernels.hip)
 // Second stage: one lane per candidate.
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,

@@ -586,32 +586,51 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     unsigned long long ncand = 0;
     for (;;) {
       HIPCHK(h, h->cand.ensure(cand_cap * sizeof(Candidate)));
-      HIPCHK(h, hipMemsetAsync(ctr, 0, 64, h->stream));
+      HIPCHK(h, hipMemsetAsync(ctr, 0, 80, h->stream));
       if (use_index) {
-        HIPCHK(h, h->inv_big.ensure((size_t)nq * 4));
+        HIPCHK(h, h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
         const bool tiers = index_query_tiers() && !(tv && tv[0] == '1');
         // (an index of 2^24 entries or more, or numMinMatches beyond the first tier's 8-bit counters: every query takes the dense tier)
         const bool first_ok = index_query_first_tier_ok(h->n_entries, sp.num_min_matches);
+        int32_t* listA = h->inv_big.as<int32_t>();
+        int32_t* listB = listA + nq;
         time_begin(h, MHAP_K_INDEX_QUERY);
         launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && first_ok ? h->inv_big.as<int32_t>() : nullptr, ctr + 6, !first_ok);
+                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && first_ok ? listA : nullptr, ctr + 6, first_ok ? 0 : 2);
         time_end(h);
         HIPCHK(h, hipGetLastError());
-        unsigned long long c5[7] = {0, 0, 0, 0, 0, 0, 0};
-        HIPCHK(h, hipMemcpyAsync(c5, ctr, 56, hipMemcpyDeviceToHost, h->stream));
+        unsigned long long c5[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return rc;
-        if (c5[6] > 0 && c5[0] <= cand_cap) {
-          // queries whose hits outgrow the first tier's LDS table (repeats): second tier, dense counters
+        // queries whose hits outgrow the first tier's table.  A small index (a few dense ranges): dense counters at once.  A large
+        // one: the middle tier's 16 384-entry table first — ordinary reads of a big data set have thousands of hits, and the dense
+        // tier would make a pass per 65 536 stored entries for each of them — and dense counters for what outgrows that too (repeats).
+        const int32_t* dense_list = listA;
+        unsigned long long n_dense = c5[6];
+        const char* midv = getenv("MHAP_INDEX_MID");   // "1" / "0": with / without the middle tier whatever the index size (tests)
+        const bool use_mid = midv ? midv[0] == '1' : index_query_dense_ranges(h->n_entries) > 4;
+        if (c5[6] > 0 && c5[0] <= cand_cap && use_mid) {
           time_begin(h, MHAP_K_INDEX_QUERY);
-          launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->inv_big.as<int32_t>(), (int)c5[6],
-                             h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                             (unsigned long long)cand_cap, ctr + 3, ctr + 4, nullptr, nullptr, true);
+          launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,
+                             h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, ctr + 3, ctr + 4, listB, ctr + 8, 1);
           time_end(h);
           HIPCHK(h, hipGetLastError());
-          HIPCHK(h, hipMemcpyAsync(c5, ctr, 56, hipMemcpyDeviceToHost, h->stream));
+          HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
+          rc = sync_stream(h);
+          if (rc != MHAP_OK) return rc;
+          dense_list = listB; n_dense = c5[8];
+        }
+        if (n_dense > 0 && c5[0] <= cand_cap) {
+          time_begin(h, MHAP_K_INDEX_QUERY);
+          launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, dense_list, (int)n_dense,
+                             h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
+                             (unsigned long long)cand_cap, ctr + 3, ctr + 4, nullptr, nullptr, 2);
+          time_end(h);
+          HIPCHK(h, hipGetLastError());
+          HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
           rc = sync_stream(h);
           if (rc != MHAP_OK) return rc;
         }

@@ -356,8 +356,8 @@ constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lan
 #define MH_IQ_BIG_THREADS 1024
 #endif
 constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = MH_IQ_BIG_THREADS;   // second tier: 128 KB count table, one workgroup per CU
-// Two tiers.  <INV_CT, IQ_THREADS> (16 KB of LDS for the table) takes every query; one whose buckets hold more than four
-// tables' worth of postings (repeats: thousands of stored entries share a MinHash value with the query), or whose distinct hits
+// Tiers.  <INV_CT, IQ_THREADS> (8 KB of LDS for the table) takes every query; one whose buckets hold more postings than the
+// table can count (repeats: thousands of stored entries share a MinHash value with the query), or whose distinct hits
 // outgrow the table, is appended to `big` and re-run by <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in
 // one pass; only beyond that a hit set is split into hash-partition passes over the stored entries (split in two until every
 // part fits), which bounds a query's cost by its own postings.  big == nullptr: split right away.
@@ -403,7 +403,10 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     __syncthreads();
     tot = 0;
     for (unsigned w = 0; w < IQ_THREADS / 64; w++) tot += wsum[w];
-    if (tot > 4ULL * INV_CT) {
+    // (tot counts every posting of the H buckets: the hits plus ~ne/nb strangers per bucket; distinct hits <= hits.  Beyond a
+    // quarter over the table's capacity the count would very likely overflow half-way and be thrown away)
+    const unsigned long long strangers = (unsigned long long)sp.H * ix.ne / ix.nb;
+    if (tot > strangers + (5ULL * (INV_CT * 3 / 4)) / 4) {
       if (threadIdx.x == 0) big[atomicAdd(big_count, 1ULL)] = qe;
       return;
     }
@@ -736,18 +739,27 @@ bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
 // the first tier's packed table holds entry indices below 2^24 - 1 and counts up to IQ_SAT
 bool index_query_first_tier_ok(int64_t entries, int num_min_matches) { return entries < (1 << 24) - 1 && num_min_matches <= IQ_SAT; }
 
+// tier 0: the first tier (one wavefront per query, 2048-entry table); tier 1: the same kernel with a 16 384-entry table and 512 lanes
+// (queries of a LARGE index that outgrow the first table but have thousands, not hundreds of thousands, of hits: the dense tier would
+// make a pass per 65 536 stored entries for them); tier 2: the dense tier.  big / big_count: where tiers 0 and 1 list the queries
+// they hand on (nullptr: they split hit sets into hash-partition passes instead).
+constexpr int INV_CT_MID = 16384, IQ_THREADS_MID = 512;
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, bool big_tier) {
+                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, int tier) {
   if (nq <= 0) return;
-  if (!big_tier)
+  if (tier == 0)
     hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
                        meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
+  else if (tier == 1)
+    hipLaunchKernelGGL((index_query_kernel<INV_CT_MID, IQ_THREADS_MID, 1>), dim3((unsigned)nq), dim3(IQ_THREADS_MID), 0, st, ix, qminhash, qrow_stride, qlist, nq,
+                       ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
   else
     hipLaunchKernelGGL(index_query_dense_kernel, dim3((unsigned)nq), dim3(DQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids, meta, qmeta, sp,
                        cand, cand_count, cand_cap, split_count, elements);
 }
+int index_query_dense_ranges(int64_t entries) { return (int)((entries + (1 << DQ_RANGE_LOG) - 1) >> DQ_RANGE_LOG); }
 
 // =============================================================================================
 // Second stage.  Persistent lanes: lane g handles candidates g, g+G, ...  Scratch (3 int arrays of

@@ -490,18 +490,22 @@ def test_index_query_tiers_on_huge_hit_sets(monkeypatch):
           "minhash": mh, "ordered": np.repeat(base["ordered"][:1], n, axis=0), "ordered_size": np.repeat(base["ordered_size"][:1], n),
           "ordered_seqlen": np.repeat(base["ordered_seqlen"][:1], n)}
     out = {}
-    for mode in ("index", "first-tier-only", "bruteforce"):
+    for mode in ("index", "first-tier-only", "middle-tier", "bruteforce"):
         if mode == "bruteforce":
             monkeypatch.setenv("MHAP_CANDIDATES", "bruteforce")
         if mode == "first-tier-only":
             monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
+        if mode == "middle-tier":                  # the tier between the two that a large index gets: its 16 384-entry table holds these hit sets
+            monkeypatch.setenv("MHAP_INDEX_MID", "1")
         with MinHashSearch(p) as ms:
             ms.add_sketches(sk)
             out[mode] = (_sorted_records(ms.find_matches()), ms.stats())
         monkeypatch.delenv("MHAP_INDEX_TIERS", raising=False)
+        monkeypatch.delenv("MHAP_INDEX_MID", raising=False)
     monkeypatch.delenv("MHAP_CANDIDATES")
-    (ri, si), (r1, s1), (rb, sb) = out["index"], out["first-tier-only"], out["bruteforce"]
-    assert np.array_equal(ri, rb) and np.array_equal(r1, rb) and len(ri) == ncopy * (ncopy - 1) // 2
+    (ri, si), (r1, s1), (rm, sm), (rb, sb) = out["index"], out["first-tier-only"], out["middle-tier"], out["bruteforce"]
+    assert np.array_equal(ri, rb) and np.array_equal(r1, rb) and np.array_equal(rm, rb) and len(ri) == ncopy * (ncopy - 1) // 2
+    assert sm["index_splits"] == 0 and sm["table_elements"] == si["table_elements"] and sm["candidates_compared"] == si["candidates_compared"]
     assert si["index_splits"] == 0 and s1["index_splits"] > 0 and si["slot_compares"] == 0 and sb["slot_compares"] > 0
     assert si["candidates_compared"] == s1["candidates_compared"] == sb["candidates_compared"] == ncopy * (ncopy - 1) // 2
     want_elements = 2 * n * n + 14 * (ncopy * ncopy + (n - ncopy))
@@ -548,9 +552,12 @@ def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
     p = MhapParams(num_hashes=64, ordered_sketch_size=256)
     monkeypatch.setenv("MHAP_DEBUG_INDEX", "1")
     out = {}
-    for mode in ("tiers", "first-tier-only"):
+    for mode in ("tiers", "first-tier-only", "middle-tier"):
         if mode == "first-tier-only":
             monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
+        if mode == "middle-tier":                  # first tier -> 16 384-entry table -> dense counters for what outgrows that too
+            monkeypatch.delenv("MHAP_INDEX_TIERS")
+            monkeypatch.setenv("MHAP_INDEX_MID", "1")
         with MinHashSearch(p, kmer_filter=flt) as ms:
             ms.add_data(fa)
             recs = _sorted_records(ms.find_matches())
@@ -559,16 +566,16 @@ def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
                 assert ms.size() == 2 * n > 65536
                 sk = ms.export()
         out[mode] = (recs, st)
-    monkeypatch.delenv("MHAP_INDEX_TIERS")
+    monkeypatch.delenv("MHAP_INDEX_MID")
     stored = sk["status"] == 0
     query = stored & (sk["is_fwd"] != 0)
     want = 0
     for s in range(sk["minhash"].shape[1]):
         vals, cnt = np.unique(sk["minhash"][stored, s], return_counts=True)
         want += int(cnt[np.searchsorted(vals, sk["minhash"][query, s])].sum())
-    (ra, sa), (rb, sb) = out["tiers"], out["first-tier-only"]
-    assert np.array_equal(ra, rb) and len(ra) > 1000
-    assert sa["table_elements"] == want == sb["table_elements"]
+    (ra, sa), (rb, sb), (rm, sm) = out["tiers"], out["first-tier-only"], out["middle-tier"]
+    assert np.array_equal(ra, rb) and np.array_equal(ra, rm) and len(ra) > 1000
+    assert sa["table_elements"] == want == sb["table_elements"] == sm["table_elements"]
     assert sa["index_splits"] > 0          # a second entry range was needed for some query
 
 

@@ -10,9 +10,10 @@ timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VM
 mkdir -p gpurun_out/$R
 cp $(find gpurun_out/prof_final -name "prof_kernel_stats.csv" | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats.csv
 python tools/pmc_summary.py $(find gpurun_out/pmc_FETCH_SIZE -name "pmc_counter_collection.csv" | head -1) $(find gpurun_out/pmc_WRITE_SIZE -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_traffic.json
-grep -h "minhash_kernel" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) | cut -c1-60,400- | head -20 > /dev/null
+grep -h "minhash_" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) | cut -c1-60,400- | head -20 > /dev/null
 head -1 $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_minhash_instmix.csv
-grep -h "minhash_kernel" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) >> gpurun_out/$R/${R}_pmc_minhash_instmix.csv
+grep -h "minhash_" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) >> gpurun_out/$R/${R}_pmc_minhash_instmix.csv
+cp gpurun_out/$R/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json   # bench.py reads the byte counts from profiles/ (same source digest)
 timeout 600 python bench.py > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
 tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
 MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
