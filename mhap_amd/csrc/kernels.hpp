@@ -73,17 +73,19 @@ void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int
 void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
-                    const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, unsigned long long* merge,
+                    const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, const uint64_t* jump_w1, unsigned long long* merge,
                     int max_nk);   // counter: base of the sketch phase's counter block; qbuf: minhash_queue_bytes(2 * nblocks) of device memory (the
                     // waves' deferred-candidate queues); unjump: inverse jump tables; merge: minhash_merge_bytes(nblocks, H); max_nk: k-mers of the longest strand
 size_t minhash_merge_bytes(int nblocks, int H);
-void build_xorshift_unjump_tables(int na, uint64_t* out);   // M^-(g a), a = 1..na, laid out like the forward tables
+void build_xorshift_unjump_tables(int na, int nq, uint64_t* out);   // M^-(g a), a = 1..na, then M^-(g na q), q = 1..nq: laid out like the forward tables
 int minhash_wgs_per_cu(int H);   // resident MinHash workgroups per CU (LDS and register budget)
 size_t minhash_queue_bytes(int nblocks_total);
 // GF(2) jump-ahead tables of the xorshift64 step, two levels: na tables of 8x256 words for M^(g a), a = 1..na (g = 2^XS_JUMP_LOG2),
 // then nq tables for M^(g na q), q = 1..nq (weighted chains run past H steps: one coarse + one fine table application)
 constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 83.9 / 84.5 / 85.8 ms MinHash at C2 (2 MB of tables at H = 512)
 constexpr int XS_JUMP_NQ = BS_WMAX;
+constexpr int W1_JUMP_NA = 16;     // fine tables of the weight-1 kernel's own (small) set: M^4 .. M^64, then coarse ones M^(64 q)
+inline int w1_jump_tables(int H) { return W1_JUMP_NA + ((H + 1) >> XS_JUMP_LOG2) / W1_JUMP_NA + 1; }
 void build_xorshift_jump_tables(int na, int nq, uint64_t* out);
 void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
 size_t ordered_lds_bytes(int cap, int code_words, int stage_wide);

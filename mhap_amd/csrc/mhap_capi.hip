@@ -99,7 +99,7 @@ struct mhap_handle {
   // filter
   DevBuf f_keys, f_vals, f_bloom;
   FilterTable ft{};
-  DevBuf score_tbl, jump_tbl, unjump_tbl, hash_luts;
+  DevBuf score_tbl, jump_tbl, unjump_tbl, jump_w1_tbl, hash_luts;
 
   // index (owned or external)
   bool external = false;
@@ -432,7 +432,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     time_begin(h, MHAP_K_MINHASH);
     launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
                    h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
-                   meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(),
+                   meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(), h->jump_w1_tbl.as<uint64_t>(),
                    h->mhmerge.as<unsigned long long>(), std::max(0, B.max_len - k + 1));
     HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
@@ -826,9 +826,18 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
       seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
   }
+  {   // the weight-1 MinHash kernel's own small two-level set (its drains look tables up a thousand times per strand: they must stay in L2)
+    const int nt = w1_jump_tables(P.num_hashes);
+    std::vector<uint64_t> jt((size_t)nt * 2048);
+    build_xorshift_jump_tables(W1_JUMP_NA, nt - W1_JUMP_NA, jt.data());
+    if (h->jump_w1_tbl.ensure(jt.size() * 8) != hipSuccess || hipMemcpy(h->jump_w1_tbl.p, jt.data(), jt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
+    }
+  }
   {   // ... and their inverses (the weight-1 MinHash kernel turns a slot's minimal chain value back into the winning key)
-    std::vector<uint64_t> ut((size_t)h->jump_na * 2048);
-    build_xorshift_unjump_tables(h->jump_na, ut.data());
+    const int nt = w1_jump_tables(P.num_hashes);
+    std::vector<uint64_t> ut((size_t)nt * 2048);
+    build_xorshift_unjump_tables(W1_JUMP_NA, nt - W1_JUMP_NA, ut.data());
     if (h->unjump_tbl.ensure(ut.size() * 8) != hipSuccess || hipMemcpy(h->unjump_tbl.p, ut.data(), ut.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
       seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
@@ -853,7 +862,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& t : h->pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
-                    &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
+                    &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->jump_w1_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
                     &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
@@ -1333,12 +1342,25 @@ int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out) {
 // for the next multiple of 4 steps, then up to 3 steps forward)
 int mhap_selftest_xorshift_unjump(uint64_t x, int32_t nsteps, uint64_t* out) {
   if (!out || nsteps < 1 || nsteps > (1 << 15)) return MHAP_E_INVALID;
-  const int a = (nsteps + (1 << XS_JUMP_LOG2) - 1) >> XS_JUMP_LOG2, r = (a << XS_JUMP_LOG2) - nsteps;
-  std::vector<uint64_t> ut((size_t)a * 2048);
-  build_xorshift_unjump_tables(a, ut.data());
-  const uint64_t* T = ut.data() + (size_t)(a - 1) * 2048;
-  uint64_t y = 0;
-  for (int i = 0; i < 8; i++) y ^= T[i * 256 + (int)((x >> (8 * i)) & 255u)];
+  int a = (nsteps + (1 << XS_JUMP_LOG2) - 1) >> XS_JUMP_LOG2;
+  const int r = (a << XS_JUMP_LOG2) - nsteps;
+  const int qa = a > W1_JUMP_NA ? (a - 1) / W1_JUMP_NA : 0;      // two levels, as in w1_key_of
+  a -= qa * W1_JUMP_NA;
+  std::vector<uint64_t> ut((size_t)(W1_JUMP_NA + qa) * 2048);
+  build_xorshift_unjump_tables(W1_JUMP_NA, qa, ut.data());
+  uint64_t y = x;
+  if (qa > 0) {
+    const uint64_t* T = ut.data() + (size_t)(W1_JUMP_NA + qa - 1) * 2048;
+    uint64_t z = 0;
+    for (int i = 0; i < 8; i++) z ^= T[i * 256 + (int)((y >> (8 * i)) & 255u)];
+    y = z;
+  }
+  {
+    const uint64_t* T = ut.data() + (size_t)(a - 1) * 2048;
+    uint64_t z = 0;
+    for (int i = 0; i < 8; i++) z ^= T[i * 256 + (int)((y >> (8 * i)) & 255u)];
+    y = z;
+  }
   for (int t = 0; t < r; t++) y = xorshift_step(y);
   *out = y;
   return MHAP_OK;

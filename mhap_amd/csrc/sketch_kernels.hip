@@ -1339,13 +1339,27 @@ struct W1Args {
   unsigned long long* prof;          // MHAP_MINHASH_PROF: wave-clock sums {key load + transpose, first-row slots, later-row slots, drains, rows, first rows, candidates}
 };
 
-// the key behind chain value x after n >= 1 steps: inverse table for the next multiple of 4, then up to 3 steps forward
+// the key behind chain value x after n >= 1 steps: inverse tables for the next multiple of 4 (coarse, then fine), then up to 3 steps forward
 __device__ __forceinline__ uint64_t w1_key_of(uint64_t x, int n, const uint64_t* __restrict__ unjump) {
-  const int a = (n + (1 << XS_JUMP_LOG2) - 1) >> XS_JUMP_LOG2, r = (a << XS_JUMP_LOG2) - n;
-  const uint32_t tb = (uint32_t)(a - 1) * 2048u;
-  uint64_t y = 0;
+  int a = (n + (1 << XS_JUMP_LOG2) - 1) >> XS_JUMP_LOG2;
+  const int r = (a << XS_JUMP_LOG2) - n;
+  const int qa = a > W1_JUMP_NA ? (a - 1) / W1_JUMP_NA : 0;      // two levels, like the forward set (w1_flush)
+  a -= qa * W1_JUMP_NA;
+  uint64_t y = x;
+  if (qa > 0) {
+    const uint32_t tb = (uint32_t)(W1_JUMP_NA + qa - 1) * 2048u;
+    uint64_t z = 0;
 #pragma unroll
-  for (int i = 0; i < 8; i++) y ^= unjump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+    for (int i = 0; i < 8; i++) z ^= unjump[tb + (uint32_t)(i * 256) + ((uint32_t)(y >> (8 * i)) & 255u)];
+    y = z;
+  }
+  {
+    const uint32_t tb = (uint32_t)(a - 1) * 2048u;
+    uint64_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z ^= unjump[tb + (uint32_t)(i * 256) + ((uint32_t)(y >> (8 * i)) & 255u)];
+    y = z;
+  }
 #pragma unroll
   for (int t = 0; t < (1 << XS_JUMP_LOG2) - 1; t++) { const uint64_t ny = xorshift_step(y); y = (t < r) ? ny : y; }
   return y;
@@ -1362,8 +1376,21 @@ __device__ __forceinline__ void w1_flush(int64_t* best, const uint32_t* __restri
       const uint32_t e = q[b0 + lane];
       const int j = (int)(e & 31u), l = (int)((e >> 5) & 63u), s = (int)(e >> 17);
       const int nsteps = s + 1;
-      const int a = nsteps >> XS_JUMP_LOG2, r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+      int a = nsteps >> XS_JUMP_LOG2;
+      const int r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+      // two levels of tables — M^(4 W1_JUMP_NA q), then M^(4 a), a <= W1_JUMP_NA: 24 tables of 16 KB at H = 512, which stay in the L2
+      // beside everything else the kernel touches.  One level (H/4 tables, 2 MB per XCD's L2) missed about one lookup in ten:
+      // 27 GB of fabric reads per C2 step for a kernel whose algorithmic traffic is 3 GB (r03 PMC pass)
+      const int qa = a > W1_JUMP_NA ? (a - 1) / W1_JUMP_NA : 0;
+      a -= qa * W1_JUMP_NA;
       uint64_t x = ks_key(ks, rb + j * 64 + l);
+      if (qa > 0) {
+        const uint32_t tb = (uint32_t)(W1_JUMP_NA + qa - 1) * 2048u;
+        uint64_t y = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+        x = y;
+      }
       if (a > 0) {
         const uint32_t tb = (uint32_t)(a - 1) * 2048u;
         uint64_t y = 0;
@@ -1559,15 +1586,24 @@ void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
   }
 }
 // the same for the inverse map: out[(a-1)*2048 + i*256 + v] = M^-(g a) applied to (v << 8i), a = 1..na
-void build_xorshift_unjump_tables(int na, uint64_t* out) {
-  uint64_t col[64], nxt[64], base[64];
+void build_xorshift_unjump_tables(int na, int nq, uint64_t* out) {
+  uint64_t col[64], nxt[64], base[64], big[64];
   auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
+  auto emit = [&](const uint64_t* c, uint64_t* T) {
+    for (int i = 0; i < 8; i++)
+      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(c, (uint64_t)v << (8 * i));
+  };
   for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < (1 << XS_JUMP_LOG2); t++) x = xorshift_unstep(x); col[j] = base[j] = x; }
   for (int a = 1; a <= na; a++) {
-    uint64_t* T = out + (size_t)(a - 1) * 2048;
-    for (int i = 0; i < 8; i++)
-      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(col, (uint64_t)v << (8 * i));
+    emit(col, out + (size_t)(a - 1) * 2048);
+    if (a == na) for (int j = 0; j < 64; j++) big[j] = col[j];   // M^-(g na)
     for (int j = 0; j < 64; j++) nxt[j] = apply(base, col[j]);
+    for (int j = 0; j < 64; j++) col[j] = nxt[j];
+  }
+  for (int j = 0; j < 64; j++) col[j] = big[j];
+  for (int q = 1; q <= nq; q++) {                                 // coarse: M^-(g na q)
+    emit(col, out + (size_t)(na + q - 1) * 2048);
+    for (int j = 0; j < 64; j++) nxt[j] = apply(big, col[j]);
     for (int j = 0; j < 64; j++) col[j] = nxt[j];
   }
 }
@@ -1595,7 +1631,7 @@ size_t minhash_merge_bytes(int nblocks, int H) { return (size_t)nblocks * 4 * (s
 void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
-                    const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, unsigned long long* merge, int max_nk) {
+                    const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, const uint64_t* jump_w1, unsigned long long* merge, int max_nk) {
   // counter: the sketch phase's counter block — [1] / [2] work counters of the two launches, [4] / [5] lengths of their strand lists
   // (written by kmer_weight_kernel), [9] / [11] strands sketched.  qbuf: minhash_queue_bytes(2 * nblocks) (one half per launch);
   // merge: minhash_merge_bytes(nblocks, H); max_nk: k-mers of the launch's longest strand
@@ -1663,7 +1699,7 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
       a.rmax = max_nk > 0 ? (max_nk + 2047) >> 11 : 1;
       a.k = k; a.k2 = k2; a.H = H; a.counter = counter_u; a.stat = counter_u + 8;
       a.out_rows = out_rows; a.out_stride = out_stride; a.out_status = out_status; a.status_stride = status_stride;
-      a.jump = jump; a.unjump = unjump; a.jump_na = jump_na; a.qbuf = qbuf; a.merge = merge;
+      a.jump = jump_w1; a.unjump = unjump; a.jump_na = W1_JUMP_NA; a.qbuf = qbuf; a.merge = merge;   // (its own two-level table set)
       const long long items = a.n_whole + a.n_tail * (long long)a.rmax;
       const int nb = (int)std::min<long long>(nblocks, (items + 3) / 4);
       const size_t lds1 = (size_t)H * 8 * 4 + lut_bytes;
