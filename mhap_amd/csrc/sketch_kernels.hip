@@ -798,6 +798,9 @@ constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wav
                                      // queue is drained at the END of a row only — where the 64 plane registers are dead — and the slot loop carries no
                                      // drain code.  Round 2 kept 640 entries in LDS and drained mid-row: the drain's state stayed live across the slot loop
                                      // (122 VGPRs) and its LDS kept a fifth workgroup off the CU.
+                                     // (Round 3 also tried the first 1024 entries of a row in LDS with the global queue as overflow, to keep the entries'
+                                     // 4-byte stores — each a 32-byte write on the memory side, 4-7 GB per C2 step in the PMC pass next to 0.4 GB of
+                                     // output — off the fabric: 16 KB more LDS per workgroup cost the fourth resident workgroup per CU, 88.6 -> 100.8 ms.)
 constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash (the murmur3_x86_32 part of the tables is not needed here)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
