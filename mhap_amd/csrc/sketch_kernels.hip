@@ -801,6 +801,10 @@ constexpr int BS_QCAP = MH_QCAP;     // deferred-candidate queue entries per wav
                                      // (Round 3 also tried the first 1024 entries of a row in LDS with the global queue as overflow, to keep the entries'
                                      // 4-byte stores — each a 32-byte write on the memory side, 4-7 GB per C2 step in the PMC pass next to 0.4 GB of
                                      // output — off the fabric: 16 KB more LDS per workgroup cost the fourth resident workgroup per CU, 88.6 -> 100.8 ms.)
+                                     // (And a trimmed bs_defer — the trigger's ballot reused, the slot index from mbcnt on top of the fill count, a clamp
+                                     // instead of the bounds branch: in the first-row loop alone 1385 -> 1244 clocks per step there, but 1387 -> 1432 in
+                                     // the later rows it did not touch, 88.6 -> 91.5 ms; in the later-row loop 12 spill accesses per trigger, 107 ms.
+                                     // The kernel sits at its 128-VGPR budget; whatever adds a live value to the trigger path pays in spills.)
 constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash (the murmur3_x86_32 part of the tables is not needed here)
 
 // One xorshift64 step of the 32 chains.  With A = x ^ (x << 21) the result is C = (I + L^4)(I + R^35) A; plane by plane:
