@@ -340,27 +340,23 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 #ifndef MH_IQ_THREADS
 #define MH_IQ_THREADS 64
 #endif
-constexpr int IQ_THREADS = MH_IQ_THREADS;   // lanes per query: measured 64 / 128 / 256 / 512 lanes -> 5.2 / 4.1 / 6.1 / 10.8 ms at C2 (four workgroups per
-                                  // CU by LDS either way: more lookups in flight per CU only thrash the memory side)
+constexpr int IQ_THREADS = MH_IQ_THREADS;   // lanes per query: 64 / 128 / 256 at C2: 4.04 / 4.30 / 6.35 ms with a 2048-entry two-word table, 3.3 with the
+                                  // packed one (one rank of eight: 2.5 / 3.4 / 5.7): one wavefront's barriers are free and its 8 KB let 15 of them share a CU
 constexpr int IQ_SAT = 180;       // hit counts of the first tier saturate here (8-bit counters)
 constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
 #ifndef MH_IQ_SPT
-#define MH_IQ_SPT 1   // 1 / 2 / 4 at C2: 4.7 / 4.7 / 5.7 ms (4 costs a workgroup per CU its LDS queue; the memory side, not the latency, bounds the lookups)
+#define MH_IQ_SPT 1   // 1 / 2 / 4 at C2 with 128 lanes: 4.7 / 4.7 / 5.7 ms; with 64: 4.08 / 4.07 / 4.44 (the queue's LDS costs resident workgroups)
 #endif
 constexpr int IQ_SPT = MH_IQ_SPT;   // slots a lane of the first tier looks up per trip (their loads are in flight together)
 constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lane that looked it up; longer ones are streamed by the workgroup
 #ifndef MH_IQ_BIG_CT
-#define MH_IQ_BIG_CT 16384
+#define MH_IQ_BIG_CT 16384   // (0: no further tiers — every hit set that outgrows the first tier's table is split there)
 #endif
-#ifndef MH_IQ_BIG_THREADS
-#define MH_IQ_BIG_THREADS 1024
-#endif
-constexpr int INV_CT_BIG = MH_IQ_BIG_CT ? MH_IQ_BIG_CT : 4096, IQ_THREADS_BIG = MH_IQ_BIG_THREADS;   // second tier: 128 KB count table, one workgroup per CU
-// Tiers.  <INV_CT, IQ_THREADS> (8 KB of LDS for the table) takes every query; one whose buckets hold more postings than the
-// table can count (repeats: thousands of stored entries share a MinHash value with the query), or whose distinct hits
-// outgrow the table, is appended to `big` and re-run by <INV_CT_BIG, IQ_THREADS_BIG>, whose table holds 12 288 distinct hits in
-// one pass; only beyond that a hit set is split into hash-partition passes over the stored entries (split in two until every
-// part fits), which bounds a query's cost by its own postings.  big == nullptr: split right away.
+// Tiers (launch_index_query).  <INV_CT, IQ_THREADS> takes every query; one whose buckets hold more postings than the table can
+// count (repeats: thousands of stored entries share a MinHash value with the query), or whose distinct hits outgrow the table, is
+// appended to `big` and handed on: to the dense tier (index_query_dense_kernel), on a large index through <INV_CT_MID,
+// IQ_THREADS_MID> first.  big == nullptr (MHAP_INDEX_TIERS=1, tests): the hit set is split into hash-partition passes over the
+// stored entries instead (split in two until every part fits), which bounds a query's cost by its own postings.
 template <int INV_CT, int IQ_THREADS, int SPT>
 __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
