@@ -964,7 +964,12 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
   // shortcut: the chains that are negative with nine leading zero magnitude bits (two are expected among 2048, and if there is
   // any the minimum is among them); the plane-by-plane walk below only runs for the ~14 % of slots without one.  Measured with
   // 8 / 9 / 10 planes: 83.6 / 77.8 / 79.7 ms at C2 (more planes = more walks, fewer = more candidates to drain).
-  const uint32_t pre = ACT & P[63] & ~(((P[62] | P[61]) | (P[60] | P[59])) | ((P[58] | P[57]) | (P[56] | P[55])) | P[54]);
+  // (three-input ORs as v_bitop3_b32: the compiler's v_or3_b32 is half rate on gfx950)
+  uint32_t o = __builtin_amdgcn_bitop3_b32(P[62], P[61], P[60], BS_TT_OR3);
+  o = __builtin_amdgcn_bitop3_b32(o, P[59], P[58], BS_TT_OR3);
+  o = __builtin_amdgcn_bitop3_b32(o, P[57], P[56], BS_TT_OR3);
+  o = __builtin_amdgcn_bitop3_b32(o, P[55], P[54], BS_TT_OR3);
+  const uint32_t pre = __builtin_amdgcn_bitop3_b32(ACT, P[63], o, 0x40);   // ACT & sign & ~o   (table index = 4a + 2b + c)
   if (__any(pre != 0u)) return pre;
   uint32_t cand = ACT & P[63];                 // negative values first (signed compare)
   if (!__any(cand != 0u)) cand = ACT;
@@ -1040,14 +1045,21 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
 // runs while any lane has bits left).  The fill count lives in a wave-uniform register and queue slots are handed out with
 // ballot + mbcnt (no atomic, no read-back).  Entries beyond the capacity are dropped; the count keeps running, so the drain sees it.
 __device__ __forceinline__ void bs_defer(uint32_t* __restrict__ q, int& qn, int s, int c, uint32_t cand) {
-  // (the lane id is recomputed here — two ops — rather than kept alive, or spilled, across the slot loop for this cold path)
-  const uint32_t lane = __builtin_amdgcn_mbcnt_hi(0xFFFFFFFFu, __builtin_amdgcn_mbcnt_lo(0xFFFFFFFFu, 0u));
-  const uint32_t head = ((uint32_t)s << 17) | ((uint32_t)c << 11) | (lane << 5);
+  // Both MinHash kernels sit at their VGPR limit in the slot loop, and whatever this path keeps alive is spilled: the lane id, hoisted
+  // out of the loop by the compiler (the mbcnt builtins are pure), and the queue's base as a VGPR pair were reloaded from scratch —
+  // a memory round trip and an s_waitcnt vmcnt(0) each — in front of every queue store (later rows of the weight-1 kernel: 1387 ->
+  // 1162 clocks per step without them).  So: the lane id from volatile asm right where the entry is put together, the base as a
+  // scalar pair (the callers' readfirstlane), and nothing computed ahead of the loop.
+  const uint32_t shead = ((uint32_t)s << 17) | ((uint32_t)c << 11);   // (wave-uniform: scalar)
   unsigned long long m = __ballot(cand != 0u);
   do {
     if (cand) {
       const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (idx < BS_QCAP) q[idx] = head | (uint32_t)__builtin_ctz(cand);
+      if (idx < BS_QCAP) {
+        uint32_t lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(lane));
+        ((__attribute__((address_space(1))) uint32_t*)q)[idx] = shead | (lane << 5) | (uint32_t)__builtin_ctz(cand);   // (global_store with the scalar base)
+      }
       cand &= cand - 1u;
     }
     qn += __popcll(m);
@@ -1141,6 +1153,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
   int64_t* best = (int64_t*)wbase;
   int32_t* bpos = (int32_t*)(best + H);
   uint32_t* bsq = qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * BS_QCAP;   // this wave's deferred-candidate queue (global memory)
+  {   // the window's base as a scalar pair: the queue stores then take it as their SGPR base + a 32-bit lane offset (as a VGPR pair it
+      // was spilled, and reloaded from scratch in front of every queue store)
+    const unsigned long long qa = (unsigned long long)(uintptr_t)bsq;
+    const uint32_t qlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qa), qhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qa >> 32));
+    bsq = (uint32_t*)(uintptr_t)(((unsigned long long)qhi << 32) | qlo);
+  }
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
   for (;;) {
     unsigned long long tk = 0;
@@ -1472,6 +1490,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES
   __syncthreads();
   int64_t* best = (int64_t*)(smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * (size_t)H * 8);
   uint32_t* q = a.qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * BS_QCAP;
+  {   // the window's base as a scalar pair: the queue stores then take it as their SGPR base + a 32-bit lane offset (as a VGPR pair it
+      // was spilled, and reloaded from scratch in front of every queue store)
+    const unsigned long long qa = (unsigned long long)(uintptr_t)q;
+    const uint32_t qlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)qa), qhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(qa >> 32));
+    q = (uint32_t*)(uintptr_t)(((unsigned long long)qhi << 32) | qlo);
+  }
   const long long nitems = a.n_whole + a.n_tail * (long long)a.rmax;
   unsigned long long nst = 0;
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};

@@ -41,7 +41,7 @@ def main(iters, seed0):
                 Lg = rnd.randrange(13000, 40000)
                 seqs.append(mutate(rnd, (G * (Lg // len(G) + 2))[rnd.randrange(0, len(G)):][:Lg], 0.05))
         fa = FastaData.from_strings(seqs)
-        kw = dict(kmer_size=rnd.choice([16, 16, 16, 12, 14, 18, 21]), num_hashes=rnd.choice([16, 64, 128, 200, 512]),
+        kw = dict(kmer_size=rnd.choice([16, 16, 16, 12, 14, 18, 21]), num_hashes=rnd.choice([16, 64, 128, 200, 512, 13, 100, 257]),
                   ordered_kmer_size=rnd.choice([12, 12, 8, 10, 13]), ordered_sketch_size=rnd.choice([32, 100, 300, 512, 1536]),
                   num_min_matches=rnd.choice([1, 2, 3, 5]), threshold=rnd.choice([0.0, 0.5, 0.78, 0.9]), max_shift=rnd.choice([0.05, 0.2, 0.4]),
                   min_store_length=rnd.choice([0, 0, 500, 2000]), min_olap_length=rnd.choice([0, 50, 116, 500]))
