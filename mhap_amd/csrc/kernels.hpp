@@ -84,7 +84,10 @@ size_t minhash_queue_bytes(int nblocks_total);
 // then nq tables for M^(g na q), q = 1..nq (weighted chains run past H steps: one coarse + one fine table application)
 constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 83.9 / 84.5 / 85.8 ms MinHash at C2 (2 MB of tables at H = 512)
 constexpr int XS_JUMP_NQ = BS_WMAX;
-constexpr int W1_JUMP_NA = 16;     // fine tables of the weight-1 kernel's own (small) set: M^4 .. M^64, then coarse ones M^(64 q)
+#ifndef MH_W1_JUMP_NA
+#define MH_W1_JUMP_NA 16
+#endif
+constexpr int W1_JUMP_NA = MH_W1_JUMP_NA;     // fine tables of the weight-1 kernel's own (small) set: M^4 .. M^64, then coarse ones M^(64 q)
 inline int w1_jump_tables(int H) { return W1_JUMP_NA + ((H + 1) >> XS_JUMP_LOG2) / W1_JUMP_NA + 1; }
 void build_xorshift_jump_tables(int na, int nq, uint64_t* out);
 void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
