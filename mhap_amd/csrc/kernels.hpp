@@ -130,7 +130,7 @@ void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminh
                         unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, int tier);
 int index_query_dense_ranges(int64_t entries);   // passes the dense tier makes over an index of this size
 bool index_query_tiers();
-bool index_query_first_tier_ok(int64_t entries, int num_min_matches);   // false: every query goes to the dense tier   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
+bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches);   // tier 0 / 1: can its packed hit-count words hold this index and threshold?   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
 // (tiers: 0 the first, 1 the same kernel with a large table, 2 dense counters — launch_index_query in search_kernels.hip)
 // Second stage: one lane per candidate.
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,

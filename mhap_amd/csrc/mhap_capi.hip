@@ -591,8 +591,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         HIPCHK(h, h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
         const bool tiers = index_query_tiers() && !(tv && tv[0] == '1');
-        // (an index of 2^24 entries or more, or numMinMatches beyond the first tier's 8-bit counters: every query takes the dense tier)
-        const bool first_ok = index_query_first_tier_ok(h->n_entries, sp.num_min_matches);
+        // (an index or a numMinMatches the first tier's packed hit-count words cannot hold: every query takes the dense tier)
+        const char* dv = getenv("MHAP_INDEX_DENSE");    // "1": every query takes the dense tier (tests)
+        const bool first_ok = index_query_tier_ok(0, h->n_entries, sp.num_min_matches) && !(dv && dv[0] == '1');
         int32_t* listA = h->inv_big.as<int32_t>();
         int32_t* listB = listA + nq;
         time_begin(h, MHAP_K_INDEX_QUERY);
@@ -611,7 +612,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         const int32_t* dense_list = listA;
         unsigned long long n_dense = c5[6];
         const char* midv = getenv("MHAP_INDEX_MID");   // "1" / "0": with / without the middle tier whatever the index size (tests)
-        const bool use_mid = midv ? midv[0] == '1' : index_query_dense_ranges(h->n_entries) > 4;
+        const bool use_mid = (midv ? midv[0] == '1' : index_query_dense_ranges(h->n_entries) > 4) && index_query_tier_ok(1, h->n_entries, sp.num_min_matches);
         if (c5[6] > 0 && c5[0] <= cand_cap && use_mid) {
           time_begin(h, MHAP_K_INDEX_QUERY);
           launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,

@@ -335,14 +335,13 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
   hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
 }
 
-// One workgroup (one wavefront) per query.  LDS: tbl[CT], a hit-count table of packed words: entry + 1 in the low 24 bits, its
-// (saturating) hit count in the high 8.
+// One workgroup (one wavefront) per query.  LDS: tbl[CT], a hit-count table of packed words: entry + 1 in the low `ebits` bits (as
+// many as the index needs), its saturating hit count in the bits above.
 #ifndef MH_IQ_THREADS
 #define MH_IQ_THREADS 64
 #endif
 constexpr int IQ_THREADS = MH_IQ_THREADS;   // lanes per query: 64 / 128 / 256 at C2: 4.04 / 4.30 / 6.35 ms with a 2048-entry two-word table, 3.3 with the
                                   // packed one (one rank of eight: 2.5 / 3.4 / 5.7): one wavefront's barriers are free and its 8 KB let 15 of them share a CU
-constexpr int IQ_SAT = 180;       // hit counts of the first tier saturate here (8-bit counters)
 constexpr int IQ_STACK = 48;      // pending (prefix, bits) parts of a query whose hit set is being split
 #ifndef MH_IQ_SPT
 #define MH_IQ_SPT 1   // 1 / 2 / 4 at C2 with 128 lanes: 4.7 / 4.7 / 5.7 ms; with 64: 4.08 / 4.07 / 4.44 (the queue's LDS costs resident workgroups)
@@ -425,9 +424,13 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     unsigned long long mine = 0;
     // count one hit of stored entry `me` (the id/length rules do not depend on the count: they are applied to the few entries that
     // reach numMinMatches, below, so that the lookup loop's only global loads are the index words)
-    // (the count is read before it is raised and left alone from `sat` on, so it passes `sat` by at most the adds in flight — one
-    // per lane — and never wraps; the host keeps queries out of this tier when numMinMatches > IQ_SAT or entries do not fit 24 bits)
-    const uint32_t sat = (uint32_t)(sp.num_min_matches < IQ_SAT ? sp.num_min_matches : IQ_SAT);
+    // The count is read before it is raised and left alone from `sat` on, so it passes `sat` by at most the adds in flight — one per
+    // lane of the workgroup — and the field must hold sat + IQ_THREADS: index_query_tier_ok() keeps a launch out of this kernel when
+    // the bits the entries leave are too few for that (the 512-lane middle tier needs 10, i.e. an index below 2^22 entries).
+    const int ebits = 32 - __builtin_clz(ix.ne | 1u);                   // entry + 1 <= ne fits
+    const uint32_t emask = ebits >= 32 ? 0xFFFFFFFFu : ((1u << ebits) - 1u), cone = ebits >= 32 ? 0u : (1u << ebits);
+    const uint32_t cmax = ebits >= 32 ? 0u : (0xFFFFFFFFu >> ebits);
+    const uint32_t sat = (uint32_t)sp.num_min_matches < cmax - (uint32_t)IQ_THREADS ? (uint32_t)sp.num_min_matches : cmax - (uint32_t)IQ_THREADS;
     auto count_hit = [&](int me) {
       const uint32_t hm = inv_mix((uint32_t)me);
       if (((hm >> CT_LOG) & pmask) != prefix) return;
@@ -435,12 +438,12 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       uint32_t slot = hm & (INV_CT - 1);
       for (int tries = 0; tries < INV_CT; tries++) {
         uint32_t w = __hip_atomic_load(&tbl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if ((w & 0xFFFFFFu) == 0) {
+        if ((w & emask) == 0) {
           if (__hip_atomic_load(&s_distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (INV_CT * 3) / 4) { s_over = 1; break; }
           const uint32_t old = atomicCAS(&tbl[slot], 0u, id);
           if (old == 0) { atomicAdd(&s_distinct, 1u); w = id; } else w = old;
         }
-        if ((w & 0xFFFFFFu) == id) { if ((w >> 24) < sat) atomicAdd(&tbl[slot], 1u << 24); break; }
+        if ((w & emask) == id) { if ((w >> ebits) < sat) atomicAdd(&tbl[slot], cone); break; }
         slot = (slot + 1) & (INV_CT - 1);
       }
     };
@@ -567,8 +570,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
       const int j = threadIdx.x + IQ_THREADS * t;
       const uint32_t w = tbl[j];
-      if ((w & 0xFFFFFFu) != 0 && (int)(w >> 24) >= sp.num_min_matches) {                          // MinHashSearch.java:204
-        const int me = (int)(w & 0xFFFFFFu) - 1;
+      if ((w & emask) != 0 && (int)(w >> ebits) >= sp.num_min_matches) {                          // MinHashSearch.java:204
+        const int me = (int)(w & emask) - 1;
         if (pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) { mymask |= 1u << t; mycount++; }   // :200-225
       }
     }
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
 #pragma unroll
     for (int t = 0; t < INV_CT / IQ_THREADS; t++) {
       if (mymask & (1u << t)) {
-        if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)(tbl[threadIdx.x + IQ_THREADS * t] & 0xFFFFFFu) - 1; }
+        if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)(tbl[threadIdx.x + IQ_THREADS * t] & emask) - 1; }
         slot++;
       }
     }
@@ -732,8 +735,15 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
 }
 
 bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
-// the first tier's packed table holds entry indices below 2^24 - 1 and counts up to IQ_SAT
-bool index_query_first_tier_ok(int64_t entries, int num_min_matches) { return entries < (1 << 24) - 1 && num_min_matches <= IQ_SAT; }
+// whether the packed table words of tier 0 (IQ_THREADS lanes) / tier 1 (IQ_THREADS_MID lanes) can count to numMinMatches for an index
+// of this many entries: the count field (the bits the entry index leaves) must hold numMinMatches + one add in flight per lane
+bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches) {
+  if (entries < 1 || entries >= (1LL << 31)) return false;
+  int ebits = 1;
+  while ((1LL << ebits) <= entries) ebits++;            // entry + 1 <= entries < 2^ebits
+  const long long cmax = (1LL << (32 - ebits)) - 1;
+  return (long long)num_min_matches + (tier == 0 ? IQ_THREADS : 512) <= cmax;
+}
 
 // tier 0: the first tier (one wavefront per query, 2048-entry table); tier 1: the same kernel with a 16 384-entry table and 512 lanes
 // (queries of a LARGE index that outgrow the first table but have thousands, not hundreds of thousands, of hits: the dense tier would

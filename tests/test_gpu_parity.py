@@ -512,10 +512,11 @@ def test_index_query_tiers_on_huge_hit_sets(monkeypatch):
     assert si["table_elements"] == want_elements and s1["table_elements"] == want_elements
 
 
-def test_large_num_min_matches_takes_the_dense_tier():
-    """--num-min-matches beyond what the first tier's 8-bit hit counters can tell apart (180): every query is counted by the dense
-    tier.  Near-identical copies of one read share most of their 512 MinHash values; records, compared pairs and processed elements
-    equal the oracle's at numMinMatches = 3 (first tier), 150 (first tier, close to its limit) and 250 (dense tier)."""
+def test_num_min_matches_up_to_the_slot_count_in_every_tier(monkeypatch):
+    """--num-min-matches far beyond the default: the first tier's packed words give the hit count the bits the entry index leaves
+    (a count must reach numMinMatches plus one add in flight per lane without wrapping), the dense tier (MHAP_INDEX_DENSE=1: every
+    query) counts in 16 bits.  Near-identical copies of one read share most of their 512 MinHash values; records, compared pairs
+    and processed elements equal the oracle's at numMinMatches = 3, 150 and 250 in both."""
     rnd = random.Random(9)
     base = _rand_seq(rnd, 3000)
     seqs = [_rand_seq(rnd, 3000) for _ in range(40)]
@@ -528,13 +529,17 @@ def test_large_num_min_matches_takes_the_dense_tier():
     for nmm in (3, 150, 250):
         p = MhapParams(num_hashes=512, ordered_sketch_size=512, num_min_matches=nmm)
         want = O.run_self(fa, H=512, S=512, num_min_matches=nmm, nthreads=8)
-        with MinHashSearch(p) as ms:
-            ms.add_data(fa)
-            got = ms.find_matches()
-            st = ms.stats()
-        assert np.array_equal(_sorted_records(got), _sorted_records(want["records"])), nmm
-        assert st["table_elements"] == want["elements"] and st["candidates_compared"] == want["compared"], nmm
-        assert len(got) >= 30 if nmm < 250 else len(got) > 0, (nmm, len(got))
+        for dense in (False, True):
+            if dense:
+                monkeypatch.setenv("MHAP_INDEX_DENSE", "1")
+            with MinHashSearch(p) as ms:
+                ms.add_data(fa)
+                got = ms.find_matches()
+                st = ms.stats()
+            monkeypatch.delenv("MHAP_INDEX_DENSE", raising=False)
+            assert np.array_equal(_sorted_records(got), _sorted_records(want["records"])), (nmm, dense)
+            assert st["table_elements"] == want["elements"] and st["candidates_compared"] == want["compared"], (nmm, dense)
+            assert len(got) >= 30 if nmm < 250 else len(got) > 0, (nmm, dense, len(got))
 
 
 def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
