@@ -608,7 +608,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         if (rc != MHAP_OK) return rc;
         // queries whose hits outgrow the first tier's table.  A small index (a few dense ranges): dense counters at once.  A large
         // one: the middle tier's 16 384-entry table first — ordinary reads of a big data set have thousands of hits, and the dense
-        // tier would make a pass per 65 536 stored entries for each of them — and dense counters for what outgrows that too (repeats).
+        // tier would make a pass per 32 768 stored entries for each of them — and dense counters for what outgrows that too (repeats).
         const int32_t* dense_list = listA;
         unsigned long long n_dense = c5[6];
         const char* midv = getenv("MHAP_INDEX_MID");   // "1" / "0": with / without the middle tier whatever the index size (tests)

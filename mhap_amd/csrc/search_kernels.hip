@@ -597,11 +597,18 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
 
 // Second tier: DENSE counts.  A query the first tier hands over has thousands of distinct hits — on repeat-rich reads most of the
 // index — and a hash table of them in LDS (rounds 1-2: 12 288 entries, beyond that hash-partition passes that each stream all of
-// the query's postings again; 21 190 splits per step on the C5 slice) is the wrong structure: 128 KB of LDS hold a saturating
-// 16-bit counter for each of 65 536 stored entries, indexed by the entry itself — no keys, no probing, no overflow.  An index
-// with more entries is covered in passes over entry ranges of 65 536; the first pass notes which ranges the query's postings
+// the query's postings again; 21 190 splits per step on the C5 slice) is the wrong structure: 64 KB of LDS hold a saturating
+// 16-bit counter for each of 32 768 stored entries, indexed by the entry itself — no keys, no probing, no overflow.  An index
+// with more entries is covered in passes over entry ranges of 32 768; the first pass notes which ranges the query's postings
 // fall into and the others are skipped.
-constexpr int DQ_THREADS = 1024, DQ_RANGE_LOG = 16, DQ_MAX_RANGES = 4096;   // (an index of more than 4096 ranges = 2^28 entries runs every pass)
+#ifndef MH_DQ_THREADS
+#define MH_DQ_THREADS 512    // 1024 lanes + 65 536-entry ranges (one workgroup per CU) / 512 + 32 768 (two): C5 slice 12.2 / 10.8 ms — one
+                            // query's zeroing and scan overlap the other's streaming, at the price of a third range pass over its 80 000 entries
+#endif
+#ifndef MH_DQ_RANGE_LOG
+#define MH_DQ_RANGE_LOG 15
+#endif
+constexpr int DQ_THREADS = MH_DQ_THREADS, DQ_RANGE_LOG = MH_DQ_RANGE_LOG, DQ_MAX_RANGES = 4096;   // (an index of more than 4096 ranges = 2^28 entries runs every pass)
 __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                                        const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
                                                                        const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
@@ -747,7 +754,7 @@ bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches) {
 
 // tier 0: the first tier (one wavefront per query, 2048-entry table); tier 1: the same kernel with a 16 384-entry table and 512 lanes
 // (queries of a LARGE index that outgrow the first table but have thousands, not hundreds of thousands, of hits: the dense tier would
-// make a pass per 65 536 stored entries for them); tier 2: the dense tier.  big / big_count: where tiers 0 and 1 list the queries
+// make a pass per 32 768 stored entries for them); tier 2: the dense tier.  big / big_count: where tiers 0 and 1 list the queries
 // they hand on (nullptr: they split hit sets into hash-partition passes instead).
 constexpr int INV_CT_MID = 16384, IQ_THREADS_MID = 512;
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,

@@ -544,7 +544,7 @@ def test_num_min_matches_up_to_the_slot_count_in_every_tier(monkeypatch):
 
 def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
     """A repeat-rich sample (the C5 slice's generator: a 300-bp repeat family planted every 3 kb) with more than 65 536 stored
-    entries: the second tier's dense counters cover the index in two entry ranges.  Records equal the first-tier-only path's
+    entries: the second tier's dense counters cover the index in three entry ranges of 32 768.  Records equal the first-tier-only path's
     (hash-partition passes), the index finds every posting where a lookup expects it (MHAP_DEBUG_INDEX self-check), and the
     processed-elements statistic equals an independent count from the exported MinHash rows."""
     from mhap_amd import workloads as W
