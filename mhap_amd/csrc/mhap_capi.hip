@@ -91,6 +91,7 @@ struct mhap_handle {
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0;
+  bool iq_start_mid = false;   // queries of this index start in the middle query tier (set by a chunk that mostly ended up there)
   int64_t reserve_reads = 0;       // mhap_index_reserve: reads the empty index is about to receive, over one or more adds
   std::string err;
   int Hrow = 1;      // minhash row stride (ints)
@@ -526,7 +527,7 @@ int ensure_inverted_index(mhap_handle* h) {
     fprintf(stderr, "[index] self-check: %llu of %lld postings missing\n", missing, (long long)ne * H);
     if (missing) return fail(h, MHAP_E_STATE, "inverted index self-check failed");
   }
-  h->inv_ready = true; h->inv_ne = ne;
+  h->inv_ready = true; h->inv_ne = ne; h->iq_start_mid = false;
   return MHAP_OK;
 }
 
@@ -596,33 +597,40 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         const bool first_ok = index_query_tier_ok(0, h->n_entries, sp.num_min_matches) && !(dv && dv[0] == '1');
         int32_t* listA = h->inv_big.as<int32_t>();
         int32_t* listB = listA + nq;
+        const char* midv = getenv("MHAP_INDEX_MID");   // "1" / "0": with / without the middle tier whatever the index size (tests)
+        const bool use_mid = tiers && first_ok && (midv ? midv[0] == '1' : index_query_dense_ranges(h->n_entries) > 4) &&
+                             index_query_tier_ok(1, h->n_entries, sp.num_min_matches);
+        // Tiers (search_kernels.hip).  Queries whose hits outgrow the first tier's table: a small index (a few dense ranges) counts them
+        // with dense counters at once; a large one in the middle tier's 8192-entry table first — ordinary reads of a big data set have
+        // thousands of hits, and the dense tier would make a pass per 32 768 stored entries for each of them — and dense counters for
+        // what outgrows that too (repeats).  When more than half of a chunk's queries left the first tier for the middle one (all of
+        // C4), the next chunks START there: the first tier's look at the bucket lengths was their only use of it.
+        const int t0 = !first_ok ? 2 : (use_mid && h->iq_start_mid ? 1 : 0);
         time_begin(h, MHAP_K_INDEX_QUERY);
         launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && first_ok ? listA : nullptr, ctr + 6, first_ok ? 0 : 2);
+                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && t0 < 2 ? listA : nullptr, ctr + 6, t0);
         time_end(h);
         HIPCHK(h, hipGetLastError());
         unsigned long long c5[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return rc;
-        // queries whose hits outgrow the first tier's table.  A small index (a few dense ranges): dense counters at once.  A large
-        // one: the middle tier's 16 384-entry table first — ordinary reads of a big data set have thousands of hits, and the dense
-        // tier would make a pass per 32 768 stored entries for each of them — and dense counters for what outgrows that too (repeats).
         const int32_t* dense_list = listA;
         unsigned long long n_dense = c5[6];
-        const char* midv = getenv("MHAP_INDEX_MID");   // "1" / "0": with / without the middle tier whatever the index size (tests)
-        const bool use_mid = (midv ? midv[0] == '1' : index_query_dense_ranges(h->n_entries) > 4) && index_query_tier_ok(1, h->n_entries, sp.num_min_matches);
-        if (c5[6] > 0 && c5[0] <= cand_cap && use_mid) {
-          time_begin(h, MHAP_K_INDEX_QUERY);
-          launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,
-                             h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, ctr + 3, ctr + 4, listB, ctr + 8, 1);
-          time_end(h);
-          HIPCHK(h, hipGetLastError());
-          HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
-          rc = sync_stream(h);
-          if (rc != MHAP_OK) return rc;
-          dense_list = listB; n_dense = c5[8];
+        if (t0 == 0 && use_mid && c5[0] <= cand_cap) {
+          if (2 * c5[6] > (unsigned long long)nq) h->iq_start_mid = true;
+          if (c5[6] > 0) {
+            time_begin(h, MHAP_K_INDEX_QUERY);
+            launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,
+                               h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, ctr + 3, ctr + 4, listB, ctr + 8, 1);
+            time_end(h);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
+            rc = sync_stream(h);
+            if (rc != MHAP_OK) return rc;
+            dense_list = listB; n_dense = c5[8];
+          }
         }
         if (n_dense > 0 && c5[0] <= cand_cap) {
           time_begin(h, MHAP_K_INDEX_QUERY);

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     // reach numMinMatches, below, so that the lookup loop's only global loads are the index words)
     // The count is read before it is raised and left alone from `sat` on, so it passes `sat` by at most the adds in flight — one per
     // lane of the workgroup — and the field must hold sat + IQ_THREADS: index_query_tier_ok() keeps a launch out of this kernel when
-    // the bits the entries leave are too few for that (the 512-lane middle tier needs 10, i.e. an index below 2^22 entries).
+    // the bits the entries leave are too few for that (the middle tier is given 10 bits, i.e. an index below 2^22 entries).
     const int ebits = 32 - __builtin_clz(ix.ne | 1u);                   // entry + 1 <= ne fits
     const uint32_t emask = ebits >= 32 ? 0xFFFFFFFFu : ((1u << ebits) - 1u), cone = ebits >= 32 ? 0u : (1u << ebits);
     const uint32_t cmax = ebits >= 32 ? 0u : (0xFFFFFFFFu >> ebits);
@@ -749,14 +749,21 @@ bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches) {
   int ebits = 1;
   while ((1LL << ebits) <= entries) ebits++;            // entry + 1 <= entries < 2^ebits
   const long long cmax = (1LL << (32 - ebits)) - 1;
-  return (long long)num_min_matches + (tier == 0 ? IQ_THREADS : 512) <= cmax;
+  return (long long)num_min_matches + (tier == 0 ? IQ_THREADS : 512) <= cmax;   // (512: an upper bound of the middle tier's lanes)
 }
 
-// tier 0: the first tier (one wavefront per query, 2048-entry table); tier 1: the same kernel with a 16 384-entry table and 512 lanes
+// tier 0: the first tier (one wavefront per query, 2048-entry table); tier 1: the same kernel with an 8192-entry table and 256 lanes
 // (queries of a LARGE index that outgrow the first table but have thousands, not hundreds of thousands, of hits: the dense tier would
 // make a pass per 32 768 stored entries for them); tier 2: the dense tier.  big / big_count: where tiers 0 and 1 list the queries
 // they hand on (nullptr: they split hit sets into hash-partition passes instead).
-constexpr int INV_CT_MID = 16384, IQ_THREADS_MID = 512;
+#ifndef MH_IQ_MID_CT
+#define MH_IQ_MID_CT 8192    // 16384 entries + 512 lanes / 8192 + 256 / 4096 + 128 on all of C4: 136 / 81 / 78 ms of index query (more workgroups per
+                            // CU again); 8192 holds the 2-3 thousand hits of an ordinary read of a large data set with room to spare
+#endif
+#ifndef MH_IQ_MID_THREADS
+#define MH_IQ_MID_THREADS 256
+#endif
+constexpr int INV_CT_MID = MH_IQ_MID_CT, IQ_THREADS_MID = MH_IQ_MID_THREADS;
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,

@@ -447,8 +447,8 @@ def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     assert len(want["records"]) > 5_000_000
     want_sorted = _sorted_records(want["records"])
     for tiers, splits in (("2", False), ("1", True)):
-        # default: a hit set that outgrows the 4096-entry table is re-run by the second tier's 16384-entry table (no split at
-        # 3320 distinct hits); first tier alone: it is split into hash-partition passes
+        # default: a hit set that outgrows the first tier's table is counted by the dense second tier (no split at 3320 distinct hits);
+        # first tier alone: it is split into hash-partition passes
         monkeypatch.setenv("MHAP_INDEX_TIERS", tiers)
         with MinHashSearch(p) as ms:
             ms.add_data(fa)
@@ -495,7 +495,7 @@ def test_index_query_tiers_on_huge_hit_sets(monkeypatch):
             monkeypatch.setenv("MHAP_CANDIDATES", "bruteforce")
         if mode == "first-tier-only":
             monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
-        if mode == "middle-tier":                  # the tier between the two that a large index gets: its 16 384-entry table holds these hit sets
+        if mode == "middle-tier":                  # the tier between the two that a large index gets (its 8192-entry table hands these 14 000-entry hit sets on to the dense counters)
             monkeypatch.setenv("MHAP_INDEX_MID", "1")
         with MinHashSearch(p) as ms:
             ms.add_sketches(sk)
@@ -560,7 +560,7 @@ def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
     for mode in ("tiers", "first-tier-only", "middle-tier"):
         if mode == "first-tier-only":
             monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
-        if mode == "middle-tier":                  # first tier -> 16 384-entry table -> dense counters for what outgrows that too
+        if mode == "middle-tier":                  # first tier -> 8192-entry table -> dense counters for what outgrows that too
             monkeypatch.delenv("MHAP_INDEX_TIERS")
             monkeypatch.setenv("MHAP_INDEX_MID", "1")
         with MinHashSearch(p, kmer_filter=flt) as ms:
