@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--error-rate", type=float, default=0.15)
     ap.add_argument("--cpu-sample-reads", type=int, default=0, help="0 = auto (about 15-20 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip parity_check / cpu_baseline / end_to_end (kernel A/B runs)")
+    ap.add_argument("--soak-seconds", type=float, default=-1.0,
+                    help="after the timed region: repeat the step, untimed for `value`, for about this long and report the per-step spread "
+                         "(settled clocks; also keeps the GPU busy long enough for a 5 s utilisation sampler to see it).  Default 8, "
+                         "0 with --no-cpu-baseline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,11 +210,27 @@ def main():
     fence()
     # output fingerprint of the last step (outside the timed region): SHA-256 of the sorted record lines on one GPU, and an
     # order- and shard-independent checksum (sum of the first 8 digest bytes of every line, mod 2^64) that is comparable across N
-    lines = sorted(mhap_amd.records_to_lines(recs))
-    sha = hashlib.sha256("\n".join(lines).encode()).hexdigest() if world == 1 else None
-    csum = 0
-    for ln in lines:
-        csum = (csum + int.from_bytes(hashlib.sha256(ln.encode()).digest()[:8], "little")) & ((1 << 64) - 1)
+    # (beyond a few million records the text of every line is not formed in Python: `records_checksum` is then an order-independent
+    #  mix of the binary record fields — comparable across N and across runs of the same build, not with the text-based one)
+    big_output = len(recs) > 4_000_000
+    if big_output:
+        sha = None
+        m64 = np.zeros(len(recs), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for f in ("from_id", "to_id", "a1", "a2", "alen", "b1", "b2", "blen", "to_rc"):
+                m64 = (m64 ^ recs[f].astype(np.int64).view(np.uint64)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
+                m64 ^= m64 >> np.uint64(29)
+            for f in ("score", "raw"):
+                m64 = (m64 ^ np.ascontiguousarray(recs[f], dtype=np.float64).view(np.uint64)) * np.uint64(0xBF58476D1CE4E5B9) + np.uint64(1)
+                m64 ^= m64 >> np.uint64(31)
+            csum = int(m64.sum(dtype=np.uint64))
+        lines = None
+    else:
+        lines = sorted(mhap_amd.records_to_lines(recs))
+        sha = hashlib.sha256("\n".join(lines).encode()).hexdigest() if world == 1 else None
+        csum = 0
+        for ln in lines:
+            csum = (csum + int.from_bytes(hashlib.sha256(ln.encode()).digest()[:8], "little")) & ((1 << 64) - 1)
 
     rdev = dev if backend == "nccl" else torch.device("cpu")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
@@ -229,6 +249,25 @@ def main():
     limbs = [int(v) for v in csum_t.tolist()]
     records_checksum = (limbs[0] + (limbs[1] << 16) + (limbs[2] << 32) + (limbs[3] << 48)) & ((1 << 64) - 1)
     sec_per_step = elapsed / max(args.steps, 1)
+
+    # soak leg (outside the timed region, before any CPU-side leg): the same step repeated for ~8 s.  The step count derives from the
+    # rank-max step time, so every rank of an N > 1 run takes the same number of collective searches.
+    soak_s = args.soak_seconds if args.soak_seconds >= 0 else (0.0 if args.no_cpu_baseline else 8.0)
+    soak = None
+    if soak_s > 0 and sec_per_step > 0:
+        n_soak = int(max(1, min(2000, round(soak_s / sec_per_step))))
+        per = []
+        fence()
+        for _ in range(n_soak):
+            ts = time.perf_counter()
+            step()
+            ms.synchronize()
+            per.append(time.perf_counter() - ts)
+        fence()
+        per_ms = np.array(per) * 1e3
+        soak = {"steps": n_soak, "mean_ms_per_step": round(float(per_ms.mean()), 3), "median_ms_per_step": round(float(np.median(per_ms)), 3),
+                "min_ms": round(float(per_ms.min()), 3), "max_ms": round(float(per_ms.max()), 3),
+                "what": "the timed step repeated back to back after the timed region (this rank's wall time per step, no barrier in between)"}
 
     if rank == 0:
         K = max(args.steps, 1)
@@ -250,7 +289,11 @@ def main():
             alg_bytes = sketch_bytes_per_read(L, H, S, k2) * reads_per_launch
         achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic, traffic_src = pmc_traffic(dom + "_kernel", args.config, n_total, L, world)
-        roofline = {"bound": "hbm", "kernel": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # the name rocprofv3 prints for the dominant kernel (profiles/rNN_rocprofv3_kernel_stats.csv): weight-1 strands (every strand
+        # without -f) run minhash_w1_kernel, weighted ones minhash_kernel<4,true,true>; the PMC summary files both under "minhash_kernel"
+        rocprof_name = {"minhash": "minhash_kernel<4,true,true> (+ minhash_w1_kernel)" if cfg.get("filter") else "minhash_w1_kernel",
+                        "overlap": "overlap_join_kernel", "index_build": "index_tile_kernel + index_bins_kernel"}.get(dom, dom + "_kernel")
+        roofline = {"bound": "hbm", "kernel": rocprof_name, "pmc_summary_key": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                     "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
                     "note": "SURVEY §8(d) recipe (algorithmic HBM bytes / launch time vs 8 TB/s).  The dominant kernel is integer-VALU "
@@ -269,7 +312,7 @@ def main():
         xs_rate = steps_per_read * n_local / mh_s if mh_s > 0 else 0.0
         ceil_spec = 32 * VALU_SPEC / BITSLICED_OPS_PER_32_STEPS
         ceil_meas = 32 * VALU_MEASURED / BITSLICED_OPS_PER_32_STEPS
-        valu = {"bound": "valu", "kernel": "minhash_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
+        valu = {"bound": "valu", "kernel": "minhash_kernel<4,true,true> (+ minhash_w1_kernel)" if cfg.get("filter") else "minhash_w1_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
                 "ceiling_spec_steps_per_s": round(ceil_spec, 1), "frac_of_spec_ceiling": round(xs_rate / ceil_spec, 4),
                 "ceiling_measured_clock_steps_per_s": round(ceil_meas, 1), "frac_of_measured_ceiling": round(xs_rate / ceil_meas, 4),
                 "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes): one step of 32 chains is 107 full-rate ops "
@@ -320,8 +363,10 @@ def main():
             "index_elements_per_step": int(st["table_elements"]),
             "overlap_slow_pairs_per_step": int(st["slow_pairs"]),
             "records_sha256_sorted_lines": sha, "records_checksum": "%016x" % records_checksum,
+            "records_checksum_kind": "binary fields (output too large for text lines in Python)" if big_output else "sha256 of text lines, summed",
             "hbm_traffic_by_kernel": hbm_by_kernel,
             "roofline": roofline, "valu": valu, "roofline_stage2": roofline_stage2,
+            "soak": soak,
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),
             "value_incl_host_pack_and_pcie": round(total_records / (sec_per_step + t_stage), 2),

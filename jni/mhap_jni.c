@@ -38,7 +38,7 @@
 
 /* parked records: a list of blocks the sink appends to (the library calls the sink one batch at a time, also with several ranks) */
 typedef struct rec_block { struct rec_block* next; int64_t n, taken; mhap_record recs[1]; } rec_block;
-typedef struct { mhap_group* g; rec_block *head, *tail; int64_t parked; int oom; } engine;
+typedef struct { mhap_group* g; rec_block *head, *tail; int64_t parked; int oom; int32_t H, S; } engine;
 
 static engine* E(jlong h) { return (engine*)(intptr_t)h; }
 
@@ -95,9 +95,19 @@ static int copy_batch(JNIEnv* env, read_batch* b, jbyteArray bases, jlongArray o
   b->ids = (int64_t*)malloc(((size_t)n + 1) * sizeof(int64_t));
   if (!b->bases || !b->offsets || !b->lengths || !b->ids) { free_batch(b); throw_mhap(env, "out of memory while copying a read batch"); return 1; }
   (*env)->GetByteArrayRegion(env, bases, 0, nb, (jbyte*)b->bases);
-  (*env)->GetLongArrayRegion(env, offsets, 0, n, (jlong*)b->offsets);
-  (*env)->GetIntArrayRegion(env, lengths, 0, n, (jint*)b->lengths);
-  (*env)->GetLongArrayRegion(env, ids, 0, n, (jlong*)b->ids);
+  if (!(*env)->ExceptionCheck(env)) (*env)->GetLongArrayRegion(env, offsets, 0, n, (jlong*)b->offsets);
+  if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, lengths, 0, n, (jint*)b->lengths);
+  if (!(*env)->ExceptionCheck(env)) (*env)->GetLongArrayRegion(env, ids, 0, n, (jlong*)b->ids);
+  if ((*env)->ExceptionCheck(env)) { free_batch(b); return 1; }   /* ArrayIndexOutOfBoundsException is pending */
+  {
+    jint i;   /* every read must lie inside the bases array: the library trusts offsets and lengths */
+    for (i = 0; i < n; i++)
+      if (b->lengths[i] < 0 || b->offsets[i] < 0 || b->offsets[i] > (int64_t)nb || (int64_t)b->lengths[i] > (int64_t)nb - b->offsets[i]) {
+        free_batch(b);
+        throw_mhap(env, "a read of the batch lies outside its bases array");
+        return 1;
+      }
+  }
   return 0;
 }
 
@@ -124,6 +134,7 @@ JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeCrea
   if (!e) { throw_mhap(env, "out of memory"); return 0; }
   err[0] = 0;
   if (mhap_group_create(&p, devs, (int32_t)nd, &e->g, err, sizeof err) != MHAP_OK) { free(e); throw_mhap(env, err); return 0; }
+  e->H = numHashes; e->S = orderedSketchSize;
   return (jlong)(intptr_t)e;
 }
 
@@ -209,22 +220,31 @@ JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFind
     jintArray orderedSize, jintArray orderedSeqLength, jint m) {
   engine* e = E(handle);
   const jsize nmh = (*env)->GetArrayLength(env, minHashes), nod = (*env)->GetArrayLength(env, ordered);
-  int64_t* i = (int64_t*)malloc(((size_t)m + 1) * 8);
-  int32_t* sl = (int32_t*)malloc(((size_t)m + 1) * 4);
-  int32_t* mh = (int32_t*)malloc(((size_t)nmh + 1) * 4);
-  int32_t* od = (int32_t*)malloc(((size_t)nod + 1) * 4);
-  int32_t* os = (int32_t*)malloc(((size_t)m + 1) * 4);
-  int32_t* ol = (int32_t*)malloc(((size_t)m + 1) * 4);
+  int64_t *i; int32_t *sl, *mh, *od, *os, *ol;
   int rc = MHAP_E_NOMEM, r;
   mhap_handle* bad = NULL;
   (void)cls;
-  if (i && sl && mh && od && os && ol && m >= 0) {
+  /* the library reads m rows of --num-hashes ints and m rows of --ordered-sketch-size (hash, pos) pairs: short arrays are an error
+   * here, not an over-read there */
+  if (m < 0 || (*env)->GetArrayLength(env, ids) < m || (*env)->GetArrayLength(env, seqLength) < m || (*env)->GetArrayLength(env, orderedSize) < m ||
+      (*env)->GetArrayLength(env, orderedSeqLength) < m || (int64_t)nmh < (int64_t)m * e->H || (int64_t)nod < (int64_t)m * e->S * 2) {
+    throw_mhap(env, "query sketch arrays are shorter than the sketch count asks for");
+    return -1;
+  }
+  i = (int64_t*)malloc(((size_t)m + 1) * 8);
+  sl = (int32_t*)malloc(((size_t)m + 1) * 4);
+  mh = (int32_t*)malloc(((size_t)nmh + 1) * 4);
+  od = (int32_t*)malloc(((size_t)nod + 1) * 4);
+  os = (int32_t*)malloc(((size_t)m + 1) * 4);
+  ol = (int32_t*)malloc(((size_t)m + 1) * 4);
+  if (i && sl && mh && od && os && ol) {
     (*env)->GetLongArrayRegion(env, ids, 0, m, (jlong*)i);
-    (*env)->GetIntArrayRegion(env, seqLength, 0, m, (jint*)sl);
-    (*env)->GetIntArrayRegion(env, minHashes, 0, nmh, (jint*)mh);
-    (*env)->GetIntArrayRegion(env, ordered, 0, nod, (jint*)od);
-    (*env)->GetIntArrayRegion(env, orderedSize, 0, m, (jint*)os);
-    (*env)->GetIntArrayRegion(env, orderedSeqLength, 0, m, (jint*)ol);
+    if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, seqLength, 0, m, (jint*)sl);
+    if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, minHashes, 0, nmh, (jint*)mh);
+    if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, ordered, 0, nod, (jint*)od);
+    if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, orderedSize, 0, m, (jint*)os);
+    if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, orderedSeqLength, 0, m, (jint*)ol);
+    if ((*env)->ExceptionCheck(env)) { free(i); free(sl); free(mh); free(od); free(os); free(ol); return -1; }
     rc = MHAP_OK;
     for (r = 0; r < mhap_group_size(e->g) && rc == MHAP_OK && !e->oom; r++) {
       bad = mhap_group_rank(e->g, r);

@@ -54,7 +54,7 @@ def _stale(target, digest):
 
 
 # -amdgpu-sched-strategy=max-memory-clause: the machine scheduler variant that keeps memory instructions clustered.  A/B on the
-# whole library at C2 (tools/gpu_round3_o.sh, alternating runs on one box): MinHash 88.8 -> 86.9 ms, join 4.84 -> 4.71, step 111.2 ->
+# whole library at C2 (tools/minhash_ab.sh-style alternating runs on one box): MinHash 88.8 -> 86.9 ms, join 4.84 -> 4.71, step 111.2 ->
 # 109.1; max-ilp, the AMDGPU register-pressure trackers, an occupancy-only metric bias and no high-RP reschedule stage: +-0.5 ms.
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-Wno-pass-failed", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
 

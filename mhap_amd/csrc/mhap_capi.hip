@@ -564,6 +564,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     if (rcb != MHAP_OK) return rcb;
   }
 
+  h->iq_start_mid = false;   // decided anew by the first chunks of every search
   for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
     const int nq = (int)std::min<int64_t>(qchunk, (int64_t)ql.size() - c0);
     const int ntq = (nq + CAND_TQ - 1) / CAND_TQ;
@@ -619,7 +620,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         const int32_t* dense_list = listA;
         unsigned long long n_dense = c5[6];
         if (t0 == 0 && use_mid && c5[0] <= cand_cap) {
-          if (2 * c5[6] > (unsigned long long)nq) h->iq_start_mid = true;
+          // (a chunk of a few thousand queries at least: one repeat-rich read of a small -q batch must not send every later
+          //  query of this search through the 256-lane tier, which costs ordinary queries about twice the first tier's time)
+          if (nq >= 4096 && 2 * c5[6] > (unsigned long long)nq) h->iq_start_mid = true;
           if (c5[6] > 0) {
             time_begin(h, MHAP_K_INDEX_QUERY);
             launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,

@@ -11,7 +11,21 @@
 //   * peer copies (one process, N devices: mhap_group_*): every rank pulls the other ranks' rows with hipMemcpyPeerAsync —
 //     on a fully connected xGMI node the direct all-gather uses all 7 links of a GPU at once; ranks may also share a device.
 #include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+// A ROCm install without the RCCL development headers: the library is bound with dlopen at run time anyway, so the handful of
+// types the calls below need are declared here (rccl.h of RCCL 2.x: an opaque communicator, a 128-byte id, plain enums).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4,
+               ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7, ncclNumResults = 8 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+}
+#endif
 
 #include <atomic>
 #include <chrono>
@@ -44,6 +58,8 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional (watchdog)
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional (watchdog)
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
 };
@@ -67,6 +83,8 @@ RcclApi& rccl() {
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.lib, "ncclCommGetAsyncError");
+    api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
     if (!api.why.empty()) { api.lib = nullptr; }
   });
   return api;
@@ -84,7 +102,29 @@ struct Transport {
   virtual void quiesce() {}
   // this rank gives up: ranks of the same process waiting for it must not wait for ever
   virtual void abort() {}
+  // false (+ why): a peer of this exchange has failed or left — nothing it was to send will arrive
+  virtual bool healthy(std::string&) { return true; }
   virtual const char* name() const = 0;
+
+  // Wait for an event that depends on the other ranks without trusting them to be alive: poll it, ask the transport now and then
+  // whether a peer has failed (RCCL: ncclCommGetAsyncError; peers of one process: the hub's flag), and give up after
+  // MHAP_DIST_TIMEOUT_S (default 1800).  Giving up aborts the transport — an RCCL communicator is torn down with ncclCommAbort,
+  // which also ends the collective kernels this rank has in flight — so neither this rank nor the surviving ones hang in a gather.
+  int wait_event(hipEvent_t ev, std::string& err) {
+    static const double limit_ms = []() { const char* e = getenv("MHAP_DIST_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return (v > 0 ? v : 1800.0) * 1e3; }();
+    const double t0 = now_ms();
+    for (unsigned spin = 1;; spin++) {
+      const hipError_t e = hipEventQuery(ev);
+      if (e == hipSuccess) return MHAP_OK;
+      if (e != hipErrorNotReady) { err = std::string("exchange event: ") + hipGetErrorString(e); abort(); return MHAP_E_HIP; }
+      if ((spin & 255u) == 0) {
+        std::string why;
+        if (!healthy(why)) { err = "exchange aborted: " + why; abort(); return MHAP_E_STATE; }
+        if (now_ms() - t0 > limit_ms) { err = "exchange timed out after " + std::to_string((int)(limit_ms / 1e3)) + " s waiting for the other ranks (MHAP_DIST_TIMEOUT_S)"; abort(); return MHAP_E_STATE; }
+      }
+      if (spin > 4096) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+    }
+  }
 };
 
 struct RcclTransport : Transport {
@@ -92,11 +132,26 @@ struct RcclTransport : Transport {
   bool owns = true;
   DevBuf scratch;
   int device = 0;
+  hipEvent_t ev_host = nullptr;
   ~RcclTransport() override {
     scratch.release();
+    if (ev_host) (void)hipEventDestroy(ev_host);
     if (comm && owns && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
   }
+  bool healthy(std::string& why) override {
+    if (!comm) { why = "the RCCL communicator was aborted"; return false; }
+    if (!rccl().CommGetAsyncError) return true;
+    ncclResult_t st = ncclSuccess;
+    if (rccl().CommGetAsyncError(comm, &st) != ncclSuccess) { why = "ncclCommGetAsyncError failed"; return false; }
+    if (st == ncclSuccess || st == ncclInProgress) return true;
+    why = std::string("RCCL reports an asynchronous error: ") + rccl().GetErrorString(st);
+    return false;
+  }
+  void abort() override {
+    if (comm && rccl().CommAbort) { (void)rccl().CommAbort(comm); comm = nullptr; }   // (aborted communicators are not destroyed again)
+  }
   int allgather(const void* send, void* recv, size_t bytes, hipStream_t st, std::string& err) override {
+    if (!comm) { err = "the RCCL communicator was aborted"; return MHAP_E_STATE; }
     const ncclResult_t r = rccl().AllGather(send, recv, bytes, ncclChar, comm, st);
     if (r != ncclSuccess) { err = std::string("ncclAllGather: ") + rccl().GetErrorString(r); return MHAP_E_HIP; }
     return MHAP_OK;
@@ -106,9 +161,13 @@ struct RcclTransport : Transport {
     char* d = scratch.as<char>();
     hipStream_t st = nullptr;   // the null stream: this is a rendezvous, not a hot path
     if (hipMemcpy(d, in, bytes, hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy (exchange scratch)"; return MHAP_E_HIP; }
-    const int rc = allgather(d, d + bytes, bytes, st, err);
+    int rc = allgather(d, d + bytes, bytes, st, err);
     if (rc != MHAP_OK) return rc;
-    if (hipStreamSynchronize(st) != hipSuccess || hipMemcpy(out, d + bytes, bytes * (size_t)nranks, hipMemcpyDeviceToHost) != hipSuccess) {
+    if (!ev_host && hipEventCreateWithFlags(&ev_host, hipEventDisableTiming) != hipSuccess) { err = "cannot create the exchange event"; return MHAP_E_HIP; }
+    if (hipEventRecord(ev_host, st) != hipSuccess) { err = "hipEventRecord (exchange)"; return MHAP_E_HIP; }
+    rc = wait_event(ev_host, err);   // (not hipStreamSynchronize: a rank that never arrives must not hang this one for ever)
+    if (rc != MHAP_OK) return rc;
+    if (hipMemcpy(out, d + bytes, bytes * (size_t)nranks, hipMemcpyDeviceToHost) != hipSuccess) {
       err = "exchange of the row counts failed"; return MHAP_E_HIP;
     }
     return MHAP_OK;
@@ -134,6 +193,10 @@ struct PeerHub {
     return !failed;
   }
   void abort() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+  bool has_failed() { std::lock_guard<std::mutex> lk(mu); return failed; }
+  // every rank thread has returned (on_ranks joined them): the next collective call starts from a clean hub, so one failed search
+  // (a transient out-of-memory, say) does not kill the group for good
+  void reset() { std::lock_guard<std::mutex> lk(mu); failed = false; arrived = 0; gen++; }
 };
 struct PeerTransport : Transport {
   PeerHub* hub = nullptr;
@@ -144,7 +207,10 @@ struct PeerTransport : Transport {
     for (int r = 0; r < nranks && ok; r++) {
       char* dst = (char*)recv + (size_t)r * bytes;
       if (r != rank) ok = ok && hipStreamWaitEvent(st, hub->ev[(size_t)r], 0) == hipSuccess;
-      if (hub->dev[(size_t)r] == hub->dev[(size_t)rank]) ok = ok && hipMemcpyAsync(dst, hub->ptr[(size_t)r], bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+      // (MHAP_GROUP_FORCE_PEER=1: the peer-copy call also between ranks that share a device — a copy dev0 -> dev0 is legal — so the
+      //  cross-device branch can be exercised on a one-GPU box)
+      static const bool force_peer = []() { const char* e = getenv("MHAP_GROUP_FORCE_PEER"); return e && e[0] == '1'; }();
+      if (hub->dev[(size_t)r] == hub->dev[(size_t)rank] && !force_peer) ok = ok && hipMemcpyAsync(dst, hub->ptr[(size_t)r], bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
       else ok = ok && hipMemcpyPeerAsync(dst, hub->dev[(size_t)rank], hub->ptr[(size_t)r], hub->dev[(size_t)r], bytes, st) == hipSuccess;
     }
     // the events of this round are consumed (waits enqueued) before any rank records the next one
@@ -164,6 +230,7 @@ struct PeerTransport : Transport {
     return MHAP_OK;
   }
   void abort() override { hub->abort(); }
+  bool healthy(std::string& why) override { if (hub->has_failed()) { why = "another rank failed"; return false; } return true; }
   void quiesce() override { (void)hub->barrier(); }
   const char* name() const override { return "peer"; }
 };
@@ -179,6 +246,7 @@ struct DistState {
   std::vector<int64_t> ids_all, ids_local;
   double t_small = 0, t_wait_big = 0, t_total = 0;
   bool gate_ran = false;
+  std::string gate_err;
   ~DistState() {
     DevBuf* bufs[] = {&s_mh, &s_od, &s_mt, &s_ids, &g_mh, &g_od, &g_mt, &g_ids, &q_mh, &q_od, &q_mt};
     for (DevBuf* b : bufs) b->release();
@@ -199,6 +267,7 @@ int dfail(const HandleView& v, int code, const std::string& msg) { *v.err = msg;
       return dfail((v), _e == hipErrorOutOfMemory ? MHAP_E_NOMEM : MHAP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
   } while (0)
 
+// attach() OWNS tr from here on, on every path: it ends up in the handle's DistState or is deleted with it
 int attach(mhap_handle* h, Transport* tr) {
   HandleView v = handle_view(h);
   (void)hipSetDevice(v.device);
@@ -217,10 +286,10 @@ int attach(mhap_handle* h, Transport* tr) {
 int gate_cb(void* user) {
   DistState* d = (DistState*)user;
   const double t0 = now_ms();
-  const hipError_t e = hipEventSynchronize(d->ev_big);   // the ordered rows of every rank have arrived
+  const int rc = d->tr->wait_event(d->ev_big, d->gate_err);   // the ordered rows of every rank have arrived
   d->t_wait_big += now_ms() - t0;
   d->gate_ran = true;
-  return e == hipSuccess ? 0 : 1;
+  return rc == MHAP_OK ? 0 : 1;
 }
 
 // Gather `rows` forward rows of this rank (row j at src + j * src_pitch_rows rows) from every rank and search them against this
@@ -273,14 +342,16 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   DCHK(v, hipEventRecord(d->ev_big, cs));
   // meanwhile: this rank's inverted index (a no-op when the add built it eagerly)
   rc = mhap_index_prepare(h); if (rc != MHAP_OK) return rc;
-  DCHK(v, hipEventSynchronize(d->ev_small));
+  rc = tr->wait_event(d->ev_small, *v.err); if (rc != MHAP_OK) return rc;
   d->ids_all.resize((size_t)N * np);
   DCHK(v, hipMemcpy(d->ids_all.data(), d->g_ids.p, (size_t)N * np * 8, hipMemcpyDeviceToHost));
   d->t_small = now_ms() - t0;
   rc = mhap_set_second_stage_gate(h, gate_cb, d); if (rc != MHAP_OK) return rc;
   rc = mhap_find_matches_device(h, d->g_mh.p, d->g_od.p, d->g_mt.p, d->ids_all.data(), (int64_t)N * n_pad, to_self, sink, user);
   (void)mhap_set_second_stage_gate(h, nullptr, nullptr);
-  if (!d->gate_ran) (void)hipEventSynchronize(d->ev_big);   // no candidates here: the gather still has to finish before the buffers are reused
+  if (rc != MHAP_OK && !d->gate_err.empty()) *v.err = d->gate_err;   // (the gate's reason, not "the gate aborted the search")
+  d->gate_err.clear();
+  if (rc == MHAP_OK && !d->gate_ran) rc = tr->wait_event(d->ev_big, *v.err);   // no candidates here: the gather still has to finish before the buffers are reused
   finished = rc == MHAP_OK;
   if (finished) tr->quiesce();
   d->t_total = now_ms() - t0;
@@ -321,9 +392,7 @@ int mhap_dist_init(mhap_handle* h, int32_t rank, int32_t nranks, const void* id)
   tr->rank = rank; tr->nranks = nranks; tr->device = v.device;
   const ncclResult_t r = api.CommInitRank(&tr->comm, nranks, u, rank);
   if (r != ncclSuccess) { tr->comm = nullptr; delete tr; return dfail(v, MHAP_E_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r)); }
-  const int rc = attach(h, tr);
-  if (rc != MHAP_OK) delete tr;
-  return rc;
+  return attach(h, tr);   // (owns tr, also when it fails)
 }
 
 int mhap_dist_finalize(mhap_handle* h) {
@@ -404,11 +473,20 @@ int fan_sink(const mhap_record* r, int64_t n, void* user) {
 int on_ranks(mhap_group* g, const std::function<int(int)>& fn) {
   std::vector<int> rcs((size_t)g->n, MHAP_OK);
   std::vector<std::thread> th;
-  for (int r = 1; r < g->n; r++) th.emplace_back([&, r]() { rcs[(size_t)r] = fn(r); });
-  rcs[0] = fn(0);
+  // (a rank that fails before it reaches the exchange must not leave the others at the hub's barrier)
+  auto run = [&](int r) { rcs[(size_t)r] = fn(r); if (rcs[(size_t)r] != MHAP_OK && g->hub) g->hub->abort(); };
+  for (int r = 1; r < g->n; r++) th.emplace_back([&, r]() { run(r); });
+  run(0);
   for (auto& t : th) t.join();
-  for (int r = 0; r < g->n; r++)
-    if (rcs[(size_t)r] != MHAP_OK) { g->err = "rank " + std::to_string(r) + ": " + mhap_last_error(g->h[(size_t)r]); return rcs[(size_t)r]; }
+  if (g->hub) g->hub->reset();
+  // the error to report is the root cause: a rank that says "another rank failed" is a victim
+  int pick = -1;
+  for (int r = 0; r < g->n; r++) {
+    if (rcs[(size_t)r] == MHAP_OK) continue;
+    const bool victim = strstr(mhap_last_error(g->h[(size_t)r]), "another rank failed") != nullptr;
+    if (pick < 0 || (!victim && strstr(mhap_last_error(g->h[(size_t)pick]), "another rank failed") != nullptr)) pick = r;
+  }
+  if (pick >= 0) { g->err = "rank " + std::to_string(pick) + ": " + mhap_last_error(g->h[(size_t)pick]); return rcs[(size_t)pick]; }
   return MHAP_OK;
 }
 
@@ -454,7 +532,7 @@ int mhap_group_create(const mhap_params* params, const int32_t* devices, int32_t
     for (int k = 0; k < n; k++) {
       RcclTransport* tr = new RcclTransport();
       tr->rank = k; tr->nranks = n; tr->comm = comms[(size_t)k]; tr->device = g->dev[(size_t)k];
-      if (attach(g->h[(size_t)k], tr) != MHAP_OK) { delete tr; seterr(mhap_last_error(g->h[(size_t)k])); mhap_group_destroy(g); return MHAP_E_HIP; }
+      if (attach(g->h[(size_t)k], tr) != MHAP_OK) { seterr(mhap_last_error(g->h[(size_t)k])); mhap_group_destroy(g); return MHAP_E_HIP; }
     }
   } else {
     g->hub = new PeerHub(n);
@@ -473,7 +551,7 @@ int mhap_group_create(const mhap_params* params, const int32_t* devices, int32_t
     for (int k = 0; k < n; k++) {
       PeerTransport* tr = new PeerTransport();
       tr->rank = k; tr->nranks = n; tr->hub = g->hub;
-      if (attach(g->h[(size_t)k], tr) != MHAP_OK) { delete tr; seterr(mhap_last_error(g->h[(size_t)k])); mhap_group_destroy(g); return MHAP_E_HIP; }
+      if (attach(g->h[(size_t)k], tr) != MHAP_OK) { seterr(mhap_last_error(g->h[(size_t)k])); mhap_group_destroy(g); return MHAP_E_HIP; }
     }
   }
   *out = g;

@@ -27,5 +27,6 @@ struct JNINativeInterface_ {
   void (*GetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, jlong*);
   jlongArray (*NewLongArray)(JNIEnv*, jsize);
   void (*SetLongArrayRegion)(JNIEnv*, jlongArray, jsize, jsize, const jlong*);
+  jboolean (*ExceptionCheck)(JNIEnv*);
 };
 #endif
