@@ -90,7 +90,12 @@ def main():
                     help="after the timed region: repeat the step, untimed for `value`, for about this long and report the per-step spread "
                          "(settled clocks; also keeps the GPU busy long enough for a 5 s utilisation sampler to see it).  Default 8, "
                          "0 with --no-cpu-baseline")
+    ap.add_argument("--preflight", action="store_true",
+                    help="check what an N-GPU run needs (devices, RCCL entry points, peer access, rendezvous variables) and print why "
+                         "it cannot run instead of hanging in a collective; exit code 0 = ready")
     args = ap.parse_args()
+    if args.preflight:
+        raise SystemExit(preflight(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,6 +104,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if world > 1 and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible — one rank per GPU "
+                         "(python bench.py --gpus N --preflight says what is missing)")
     backend = "nccl"
     torch.cuda.set_device(local_rank)
     dist = None
@@ -381,6 +389,40 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def preflight(n):
+    """What `bench.py --gpus n` under torch.distributed.run needs, checked without entering any collective."""
+    import ctypes
+    rep = {"gpus_requested": n, "checks": {}, "ready": True}
+
+    def check(name, ok, detail):
+        rep["checks"][name] = {"ok": bool(ok), "detail": detail}
+        if not ok:
+            rep["ready"] = False
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    check("devices", have >= n, f"{have} visible (HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES')}, ROCR_VISIBLE_DEVICES={os.environ.get('ROCR_VISIBLE_DEVICES')})")
+    check("torch_rccl_backend", torch.distributed.is_available() and torch.distributed.is_nccl_available(), "torch.distributed nccl (= RCCL) backend")
+    try:
+        lib = mhap_amd.load_library()
+        buf = ctypes.create_string_buffer(128)
+        rc = lib.mhap_dist_unique_id(buf, ctypes.c_size_t(128)) if have > 0 else -1
+        check("library_rccl_entry_points", rc == 0, "mhap_dist_unique_id (dlopen of the process's librccl + ncclGetUniqueId): rc %d" % rc)
+    except Exception as e:   # noqa: BLE001
+        check("library_rccl_entry_points", False, repr(e))
+    if have >= 2:
+        bad = [(a, b) for a in range(min(n, have)) for b in range(min(n, have)) if a != b and not torch.cuda.can_device_access_peer(a, b)]
+        check("peer_access", not bad, "every pair of the first %d devices" % min(n, have) if not bad else f"no peer access between {bad[:8]}")
+    else:
+        check("peer_access", n <= 1, "needs two devices to test")
+    check("ipc_mode", os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0", "HSA_ENABLE_IPC_MODE_LEGACY=%s (the host driver only supports dmabuf IPC: must be 0 for multi-process RCCL)"
+          % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+    if n > 1:
+        rep["launch"] = (f"python -m torch.distributed.run --nnodes=1 --nproc-per-node {n} --master-addr 127.0.0.1 --master-port 29500 "
+                         f"bench.py --gpus {n} --steps K --warmup W")
+    print(json.dumps(rep), flush=True)
+    return 0 if rep["ready"] else 1
 
 
 def pmc_traffic(kernel, config, n_total, L, world):

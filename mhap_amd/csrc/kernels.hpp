@@ -113,12 +113,16 @@ struct InvIndex {
   uint32_t nb, shift;    // buckets per slot (a power of two, 1024 .. 2^20), bucket = mix >> shift
   uint64_t slot_stride;  // postings one slot has room for
   uint32_t ne;           // entries the index was sized for (an upper bound of any query's distinct hits)
+  uint32_t grouped;      // != 0: every bucket longer than group_t postings is ordered by entry class (entry >> class_log): the dense query
+                         // tier then streams, per pass over a range of entries, only the part of a long bucket that lies in it
+  uint32_t group_t, class_log;   // (index_group_params: 256 and 15 unless MHAP_INDEX_GROUP_T / MHAP_INDEX_CLASS_LOG say otherwise — tests)
   // scratch of the build
   uint2* staged;         // [H][slot_stride]: the postings grouped by coarse bin
   uint32_t* tile_counts; // [H][tiles][coarse bins]
   uint32_t* bin_start;   // [H][coarse bins + 1]
 };
 int index_tiles(int ne);
+void index_group_params(int64_t entries, InvIndex& ix);   // sets grouped / group_t / class_log for an index of this many entries
 int index_coarse_bins();
 int index_max_buckets_log();
 void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,

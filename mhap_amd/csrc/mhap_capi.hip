@@ -304,6 +304,7 @@ static int inv_alloc(mhap_handle* h, int64_t ne) {
   h->inv.nb = (uint32_t)nb; h->inv.shift = 32 - lg;
   h->inv.slot_stride = (uint64_t)stride;
   h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
+  index_group_params(ne, h->inv);
   return MHAP_OK;
 }
 

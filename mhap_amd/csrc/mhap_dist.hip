@@ -209,7 +209,8 @@ struct PeerTransport : Transport {
       if (r != rank) ok = ok && hipStreamWaitEvent(st, hub->ev[(size_t)r], 0) == hipSuccess;
       // (MHAP_GROUP_FORCE_PEER=1: the peer-copy call also between ranks that share a device — a copy dev0 -> dev0 is legal — so the
       //  cross-device branch can be exercised on a one-GPU box)
-      static const bool force_peer = []() { const char* e = getenv("MHAP_GROUP_FORCE_PEER"); return e && e[0] == '1'; }();
+      const char* fpe = getenv("MHAP_GROUP_FORCE_PEER");
+      const bool force_peer = fpe && fpe[0] == '1';
       if (hub->dev[(size_t)r] == hub->dev[(size_t)rank] && !force_peer) ok = ok && hipMemcpyAsync(dst, hub->ptr[(size_t)r], bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
       else ok = ok && hipMemcpyPeerAsync(dst, hub->dev[(size_t)rank], hub->ptr[(size_t)r], hub->dev[(size_t)r], bytes, st) == hipSuccess;
     }

@@ -10,6 +10,8 @@
 //                      through LDS, 8x8 register micro-tile per lane, triangular tile skipping in self mode.
 //   overlap_join_kernel : BottomOverlapSketch.getOverlapInfo per candidate, one wavefront each, from the equal-hash join.
 //   overlap_kernel   : the same per candidate, one lane each, literal merge (overlap_lane.hpp): pairs the join path hands back.
+#include <cstdlib>
+#include <cstring>
 #include "kernels.hpp"
 #include "overlap_lane.hpp"
 
@@ -301,6 +303,72 @@ __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix)
   }
 }
 
+// Step 5, large indexes only (index_wants_grouping): the postings of every LONG bucket — a value thousands of stored entries share:
+// a repeat — are put in ascending order of their entry CLASS (entry >> IB_CLASS_LOG), by a counting sort through `staged` (free again
+// once step 4 is done).  The dense query tier counts hits in passes over ranges of stored entries; before this step every pass of a
+// repeat-carrying query streamed all of its buckets again and kept the 1/npass that fell into its range (39 passes at 1.25 M entries:
+// 14 us per query on one rank's share of BASELINE configs[4], 560 ms for 40 000 queries); with the classes in order a pass finds its
+// part of a long bucket by bisection and streams only that.  One workgroup per (slot, bin), like step 4.
+constexpr int IB_GROUP_T = 256;          // buckets up to this long are streamed whole by every pass (InvIndex::group_t)
+constexpr int IB_CLASS_LOG = 15;         // entries per class: the finest range a dense pass covers (ranges are power-of-two multiples of it; InvIndex::class_log)
+constexpr int IB_MAX_CLASSES = 8192;     // class counters in LDS (2^28 entries); an index beyond that is left ungrouped
+constexpr int IB_GRP_THREADS = 256;
+__global__ __launch_bounds__(IB_GRP_THREADS) void index_group_kernel(InvIndex ix) {
+  __shared__ uint32_t cls[IB_MAX_CLASSES];
+  __shared__ uint32_t longs[IB_GRP_THREADS];
+  __shared__ uint32_t s_nlong, s_carry;
+  __shared__ uint32_t wsum[IB_GRP_THREADS / 64];
+  const int s = blockIdx.x >> IB_BINS_LOG, bin = blockIdx.x & (IB_BINS - 1);
+  const int sub = (int)(ix.nb >> IB_BINS_LOG), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const uint32_t* ends = ix.ends + (size_t)s * ((size_t)ix.nb + 1) + (size_t)bin * sub;   // ends[i] .. ends[i + 1]: bucket i of this bin
+  uint2* items = ix.items + (size_t)s * ix.slot_stride;
+  uint2* staged = ix.staged + (size_t)s * ix.slot_stride;
+  const int nclass = (int)((ix.ne + (1u << ix.class_log) - 1) >> ix.class_log);
+  for (int w0 = 0; w0 < sub; w0 += IB_GRP_THREADS) {     // windows of IB_GRP_THREADS buckets: the list of a window's long ones cannot overflow
+    __syncthreads();
+    if (threadIdx.x == 0) s_nlong = 0;
+    __syncthreads();
+    {
+      const int i = w0 + (int)threadIdx.x;
+      if (i < sub && ends[i + 1] - ends[i] > ix.group_t) longs[atomicAdd(&s_nlong, 1u)] = (uint32_t)i;
+    }
+    __syncthreads();
+    const uint32_t nl = s_nlong;
+    for (uint32_t li = 0; li < nl; li++) {
+      const uint32_t b = longs[li], lo = ends[b], n = ends[b + 1] - lo;
+      for (int c = threadIdx.x; c < nclass; c += IB_GRP_THREADS) cls[c] = 0;
+      if (threadIdx.x == 0) s_carry = 0;
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n; i += IB_GRP_THREADS) {
+        const uint2 x = items[lo + i];
+        staged[lo + i] = x;
+        atomicAdd(&cls[x.y >> ix.class_log], 1u);
+      }
+      __syncthreads();
+      for (int cb = 0; cb < nclass; cb += IB_GRP_THREADS) {        // exclusive scan of the class counts
+        const int c = cb + (int)threadIdx.x;
+        const uint32_t v = c < nclass ? cls[c] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = s_carry, total = 0;
+        for (int w = 0; w < IB_GRP_THREADS / 64; w++) { const uint32_t t = wsum[w]; if (w < wv) before += t; total += t; }
+        if (c < nclass) cls[c] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+      }
+      for (uint32_t i = threadIdx.x; i < n; i += IB_GRP_THREADS) {
+        const uint2 x = staged[lo + i];
+        items[lo + atomicAdd(&cls[x.y >> ix.class_log], 1u)] = x;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // Self-check (MHAP_DEBUG_INDEX=1, tests): every stored (entry, slot) finds its posting in its bucket; counts the ones that do not.
 __global__ void index_verify_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta, int ne, int H, InvIndex ix,
                                     unsigned long long* __restrict__ missing) {
@@ -311,7 +379,12 @@ __global__ void index_verify_kernel(const int32_t* __restrict__ minhash, int64_t
   const uint32_t hv = inv_mix((uint32_t)minhash[(int64_t)e * row_stride + s]);
   const uint32_t* E = ix.ends + (size_t)s * ((size_t)ix.nb + 1) + (hv >> ix.shift);
   const uint2* P = ix.items + (size_t)s * ix.slot_stride;
-  for (uint32_t i = E[0]; i < E[1]; i++) if (P[i].x == hv && P[i].y == (uint32_t)e) return;
+  // (a grouped index: a long bucket's postings are in ascending class order — checked from this entry's own posting backwards)
+  for (uint32_t i = E[0]; i < E[1]; i++)
+    if (P[i].x == hv && P[i].y == (uint32_t)e) {
+      if (ix.grouped && E[1] - E[0] > ix.group_t && i > E[0] && (P[i - 1].y >> ix.class_log) > (P[i].y >> ix.class_log)) break;
+      return;
+    }
   atomicAdd(missing, 1ULL);
 }
 void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,
@@ -333,6 +406,19 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
   hipLaunchKernelGGL(index_offsets_kernel, dim3((unsigned)H), dim3(IB_BINS), 0, st, ix, tiles);
   hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
   hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
+  if (ix.grouped) hipLaunchKernelGGL(index_group_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_GRP_THREADS), 0, st, ix);
+}
+// (called when the index is sized: an index the compact dense tier covers in one pass gains nothing from the order, and the class
+//  counters bound the size from above.  MHAP_INDEX_GROUP=0|1 never / always, MHAP_INDEX_GROUP_T, MHAP_INDEX_CLASS_LOG: tests, which
+//  have to make a few hundred entries look like a million)
+void index_group_params(int64_t entries, InvIndex& ix) {
+  // (read at every build: tests switch them inside one process)
+  const int force = []() { const char* e = getenv("MHAP_INDEX_GROUP"); return e ? atoi(e) : -1; }();
+  const int gt = []() { const char* e = getenv("MHAP_INDEX_GROUP_T"); const int v = e ? atoi(e) : 0; return v > 0 ? v : IB_GROUP_T; }();
+  const int cl = []() { const char* e = getenv("MHAP_INDEX_CLASS_LOG"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 24 ? v : IB_CLASS_LOG; }();
+  ix.group_t = (uint32_t)gt; ix.class_log = (uint32_t)cl;
+  const bool fits = entries <= ((int64_t)IB_MAX_CLASSES << cl);
+  ix.grouped = (fits && (force >= 0 ? force != 0 : entries > (1LL << 17))) ? 1u : 0u;
 }
 
 // One workgroup (one wavefront) per query.  LDS: tbl[CT], a hit-count table of packed words: entry + 1 in the low `ebits` bits (as
@@ -741,6 +827,194 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
   }
 }
 
+// Dense tier, compact form (round 4): --num-hashes <= 512 (one slot per lane) and numMinMatches <= 4 — every BASELINE configuration.
+// Differences from the kernel above:
+//  * a THERMOMETER of 4 bits per stored entry instead of a 16-bit counter: hit k of an entry sets bit k (atomicOr; the returned word
+//    says whether the bit was already there, in which case the next one is tried), "count >= numMinMatches" is one bit.  OR is
+//    idempotent, so no add in flight can carry into a neighbour, and 64 KB of LDS cover 131 072 stored entries per pass instead of
+//    32 768: a quarter of the passes;
+//  * the H buckets are looked up ONCE (registers), not once per pass;
+//  * on a grouped index (index_group_kernel) a pass streams only ITS part of a long bucket: the parts' bounds are found by
+//    bisection, all passes and buckets at once, before the first pass.  One rank's share of BASELINE configs[4] (1.25 M entries,
+//    repeat-carrying queries with 250 000 postings each): every posting is now streamed once instead of 39 times.
+constexpr int DQ2_THREADS = 512, DQ2_RANGE_LOG = 17, DQ2_WORDS = 1 << (DQ2_RANGE_LOG - 3), DQ2_MAX_RANGES = 1024, DQ2_BOUNDS = 512;
+constexpr uint32_t DQ2_NOGRP = 0x3FFu;
+__global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
+                                                                         const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
+                                                                         const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
+                                                                         const int32_t* __restrict__ qmeta, SearchParams sp, Candidate* __restrict__ cand,
+                                                                         unsigned long long* __restrict__ cand_count, unsigned long long cand_cap,
+                                                                         unsigned long long* __restrict__ split_count, unsigned long long* __restrict__ elements,
+                                                                         const uint32_t range_log /* <= DQ2_RANGE_LOG: entries per pass (tests shrink it) */) {
+  __shared__ uint32_t cnt[DQ2_WORDS];                   // eight 4-bit thermometers per word
+  __shared__ uint2 seglist[DQ2_THREADS];                // queued buckets (longer than IQ_INLINE): (first posting within the slot, length),
+  __shared__ uint2 segkey[DQ2_THREADS];                 // ... (slot | bounds row << 16, the query's mix there)
+  __shared__ unsigned long long segpre[DQ2_THREADS + 1];
+  __shared__ uint32_t bounds[DQ2_BOUNDS];               // per grouped long bucket: npass + 1 offsets, the starts of the passes' parts
+  __shared__ unsigned long long wsum[DQ2_THREADS / 64];
+  __shared__ uint32_t rmask[DQ2_MAX_RANGES / 32];       // ranges of stored entries the query's postings fall into
+  __shared__ uint32_t s_nseg, s_ng, s_emit;
+  __shared__ unsigned long long s_base;
+  const int qi = blockIdx.x;
+  if (qi >= nq) return;
+  const int qe = qlist[qi];
+  const int32_t* qm = qmeta + (int64_t)qe * META_W;
+  const int64_t qid = qids[qe];
+  const int qlen = qm[2];
+  const int32_t* qrow = qminhash + (int64_t)qe * qrow_stride;
+  const size_t eper = (size_t)ix.nb + 1;
+  const uint32_t npass = (ix.ne + (1u << range_log) - 1) >> range_log;
+  const int nmm = sp.num_min_matches < 1 ? 1 : sp.num_min_matches;     // (<= 4: launch_index_query)
+  const uint32_t topmask = 0x11111111u << (nmm - 1);
+  // ---- the H lookups, once ----
+  const int s = (int)threadIdx.x;
+  uint32_t hv = 0, lo = 0, n = 0;
+  if (s < sp.H) {
+    hv = inv_mix((uint32_t)qrow[s]);
+    const uint32_t* E = ix.ends + (size_t)s * eper + (hv >> ix.shift);
+    lo = E[0]; n = E[1] - lo;
+  }
+  if (threadIdx.x < DQ2_MAX_RANGES / 32) rmask[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { s_nseg = 0; s_ng = 0; }
+  __syncthreads();
+  const uint32_t per = npass + 1;
+  const uint32_t gcap = (ix.grouped && range_log >= ix.class_log && npass > 1 && per <= (uint32_t)DQ2_BOUNDS) ? (uint32_t)DQ2_BOUNDS / per : 0u;
+  if (n > (uint32_t)IQ_INLINE) {
+    const uint32_t at = atomicAdd(&s_nseg, 1u);
+    uint32_t g = DQ2_NOGRP;
+    if (gcap && n > ix.group_t) { const uint32_t g2 = atomicAdd(&s_ng, 1u); if (g2 < gcap) g = g2; }   // (no room: streamed whole by every pass)
+    seglist[at] = make_uint2(lo, n); segkey[at] = make_uint2((uint32_t)s | (g << 16), hv);
+  }
+  __syncthreads();
+  const uint32_t nseg = s_nseg;
+  if (gcap) {
+    // bounds[g][p] = first posting of the bucket whose entry lies in range p or beyond (classes ascend within a long bucket)
+    for (uint32_t i = threadIdx.x; i < nseg * per; i += DQ2_THREADS) {
+      const uint32_t at = i / per, p = i % per, g = segkey[at].x >> 16;
+      if (g == DQ2_NOGRP) continue;
+      const uint2 sl = seglist[at];
+      uint32_t b = 0;
+      if (p == npass) b = sl.y;
+      else if (p > 0) {
+        const uint2* P = ix.items + (size_t)(segkey[at].x & 0xFFFFu) * ix.slot_stride + sl.x;
+        uint32_t a = 0, z = sl.y;                                   // first j in [0, n) with class(j) >= p
+        while (a < z) { const uint32_t m = (a + z) >> 1; if ((P[m].y >> range_log) < p) a = m + 1; else z = m; }
+        b = a;
+      }
+      bounds[g * per + p] = b;
+    }
+    __syncthreads();
+    const uint32_t ng = s_ng < gcap ? s_ng : gcap;
+    if (npass <= (uint32_t)DQ2_MAX_RANGES)
+      for (uint32_t i = threadIdx.x; i < ng * npass; i += DQ2_THREADS) {
+        const uint32_t g = i / npass, p = i % npass;
+        if (p && bounds[g * per + p + 1] > bounds[g * per + p]) atomicOr(&rmask[p >> 5], 1u << (p & 31));
+      }
+  }
+  unsigned long long mine = 0;
+  for (uint32_t pass = 0; pass < npass; pass++) {
+    __syncthreads();
+    if (pass > 0 && npass <= (uint32_t)DQ2_MAX_RANGES && !((rmask[pass >> 5] >> (pass & 31)) & 1u)) continue;   // (uniform)
+    const uint32_t span = min(1u << range_log, ix.ne - (pass << range_log));   // stored entries of this range (the last one is partial)
+    for (uint32_t j = threadIdx.x; j < (span + 7) / 8; j += DQ2_THREADS) cnt[j] = 0;
+    if (threadIdx.x == 0) s_emit = 0;
+    __syncthreads();
+    // one hit of stored entry `me` (celem: this posting has not been seen by an earlier pass — "table elements processed", :173)
+#define DQ2_HIT(me_, celem)                                                                                           \
+    do {                                                                                                              \
+      const uint32_t me = (me_);                                                                                      \
+      if (celem) mine++;                                                                                              \
+      if (pass == 0 && npass > 1) { const uint32_t r = me >> range_log; if (r && r < (uint32_t)DQ2_MAX_RANGES) atomicOr(&rmask[r >> 5], 1u << (r & 31)); }   \
+      if ((me >> range_log) == pass) {                                                                            \
+        const uint32_t wi = (me & ((1u << range_log) - 1)) >> 3;                                                  \
+        const int sh = (int)(me & 7u) * 4;                                                                            \
+        for (int k = 0; k < nmm; k++) { const uint32_t old = atomicOr(&cnt[wi], (1u << k) << sh); if (!((old >> sh) & (1u << k))) break; }   \
+      }                                                                                                               \
+    } while (0)
+    if (n && n <= (uint32_t)IQ_INLINE) {
+      const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
+      for (uint32_t u = 0; u < n; u++) { const uint2 x = P[u]; if (x.x == hv) DQ2_HIT(x.y, pass == 0); }
+    }
+    if (nseg) {
+      // the queued buckets — of a grouped one this pass's part — as ONE index space (exclusive prefix of the lengths in segpre)
+      unsigned long long len = 0;
+      if (threadIdx.x < nseg) {
+        const uint32_t g = segkey[threadIdx.x].x >> 16;
+        len = g == DQ2_NOGRP ? seglist[threadIdx.x].y : bounds[g * per + pass + 1] - bounds[g * per + pass];
+      }
+      unsigned long long incl = len;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const unsigned long long v = __shfl_up(incl, off); if ((threadIdx.x & 63) >= (unsigned)off) incl += v; }
+      if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      unsigned long long wbase = 0, total = 0;
+      for (unsigned w = 0; w < DQ2_THREADS / 64; w++) { const unsigned long long t = wsum[w]; if (w < (threadIdx.x >> 6)) wbase += t; total += t; }
+      if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
+      if (threadIdx.x == 0) segpre[nseg] = total;
+      __syncthreads();
+      uint32_t g = 0;   // queue entry of this lane's current posting (its postings come in ascending order)
+      for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += DQ2_THREADS * 8) {
+        uint2 e[8];
+        uint32_t want[8];
+        bool fresh[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const unsigned long long i = i0 + (unsigned long long)DQ2_THREADS * u;
+          e[u] = make_uint2(0u, 0u); want[u] = 1u; fresh[u] = false;              // (never equal)
+          if (i < total) {
+            while (i >= segpre[g + 1]) g++;
+            const uint2 key = segkey[g];
+            const uint32_t grp = key.x >> 16;
+            const uint32_t off = grp == DQ2_NOGRP ? 0u : bounds[grp * per + pass];
+            e[u] = ix.items[(size_t)(key.x & 0xFFFFu) * ix.slot_stride + (size_t)seglist[g].x + (size_t)off + (size_t)(i - segpre[g])];
+            want[u] = key.y;
+            fresh[u] = grp != DQ2_NOGRP || pass == 0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (e[u].x == want[u]) DQ2_HIT(e[u].y, fresh[u]);
+      }
+    }
+#undef DQ2_HIT
+    __syncthreads();
+    if (pass > 0 && threadIdx.x == 0) atomicAdd(split_count, 1ULL);   // a pass beyond the first = the hit set was split
+    // emit this range's candidates as ONE contiguous block (one global atomic).  Lane t owns words t, t + 512, ... of the counters
+    // (conflict-free); entries that reached numMinMatches but fail the id / length rules lose their top bit in the first sweep, so
+    // the second one only enumerates bits.
+    const uint32_t nwords = (span + 7) / 8;
+    int mycount = 0;
+    for (uint32_t wi = threadIdx.x; wi < nwords; wi += DQ2_THREADS) {
+      uint32_t w = cnt[wi], m = w & topmask;
+      while (m) {
+        const int b = __builtin_ctz(m);
+        m &= m - 1;
+        const uint32_t me = (pass << range_log) + wi * 8 + (uint32_t)(b >> 2);
+        if (me < ix.ne && pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) mycount++;   // MinHashSearch.java:200-225
+        else w &= ~(1u << b);
+      }
+      cnt[wi] = w;
+    }
+    uint32_t local = 0;
+    if (mycount) local = atomicAdd(&s_emit, (uint32_t)mycount);
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_emit ? atomicAdd(cand_count, (unsigned long long)s_emit) : 0ULL;
+    __syncthreads();
+    unsigned long long slot = s_base + local;
+    if (mycount)
+      for (uint32_t wi = threadIdx.x; wi < nwords; wi += DQ2_THREADS) {
+        uint32_t m = cnt[wi] & topmask;
+        while (m) {
+          const int b = __builtin_ctz(m);
+          m &= m - 1;
+          if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)((pass << range_log) + wi * 8 + (uint32_t)(b >> 2)); }
+          slot++;
+        }
+      }
+  }
+  if (mine) atomicAdd(elements, mine);           // "table elements processed" (:173): every posting with the query's value, once
+}
+
 bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
 // whether the packed table words of tier 0 (IQ_THREADS lanes) / tier 1 (IQ_THREADS_MID lanes) can count to numMinMatches for an index
 // of this many entries: the count field (the bits the entry index leaves) must hold numMinMatches + one add in flight per lane
@@ -775,9 +1049,16 @@ void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminh
   else if (tier == 1)
     hipLaunchKernelGGL((index_query_kernel<INV_CT_MID, IQ_THREADS_MID, 1>), dim3((unsigned)nq), dim3(IQ_THREADS_MID), 0, st, ix, qminhash, qrow_stride, qlist, nq,
                        ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
-  else
-    hipLaunchKernelGGL(index_query_dense_kernel, dim3((unsigned)nq), dim3(DQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids, meta, qmeta, sp,
-                       cand, cand_count, cand_cap, split_count, elements);
+  else {
+    const bool old_dense = []() { const char* e = getenv("MHAP_DENSE_TIER"); return e && strcmp(e, "counters") == 0; }();   // (the 16-bit-counter kernel for every case: tests)
+    const uint32_t range_log = []() { const char* e = getenv("MHAP_DENSE_RANGE_LOG"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 3 && v <= DQ2_RANGE_LOG ? v : DQ2_RANGE_LOG); }();
+    if (sp.H <= DQ2_THREADS && sp.num_min_matches <= 4 && !old_dense)
+      hipLaunchKernelGGL(index_query_dense4_kernel, dim3((unsigned)nq), dim3(DQ2_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids, meta, qmeta, sp,
+                         cand, cand_count, cand_cap, split_count, elements, range_log);
+    else
+      hipLaunchKernelGGL(index_query_dense_kernel, dim3((unsigned)nq), dim3(DQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids, meta, qmeta, sp,
+                         cand, cand_count, cand_cap, split_count, elements);
+  }
 }
 int index_query_dense_ranges(int64_t entries) { return (int)((entries + (1 << DQ_RANGE_LOG) - 1) >> DQ_RANGE_LOG); }
 

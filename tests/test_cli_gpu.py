@@ -252,6 +252,20 @@ def test_bench_distributed_path_through_the_library_one_rccl_rank():
     assert r2["phase_wall_ms"]["exchange"] >= 0.0
 
 
+def test_bench_preflight_says_what_an_n_gpu_run_needs():
+    """bench.py --preflight: one GPU is ready (devices, the library's RCCL entry points, the IPC mode); eight on this one-GPU box are
+    not, and the report names the missing devices instead of a collective hanging."""
+    import sys
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight", "--gpus", "1"], capture_output=True, text=True, timeout=300)
+    r1 = json.loads(one.stdout.strip().split("\n")[-1])
+    assert one.returncode == 0 and r1["ready"] and r1["checks"]["library_rccl_entry_points"]["ok"], (one.stdout, one.stderr[-1000:])
+    import torch
+    if torch.cuda.device_count() < 8:
+        many = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight", "--gpus", "8"], capture_output=True, text=True, timeout=300)
+        r8 = json.loads(many.stdout.strip().split("\n")[-1])
+        assert many.returncode == 1 and not r8["ready"] and not r8["checks"]["devices"]["ok"] and "torch.distributed.run" in r8["launch"]
+
+
 def test_cli_gpus_flag_shards_the_index_and_keeps_the_records(tmp_path):
     """mhap-hip --devices 0,0[,0]: two and three ranks (sharing this box's one GPU) — reads dealt round-robin, one index shard
     per rank, the forward query rows gathered inside the library — print exactly the records of the one-GPU run, in self mode

@@ -308,6 +308,33 @@ def test_rccl_rank_of_one_and_errors_of_the_sharded_search():
             ms.dist_find_matches()
 
 
+def test_group_survives_a_failing_rank_and_reports_its_reason(monkeypatch):
+    """One rank of a group of three fails BEFORE it reaches the exchange (its shard is not made of sketched reads): the other ranks,
+    already at the hub's barrier, are released instead of waiting for ever; the group reports the failing rank's reason, not a
+    victim's "another rank failed"; and once the shards are valid again the same group searches correctly (the hub is reset when all
+    rank threads have returned).  Run twice: plain device copies, and with the peer-copy call forced between ranks that share the
+    device (MHAP_GROUP_FORCE_PEER=1: the branch a multi-GPU node takes)."""
+    fa = mhap_amd.synth_reads(300, 2500, seed=207, error_rate=0.06)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=256, device=0)
+    want = O.record_lines(O.run_self(fa, H=64, S=256, nthreads=8)["records"])
+    for force in ("0", "1"):
+        monkeypatch.setenv("MHAP_GROUP_FORCE_PEER", force)
+        with mhap_amd.MinHashSearchGroup(p, n=3, devices=[0, 0, 0]) as g:
+            g.add_data(fa)
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want and len(want) > 50
+            r1 = g.rank(1)
+            tables = r1.export()
+            r1.clear()
+            keep = np.arange(len(tables["ids"])) % 2 == 0       # forward entries only: rank 1's shard is not pairs any more
+            r1.add_sketches({k: v[keep] for k, v in tables.items() if k != "status"})
+            with pytest.raises(mhap_amd.MhapError, match="rank 1: .*pairs"):
+                g.find_matches()
+            g.clear()
+            g.add_data(fa)
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want
+    monkeypatch.delenv("MHAP_GROUP_FORCE_PEER")
+
+
 def _awkward_fasta(path, fa, width=70):
     """The reads of `fa` as a FASTA file that exercises the parser: wrapped lines, lower case, CRLF, an IUPAC read, reads below
     --min-olap-length and below k, empty records, names with white space and commas (ids count non-empty records only)."""
@@ -544,9 +571,12 @@ def test_num_min_matches_up_to_the_slot_count_in_every_tier(monkeypatch):
 
 def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
     """A repeat-rich sample (the C5 slice's generator: a 300-bp repeat family planted every 3 kb) with more than 65 536 stored
-    entries: the second tier's dense counters cover the index in three entry ranges of 32 768.  Records equal the first-tier-only path's
-    (hash-partition passes), the index finds every posting where a lookup expects it (MHAP_DEBUG_INDEX self-check), and the
-    processed-elements statistic equals an independent count from the exported MinHash rows."""
+    entries through every form of the dense second tier: the compact kernel (4-bit thermometers, 131 072 entries per pass: one pass
+    here), the same with 8 192 entries per pass on an index whose long buckets are class-ordered (a pass streams only its part of a
+    bucket, found by bisection) and on an unordered one (every pass streams every bucket), and the 16-bit-counter kernel (three ranges
+    of 32 768).  Records equal the first-tier-only path's (hash-partition passes) and the middle tier's, the index finds every posting
+    where a lookup expects it and long buckets in class order (MHAP_DEBUG_INDEX self-check), and the processed-elements statistic
+    equals an independent count from the exported MinHash rows in every mode."""
     from mhap_amd import workloads as W
     import tempfile, os
     n = 34000
@@ -556,13 +586,19 @@ def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
     flt = mhap_amd.FrequencyCounts.from_file(path, filter_cutoff=1e-5, repeat_weight=0.9)
     p = MhapParams(num_hashes=64, ordered_sketch_size=256)
     monkeypatch.setenv("MHAP_DEBUG_INDEX", "1")
+    modes = {
+        "tiers": {},
+        "grouped-multipass": {"MHAP_INDEX_GROUP": "1", "MHAP_INDEX_GROUP_T": "8", "MHAP_INDEX_CLASS_LOG": "12", "MHAP_DENSE_RANGE_LOG": "13"},
+        "ungrouped-multipass": {"MHAP_INDEX_GROUP": "0", "MHAP_DENSE_RANGE_LOG": "13"},
+        "grouped-all-dense": {"MHAP_INDEX_GROUP": "1", "MHAP_INDEX_GROUP_T": "3", "MHAP_INDEX_CLASS_LOG": "10", "MHAP_DENSE_RANGE_LOG": "11", "MHAP_INDEX_DENSE": "1"},
+        "counters": {"MHAP_DENSE_TIER": "counters"},
+        "first-tier-only": {"MHAP_INDEX_TIERS": "1"},
+        "middle-tier": {"MHAP_INDEX_MID": "1"},     # first tier -> 8192-entry table -> dense counters for what outgrows that too
+    }
     out = {}
-    for mode in ("tiers", "first-tier-only", "middle-tier"):
-        if mode == "first-tier-only":
-            monkeypatch.setenv("MHAP_INDEX_TIERS", "1")
-        if mode == "middle-tier":                  # first tier -> 8192-entry table -> dense counters for what outgrows that too
-            monkeypatch.delenv("MHAP_INDEX_TIERS")
-            monkeypatch.setenv("MHAP_INDEX_MID", "1")
+    for mode, env in modes.items():
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         with MinHashSearch(p, kmer_filter=flt) as ms:
             ms.add_data(fa)
             recs = _sorted_records(ms.find_matches())
@@ -570,24 +606,30 @@ def test_dense_second_tier_ranges_and_independent_element_count(monkeypatch):
             if mode == "tiers":
                 assert ms.size() == 2 * n > 65536
                 sk = ms.export()
+        for k in env:
+            monkeypatch.delenv(k)
         out[mode] = (recs, st)
-    monkeypatch.delenv("MHAP_INDEX_MID")
     stored = sk["status"] == 0
     query = stored & (sk["is_fwd"] != 0)
     want = 0
     for s in range(sk["minhash"].shape[1]):
         vals, cnt = np.unique(sk["minhash"][stored, s], return_counts=True)
         want += int(cnt[np.searchsorted(vals, sk["minhash"][query, s])].sum())
-    (ra, sa), (rb, sb), (rm, sm) = out["tiers"], out["first-tier-only"], out["middle-tier"]
-    assert np.array_equal(ra, rb) and np.array_equal(ra, rm) and len(ra) > 1000
-    assert sa["table_elements"] == want == sb["table_elements"] == sm["table_elements"]
-    assert sa["index_splits"] > 0          # a second entry range was needed for some query
+    ra, sa = out["tiers"]
+    assert len(ra) > 1000
+    for mode, (r, st) in out.items():
+        assert np.array_equal(ra, r), mode
+        assert st["table_elements"] == want, (mode, st["table_elements"], want)
+    for mode in ("grouped-multipass", "ungrouped-multipass", "grouped-all-dense", "counters"):
+        assert out[mode][1]["index_splits"] > 0, mode          # further entry ranges were needed for some query
 
 
-def test_inverted_index_with_a_shared_repeat():
+def test_inverted_index_with_a_shared_repeat(monkeypatch):
     """5 200 reads that all carry the same 2 kb repeat at H = 512 (the repeat's k-mers win most MinHash slots, so thousands of
     entries share the value of a slot): insertion stays O(1) per posting (overflow lists), large hit sets go to the second query tier, records
-    equal the oracle's and the index build time stays bounded."""
+    equal the oracle's and the index build time stays bounded.  A second run makes the 10 400 entries look like a million to the
+    dense tier: buckets of thousands of postings class-ordered in classes of 256 entries, 21 passes of 512 entries, more long buckets
+    per query than the bounds table has rows for (those are streamed whole by every pass)."""
     rnd = random.Random(77)
     rep = _rand_seq(rnd, 2000)
     seqs = []
@@ -607,6 +649,14 @@ def test_inverted_index_with_a_shared_repeat():
     assert st["table_elements"] == want["elements"] and st["candidates_compared"] == want["compared"]
     assert st["index_splits"] == 0      # hit sets of 10 400 entries: over the first tier's table, within the second tier's
     assert kt["index_build"]["ms"] < 200.0, kt["index_build"]      # 5.3 M postings; quadratic runs took seconds
+    for k, v in {"MHAP_INDEX_GROUP": "1", "MHAP_INDEX_GROUP_T": "64", "MHAP_INDEX_CLASS_LOG": "8", "MHAP_DENSE_RANGE_LOG": "9", "MHAP_DEBUG_INDEX": "1"}.items():
+        monkeypatch.setenv(k, v)
+    with MinHashSearch(p) as ms:
+        ms.add_data(fa)
+        got2 = ms.find_matches()
+        st2 = ms.stats()
+    assert np.array_equal(_sorted_records(got2), _sorted_records(want["records"]))
+    assert st2["table_elements"] == want["elements"] and st2["candidates_compared"] == want["compared"] and st2["index_splits"] > 0
 
 
 def test_minhash_large_num_hashes_and_short_strands():

@@ -425,3 +425,14 @@ def test_bit_sliced_step_order_matches_its_generator():
     body = body[:body.index("\n}\n")]
     have = [ln.strip() for ln in body.splitlines() if ln.strip().startswith(("const uint32_t T", "P["))]
     assert have == stmts
+
+
+def test_bench_preflight_without_a_gpu_reports_instead_of_hanging():
+    """bench.py --preflight --gpus 2 on a box without GPUs: exit code 1 and a JSON report that names what is missing."""
+    import json, subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight", "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    rep = json.loads(r.stdout.strip().split("\n")[-1])
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode == 1 and not rep["ready"] and not rep["checks"]["devices"]["ok"]
+    assert set(rep["checks"]) >= {"devices", "torch_rccl_backend", "library_rccl_entry_points", "peer_access", "ipc_mode"}
