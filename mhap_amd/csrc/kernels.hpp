@@ -137,6 +137,7 @@ bool index_query_tiers();
 bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches);   // tier 0 / 1: can its packed hit-count words hold this index and threshold?   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)
 // (tiers: 0 the first, 1 the same kernel with a large table, 2 dense counters — launch_index_query in search_kernels.hip)
 // Second stage: one lane per candidate.
+void oj_stats_dump();   // -DMH_OJ_STATS builds: print and reset the join kernel's exit statistics
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
                     const int32_t* qmeta, const SearchParams& sp, const double* score_table, int32_t* scratch, int64_t scratch_per_lane,
@@ -151,6 +152,11 @@ void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, cons
                          unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
                          int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
                          unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,
-                         unsigned long long* slow_count, unsigned long long* work);
+                         unsigned long long* slow_count, unsigned long long* work, const uint16_t* ph = nullptr, const uint16_t* qph = nullptr,
+                         const int32_t* pass_min = nullptr);
+// position histograms of an ordered table (64 cumulative 16-bit counts per entry) and the join kernel's early "below the threshold":
+// ph / qph = histograms of the stored / the query table, pass_min[kk] = smallest inter with score_table[inter, kk'] >= threshold for any kk' >= kk
+void launch_poshist(hipStream_t st, const int32_t* ordered, int64_t stride, const int32_t* meta, int64_t n, uint16_t* out);
+constexpr int POSHIST_BINS = 64;
 
 }  // namespace mhap

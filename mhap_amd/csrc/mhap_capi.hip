@@ -91,6 +91,7 @@ struct mhap_handle {
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0;
+  bool ph_ready = false; int64_t ph_ne = 0;   // poshist holds the position histograms of entries [0, ph_ne) (reset wherever inv_ready is)
   bool iq_start_mid = false;   // queries of this index start in the middle query tier (set by a chunk that mostly ended up there)
   int64_t reserve_reads = 0;       // mhap_index_reserve: reads the empty index is about to receive, over one or more adds
   std::string err;
@@ -100,7 +101,7 @@ struct mhap_handle {
   // filter
   DevBuf f_keys, f_vals, f_bloom;
   FilterTable ft{};
-  DevBuf score_tbl, jump_tbl, unjump_tbl, jump_w1_tbl, hash_luts;
+  DevBuf score_tbl, jump_tbl, unjump_tbl, jump_w1_tbl, hash_luts, pass_min_tbl, poshist, q_poshist;
 
   // index (owned or external)
   bool external = false;
@@ -197,6 +198,18 @@ int build_score_table(mhap_handle* h) {
   }, 8);
   HIPCHK(h, h->score_tbl.ensure((size_t)n * 8));
   HIPCHK(h, hipMemcpy(h->score_tbl.p, tbl.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+  // pass_min[kk] = the smallest number of shared k-mers that reaches the threshold for ANY k' >= kk, read off the table itself
+  // (no monotonicity assumed): a pair with fewer joined k-mers than pass_min[lower bound of its k] cannot be accepted
+  // (search_kernels.hip, poshist_kernel).  MinHashSearch.java:229 accepts score >= acceptScore.
+  std::vector<int32_t> pm((size_t)S + 2, INT32_MAX);
+  for (int kk = S; kk >= 0; kk--) {
+    int32_t best = kk < S ? pm[(size_t)kk + 1] : INT32_MAX;
+    for (int it = 0; it <= kk; it++)
+      if (tbl[(size_t)score_index(it, kk)] >= h->P.threshold) { best = std::min<int32_t>(best, it); break; }
+    pm[(size_t)kk] = best;
+  }
+  HIPCHK(h, h->pass_min_tbl.ensure(pm.size() * 4));
+  HIPCHK(h, hipMemcpy(h->pass_min_tbl.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
   return MHAP_OK;
 }
 
@@ -504,6 +517,7 @@ struct QuerySide {
   const int32_t* d_meta;
   const int64_t* d_ids;
   const int64_t* h_ids; const int32_t* h_seqlen;
+  int64_t n_rows;   // rows of the query tables
 };
 
 // Run candidate + second stage for the query entries in `ql` (entry indices into the query side).
@@ -566,6 +580,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   }
 
   h->iq_start_mid = false;   // decided anew by the first chunks of every search
+  bool q_ph_done = false;    // the query side's position histograms exist (second stage, early "below the threshold")
   for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
     const int nq = (int)std::min<int64_t>(qchunk, (int64_t)ql.size() - c0);
     const int ntq = (nq + CAND_TQ - 1) / CAND_TQ;
@@ -697,10 +712,36 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       const int chunk = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)ncand / std::max<int64_t>(resident_waves, 1)));
       const int64_t want = ((int64_t)ncand + (int64_t)wpb * chunk - 1) / ((int64_t)wpb * chunk);
       const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * per_cu, want));
+      // Early "below the threshold" from position histograms (search_kernels.hip, poshist_kernel): pays when the joined k-mers of a pair
+      // are few next to its windows — repeat-induced candidates, i.e. many candidates per query (the TEAM shape's regime); at C2 (40
+      // joined k-mers per pair) it rejects nothing and the histograms would cost a pass over the ordered table.  MHAP_OVERLAP_PRUNE=0|1.
+      const char* pe = getenv("MHAP_OVERLAP_PRUNE");
+      const bool prune = pe ? pe[0] == '1' : (int64_t)ncand >= 16LL * nq;
+      const uint16_t *ph = nullptr, *qph = nullptr;
+      if (prune) {
+        time_begin(h, MHAP_K_OVERLAP);
+        if (!(h->ph_ready && h->ph_ne == h->n_entries)) {
+          HIPCHK(h, h->poshist.ensure((size_t)h->n_entries * POSHIST_BINS * 2));
+          launch_poshist(h->stream, h->d_ordered, 2LL * S, h->d_meta, h->n_entries, h->poshist.as<uint16_t>());
+          h->ph_ready = true; h->ph_ne = h->n_entries;
+        }
+        ph = h->poshist.as<uint16_t>();
+        if (qs.d_ordered == h->d_ordered && qs.d_meta == h->d_meta) qph = ph;
+        else {
+          if (!q_ph_done) {      // (after the gate: the query rows of a sharded search have all arrived)
+            HIPCHK(h, h->q_poshist.ensure((size_t)qs.n_rows * POSHIST_BINS * 2));
+            launch_poshist(h->stream, qs.d_ordered, qs.ord_stride, qs.d_meta, qs.n_rows, h->q_poshist.as<uint16_t>());
+            q_ph_done = true;
+          }
+          qph = h->q_poshist.as<uint16_t>();
+        }
+        time_end(h);
+        HIPCHK(h, hipGetLastError());
+      }
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap_join(h->stream, shape, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                           qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,
-                          (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7);
+                          (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7, ph, qph, h->pass_min_tbl.as<int32_t>());
       time_end(h);
       HIPCHK(h, hipGetLastError());
       HIPCHK(h, hipMemcpyAsync(&nslow, ctr + 5, 8, hipMemcpyDeviceToHost, h->stream));
@@ -724,6 +765,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     int rc = sync_stream(h);
     if (rc != MHAP_OK) return rc;
     HPROF("overlap done");
+    oj_stats_dump();
     const unsigned long long nrec = counts[1];
     h->stats.candidates_compared += (int64_t)counts[2];
     if (nrec == 0) continue;
@@ -964,7 +1006,7 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   HPROF("finish_add begin");
-  h->inv_ready = false;   // the entry set changes
+  h->inv_ready = false; h->ph_ready = false;   // the entry set changes
   h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
   for (int64_t i = 0; i < n; i++) {
     h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
@@ -1011,7 +1053,7 @@ int mhap_index_add_staged(mhap_handle* h) {
   int rc = ensure_index_capacity(h, want_entries);
   if (rc != MHAP_OK) return rc;
   const int S = h->P.ordered_sketch_size;
-  h->inv_ready = false;   // (the inverted index is built by the first search: a sort of all postings, 2 ms per 100 M)
+  h->ph_ready = false; h->inv_ready = false;   // (the inverted index is built by the first search: a sort of all postings, 2 ms per 100 M)
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
   if (rc != MHAP_OK) return rc;
   rc = finish_add(h, first, h->st_ids.data(), n);
@@ -1076,7 +1118,7 @@ int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* i
   HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)m * 8, hipMemcpyHostToDevice));
   rc = mirror_meta(h, h->d_meta, first, m);
   if (rc != MHAP_OK) return rc;
-  h->n_entries = first + m; h->inv_ready = false;
+  h->n_entries = first + m; h->inv_ready = false; h->ph_ready = false;
   h->stats.strands_indexed += m;
   return MHAP_OK;
 }
@@ -1111,7 +1153,7 @@ int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids
 
 int mhap_index_clear(mhap_handle* h) {
   if (!h) return MHAP_E_INVALID;
-  h->n_entries = 0; h->external = false; h->inv_ready = false; h->reserve_reads = 0;
+  h->n_entries = 0; h->external = false; h->inv_ready = false; h->ph_ready = false; h->reserve_reads = 0;
   h->ids.clear(); h->fwd.clear(); h->seqlen.clear(); h->status.clear();
   h->d_minhash = h->own_minhash.as<int32_t>(); h->d_ordered = h->own_ordered.as<int32_t>(); h->d_meta = h->own_meta.as<int32_t>();
   h->stats = mhap_stats{};
@@ -1149,7 +1191,7 @@ int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_
   HIPCHK(h, h->d_ids.ensure((size_t)std::max<int64_t>(m, 1) * 8));
   if (m > 0) HIPCHK(h, hipMemcpy(h->d_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
   if (m > 0) { int rc = mirror_meta(h, h->d_meta, 0, m); if (rc != MHAP_OK) return rc; }
-  h->n_entries = m; h->inv_ready = false;
+  h->n_entries = m; h->inv_ready = false; h->ph_ready = false;
   for (int64_t e = 0; e < m; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
   return MHAP_OK;
 }
@@ -1172,7 +1214,7 @@ static int self_search(mhap_handle* h, int64_t q_first, int64_t q_count, int64_t
   for (int64_t e = 1; e < h->n_entries && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
   // tile skipping needs: ids sorted with entry order, every entry "long" (minStore == 0 -> only m.id < q.id survives)
   const bool tri = mono && h->P.min_store_length == 0 && !getenv("MHAP_NO_TRIANGULAR");
-  QuerySide qs{h->d_minhash, h->Hrow, h->d_ordered, 2LL * h->P.ordered_sketch_size, h->d_meta, h->d_ids.as<int64_t>(), h->ids.data(), h->seqlen.data()};
+  QuerySide qs{h->d_minhash, h->Hrow, h->d_ordered, 2LL * h->P.ordered_sketch_size, h->d_meta, h->d_ids.as<int64_t>(), h->ids.data(), h->seqlen.data(), h->n_entries};
   HPROF("search_core begin");
   const int rcs = search_core(h, qs, ql, true, tri, sink, user);
   HPROF("search_core end");
@@ -1215,7 +1257,7 @@ int mhap_find_matches_reads(mhap_handle* h, const char* bases, const int64_t* of
   }
   HIPCHK(h, hipMemcpy(h->q_ids.p, qids.data(), qids.size() * 8, hipMemcpyHostToDevice));
   QuerySide qs{h->q_minhash.as<int32_t>(), h->Hrow, h->q_ordered.as<int32_t>(), 2LL * S, h->q_meta.as<int32_t>(), h->q_ids.as<int64_t>(),
-               qids.data(), qlen.data()};
+               qids.data(), qlen.data(), 2 * n};
   return search_core(h, qs, ql, false, false, sink, user);
 }
 
@@ -1243,7 +1285,7 @@ int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t
   HIPCHK(h, hipMemcpy(h->q_meta.p, meta.data(), meta.size() * 4, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
   QuerySide qs{h->q_minhash.as<int32_t>(), h->Hrow, h->q_ordered.as<int32_t>(), 2LL * S, h->q_meta.as<int32_t>(), h->q_ids.as<int64_t>(), ids,
-               seq_length};
+               seq_length, m};
   return search_core(h, qs, ql, false, false, sink, user);
 }
 
@@ -1265,7 +1307,7 @@ int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void
   HIPCHK(h, h->q_ids.ensure((size_t)m * 8));
   HIPCHK(h, hipMemcpy(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
   QuerySide qs{(const int32_t*)d_q_minhash, h->Hrow, (const int32_t*)d_q_ordered, 2LL * S, (const int32_t*)d_q_meta, h->q_ids.as<int64_t>(), ids,
-               qlen.data()};
+               qlen.data(), m};
   return search_core(h, qs, ql, to_self != 0, false, sink, user);
 }
 

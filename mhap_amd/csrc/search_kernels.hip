@@ -10,6 +10,7 @@
 //                      through LDS, 8x8 register micro-tile per lane, triangular tile skipping in self mode.
 //   overlap_join_kernel : BottomOverlapSketch.getOverlapInfo per candidate, one wavefront each, from the equal-hash join.
 //   overlap_kernel   : the same per candidate, one lane each, literal merge (overlap_lane.hpp): pairs the join path hands back.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "kernels.hpp"
@@ -1212,6 +1213,14 @@ __device__ __forceinline__ ShiftStats oj_shift_stats(bool have, int med, int len
   return st;
 }
 
+#ifdef MH_OJ_STATS
+// (diagnostic build: where the pairs of the join kernel end — {nj < 3, no record in pass 1, in pass 2, < 3 valid, below the threshold,
+//  accepted, sum of nj, sum of in-window joined k-mers of the scored pairs}; printed by launch_overlap_join's caller through oj_stats_dump)
+__device__ unsigned long long g_oj_stats[8];
+#define OJ_STAT(k, v) do { if (lane == 0) atomicAdd(&g_oj_stats[k], (unsigned long long)(v)); } while (0)
+#else
+#define OJ_STAT(k, v) do { } while (0)
+#endif
 struct OjWindows { int v1lo, v1hi, v2lo, v2hi, med, absmax; };
 __device__ __forceinline__ OjWindows oj_windows(ShiftStats st, int len1, int len2) {   // MatchData :246-276
   const int med = st.med, absmax = st.absmax;
@@ -1342,6 +1351,57 @@ __device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t
 // dependent round trips per entry, 36 % of this kernel at the C5 slice and 24 % at C2 (-DMH_OJ_JOIN_ONLY / -DMH_OJ_NO_SEARCH
 // timing builds).  (An open-addressing hash table was tried first: the probe chains' MAXIMUM over the 64 lanes, not their mean,
 // sets a wave's time — 8.0 ms at C2 against the binary search's 4.7.)
+// ---- position histograms: an exact early "below the threshold" for the join kernel ---------------------------------------------
+// Nine in ten pairs of every workload measured end BELOW THE THRESHOLD, after the two extra passes over both rows that the bottom-k
+// Jaccard needs (the ranks of the joined k-mers among the in-window entries; -DMH_OJ_STATS: 408 050 of 451 976 pairs at C2,
+// 7.1 M of 8.3 M on one rank's share of configs[4]).  A pair's score is score_table[inter, kk] with inter <= J, the joined k-mers
+// inside both windows, and kk = min(in-window entries of either sketch).  A cumulative histogram of the positions of a sketch's
+// entries (64 bins over the strand, 128 bytes per entry) bounds the in-window counts from below with two 16-bit loads per sketch;
+// pass_min[kk] = the smallest inter that reaches the threshold for any kk' >= kk (from the score table itself, on the host: no
+// monotonicity is assumed).  J < pass_min[kk_lb] => the pair cannot be accepted whatever the ranks are: it ends EMPTY-scored here.
+constexpr int PH_BINS = 64;
+__global__ __launch_bounds__(256) void poshist_kernel(const int32_t* __restrict__ ordered, int64_t stride, const int32_t* __restrict__ meta, int64_t n,
+                                                      uint16_t* __restrict__ out) {
+  __shared__ uint32_t hist[4][PH_BINS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 4 + wv;
+  if (e >= n) return;
+  const int32_t* mm = meta + e * META_W;
+  const int ne = mm[3] == 0 ? mm[0] : 0, len = mm[1];
+  const int w = len > 0 ? (len + PH_BINS - 1) / PH_BINS : 1;
+  hist[wv][lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint2* row = (const uint2*)(ordered + e * stride);
+  for (int j = lane; j < ne; j += 64) {
+    const int pos = (int)row[j].y;
+    int b = pos > 0 ? pos / w : 0;
+    b = b < PH_BINS - 1 ? b : PH_BINS - 1;
+    atomicAdd(&hist[wv][b], 1u);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t v = hist[wv][lane];
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(v, off); if (lane >= off) v += t; }
+  out[e * PH_BINS + lane] = (uint16_t)v;
+}
+void launch_poshist(hipStream_t st, const int32_t* ordered, int64_t stride, const int32_t* meta, int64_t n, uint16_t* out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(poshist_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, ordered, stride, meta, n, out);
+}
+// entries with a position in [x, y], from below: the bins that lie inside the window (bin b = positions [b w, (b + 1) w))
+__device__ __forceinline__ int ph_count_lb(const uint16_t* __restrict__ ph, int len, int x, int y) {
+  if (y < x) return 0;
+  const int w = len > 0 ? (len + PH_BINS - 1) / PH_BINS : 1;
+  const int fb = (x + w - 1) / w;
+  int lb = (y + 1) / w;                      // bins [fb, lb) are inside: whole bins among 0 .. 62 ...
+  lb = lb < PH_BINS - 1 ? lb : PH_BINS - 1;
+  if (y + 1 >= len) lb = PH_BINS;            // ... and the last one, which holds everything from 63 w on, when the window reaches the strand's end
+  if (lb <= fb) return 0;
+  return (int)ph[lb - 1] - (fb > 0 ? (int)ph[fb - 1] : 0);
+}
+
 struct OjBuckets { int first, last; uint32_t mult; };
 __device__ __forceinline__ OjBuckets oj_buckets(int first, int last, int nb) {
   OjBuckets k;
@@ -1369,7 +1429,9 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
                                                                      unsigned long long* __restrict__ rec_count, unsigned long long rec_cap,
                                                                      unsigned long long* __restrict__ compared, Candidate* __restrict__ slow,
                                                                      unsigned long long* __restrict__ slow_count, int chunk,
-                                                                     unsigned long long* __restrict__ work, int ts) {
+                                                                     unsigned long long* __restrict__ work, int ts,
+                                                                     const uint16_t* __restrict__ ph, const uint16_t* __restrict__ qph,
+                                                                     const int32_t* __restrict__ pass_min) {
   extern __shared__ int32_t oj_lds[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int spad = (sp.S + 3) & ~3, own = TABLE ? spad + ts / 2 + 2 : spad;   // ints of the hashes (+ the table: ts + 1 shorts, padded)
@@ -1537,7 +1599,8 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
 #ifdef MH_OJ_JOIN_ONLY
         if (nj >= 0) break;   // (timing experiment: everything after the join skipped; results are wrong)
 #endif
-        if (ng == 0 && nj < 3) break;   // computeEdges needs three valid records (:126): fewer joined k-mers can only end EMPTY
+        OJ_STAT(6, nj);
+        if (ng == 0 && nj < 3) { OJ_STAT(0, 1); break; }   // computeEdges needs three valid records (:126): fewer joined k-mers can only end EMPTY
         int iA[OJ_R], jB[OJ_R];   // the joined k-mers' entry indices move to registers, their LDS words become `sh`
 #pragma unroll
         for (int r = 0; r < OJ_R; r++) {
@@ -1551,10 +1614,10 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
         int count = 0, nx = 0;
         ShiftStats st = oj_shift_stats(false, 0, len1, len2, sp.max_shift);
         uint32_t fl = oj_pass(jp1, jp2, nj, ng, gi, gpa, gpb, len1, len2, st, lane, count, nx);
-        if (count <= 0) break;
+        if (count <= 0) { OJ_STAT(1, 1); break; }
         st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
         fl = oj_pass(jp1, jp2, nj, ng, gi, gpa, gpb, len1, len2, st, lane, count, nx);
-        if (count <= 0) break;
+        if (count <= 0) { OJ_STAT(2, 1); break; }
         st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
         // optimizeShifts (:156-189): neighbouring records of one query position exist only inside a group
         int removed = 0;
@@ -1594,7 +1657,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
             nvalid += __popcll(__ballot(ok));
           }
         }
-        if (nvalid < 3) break;
+        if (nvalid < 3) { OJ_STAT(3, 1); break; }
         le1 = oj_wave_min(le1); le2 = oj_wave_min(le2); re1 = oj_wave_max(re1); re2 = oj_wave_max(re2);
         const double den = (double)(nvalid - 1);
         const int32_t na1 = (int32_t)((uint32_t)nvalid * (uint32_t)le1 - (uint32_t)re1);   // int products wrap like Java's (:131-134)
@@ -1606,6 +1669,23 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
         b1 = (int)java_round((double)nb1 / den); if (b1 < 0) b1 = 0;
         b2 = (int)java_round((double)nb2 / den); if (b2 > len2) b2 = len2;
         valid = nvalid;
+        if (ph != nullptr) {
+          // the early "below the threshold" (poshist_kernel above): J = joined k-mers inside both windows + what the groups can add
+          int J = 0;
+#pragma unroll
+          for (int r = 0; r < OJ_R; r++) {
+            if (r * 64 < nj) {
+              const int t = r * 64 + lane;
+              bool in = false;
+              if (t < nj) { const int p1 = jp1[t], p2 = jp2[t]; in = p1 >= a1 && p1 <= a2 && p2 >= b1 && p2 <= b2; }
+              J += __popcll(__ballot(in));
+            }
+          }
+          for (int g = 0; g < ng; g++) { const int m = gi[g * 6 + 2], nn = gi[g * 6 + 3]; J += m < nn ? m : nn; }
+          const int s1lb = ph_count_lb(qph + (int64_t)cd.q * PH_BINS, len1, a1, a2), s2lb = ph_count_lb(ph + (int64_t)cd.m * PH_BINS, len2, b1, b2);
+          const int kklb = s1lb < s2lb ? s1lb : s2lb;
+          if (J < pass_min[kklb]) { OJ_STAT(4, 1); break; }     // score stays 0: below any threshold that was asked for
+        }
         // ---- computeKBottomSketchJaccard (:304-364): in-window counts, and for every joined k-mer (and every group's first
         // entries) its rank among the in-window entries of either sketch: prefix counts over 64-entry blocks, the lane that
         // holds entry i of the block hands the rank to the lane that holds the joined k-mer ----
@@ -1717,6 +1797,8 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
           gacc += gm;
         }
         score = score_table[score_index(inter, kk)];
+        OJ_STAT(score >= sp.threshold ? 5 : 4, 1);
+        OJ_STAT(7, before);
       } while (0);
       if (score >= sp.threshold && lane == 0) {                                                  // MinHashSearch.java:229
         const unsigned long long slot = atomicAdd(rec_count, 1ULL);
@@ -1837,13 +1919,25 @@ void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, cons
                          unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
                          int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
                          unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,
-                         unsigned long long* slow_count, unsigned long long* work) {
+                         unsigned long long* slow_count, unsigned long long* work, const uint16_t* ph, const uint16_t* qph, const int32_t* pass_min) {
   const int ts = overlap_join_table_slots(sp.S);
   oj_dispatch(shape, [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * OJ_SHAPE_WAVES[shape]), overlap_join_lds_bytes(sp.S, shape), st, cand, cand_count, cand_cap, ordered,
-                       ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk, work, ts);
+                       ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk, work, ts,
+                       ph, qph, pass_min);
     return 0;
   });
+}
+
+void oj_stats_dump() {
+#ifdef MH_OJ_STATS
+  unsigned long long h[8];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_oj_stats), sizeof h) != hipSuccess) return;
+  fprintf(stderr, "[oj stats] pairs: nj<3 %llu, no record in pass 1 %llu, in pass 2 %llu, <3 valid %llu, below threshold %llu, accepted %llu; mean nj %.2f, mean in-window joined of scored %.2f\n",
+          h[0], h[1], h[2], h[3], h[4], h[5], (double)h[6] / (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + 1), (double)h[7] / (double)(h[4] + h[5] + 1));
+  memset(h, 0, sizeof h);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_oj_stats), h, sizeof h);
+#endif
 }
 
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,

@@ -29,15 +29,20 @@ CONFIGS = {
     "c5slice": dict(reads=40000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.01), filter=True,
                     label="40000 synthetic reads x 12000 bp with a planted 300-bp repeat family (one copy per 3 kb, 1% divergence), "
                           "-f k-mer filter file, --filter-threshold 1e-5: single-GPU slice of BASELINE configs[4]"),
-    # one rank's share of BASELINE configs[4] by SIZE (5M reads over 8 GPUs = 625 000 reads x 12 kb), run as a self-overlap job on one
-    # GPU: 1.25 M index entries = 39 dense-tier ranges, the same planted repeat family and -f file as c5slice
-    "c5rank": dict(reads=625000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.01), filter=True,
-                   label="625000 synthetic reads x 12000 bp with a planted 300-bp repeat family (one copy per 3 kb, 1% divergence), "
+    # One rank's share of BASELINE configs[4] by SIZE (5M reads over 8 GPUs = 625 000 reads x 12 kb) as a self-overlap job on one GPU:
+    # 1.25 M index entries.  The planted family is the slice's (300 bp, one copy per 3 kb: Alu-like density) at 5 % divergence from the
+    # consensus instead of 1 %: candidate pairs and records of a one-consensus family grow with the SQUARE of the read count (a k-mer
+    # above --filter-threshold 1e-5 is in 12 % of all 12-kb reads by definition), and at 1 % this size has 3 000 candidates and 250
+    # records per read — 2 x 10^9 pairs and 1.6 x 10^8 records a step (10^10 records for the 8-GPU job), no job anyone runs; at 5 %
+    # (AluY/AluS-like copies) it is 340 candidates and 46 records per read, still forty times the true overlaps, with 326 k-mers over the
+    # filter's cutoff.  Both were measured at this size: profiles/r04_c5_probe.txt
+    "c5rank": dict(reads=625000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.05), filter=True,
+                   label="625000 synthetic reads x 12000 bp with a planted 300-bp repeat family (one copy per 3 kb, 5% divergence), "
                          "-f k-mer filter file, --filter-threshold 1e-5: one rank's share (by size) of BASELINE configs[4], self-overlap on one GPU"),
     # BASELINE configs[4] itself (5M reads): not a single-GPU bench config (tables + index + scratch of 10M strands exceed 288 GB); it
     # exists so that tools/emulate_rank.py can deal it over 8 ranks and run ONE rank's step against the gathered rows of all of them
-    "c5": dict(reads=5000000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.01), filter=True,
-               label="5000000 synthetic reads x 12000 bp with the planted repeat family, -f filter (BASELINE configs[4]; 8-GPU job)"),
+    "c5": dict(reads=5000000, length=12000, hashes=512, seed=SEED ^ 5, repeats=(300, 3000, 0.05), filter=True,
+               label="5000000 synthetic reads x 12000 bp with the planted repeat family (5% divergence), -f filter (BASELINE configs[4]; 8-GPU job)"),
 }
 
 

@@ -245,7 +245,7 @@ def test_index_export_roundtrip_and_query_sharding():
     assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 3
 
 
-def test_group_of_ranks_on_one_device_matches_the_oracle():
+def test_group_of_ranks_on_one_device_matches_the_oracle(monkeypatch):
     """The multi-GPU path inside the library (mhap_group_*: reads dealt round-robin, one index shard per rank, forward query rows
     gathered by peer copies, every rank scoring all queries against its shard under the toSelf id rules) with 2, 3 and 4 ranks
     sharing this box's one GPU: self overlap, -q mode (toSelf = false), a ragged data set (short and unsketchable reads, fewer
@@ -273,6 +273,11 @@ def test_group_of_ranks_on_one_device_matches_the_oracle():
             for lo, hi in ((0, 5), (5, 333), (333, len(fa))):
                 g.add_data(fa.subset(np.arange(lo, hi)))
             assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want, n
+            if n == 3:   # the second stage's early "below the threshold" on gathered query rows (their histograms are made after the gate)
+                monkeypatch.setenv("MHAP_OVERLAP_PRUNE", "1")
+                assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want
+                assert sorted(mhap_amd.records_to_lines(g.find_matches_stream(q))) == want_q
+                monkeypatch.delenv("MHAP_OVERLAP_PRUNE")
     # ragged: reads below --min-olap-length, reads shorter than k, and fewer sketchable reads than ranks
     seqs = [fa.sequence(i) for i in range(6)] + ["ACGT" * 20, "ACGTACGTAC", fa.sequence(6)[:130]]
     small = mhap_amd.FastaData.from_strings(seqs)
@@ -722,6 +727,12 @@ def test_overlap_join_groups_and_lane_fallback(monkeypatch):
         monkeypatch.delenv("MHAP_OVERLAP", raising=False)
         assert a == O.record_lines(want["records"]), kw
         assert b == a
+        # the early "below the threshold" from position histograms, forced on (by default only candidate-rich chunks use it) and off
+        for prune in ("1", "0"):
+            monkeypatch.setenv("MHAP_OVERLAP_PRUNE", prune)
+            c, sc = _self_lines(fa, p)
+            assert c == a and sc["candidates_compared"] == sa["candidates_compared"], (kw, prune)
+        monkeypatch.delenv("MHAP_OVERLAP_PRUNE")
         assert 0 < sa["slow_pairs"] < sa["candidates_compared"], sa
         assert sb["slow_pairs"] == 0 and sb["candidates_compared"] == sa["candidates_compared"]
         print("slow pairs", sa["slow_pairs"], "of", sa["candidates_compared"])
@@ -865,6 +876,73 @@ def test_full_config4_on_one_gpu_properties_and_subset_parity():
     print(f"c4 full: {len(recs)} records, checksum {csum:016x}, {len(want)} of them among the first {nsub} reads")
 
 
+def test_full_config5_rank_properties_and_subset_parity(tmp_path):
+    """One rank's share of BASELINE configs[4] at its true size — 625 000 reads x 12 kb, 1.25 M index entries (ten ranges of the
+    dense query tier), planted repeat family, generated -f file, --filter-threshold 1e-5 — as a self-overlap job on one GPU: the
+    size-independent properties of every record, and full parity with the CPU oracle, under the SAME filter, on the pairs among a
+    2 000-read subset (a pair's record depends on its two reads and the filter only)."""
+    from mhap_amd import workloads as W
+    fa = W.config_reads("c5rank")
+    n = len(fa)
+    assert n == 625000
+    ffile = tmp_path / "kmers.txt"
+    W.write_filter_file(fa, str(ffile), max_reads=2000)
+    flt = mhap_amd.FrequencyCounts.from_file(str(ffile), filter_cutoff=1e-5, repeat_weight=0.9)
+    assert (flt.fractions >= 1e-5).sum() > 100
+    with MinHashSearch(MhapParams(), kmer_filter=flt) as ms:
+        ms.add_data(fa)
+        recs = ms.find_matches()
+        st, kt = ms.stats(), ms.kernel_times()
+    assert st["strands_indexed"] == 2 * n and st["queries_searched"] == n
+    assert len(recs) > 5000000 and st["candidates_compared"] > 5 * len(recs) // 2
+    assert np.all(recs["to_id"] < recs["from_id"]) and np.all((recs["from_id"] <= n) & (recs["to_id"] >= 1))
+    assert np.all((recs["score"] >= 0.78) & (recs["score"] <= 1.0) & (recs["raw"] >= 3))
+    assert np.all((recs["a1"] >= 0) & (recs["a1"] <= recs["a2"]) & (recs["a2"] <= 12000 - 11) & (recs["alen"] == 12000) & (recs["blen"] == 12000))
+    assert np.all((recs["b1"] >= -1) & (recs["b2"] <= 12000) & (recs["b1"] <= recs["b2"]))
+    key = (recs["from_id"].astype(np.int64) << 21) | (recs["to_id"].astype(np.int64) << 1) | recs["to_rc"].astype(np.int64)
+    assert len(np.unique(key)) == len(recs)                                 # one record per (query, stored strand)
+    # the dense tier covered the index in ranges, each long bucket streamed once (the query stage is a fraction of the sketch time)
+    assert st["index_splits"] > 0 and kt["index_query"]["ms"] < 0.5 * kt["minhash"]["ms"], kt
+    nsub = 2000
+    oflt = O.Filter(flt.hashes, flt.fractions, 1e-5, 0.9, 3.0, False)
+    want = O.record_lines(O.run_self(fa.subset(np.arange(nsub)), nthreads=16, flt=oflt, cap=1 << 22)["records"])
+    m = (recs["from_id"] <= nsub) & (recs["to_id"] <= nsub)
+    assert sorted(mhap_amd.records_to_lines(recs[m])) == want and len(want) >= 20
+    print(f"c5rank: {len(recs)} records from {st['candidates_compared']} candidates ({st['slow_pairs']} through the per-lane kernel), "
+          f"{len(want)} among the first {nsub} reads; kernel ms " + ", ".join(f"{k}={v['ms']:.0f}" for k, v in kt.items() if v["ms"] > 0))
+
+
+def test_config3_like_read_mix_at_scale_subset_parity():
+    """Stand-in for BASELINE configs[2] (real E. coli reads: the file is in neither tree) at its scale: 50 000 reads with a log-normal
+    length mix (median 8 kb, tail to 50 kb: reads past 24 591 bases take the materialised-hash path, short ones fall under
+    --min-olap-length), runs of N in 2 % of them (raw-byte strands), default flags.  Properties of every record and full parity with
+    the oracle on the pairs among the first 1 500 reads."""
+    N, LMAX = 50000, 50000
+    fa = mhap_amd.synth_reads(N, LMAX, seed=23, error_rate=0.15, coverage=30.0 * LMAX / 9000)
+    rng = np.random.default_rng(5)
+    L = np.clip(rng.lognormal(9.0, 0.55, N).astype(np.int32), 80, LMAX)
+    L[::997] = rng.integers(10, 116, len(L[::997]))                        # a few reads under --min-olap-length (and under k)
+    fa.lengths[:] = L
+    for i in rng.choice(N, N // 50, replace=False):                        # a run of N somewhere in the read
+        w = int(rng.integers(5, 200))
+        o = int(fa.offsets[i]) + int(rng.integers(0, max(1, int(L[i]) - w)))
+        fa.bases[o:o + min(w, int(L[i]))] = ord("N")
+    assert (L > 24591).sum() > 200 and (L < 116).sum() >= 1
+    with MinHashSearch(MhapParams()) as ms:
+        ms.add_data(fa)
+        recs = ms.find_matches()
+        st = ms.stats()
+    assert st["queries_searched"] == int((L >= 116).sum()) and len(recs) > 10000
+    assert np.all(recs["to_id"] < recs["from_id"]) and np.all((recs["score"] >= 0.78) & (recs["score"] <= 1.0) & (recs["raw"] >= 3))
+    assert np.all(recs["alen"] == L[recs["from_id"] - 1]) and np.all(recs["blen"] == L[recs["to_id"] - 1])
+    assert np.all((recs["a1"] >= 0) & (recs["a1"] <= recs["a2"]) & (recs["a2"] <= recs["alen"] - 11) & (recs["b1"] >= -1) & (recs["b2"] <= recs["blen"]))
+    nsub = 1500
+    want = O.record_lines(O.run_self(fa.subset(np.arange(nsub)), nthreads=16, cap=1 << 20)["records"])
+    m = (recs["from_id"] <= nsub) & (recs["to_id"] <= nsub)
+    assert sorted(mhap_amd.records_to_lines(recs[m])) == want and len(want) >= 5
+    print(f"c3-like: {len(recs)} records, {len(want)} among the first {nsub} reads, {int((L > 24591).sum())} reads on the materialised-hash path")
+
+
 def test_config4_read_shape_slice():
     """BASELINE configs[3]/[4] read shapes (15 kb and 12 kb reads, H=512, S=1536: more than 12288 k-mers per strand takes the
     24-k-mers-per-lane weight kernel, 8 bit-sliced MinHash rows) on a slice of reads: full record parity with the oracle."""
@@ -877,7 +955,7 @@ def test_config4_read_shape_slice():
         assert len(got) > 20 and st["slow_pairs"] == 0
 
 
-def test_config5_shape_filter_and_repeats(tmp_path):
+def test_config5_shape_filter_and_repeats(tmp_path, monkeypatch):
     """BASELINE configs[4] shape: 12 kb reads with a planted repeat family, a generated -f k-mer filter file and
     --filter-threshold 1e-5 (tf-idf weights: 3 for k-mers absent from the filter, 1..3 for the popular ones, times the
     multiplicity) — the weighted k-mers run on the bit-sliced MinHash rows.  Sketch and record parity with the oracle."""
@@ -894,6 +972,10 @@ def test_config5_shape_filter_and_repeats(tmp_path):
     want = O.run_self(fa, nthreads=8, flt=oflt)
     got, st = _self_lines(fa, p, flt)
     assert got == O.record_lines(want["records"]) and len(got) > 50
+    monkeypatch.setenv("MHAP_OVERLAP_PRUNE", "1")            # second stage with the early "below the threshold" forced on
+    got_p, st_p = _self_lines(fa, p, flt)
+    monkeypatch.delenv("MHAP_OVERLAP_PRUNE")
+    assert got_p == got and st_p["candidates_compared"] == st["candidates_compared"]
     # no filter, same reads: plain tf weights (repeated k-mers inside a read take the weight-2.. classes)
     want2 = O.run_self(fa, nthreads=8)
     got2, _ = _self_lines(fa, p)
