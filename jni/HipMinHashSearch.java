@@ -83,6 +83,10 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 
 	private static native byte[] nativeTakeRecords(long handle, int maxRecords);
 
+	private static native void nativeSetStreaming(long handle, boolean on);
+
+	private static native void nativeAbandon(long handle);
+
 	private static native long[] nativeStats(long handle);
 
 	public HipMinHashSearch(FastaData data, int kmerSize, int numHashes, int orderedKmerSize, int orderedSketchSize, int numMinMatches,
@@ -250,6 +254,14 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 	 */
 	private void deliver(long parked, ArrayList<MatchResult> combined)
 	{
+		long taken = take(combined);
+		if (taken != parked)
+			throw new MhapRuntimeException("Overlap records lost between the library and Java: " + taken + " of " + parked + ".");
+	}
+
+	/** takes chunks until the library has none left (during a streaming search: until the search is over); returns the records taken */
+	private long take(ArrayList<MatchResult> combined)
+	{
 		long taken = 0;
 		byte[] chunk = nativeTakeRecords(this.handle, RECORDS_PER_TAKE);
 		while (chunk != null)
@@ -264,16 +276,70 @@ public final class HipMinHashSearch extends AbstractMatchSearch
 					outputResults(matches.subList(from, Math.min(matches.size(), from + NUM_ELEMENTS_PER_OUTPUT)));
 			chunk = nativeTakeRecords(this.handle, RECORDS_PER_TAKE);
 		}
-		if (taken != parked)
-			throw new MhapRuntimeException("Overlap records lost between the library and Java: " + taken + " of " + parked + ".");
+		return taken;
 	}
 
 	/** The self driver (impl/AbstractMatchSearch.java:121-199): every stored forward sequence against the index, toSelf = true. */
 	@Override
 	public ArrayList<MatchResult> findMatches()
 	{
-		ArrayList<MatchResult> combined = new ArrayList<MatchResult>();
-		deliver(nativeFindMatchesSelf(this.handle), combined);
+		// The search runs on a worker thread; this thread takes records while the GPUs are still searching and prints them through
+		// outputResults, as the reference's pool does every NUM_ELEMENTS_PER_OUTPUT matches (impl/AbstractMatchSearch.java:55,158).
+		// The library's sink waits when more than 4 M records are parked natively, so a human-scale search never holds its whole
+		// output in memory — native or Java (unless storeResults asks for exactly that).
+		final ArrayList<MatchResult> combined = new ArrayList<MatchResult>();
+		final long[] delivered = new long[1];
+		final Throwable[] failure = new Throwable[1];
+		final long h = this.handle;
+		nativeSetStreaming(h, true);
+		Thread searcher = new Thread(new Runnable()
+		{
+			@Override
+			public void run()
+			{
+				try
+				{
+					delivered[0] = nativeFindMatchesSelf(h);
+				}
+				catch (Throwable t)
+				{
+					failure[0] = t;
+				}
+			}
+		}, "mhap-hip-search");
+		searcher.start();
+		long taken = 0;
+		try
+		{
+			taken = take(combined);            // returns when the search is over and every parked record has been taken
+		}
+		catch (RuntimeException | Error e)
+		{
+			nativeAbandon(h);                  // the sink must not wait for a taker that is gone
+			throw e;
+		}
+		finally
+		{
+			boolean interrupted = false;
+			while (searcher.isAlive())
+			{
+				try
+				{
+					searcher.join();
+				}
+				catch (InterruptedException ie)
+				{
+					interrupted = true;
+				}
+			}
+			nativeSetStreaming(h, false);
+			if (interrupted)
+				Thread.currentThread().interrupt();
+		}
+		if (failure[0] != null)
+			throw new MhapRuntimeException(failure[0]);
+		if (taken != delivered[0])
+			throw new MhapRuntimeException("Overlap records lost between the library and Java: " + taken + " of " + delivered[0] + ".");
 		this.sequencesSearched = nativeStats(this.handle)[1];
 		flushOutput();
 		return combined;

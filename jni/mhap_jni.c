@@ -24,9 +24,15 @@
  *    include/mhap_hip.h) and returns their COUNT; the Java side then takes them out in bounded chunks (nativeTakeRecords,
  *    at most 1 << 20 records = 64 MB per byte[]) and hands each chunk to AbstractMatchSearch.outputResults — no 2 GB array limit,
  *    no silent truncation, the Java heap holds one chunk at a time;
+ *  - the self search STREAMS: HipMinHashSearch.findMatches() runs nativeFindMatchesSelf on a worker thread and takes records on the
+ *    calling thread while the GPUs are still searching (nativeTakeRecords blocks until a chunk is there or the search is over), so
+ *    outputResults runs during the search like the reference's pool does every 20 000 matches (AbstractMatchSearch.java:55,158) and
+ *    at most PARK_CAP records (256 MB) wait natively: the library's sink blocks until Java has taken some.  A C5-scale search
+ *    (10^8 records) no longer sits in native memory until it ends;
  *  - every library error becomes an unchecked MhapRuntimeException carrying mhap_last_error() / mhap_group_last_error().
  */
 #include <jni.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,10 +41,15 @@
 
 #define MHAP_EXC "edu/umd/marbl/mhap/impl/MhapRuntimeException"
 #define MAX_TAKE (1 << 20)
+#define PARK_CAP (4 << 20)   /* records parked natively before the sink waits for Java (streaming searches only) */
 
 /* parked records: a list of blocks the sink appends to (the library calls the sink one batch at a time, also with several ranks) */
 typedef struct rec_block { struct rec_block* next; int64_t n, taken; mhap_record recs[1]; } rec_block;
-typedef struct { mhap_group* g; rec_block *head, *tail; int64_t parked; int oom; int32_t H, S; } engine;
+typedef struct {
+  mhap_group* g; rec_block *head, *tail; int64_t parked, total; int oom; int32_t H, S;
+  pthread_mutex_t mu; pthread_cond_t data, space;   /* parked records: the library's sink thread appends, a Java thread takes */
+  int streaming, done, abandoned;                   /* streaming: bounded parking; done: no search is running; abandoned: the taker gave up */
+} engine;
 
 static engine* E(jlong h) { return (engine*)(intptr_t)h; }
 
@@ -54,8 +65,11 @@ static int check(JNIEnv* env, engine* e, int rc) {
 }
 
 static void drop_records(engine* e) {
+  pthread_mutex_lock(&e->mu);
   while (e->head) { rec_block* b = e->head; e->head = b->next; free(b); }
   e->tail = NULL; e->parked = 0; e->oom = 0;
+  pthread_cond_broadcast(&e->space);
+  pthread_mutex_unlock(&e->mu);
 }
 
 static int park_sink(const mhap_record* recs, int64_t n, void* user) {
@@ -66,17 +80,26 @@ static int park_sink(const mhap_record* recs, int64_t n, void* user) {
   if (!b) { e->oom = 1; return 1; }
   b->next = NULL; b->n = n; b->taken = 0;
   memcpy(b->recs, recs, (size_t)n * sizeof(mhap_record));
+  pthread_mutex_lock(&e->mu);
+  while (e->streaming && e->parked > PARK_CAP && !e->abandoned) pthread_cond_wait(&e->space, &e->mu);   /* Java is behind: wait for a take */
+  if (e->abandoned) { pthread_mutex_unlock(&e->mu); free(b); return 1; }                                  /* nobody will take them: abort the search */
   if (e->tail) e->tail->next = b; else e->head = b;
   e->tail = b;
-  e->parked += n;
+  e->parked += n; e->total += n;
+  pthread_cond_broadcast(&e->data);
+  pthread_mutex_unlock(&e->mu);
   return 0;
 }
 
+static void search_begins(engine* e) { pthread_mutex_lock(&e->mu); e->done = 0; e->total = 0; pthread_mutex_unlock(&e->mu); }
+static void search_ends(engine* e) { pthread_mutex_lock(&e->mu); e->done = 1; pthread_cond_broadcast(&e->data); pthread_mutex_unlock(&e->mu); }
+
 /* a search finished with code rc: its records are parked; returns their count or throws */
 static jlong finish_search(JNIEnv* env, engine* e, int rc) {
+  search_ends(e);
   if (e->oom) { drop_records(e); throw_mhap(env, "out of memory while collecting overlap records"); return -1; }
   if (rc != MHAP_OK) { drop_records(e); check(env, e, rc); return -1; }
-  return (jlong)e->parked;
+  return (jlong)e->total;     /* records this search delivered (some may have been taken already) */
 }
 
 /* copies of the four arrays that describe a batch of reads */
@@ -134,7 +157,8 @@ JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeCrea
   if (!e) { throw_mhap(env, "out of memory"); return 0; }
   err[0] = 0;
   if (mhap_group_create(&p, devs, (int32_t)nd, &e->g, err, sizeof err) != MHAP_OK) { free(e); throw_mhap(env, err); return 0; }
-  e->H = numHashes; e->S = orderedSketchSize;
+  e->H = numHashes; e->S = orderedSketchSize; e->done = 1;
+  pthread_mutex_init(&e->mu, NULL); pthread_cond_init(&e->data, NULL); pthread_cond_init(&e->space, NULL);
   return (jlong)(intptr_t)e;
 }
 
@@ -145,6 +169,7 @@ JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeDestr
   if (!e) return;
   drop_records(e);
   mhap_group_destroy(e->g);
+  pthread_cond_destroy(&e->data); pthread_cond_destroy(&e->space); pthread_mutex_destroy(&e->mu);
   free(e);
 }
 
@@ -190,6 +215,7 @@ JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeAddRe
 JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFindMatchesSelf(JNIEnv* env, jclass cls, jlong handle) {
   engine* e = E(handle);
   (void)cls;
+  search_begins(e);
   return finish_search(env, e, mhap_group_find_matches_self(e->g, park_sink, e));
 }
 
@@ -203,6 +229,7 @@ JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFind
   int rc;
   (void)cls;
   if (copy_batch(env, &b, bases, offsets, lengths, ids, n)) return -1;
+  search_begins(e);
   rc = mhap_group_find_matches_reads(e->g, b.bases, b.offsets, b.lengths, b.ids, (int64_t)n, park_sink, e);
   free_batch(&b);
   return finish_search(env, e, rc);
@@ -245,6 +272,7 @@ JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFind
     if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, orderedSize, 0, m, (jint*)os);
     if (!(*env)->ExceptionCheck(env)) (*env)->GetIntArrayRegion(env, orderedSeqLength, 0, m, (jint*)ol);
     if ((*env)->ExceptionCheck(env)) { free(i); free(sl); free(mh); free(od); free(os); free(ol); return -1; }
+    search_begins(e);
     rc = MHAP_OK;
     for (r = 0; r < mhap_group_size(e->g) && rc == MHAP_OK && !e->oom; r++) {
       bad = mhap_group_rank(e->g, r);
@@ -252,32 +280,79 @@ JNIEXPORT jlong JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeFind
     }
   }
   free(i); free(sl); free(mh); free(od); free(os); free(ol);
-  if (rc != MHAP_OK && !e->oom) { drop_records(e); throw_mhap(env, bad ? mhap_last_error(bad) : "out of memory while copying query sketches"); return -1; }
+  if (rc != MHAP_OK && !e->oom) { search_ends(e); drop_records(e); throw_mhap(env, bad ? mhap_last_error(bad) : "out of memory while copying query sketches"); return -1; }
   return finish_search(env, e, MHAP_OK);
 }
 
 /* byte[] nativeTakeRecords(long engine, int maxRecords) -> the next chunk of parked records (packed mhap_record[], at most
- * min(maxRecords, 1 << 20) of them), or null once none are left */
+ * min(maxRecords, 1 << 20) of them); BLOCKS while a search is running and nothing is parked; null once the search is over and
+ * nothing is left */
 JNIEXPORT jbyteArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeTakeRecords(JNIEnv* env, jclass cls, jlong handle, jint maxRecords) {
   engine* e = E(handle);
   int64_t want = maxRecords < 1 ? 1 : (maxRecords > MAX_TAKE ? MAX_TAKE : maxRecords), got = 0;
   jbyteArray out;
+  rec_block *first = NULL, *last = NULL, *b;
   (void)cls;
-  if (e->parked <= 0) { drop_records(e); return NULL; }
+  /* unlink up to `want` records under the lock, copy them into the Java array outside it */
+  pthread_mutex_lock(&e->mu);
+  while (e->parked <= 0 && !e->done) pthread_cond_wait(&e->data, &e->mu);
+  if (e->parked <= 0) { pthread_mutex_unlock(&e->mu); return NULL; }
   if (want > e->parked) want = e->parked;
-  out = (*env)->NewByteArray(env, (jsize)(want * (int64_t)sizeof(mhap_record)));   /* <= 64 MB: fits a jsize */
-  if (!out) return NULL;                                                           /* OutOfMemoryError is pending */
   while (got < want && e->head) {
-    rec_block* b = e->head;
-    int64_t k = b->n - b->taken;
-    if (k > want - got) k = want - got;
-    (*env)->SetByteArrayRegion(env, out, (jsize)(got * (int64_t)sizeof(mhap_record)), (jsize)(k * (int64_t)sizeof(mhap_record)),
-                               (const jbyte*)(b->recs + b->taken));
-    b->taken += k; got += k;
-    if (b->taken == b->n) { e->head = b->next; if (!e->head) e->tail = NULL; free(b); }
+    int64_t k;
+    b = e->head;
+    k = b->n - b->taken;
+    if (k <= want - got) {                         /* the whole rest of this block */
+      e->head = b->next; if (!e->head) e->tail = NULL;
+      b->next = NULL;
+      if (last) last->next = b; else first = b;
+      last = b; got += k;
+    } else {                                        /* part of it: copied here, the block stays */
+      rec_block* part = (rec_block*)malloc(sizeof(rec_block) + (size_t)(want - got - 1) * sizeof(mhap_record));
+      if (!part) break;
+      part->next = NULL; part->n = want - got; part->taken = 0;
+      memcpy(part->recs, b->recs + b->taken, (size_t)(want - got) * sizeof(mhap_record));
+      b->taken += want - got;
+      if (last) last->next = part; else first = part;
+      last = part; got = want;
+    }
   }
   e->parked -= got;
-  return out;
+  pthread_cond_broadcast(&e->space);
+  pthread_mutex_unlock(&e->mu);
+  out = (*env)->NewByteArray(env, (jsize)(got * (int64_t)sizeof(mhap_record)));   /* <= 64 MB: fits a jsize */
+  got = 0;
+  while (first) {
+    b = first; first = b->next;
+    if (out) (*env)->SetByteArrayRegion(env, out, (jsize)(got * (int64_t)sizeof(mhap_record)), (jsize)((b->n - b->taken) * (int64_t)sizeof(mhap_record)),
+                                        (const jbyte*)(b->recs + b->taken));
+    got += b->n - b->taken;
+    free(b);
+  }
+  return out;                                                                      /* NULL: OutOfMemoryError is pending */
+}
+
+/* void nativeSetStreaming(long engine, boolean on) -> bounded parking (the sink waits for nativeTakeRecords) for the searches that follow;
+ * turning it off also releases a sink that is waiting */
+JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeSetStreaming(JNIEnv* env, jclass cls, jlong handle, jboolean on) {
+  engine* e = E(handle);
+  (void)env; (void)cls;
+  pthread_mutex_lock(&e->mu);
+  e->streaming = on ? 1 : 0; e->abandoned = 0;
+  if (on) e->done = 0;      /* a search is about to start on another thread: a take that comes first must wait for it, not see "over" */
+  pthread_cond_broadcast(&e->space);
+  pthread_mutex_unlock(&e->mu);
+}
+
+/* void nativeAbandon(long engine) -> the taking thread gives up (an exception on the Java side): a sink that waits returns "abort", the
+ * running search ends with an error instead of waiting for ever */
+JNIEXPORT void JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativeAbandon(JNIEnv* env, jclass cls, jlong handle) {
+  engine* e = E(handle);
+  (void)env; (void)cls;
+  pthread_mutex_lock(&e->mu);
+  e->abandoned = 1;
+  pthread_cond_broadcast(&e->space);
+  pthread_mutex_unlock(&e->mu);
 }
 
 /* long[] nativeStats(long engine) -> {strandsIndexed, queriesSearched, candidatesCompared, matchesFound, tableElements}, summed over the ranks

@@ -369,6 +369,30 @@ def records_to_lines(records):
     return out
 
 
+def _collect_records(call, chk):
+    """Run a search entry point with a sink that appends every batch of records to ONE growing array (each record is copied once out
+    of the library's buffer; the array doubles when it fills up — a list of per-batch copies concatenated at the end moved every
+    record twice, 2 x 1.8 GB a step on one rank's share of BASELINE configs[4]).  The sink is called from a library thread, one batch
+    at a time."""
+    state = {"buf": np.empty(1 << 14, dtype=RECORD_DTYPE), "n": 0}
+
+    def sink(recs, cnt, user):
+        n, buf = state["n"], state["buf"]
+        need = n + cnt
+        if need > buf.shape[0]:
+            nb = np.empty(max(need, 2 * buf.shape[0]), dtype=RECORD_DTYPE)
+            nb[:n] = buf[:n]
+            state["buf"] = buf = nb
+        src = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(cnt * RECORD_DTYPE.itemsize,))
+        buf[n:need] = src.view(RECORD_DTYPE)
+        state["n"] = need
+        return 0
+
+    cb = _SINK(sink)
+    chk(call(cb))
+    return state["buf"][:state["n"]]
+
+
 class MinHashSearch:
     """GPU counterpart of J/impl/MinHashSearch.java (+ the drivers of AbstractMatchSearch.java).
 
@@ -511,18 +535,7 @@ class MinHashSearch:
 
     # -- search ---------------------------------------------------------------------------------
     def _collect(self, call):
-        chunks = []
-
-        def sink(recs, n, user):
-            a = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(n * RECORD_DTYPE.itemsize,))
-            chunks.append(a.view(RECORD_DTYPE).copy())
-            return 0
-
-        cb = _SINK(sink)
-        self._chk(call(cb))
-        if len(chunks) == 1:
-            return chunks[0]
-        return np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+        return _collect_records(call, self._chk)
 
     def prepare_index(self):
         """Build the inverted index now (reads the MinHash/meta tables only; see mhap_index_prepare)."""
@@ -687,16 +700,7 @@ class MinHashSearchGroup:
         self._chk(self._lib.mhap_group_clear(self._g))
 
     def _collect(self, call):
-        chunks = []
-
-        def sink(recs, n, user):
-            a = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(n * RECORD_DTYPE.itemsize,))
-            chunks.append(a.view(RECORD_DTYPE).copy())
-            return 0
-
-        cb = _SINK(sink)
-        self._chk(call(cb))
-        return np.concatenate(chunks) if chunks else np.zeros(0, dtype=RECORD_DTYPE)
+        return _collect_records(call, self._chk)
 
     def find_matches(self):
         return self._collect(lambda cb: self._lib.mhap_group_find_matches_self(self._g, cb, None))

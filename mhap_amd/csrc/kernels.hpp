@@ -120,6 +120,7 @@ struct InvIndex {
   uint2* staged;         // [H][slot_stride]: the postings grouped by coarse bin
   uint32_t* tile_counts; // [H][tiles][coarse bins]
   uint32_t* bin_start;   // [H][coarse bins + 1]
+  uint32_t* bin_long;    // [H][coarse bins]: the bin holds a bucket longer than group_t (written by step 4 for step 5)
 };
 int index_tiles(int ne);
 void index_group_params(int64_t entries, InvIndex& ix);   // sets grouped / group_t / class_log for an index of this many entries

@@ -7,7 +7,9 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -88,7 +90,8 @@ struct mhap_handle {
   int oj_per_cu[3] = {0, 0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (per shape) at ordered sketch size oj_per_cu_S
   int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = alone, 2 = pair, 3 = team
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
-  hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr;
+  hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr, ev_ix_fork = nullptr, ev_ix_join = nullptr, ev_ord_join = nullptr;
+  hipStream_t ord_stream = nullptr, ord_stream_lo = nullptr;   // the ordered-sketch kernel next to the MinHash launch (MHAP_ORDERED_OVERLAP)
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0;
   bool ph_ready = false; int64_t ph_ne = 0;   // poshist holds the position histograms of entries [0, ph_ne) (reset wherever inv_ready is)
@@ -131,7 +134,12 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, recs, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big;
+  DevBuf qlist, rowstart, cand, slow_cand, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big;
+  // post stage of a search chunk (record read-back, conversion, sink) on a worker thread, one chunk behind the kernels: two sets of buffers
+  hipStream_t copy_stream = nullptr;
+  uint8_t* pin_rec[2] = {nullptr, nullptr};
+  size_t pin_rec_cap[2] = {0, 0};
+  std::vector<mhap_record> out_recs2[2];
   InvIndex inv{};   // device view of the inverted index in inv_ends / inv_items
   mhap_stage_gate gate = nullptr; void* gate_user = nullptr;   // mhap_set_second_stage_gate
   void* dist = nullptr;   // multi-GPU state (mhap_dist.hip)
@@ -156,14 +164,16 @@ int fail(mhap_handle* h, int code, const std::string& msg) { h->err = msg; retur
                   std::string(#expr) + ": " + hipGetErrorString(_e));                                \
   } while (0)
 
-void time_begin(mhap_handle* h, int kind, hipStream_t st = nullptr) {
+size_t time_begin(mhap_handle* h, int kind, hipStream_t st = nullptr) {
   TimedLaunch t; t.kind = kind;
   if (!h->free_events.empty()) { t.a = h->free_events.back().first; t.b = h->free_events.back().second; h->free_events.pop_back(); }
   else { (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b); }
   (void)hipEventRecord(t.a, st ? st : h->stream);
   h->pending.push_back(t);
+  return h->pending.size() - 1;
 }
 void time_end(mhap_handle* h, hipStream_t st = nullptr) { (void)hipEventRecord(h->pending.back().b, st ? st : h->stream); }
+void time_end_at(mhap_handle* h, size_t idx, hipStream_t st = nullptr) { (void)hipEventRecord(h->pending[idx].b, st ? st : h->stream); }   // (when another timed launch began in between)
 
 // call after the stream is synchronised
 void time_collect(mhap_handle* h) {
@@ -311,9 +321,10 @@ static int inv_alloc(mhap_handle* h, int64_t ne) {
   HIPCHK(h, h->inv_ends.ensure((size_t)H * (nb + 1) * 4));
   HIPCHK(h, h->inv_items.ensure((size_t)H * stride * 8));
   HIPCHK(h, h->inv_staged.ensure((size_t)H * stride * 8));
-  HIPCHK(h, h->inv_scratch.ensure((size_t)H * (tiles * cb + cb + 1) * 4));
+  HIPCHK(h, h->inv_scratch.ensure((size_t)H * (tiles * cb + 2 * cb + 1) * 4));
   h->inv.ends = h->inv_ends.as<uint32_t>(); h->inv.items = h->inv_items.as<uint2>(); h->inv.staged = h->inv_staged.as<uint2>();
   h->inv.tile_counts = h->inv_scratch.as<uint32_t>(); h->inv.bin_start = h->inv.tile_counts + (size_t)H * tiles * cb;
+  h->inv.bin_long = h->inv.bin_start + (size_t)H * (cb + 1);
   h->inv.nb = (uint32_t)nb; h->inv.shift = 32 - lg;
   h->inv.slot_stride = (uint64_t)stride;
   h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
@@ -321,7 +332,14 @@ static int inv_alloc(mhap_handle* h, int64_t ne) {
   return MHAP_OK;
 }
 
-int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta) {
+int ensure_inverted_index(mhap_handle* h, hipStream_t st = nullptr, int64_t ne_override = -1);
+
+// eager_index_entries > 0 (an add that very likely completes the index): the inverted index of entries [0, eager_index_entries) —
+// the tables' rows up to the end of this add — is built as soon as the last batch's MinHash rows and statuses exist, on the side
+// stream, next to the ordered-sketch kernel (which is bound by the LDS pipe and leaves the memory side idle): at C2 3 ms of index
+// build used to follow 4.8 ms of ordered kernel.
+int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta,
+                  int64_t eager_index_entries = 0) {
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
@@ -444,22 +462,48 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     unsigned long long lens[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(lens, ctr + 4, 16, hipMemcpyDeviceToHost, h->stream));
     { const int rs = sync_stream(h); if (rs != MHAP_OK) return rs; }
-    time_begin(h, MHAP_K_MINHASH);
+    // MHAP_ORDERED_OVERLAP=1|2: the ordered-sketch kernel (independent of the MinHash rows: it reads the strands only) on a side
+    // stream of its own (2: of the lowest priority), launched right behind the persistent MinHash grid instead of after it
+    int ord_mode = 0;
+    if (const char* e = getenv("MHAP_ORDERED_OVERLAP")) ord_mode = atoi(e);
+    hipStream_t ost = h->stream;
+    if (ord_mode == 1) ost = h->ord_stream;
+    if (ord_mode == 2) {
+      if (!h->ord_stream_lo) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(h, hipStreamCreateWithPriority(&h->ord_stream_lo, hipStreamNonBlocking, lo)); }
+      ost = h->ord_stream_lo;
+    }
+    auto do_ordered = [&]() -> int {
+      time_begin(h, MHAP_K_ORDERED, ost);
+      launch_ordered(ost, dd, nstr, max_len_codes, B.max_len, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
+                     ord_rows, ord_stride, meta_rows, META_W);
+      time_end(h, ost);
+      return MHAP_OK;
+    };
+    const size_t t_mh = time_begin(h, MHAP_K_MINHASH);
     launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
                    h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
                    meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(), h->jump_w1_tbl.as<uint64_t>(),
                    h->mhmerge.as<unsigned long long>(), std::max(0, B.max_len - k + 1));
+    if (ost != h->stream) { (void)do_ordered(); HIPCHK(h, hipEventRecord(h->ev_ord_join, ost)); }   // (the stream was idle: the host waited for the weight kernel)
     HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
-    time_end(h);
+    time_end_at(h, t_mh);
     DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
-    time_begin(h, MHAP_K_ORDERED);
-    launch_ordered(h->stream, dd, nstr, max_len_codes, B.max_len, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
-                   ord_rows, ord_stride, meta_rows, META_W);
-    time_end(h);
+    bool eager_launched = false;
+    if (eager_index_entries > 0 && &B == &plan.back() && !getenv("MHAP_NO_EAGER_INDEX")) {
+      HIPCHK(h, hipEventRecord(h->ev_ix_fork, h->stream));
+      HIPCHK(h, hipStreamWaitEvent(h->mh_stream, h->ev_ix_fork, 0));
+      const int rce = ensure_inverted_index(h, h->mh_stream, eager_index_entries);
+      if (rce != MHAP_OK) return rce;
+      HIPCHK(h, hipEventRecord(h->ev_ix_join, h->mh_stream));
+      eager_launched = true;
+    }
+    if (ost == h->stream) (void)do_ordered();
+    else HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ord_join, 0));
     DBGSYNC(h, "ordered");
     HIPCHK(h, hipGetLastError());
+    if (eager_launched) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ix_join, 0));
     int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
   }
@@ -522,29 +566,113 @@ struct QuerySide {
 
 // Run candidate + second stage for the query entries in `ql` (entry indices into the query side).
 // (re)build the inverted index for the current entries unless the table in place already covers them
-int ensure_inverted_index(mhap_handle* h) {
-  const int ne = (int)h->n_entries, H = h->P.num_hashes;
+int ensure_inverted_index(mhap_handle* h, hipStream_t st, int64_t ne_override) {
+  const int ne = (int)(ne_override >= 0 ? ne_override : h->n_entries), H = h->P.num_hashes;
+  if (!st) st = h->stream;
   if (h->inv_ready && h->inv_ne == (int64_t)ne) return MHAP_OK;
   { const int rr = inv_alloc(h, ne); if (rr != MHAP_OK) return rr; }
   HPROF("index build launch");
-  time_begin(h, MHAP_K_INDEX_BUILD);
-  launch_index_build(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, H, h->inv);
-  time_end(h);
+  time_begin(h, MHAP_K_INDEX_BUILD, st);
+  launch_index_build(st, h->d_minhash, h->Hrow, h->d_meta, ne, H, h->inv);
+  time_end(h, st);
   HIPCHK(h, hipGetLastError());
   if (getenv("MHAP_DEBUG_INDEX")) {   // self-check: every stored (entry, slot) must find its own posting
     HIPCHK(h, h->counters.ensure(256));
     unsigned long long* ctr = h->counters.as<unsigned long long>();
     unsigned long long missing = 0;
-    HIPCHK(h, hipMemsetAsync(ctr + 15, 0, 8, h->stream));
-    launch_index_verify(h->stream, h->d_minhash, h->Hrow, h->d_meta, ne, H, h->inv, ctr + 15);
-    HIPCHK(h, hipMemcpyAsync(&missing, ctr + 15, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipMemsetAsync(ctr + 15, 0, 8, st));
+    launch_index_verify(st, h->d_minhash, h->Hrow, h->d_meta, ne, H, h->inv, ctr + 15);
+    HIPCHK(h, hipMemcpyAsync(&missing, ctr + 15, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
     fprintf(stderr, "[index] self-check: %llu of %lld postings missing\n", missing, (long long)ne * H);
     if (missing) return fail(h, MHAP_E_STATE, "inverted index self-check failed");
   }
   h->inv_ready = true; h->inv_ne = ne; h->iq_start_mid = false;
   return MHAP_OK;
 }
+
+// The tail of a search chunk — device records to pinned host memory, id / length / strand conversion (MatchResult.java:46-65), the
+// caller's sink — runs on a worker thread while the main thread launches the NEXT chunk's kernels (one chunk ahead, two sets of
+// buffers).  On one rank's share of configs[4] (28.8 M records a step) that tail was 1.4 s of a 3.3 s search.  The sink is still
+// called by one thread at a time, in chunk order; it is a library thread, as the header says.
+struct PostStage {
+  mhap_handle* h; const QuerySide* qs; mhap_record_sink sink; void* user;
+  std::thread th; std::mutex mu; std::condition_variable cv;
+  bool started = false, has_job = false, busy = false, stop = false;
+  int slot = 0; unsigned long long nrec = 0;
+  int rc = MHAP_OK; std::string err; int64_t matches = 0;
+
+  int process(int sl, unsigned long long n) {
+    const size_t bytes = (size_t)n * sizeof(DevRecord);
+    if (h->pin_rec_cap[sl] < bytes) {
+      if (h->pin_rec[sl]) (void)hipHostFree(h->pin_rec[sl]);
+      h->pin_rec[sl] = nullptr; h->pin_rec_cap[sl] = 0;
+      const size_t want = bytes + bytes / 4 + 4096;
+      if (hipHostMalloc((void**)&h->pin_rec[sl], want, hipHostMallocDefault) != hipSuccess) { err = "cannot allocate pinned host memory"; return MHAP_E_HIP; }
+      h->pin_rec_cap[sl] = want;
+    }
+    const DevRecord* hrecs = (const DevRecord*)h->pin_rec[sl];
+    const void* src = sl ? h->recs2.p : h->recs.p;
+    if (hipMemcpyAsync((void*)hrecs, src, bytes, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) {
+      err = "record read-back failed"; return MHAP_E_HIP;
+    }
+    std::vector<mhap_record>& out = h->out_recs2[sl];
+    out.resize((size_t)n);
+    const QuerySide& q = *qs;
+    parallel_for((int64_t)n, host_threads(), [&](int64_t lo, int64_t hi) {
+      for (int64_t i = lo; i < hi; i++) {
+        const DevRecord& d = hrecs[(size_t)i];
+        mhap_record& r = out[(size_t)i];
+        r.from_id = q.h_ids[d.q]; r.to_id = h->ids[(size_t)d.m];
+        r.score = d.score; r.raw = (double)d.raw;
+        r.alen = q.h_seqlen[d.q]; r.blen = h->seqlen[(size_t)d.m];
+        r.a1 = d.a1; r.a2 = d.a2;                                        // from is always a forward entry
+        r.to_rc = h->fwd[(size_t)d.m] ? 0 : 1;
+        if (r.to_rc) { r.b1 = r.blen - d.b2 - 1; r.b2 = r.blen - d.b1 - 1; }   // MatchResult.java:56-57
+        else { r.b1 = d.b1; r.b2 = d.b2; }
+        r.pad = 0;
+      }
+    });
+    matches += (int64_t)n;
+    if (sink && sink(out.data(), (int64_t)n, user) != 0) { err = "record sink aborted the search"; return MHAP_E_STATE; }
+    return MHAP_OK;
+  }
+  void loop() {
+    (void)hipSetDevice(h->device);
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&]() { return has_job || stop; });
+      if (!has_job) return;
+      has_job = false; busy = true;
+      const int sl = slot; const unsigned long long n = nrec;
+      lk.unlock();
+      const int r = rc == MHAP_OK ? process(sl, n) : rc;
+      lk.lock();
+      if (rc == MHAP_OK) rc = r;
+      busy = false;
+      cv.notify_all();
+    }
+  }
+  // wait until the previous chunk's tail is done, then hand this one over (inline = no worker: run it here)
+  int submit(int sl, unsigned long long n, bool inline_run) {
+    if (inline_run && !started) { if (rc == MHAP_OK) rc = process(sl, n); return rc; }
+    std::unique_lock<std::mutex> lk(mu);
+    if (!started) { started = true; th = std::thread([this]() { loop(); }); }
+    cv.wait(lk, [&]() { return !busy && !has_job; });
+    if (rc != MHAP_OK) return rc;
+    slot = sl; nrec = n; has_job = true;
+    cv.notify_all();
+    return MHAP_OK;
+  }
+  int drain() {
+    if (started) {
+      { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&]() { return !busy && !has_job; }); stop = true; cv.notify_all(); }
+      th.join(); started = false;
+    }
+    return rc;
+  }
+  ~PostStage() { (void)drain(); }
+};
 
 int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>& ql, bool to_self, bool triangular_ok,
                 mhap_record_sink sink, void* user) {
@@ -581,8 +709,17 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
 
   h->iq_start_mid = false;   // decided anew by the first chunks of every search
   bool q_ph_done = false;    // the query side's position histograms exist (second stage, early "below the threshold")
-  for (int64_t c0 = 0; c0 < (int64_t)ql.size(); c0 += qchunk) {
+  PostStage post; post.h = h; post.qs = &qs; post.sink = sink; post.user = user;
+  // every error return below leaves through here: the worker is drained first (its buffers belong to the handle)
+  auto leave = [&](int code) { const int pr = post.drain(); h->stats.matches_found += post.matches; post.matches = 0;
+                               if (code == MHAP_OK && pr != MHAP_OK) return fail(h, pr, post.err); return code; };
+  int64_t chunk_no = 0;
+  const char* ppe = getenv("MHAP_SEARCH_PIPELINE");   // "0": the tail of every chunk inline (tests / A-B)
+  const bool pipeline = !(ppe && ppe[0] == '0');
+  int slot = 0;   // the record buffers (device + host) this chunk's kernels and tail use; flips with every tail handed over
+  for (int64_t c0 = 0, adv = 0; c0 < (int64_t)ql.size(); c0 += adv, chunk_no++) {
     const int nq = (int)std::min<int64_t>(qchunk, (int64_t)ql.size() - c0);
+    adv = nq;
     const int ntq = (nq + CAND_TQ - 1) / CAND_TQ;
     const long long* d_rowstart = nullptr;
     long long nblocks_tri = 0;
@@ -684,7 +821,11 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     }
     h->stats.queries_searched += nq;
     if (ncand == 0) continue;
-    HIPCHK(h, h->recs.ensure((size_t)ncand * sizeof(DevRecord)));
+    // a candidate-rich search (repeats): smaller chunks from here on — smaller candidate / record buffers, and the tail of a chunk
+    // (read-back, conversion, sink: PostStage) hides behind the next chunk's kernels, so less of it is left over at the end
+    if (chunk_no == 0 && (int64_t)ncand >= 64LL * nq && !getenv("MHAP_QUERY_CHUNK")) qchunk = 65536;
+    DevBuf& recbuf = slot ? h->recs2 : h->recs;
+    HIPCHK(h, recbuf.ensure((size_t)ncand * sizeof(DevRecord)));
     // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
     // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
     if (h->gate && h->gate(h->gate_user) != 0) return fail(h, MHAP_E_STATE, "second-stage gate aborted the search");
@@ -740,7 +881,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       }
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap_join(h->stream, shape, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
-                          qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->recs.as<DevRecord>(), ctr + 1,
+                          qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), recbuf.as<DevRecord>(), ctr + 1,
                           (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7, ph, qph, h->pass_min_tbl.as<int32_t>());
       time_end(h);
       HIPCHK(h, hipGetLastError());
@@ -756,7 +897,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       launch_overlap(h->stream, oblocks, use_join ? h->slow_cand.as<Candidate>() : h->cand.as<Candidate>(), use_join ? ctr + 5 : ctr + 0,
                      use_join ? (unsigned long long)ncand : (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                      qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
-                     h->recs.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2);
+                     recbuf.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2);
       time_end(h);
       HIPCHK(h, hipGetLastError());
     }
@@ -769,29 +910,14 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     const unsigned long long nrec = counts[1];
     h->stats.candidates_compared += (int64_t)counts[2];
     if (nrec == 0) continue;
-    const DevRecord* hrecs = (const DevRecord*)pinned_io(h, (size_t)nrec * sizeof(DevRecord));
-    if (!hrecs) return fail(h, MHAP_E_HIP, "cannot allocate pinned host memory");
-    HIPCHK(h, hipMemcpy((void*)hrecs, h->recs.p, (size_t)nrec * sizeof(DevRecord), hipMemcpyDeviceToHost));
-    h->out_recs.resize((size_t)nrec);
-    parallel_for((int64_t)nrec, host_threads(), [&](int64_t lo, int64_t hi) {
-      for (int64_t i = lo; i < hi; i++) {
-        const DevRecord& d = hrecs[(size_t)i];
-        mhap_record& r = h->out_recs[(size_t)i];
-        r.from_id = qs.h_ids[d.q]; r.to_id = h->ids[(size_t)d.m];
-        r.score = d.score; r.raw = (double)d.raw;
-        r.alen = qs.h_seqlen[d.q]; r.blen = h->seqlen[(size_t)d.m];
-        r.a1 = d.a1; r.a2 = d.a2;                                        // from is always a forward entry
-        r.to_rc = h->fwd[(size_t)d.m] ? 0 : 1;
-        if (r.to_rc) { r.b1 = r.blen - d.b2 - 1; r.b2 = r.blen - d.b1 - 1; }   // MatchResult.java:56-57
-        else { r.b1 = d.b1; r.b2 = d.b2; }
-        r.pad = 0;
-      }
-    });
-    HPROF("records converted");
-    h->stats.matches_found += (int64_t)nrec;
-    if (sink) { if (sink(h->out_recs.data(), (int64_t)nrec, user) != 0) return fail(h, MHAP_E_STATE, "record sink aborted the search"); }
+    // the chunk's tail: inline when it is the last chunk with no worker running (nothing left to hide it behind), else on the worker
+    const bool last = c0 + nq >= (int64_t)ql.size();
+    const int rp = post.submit(slot, nrec, !pipeline || last);
+    if (rp != MHAP_OK) return fail(h, rp, post.err);
+    slot ^= 1;
+    HPROF("chunk tail handed over");
   }
-  return MHAP_OK;
+  return leave(MHAP_OK);
 }
 
 }  // namespace
@@ -862,8 +988,11 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (hipGetDeviceProperties(&prop, dev) == hipSuccess) h->num_cus = std::max(1, prop.multiProcessorCount);
   if ((e = hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { seterr(hipGetErrorString(e)); delete h; return MHAP_E_HIP; }
   h->stream = h->own_stream;
-  if (hipStreamCreateWithFlags(&h->mh_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->ev_mh_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_mh_join, hipEventDisableTiming) != hipSuccess) { seterr("cannot create the side streams"); mhap_destroy(h); return MHAP_E_HIP; }
+  if (hipStreamCreateWithFlags(&h->mh_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_mh_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_mh_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_ix_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_ix_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_ord_join, hipEventDisableTiming) != hipSuccess ||
+      hipStreamCreateWithFlags(&h->ord_stream, hipStreamNonBlocking) != hipSuccess) { seterr("cannot create the side streams"); mhap_destroy(h); return MHAP_E_HIP; }
   h->Hrow = std::max(1, P.num_hashes);
   int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
   h->ord_cap = cap;
@@ -918,12 +1047,20 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->jump_w1_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big};
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big,
+                    &h->pass_min_tbl, &h->poshist, &h->q_poshist};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->pin_io) (void)hipHostFree(h->pin_io);
+  for (int i = 0; i < 2; i++) if (h->pin_rec[i]) (void)hipHostFree(h->pin_rec[i]);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev_mh_fork) (void)hipEventDestroy(h->ev_mh_fork);
   if (h->ev_mh_join) (void)hipEventDestroy(h->ev_mh_join);
+  if (h->ev_ord_join) (void)hipEventDestroy(h->ev_ord_join);
+  if (h->ord_stream) (void)hipStreamDestroy(h->ord_stream);
+  if (h->ord_stream_lo) (void)hipStreamDestroy(h->ord_stream_lo);
+  if (h->ev_ix_fork) (void)hipEventDestroy(h->ev_ix_fork);
+  if (h->ev_ix_join) (void)hipEventDestroy(h->ev_ix_join);
   if (h->mh_stream) (void)hipStreamDestroy(h->mh_stream);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
@@ -1053,10 +1190,17 @@ int mhap_index_add_staged(mhap_handle* h) {
   int rc = ensure_index_capacity(h, want_entries);
   if (rc != MHAP_OK) return rc;
   const int S = h->P.ordered_sketch_size;
-  h->ph_ready = false; h->inv_ready = false;   // (the inverted index is built by the first search: a sort of all postings, 2 ms per 100 M)
-  rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W);
+  h->ph_ready = false; h->inv_ready = false;
+  // The inverted index is built by the first search — unless this add very likely completes the index (the first add of an index
+  // that was not announced to be larger, or the add that reaches the announced size): then it is built here, next to the ordered kernel
+  const int64_t after = first + 2 * n;
+  const bool likely_last = (first == 0 && 2 * h->reserve_reads <= after) || (h->reserve_reads > 0 && after == 2 * h->reserve_reads);
+  rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W,
+                     likely_last ? after : 0);
   if (rc != MHAP_OK) return rc;
+  const bool built = h->inv_ready && h->inv_ne == after;
   rc = finish_add(h, first, h->st_ids.data(), n);
+  if (rc == MHAP_OK && built) h->inv_ready = true;      // (finish_add drops the index of the OLD entry set; this one covers the new one)
   return rc;
 }
 

@@ -202,6 +202,10 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // workgroup (670 loads per wave in the second tier: r03 PMC pass).
 // =============================================================================================
 __device__ __forceinline__ uint32_t inv_mix(uint32_t v) { return fmix32(v); }
+// (Round 4 tried an occupancy bitmap in front of the lookups — 4 bits per bucket, a clear bit ends a lookup after one load instead of two
+//  dependent ones; 82 % of the lookups of a C2 query find nothing.  It made the first tier SLOWER: 3.3 -> 4.8 ms at C2, 70.8 -> 78.4 at
+//  C4, 2.50 -> 2.42 for one rank of eight.  A wave is one query with eight slots per lane; nearly every wave holds some lane whose bit
+//  is set, and for those the chain is three dependent loads instead of two — the wave's time is its slowest lane's.  Removed.)
 
 #ifndef MH_IB_BINS_LOG
 #define MH_IB_BINS_LOG 7
@@ -269,7 +273,7 @@ constexpr int IB_SUB_MAX = 8192, IB_FIN_THREADS = 256;
 __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix) {
   __shared__ uint32_t cnt[IB_SUB_MAX];
   __shared__ uint32_t wsum[IB_FIN_THREADS / 64];
-  __shared__ uint32_t s_carry;
+  __shared__ uint32_t s_carry, s_long;
   const int s = blockIdx.x >> IB_BINS_LOG, bin = blockIdx.x & (IB_BINS - 1);
   const int sub = (int)(ix.nb >> IB_BINS_LOG), lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const uint32_t* bs = ix.bin_start + (size_t)s * (IB_BINS + 1) + bin;
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix)
   uint2* out = ix.items + (size_t)s * ix.slot_stride + lo;
   uint32_t* ends = ix.ends + (size_t)s * ((size_t)ix.nb + 1) + (size_t)bin * sub + 1;
   for (int i = threadIdx.x; i < sub; i += IB_FIN_THREADS) cnt[i] = 0;
-  if (threadIdx.x == 0) { s_carry = 0; if (bin == 0) ends[-1] = 0; }
+  if (threadIdx.x == 0) { s_carry = 0; s_long = 0; if (bin == 0) ends[-1] = 0; }
   __syncthreads();
   const uint32_t smask = (uint32_t)sub - 1u;
   for (uint32_t i = threadIdx.x; i < n; i += IB_FIN_THREADS) atomicAdd(&cnt[(in[i].x >> ix.shift) & smask], 1u);
@@ -294,10 +298,12 @@ __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix)
     uint32_t before = s_carry, total = 0;
     for (int w = 0; w < IB_FIN_THREADS / 64; w++) { const uint32_t t = wsum[w]; if (w < wv) before += t; total += t; }
     if (i < sub) { cnt[i] = before + incl - v; ends[i] = lo + before + incl; }
+    if (v > ix.group_t) s_long = 1;                      // (benign race: every writer stores 1)
     __syncthreads();
     if (threadIdx.x == 0) s_carry += total;
     __syncthreads();
   }
+  if (threadIdx.x == 0) ix.bin_long[blockIdx.x] = s_long;
   for (uint32_t i = threadIdx.x; i < n; i += IB_FIN_THREADS) {
     const uint2 x = in[i];
     out[atomicAdd(&cnt[(x.x >> ix.shift) & smask], 1u)] = x;
@@ -325,6 +331,7 @@ __global__ __launch_bounds__(IB_GRP_THREADS) void index_group_kernel(InvIndex ix
   uint2* items = ix.items + (size_t)s * ix.slot_stride;
   uint2* staged = ix.staged + (size_t)s * ix.slot_stride;
   const int nclass = (int)((ix.ne + (1u << ix.class_log) - 1) >> ix.class_log);
+  if (!ix.bin_long[blockIdx.x]) return;                  // (step 4 saw no long bucket in this bin: nearly every bin of an index without repeats)
   for (int w0 = 0; w0 < sub; w0 += IB_GRP_THREADS) {     // windows of IB_GRP_THREADS buckets: the list of a window's long ones cannot overflow
     __syncthreads();
     if (threadIdx.x == 0) s_nlong = 0;
@@ -419,7 +426,7 @@ void index_group_params(int64_t entries, InvIndex& ix) {
   const int cl = []() { const char* e = getenv("MHAP_INDEX_CLASS_LOG"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 24 ? v : IB_CLASS_LOG; }();
   ix.group_t = (uint32_t)gt; ix.class_log = (uint32_t)cl;
   const bool fits = entries <= ((int64_t)IB_MAX_CLASSES << cl);
-  ix.grouped = (fits && (force >= 0 ? force != 0 : entries > (1LL << 17))) ? 1u : 0u;
+  ix.grouped = (fits && (force >= 0 ? force != 0 : entries > (1LL << 18))) ? 1u : 0u;   // (more than two passes of the compact dense tier)
 }
 
 // One workgroup (one wavefront) per query.  LDS: tbl[CT], a hit-count table of packed words: entry + 1 in the low `ebits` bits (as
@@ -1176,6 +1183,15 @@ constexpr int OJ_U = MH_OJ_U;          // 64-entry blocks of the other sketch in
 #define MH_OJ_PAD 0   // (experiment: unused ints per wave, to see what the resident waves per CU are worth)
 #endif
 constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN) + MH_OJ_PAD;   // ints per wave besides the query hashes
+// Round 4: the other sketch's POSITIONS stay in registers from the join's pass over its row (one per lane and 64-entry block: 24 at
+// S = 1536), and a shared query's positions are staged in LDS next to its hashes — the two later passes over both rows that the
+// bottom-k Jaccard ranks need (nine pairs in ten get that far: -DMH_OJ_STATS) then read no memory at all.  Before: 36 KB per pair
+// (the row, then both rows' positions again), now 12.
+#ifndef MH_OJ_KEEP
+#define MH_OJ_KEEP 1
+#endif
+constexpr int OJ_KB = 24;              // blocks of the other sketch whose positions are kept (S <= 64 * OJ_KB)
+constexpr int OJ_KIT = (OJ_KB + OJ_U - 1) / OJ_U;
 
 __device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1414,6 +1430,26 @@ __device__ __forceinline__ OjBuckets oj_buckets(int first, int last, int nb) {
 __device__ __forceinline__ int oj_bucket_of(const OjBuckets& k, int h) { return (int)__umulhi((uint32_t)(h - k.first), k.mult); }
 int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; return t; }
 
+template <int IT>
+__device__ __forceinline__ void oj_keep_store(int (&pbk)[OJ_KB], const uint2 (&e)[OJ_U]) {
+#pragma unroll
+  for (int u = 0; u < OJ_U; u++) if (IT * OJ_U + u < OJ_KB) pbk[IT * OJ_U + u] = (int)e[u].y;
+}
+template <int IT>
+__device__ __forceinline__ void oj_keep_load(const int (&pbk)[OJ_KB], int (&posv)[OJ_U]) {
+#pragma unroll
+  for (int u = 0; u < OJ_U; u++) posv[u] = IT * OJ_U + u < OJ_KB ? pbk[IT * OJ_U + u] : INT32_MIN;
+}
+// (a wave-uniform switch over static indices: the array stays in registers, no indirect addressing)
+#define OJ_KEEP_SWITCH(it, OP, ...)                                                                                              \
+  switch (it) {                                                                                                                  \
+    case 0: OP<0>(__VA_ARGS__); break; case 1: OP<1>(__VA_ARGS__); break; case 2: OP<2>(__VA_ARGS__); break; case 3: OP<3>(__VA_ARGS__); break;   \
+    case 4: OP<4>(__VA_ARGS__); break; case 5: OP<5>(__VA_ARGS__); break; case 6: OP<6>(__VA_ARGS__); break; case 7: OP<7>(__VA_ARGS__); break;   \
+    case 8: OP<8>(__VA_ARGS__); break; case 9: OP<9>(__VA_ARGS__); break; case 10: OP<10>(__VA_ARGS__); break; case 11: OP<11>(__VA_ARGS__); break; \
+    default: OP<12>(__VA_ARGS__); break;                                                                                         \
+  }
+static_assert(OJ_KIT <= 13, "OJ_KEEP_SWITCH covers 13 trips");
+
 // SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its WAVES waves stage the
 //                 query's hashes (and, TABLE, build the bucket table) together — one copy in LDS — then take the run's candidates one
 //                 by one from an LDS counter.
@@ -1434,9 +1470,12 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
                                                                      const int32_t* __restrict__ pass_min) {
   extern __shared__ int32_t oj_lds[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int spad = (sp.S + 3) & ~3, own = TABLE ? spad + ts / 2 + 2 : spad;   // ints of the hashes (+ the table: ts + 1 shorts, padded)
+  constexpr bool APOS = SHARED && MH_OJ_KEEP;                          // the shared query's positions are staged too
+  const bool keepb = MH_OJ_KEEP && sp.S <= 64 * OJ_KB;                 // the other sketch's positions stay in registers
+  const int spad = (sp.S + 3) & ~3, own = (TABLE ? spad + ts / 2 + 2 : spad) + (APOS ? spad : 0);   // ints of the hashes (+ the table: ts + 1 shorts, padded) (+ the positions)
   int32_t* ah = SHARED ? oj_lds : oj_lds + (size_t)wv * (own + OJ_LDS_EXTRA);   // the query sketch's hashes,
   uint16_t* st = (uint16_t*)(ah + spad);                               // ... the bucket starts over them,
+  int32_t* ap = ah + (TABLE ? spad + ts / 2 + 2 : spad);               // ... (APOS) its positions,
   int32_t* svar = oj_lds + own;                                        // (SHARED) {-, next candidate of the run, chunk start lo, hi}
   int32_t* jp1 = SHARED ? svar + 4 + (size_t)wv * OJ_LDS_EXTRA : ah + own;   // per wave — join: position in the query / in the other sketch,
   int32_t* jp2 = jp1 + OJ_JCAP;
@@ -1461,8 +1500,10 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
       // ---- join ----
       int nj = 0, ng = 0;
       bool bad = false;
+      int pbk[OJ_KB];    // (keepb) positions of the other sketch: entry blk * 64 + lane in pbk[blk]
       if (nA > 0 && nB > 0) {
         int carry = 0;   // hash of the last entry of the previous OJ_U blocks (run detection across blocks)
+        int kit = 0;
         uint2 en[OJ_U];
 #pragma unroll
         for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = make_uint2(0u, 0u); if (j < nB) en[u] = brow[j]; }
@@ -1488,6 +1529,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
             en[u] = make_uint2(0u, 0u);
             if (jn < nB) en[u] = brow[jn];
           }
+          if (keepb) { OJ_KEEP_SWITCH(kit, oj_keep_store, pbk, e) kit++; }
           bool found[OJ_U];
           bool anyf = false;
           if constexpr (TABLE) {
@@ -1581,7 +1623,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
         const bool b_ok = lane >= 16 && lane <= 16 + OJ_GLEN && j + x < nB && (int)brow[j + x].x == h;
         const int m = __popcll(__ballot(a_ok)), nn = __popcll(__ballot(b_ok));
         if (m > OJ_GLEN || nn > OJ_GLEN) { bad = true; break; }
-        if (a_ok) gpa[g * OJ_GLEN + x] = qrow[2 * (lo + x) + 1];
+        if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)brow[j + x].y;
         if (lane == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; }
         gtot += m + nn;
@@ -1607,7 +1649,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
           const int t = r * 64 + lane;
           const uint32_t ij = t < nj ? jij[t] : 0xffffffffu;
           iA[r] = (int)(ij & 0xffffu); jB[r] = (int)(ij >> 16);
-          if (t < nj) jp1[t] = qrow[2 * iA[r] + 1];
+          if (t < nj) jp1[t] = APOS ? ap[iA[r]] : qrow[2 * iA[r] + 1];
         }
         oj_lds_sync();
         // ---- recordMatchingKmers twice (:600-606), median shift after each ----
@@ -1707,16 +1749,19 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
 #pragma unroll
         for (int u = 0; u < OJ_U; u++) {
           const int i = u * 64 + lane;
-          pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
-          pbn[u] = i < nB ? (int)brow[i].y : INT32_MIN;
+          pan[u] = (!APOS && i < nA) ? qrow[2 * i + 1] : INT32_MIN;
+          pbn[u] = (!keepb && i < nB) ? (int)brow[i].y : INT32_MIN;
         }
         for (int ib = 0; ib < nA; ib += 64 * OJ_U) {
           int posv[OJ_U];
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
-            posv[u] = pan[u];
-            const int i = ib + (u + OJ_U) * 64 + lane;
-            pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
+            if (APOS) { const int i = ib + u * 64 + lane; posv[u] = i < nA ? ap[i] : INT32_MIN; }
+            else {
+              posv[u] = pan[u];
+              const int i = ib + (u + OJ_U) * 64 + lane;
+              pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
+            }
           }
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
@@ -1737,13 +1782,16 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
             }
           }
         }
-        for (int jb = 0; jb < nB; jb += 64 * OJ_U) {
+        for (int jb = 0, kit2 = 0; jb < nB; jb += 64 * OJ_U, kit2++) {
           int posv[OJ_U];
+          if (keepb) { OJ_KEEP_SWITCH(kit2, oj_keep_load, pbk, posv) }
+          else {
 #pragma unroll
-          for (int u = 0; u < OJ_U; u++) {
-            posv[u] = pbn[u];
-            const int j = jb + (u + OJ_U) * 64 + lane;
-            pbn[u] = j < nB ? (int)brow[j].y : INT32_MIN;
+            for (int u = 0; u < OJ_U; u++) {
+              posv[u] = pbn[u];
+              const int j = jb + (u + OJ_U) * 64 + lane;
+              pbn[u] = j < nB ? (int)brow[j].y : INT32_MIN;
+            }
           }
 #pragma unroll
           for (int u = 0; u < OJ_U; u++) {
@@ -1847,6 +1895,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
             if (bal) { rend = t0 + (unsigned long long)__builtin_ctzll(bal); break; }
           }
         } else __builtin_amdgcn_wave_barrier();
+        if (APOS) for (int i = tid; i < nA; i += NT) ap[i] = qrow[2 * i + 1];
         if (!TABLE) {
           for (int i = tid; i < nA; i += NT) ah[i] = qrow[2 * i];
         } else if (nA > 0) {
@@ -1900,7 +1949,7 @@ int overlap_join_waves_per_block(int shape) { return OJ_SHAPE_WAVES[shape]; }
 size_t overlap_join_lds_bytes(int S, int shape) {
   const size_t sp = (size_t)((S + 3) & ~3), w = (size_t)OJ_SHAPE_WAVES[shape];
   if (shape == OJ_ALONE) return w * (sp + OJ_LDS_EXTRA) * 4;
-  return (sp + (shape == OJ_TEAM ? (size_t)overlap_join_table_slots(S) / 2 + 2 : 0) + 4 + w * OJ_LDS_EXTRA) * 4;
+  return (sp + (MH_OJ_KEEP ? sp : 0) + (shape == OJ_TEAM ? (size_t)overlap_join_table_slots(S) / 2 + 2 : 0) + 4 + w * OJ_LDS_EXTRA) * 4;
 }
 template <class F> static auto oj_dispatch(int shape, F f) {
   if (shape == OJ_TEAM) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_TEAM], true>);

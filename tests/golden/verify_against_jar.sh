@@ -5,6 +5,8 @@
 # Then (needs javac too) compiles tools/jvm/ScoreTableDump.java against the jar's Guava and diffs, bit for bit, the three pieces of
 # JDK / Guava arithmetic the restatement depends on with tools/jvm/native_dump.py: the (inter, k) identity table (Math.log / Math.exp
 # against glibc), String.format("%.6f") on 20 000 doubles incl. ties, and BloomFilter sizing + membership.
+# Also: the MinHash + ordered sketches of the fixture as a `.dat` file, mhap.jar -p against tools/jvm/native_dump.py dat, byte for byte.
+# Runtime on a laptop-class JVM: under a minute (six runs of mhap.jar on 60 short reads + three small dumps).
 # Usage: MHAP_JAR=/path/mhap-2.1.3.jar sh tests/golden/verify_against_jar.sh
 set -e
 cd "$(dirname "$0")"
@@ -32,8 +34,16 @@ for name, key in (("self", "sorted_records"), ("query", "query_records_no_self")
 assert bad == 0, "MISMATCH between mhap.jar and the oracle-derived fixture"
 print("fixture matches mhap.jar")
 PY
+# Second channel, no record formatting involved: the sketches themselves.  `-p` makes mhap.jar write the MinHash + ordered sketches of
+# every strand as small_reads.dat; tools/jvm/native_dump.py writes the same file from the restatement (no GPU needed); cmp, byte for byte.
+ROOT=$(cd ../.. && pwd)
+mkdir -p "$T/in" "$T/jdat"
+cp small_reads.fasta "$T/in/"
+java -jar "$MHAP_JAR" -p "$T/in" -q "$T/jdat" $FLAGS >/dev/null 2>&1
+python3 "$ROOT/tools/jvm/native_dump.py" dat small_reads.fasta "$T/native.dat" 16 64 12 256 116 >/dev/null
+if cmp -s "$T/jdat/small_reads.dat" "$T/native.dat"; then echo "ok       sketches: small_reads.dat ($(wc -c < "$T/native.dat") bytes) identical to mhap.jar -p"
+else echo "MISMATCH sketches: mhap.jar -p and the restatement write different .dat files"; cmp "$T/jdat/small_reads.dat" "$T/native.dat" | head -2; exit 1; fi
 if command -v javac >/dev/null 2>&1; then
-  ROOT=$(cd ../.. && pwd)
   javac -cp "$MHAP_JAR" -d "$T" "$ROOT/tools/jvm/ScoreTableDump.java"
   for what in "score 12 1536" "fmt6" "bloom"; do
     name=$(echo $what | cut -d' ' -f1)

@@ -72,6 +72,14 @@ def test_cli_dat_roundtrip_and_format(tmp_path):
     g = json.load(open(os.path.join(GOLD, "small_reads.json")))
     lines, _ = _run(["-s", str(dat)] + GFLAGS)
     assert lines == g["sorted_records"]
+    # the whole file, byte for byte, against the restatement's writer (tools/jvm/native_dump.py dat: what verify_against_jar.sh
+    # compares with `java -jar mhap.jar -p` on a JVM box — GPU sketches == oracle sketches == (there) the JVM's)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("native_dump", os.path.join(ROOT, "tools", "jvm", "native_dump.py"))
+    nd = importlib.util.module_from_spec(spec); spec.loader.exec_module(nd)
+    ref = tmp_path / "native.dat"
+    nd.dump_dat(str(fasta), str(ref), 16, 64, 12, 256, 116)
+    assert ref.read_bytes() == blob
 
 
 def test_cli_query_mode_and_full_ids(tmp_path):
