@@ -159,7 +159,9 @@ def main():
     t_stage = time.perf_counter() - t_stage
     dev = torch.device("cuda", local_rank)
     force_dist = world > 1 or bool(os.environ.get("MHAP_BENCH_FORCE_DIST"))   # 1 rank through the N>1 code path (RCCL on one GPU)
+    eager_note = None
     if force_dist:
+        os.environ.setdefault("MHAP_DIST_TIMEOUT_S", "600")   # (a rank that never arrives makes the others give up, not hang: mhap_dist.hip)
         # the ranks form their communicator inside the library (ncclCommInitRank); the host only hands rank 0's id round
         ms.dist_init(rank, world, mdist.broadcast_unique_id(dist, rank, MinHashSearch.dist_unique_id))
     phase = {"sketch": 0.0, "exchange": 0.0, "search": 0.0}
@@ -199,6 +201,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def job_checksum(recs):
+        """order- and shard-independent fingerprint of a step's records over all ranks (binary fields; 16-bit limbs through all_reduce)"""
+        m64 = np.zeros(len(recs), dtype=np.uint64)
+        with np.errstate(over="ignore"):
+            for f in ("from_id", "to_id", "a1", "a2", "b1", "b2", "to_rc"):
+                m64 = (m64 ^ recs[f].astype(np.int64).view(np.uint64)) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x632BE59BD9B4E019)
+                m64 ^= m64 >> np.uint64(29)
+            c = int(m64.sum(dtype=np.uint64)) if len(recs) else 0
+        t = torch.tensor([len(recs), c & 0xFFFF, (c >> 16) & 0xFFFF, (c >> 32) & 0xFFFF, c >> 48], dtype=torch.int64, device=dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return tuple(int(x) for x in t.tolist())
+
+    if force_dist and not os.environ.get("MHAP_BENCH_NO_EAGER"):
+        # Eager exchange (mhap_dist_set_eager): the add gathers the rank's rows while it computes.  It is switched on only after one
+        # step each way has produced the same records over all ranks; otherwise the run goes on with the exchange at search time.
+        ref = job_checksum(step())
+        ms.dist_set_eager(True)
+        got = job_checksum(step())
+        if got == ref:
+            eager_note = "on (records equal to the exchange-at-search-time step: %d)" % ref[0]
+        else:
+            ms.dist_set_eager(False)
+            eager_note = "off: the eager step's records differed (%s vs %s)" % (got, ref)
     for _ in range(args.warmup):
         step()
     ms.reset_kernel_times()
@@ -374,6 +400,7 @@ def main():
             "records_checksum_kind": "binary fields (output too large for text lines in Python)" if big_output else "sha256 of text lines, summed",
             "hbm_traffic_by_kernel": hbm_by_kernel,
             "roofline": roofline, "valu": valu, "roofline_stage2": roofline_stage2,
+            "eager_exchange": eager_note,
             "soak": soak,
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),

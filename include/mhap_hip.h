@@ -276,6 +276,14 @@ int mhap_dist_find_matches_reads(mhap_handle* h, const char* bases, const int64_
                                  const int64_t* ids, int64_t n, mhap_record_sink sink, void* user);
 /* wall-clock split of the last collective search on this rank, milliseconds: {pack + small gathers, index + candidate stage wait
  * on the ordered rows, whole call} */
+/* Eager exchange: with on != 0, the add that fills an EMPTY index of this rank (mhap_index_add_reads / _staged / _scan) becomes a collective
+ * call — every rank must make it, in the same order as its searches — and gathers the rank's forward rows while it is still computing:
+ * the ordered rows under the MinHash kernel, the MinHash rows under the index build.  mhap_dist_find_matches_self then starts with every
+ * rank's rows in place.  An add that cannot take part (not the first one, more than one launch group, any rank saying so) falls back
+ * to the exchange at search time on all ranks together.  Replaces nothing in the reference (it has one index in one JVM,
+ * J/impl/AbstractMatchSearch.java:67-117); it is the overlap of SURVEY.md §8(e)'s all-gather with the sketch phase. */
+int mhap_dist_set_eager(mhap_handle* h, int32_t on);
+int64_t mhap_dist_eager_searches(mhap_handle* h);   /* searches of this rank that found every rank's rows already gathered by the add */
 int mhap_dist_last_timing(mhap_handle* h, double* out3);
 
 typedef struct mhap_group mhap_group;

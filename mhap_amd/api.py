@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = [
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_selftest_xorshift_unjump", "mhap_find_matches_sketches",
     "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
-    "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing",
+    "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing", "mhap_dist_set_eager", "mhap_dist_eager_searches",
     "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",
     "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats", "mhap_abi_version", "mhap_abi_sizes",
     "mhap_index_reserve", "mhap_fasta_scan_open", "mhap_fasta_scan_free", "mhap_fasta_scan_reads", "mhap_fasta_scan_bases", "mhap_fasta_scan_info",
@@ -600,6 +600,15 @@ class MinHashSearch:
 
     def dist_init(self, rank, nranks, unique_id):
         self._chk(self._lib.mhap_dist_init(self._h, C.c_int32(rank), C.c_int32(nranks), C.c_char_p(bytes(unique_id))))
+
+    def dist_set_eager(self, on=True):
+        """Eager exchange (mhap_dist_set_eager): the add that fills this rank's empty index becomes collective and gathers the rank's
+        forward rows while it computes; the sharded search then starts with all rows in place."""
+        self._chk(self._lib.mhap_dist_set_eager(self._h, C.c_int32(1 if on else 0)))
+
+    def dist_eager_searches(self):
+        self._lib.mhap_dist_eager_searches.restype = C.c_int64
+        return int(self._lib.mhap_dist_eager_searches(self._h))
 
     def dist_finalize(self):
         self._chk(self._lib.mhap_dist_finalize(self._h))

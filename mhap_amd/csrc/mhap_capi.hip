@@ -94,6 +94,7 @@ struct mhap_handle {
   hipStream_t ord_stream = nullptr, ord_stream_lo = nullptr;   // the ordered-sketch kernel next to the MinHash launch (MHAP_ORDERED_OVERLAP)
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0;
+  uint64_t index_gen = 0;   // bumped by every change of the entry set (the eager exchange's rows describe one generation)
   bool ph_ready = false; int64_t ph_ne = 0;   // poshist holds the position histograms of entries [0, ph_ne) (reset wherever inv_ready is)
   bool iq_start_mid = false;   // queries of this index start in the middle query tier (set by a chunk that mostly ended up there)
   int64_t reserve_reads = 0;       // mhap_index_reserve: reads the empty index is about to receive, over one or more adds
@@ -339,7 +340,7 @@ int ensure_inverted_index(mhap_handle* h, hipStream_t st = nullptr, int64_t ne_o
 // stream, next to the ordered-sketch kernel (which is bound by the LDS pipe and leaves the memory side idle): at C2 3 ms of index
 // build used to follow 4.8 ms of ordered kernel.
 int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta,
-                  int64_t eager_index_entries = 0) {
+                  int64_t eager_index_entries = 0, bool eager_exchange = false, bool eager_first = false) {
   const int64_t n = h->st_n;
   if (n <= 0) return MHAP_OK;
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
@@ -372,6 +373,14 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     max_len_all = std::max(max_len_all, b.max_len);
     plan.push_back(b);
     r0 = r1;
+  }
+  // Eager exchange (mhap_dist_set_eager): the rendezvous of the ranks — collective, so every rank of the job gets here — says whether
+  // this add gathers its rows while it computes.  Only an add of one launch group can (the rows of earlier groups would have to wait).
+  bool eager_x = false;
+  if (eager_exchange) {
+    const int rx = dist_eager_begin(h, n, h->st_ids.data(), plan.size() == 1 && eager_first);
+    if (rx < 0) return rx;
+    eager_x = rx == 1;
   }
   HIPCHK(h, h->descs.ensure((size_t)max_nb * sizeof(ReadDesc)));
   HIPCHK(h, h->keys.ensure((size_t)max_key * 8));
@@ -479,17 +488,28 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       time_end(h, ost);
       return MHAP_OK;
     };
+    bool ordered_done = false;
+    if (eager_x) {
+      // eager exchange: the ordered rows first (they do not depend on the MinHash rows), so that their all-gather — 6/7 of the bytes
+      // a rank sends — runs under the MinHash kernel; its copy engines / RCCL workgroups are in place before the persistent grid starts
+      ost = h->stream;
+      (void)do_ordered();
+      ordered_done = true;
+      const int rxo = dist_eager_ordered(h, h->stream, ord_rows);
+      if (rxo != MHAP_OK) return rxo;
+    }
     const size_t t_mh = time_begin(h, MHAP_K_MINHASH);
     launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
                    h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
                    meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(), h->jump_w1_tbl.as<uint64_t>(),
                    h->mhmerge.as<unsigned long long>(), std::max(0, B.max_len - k + 1));
-    if (ost != h->stream) { (void)do_ordered(); HIPCHK(h, hipEventRecord(h->ev_ord_join, ost)); }   // (the stream was idle: the host waited for the weight kernel)
+    if (ost != h->stream && !ordered_done) { (void)do_ordered(); HIPCHK(h, hipEventRecord(h->ev_ord_join, ost)); }   // (the stream was idle: the host waited for the weight kernel)
     HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
     time_end_at(h, t_mh);
     DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)
+    if (eager_x) { const int rxm = dist_eager_minhash(h, h->stream, mh_rows, meta_rows); if (rxm != MHAP_OK) return rxm; }
     bool eager_launched = false;
     if (eager_index_entries > 0 && &B == &plan.back() && !getenv("MHAP_NO_EAGER_INDEX")) {
       HIPCHK(h, hipEventRecord(h->ev_ix_fork, h->stream));
@@ -499,7 +519,8 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       HIPCHK(h, hipEventRecord(h->ev_ix_join, h->mh_stream));
       eager_launched = true;
     }
-    if (ost == h->stream) (void)do_ordered();
+    if (ordered_done) { }
+    else if (ost == h->stream) (void)do_ordered();
     else HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ord_join, 0));
     DBGSYNC(h, "ordered");
     HIPCHK(h, hipGetLastError());
@@ -926,7 +947,7 @@ namespace mhap {
 HandleView handle_view(mhap_handle* h) {
   HandleView v;
   v.device = h->device; v.stream = h->stream; v.Hrow = h->Hrow; v.S = h->P.ordered_sketch_size; v.k = h->P.kmer_size; v.min_olap_length = h->P.min_olap_length;
-  v.n_entries = h->n_entries;
+  v.n_entries = h->n_entries; v.index_gen = h->index_gen;
   v.d_minhash = h->d_minhash; v.d_ordered = h->d_ordered; v.d_meta = h->d_meta;
   v.h_ids = h->ids.data(); v.h_fwd = h->fwd.data(); v.err = &h->err; v.dist = &h->dist;
   return v;
@@ -1143,7 +1164,7 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   HPROF("finish_add begin");
-  h->inv_ready = false; h->ph_ready = false;   // the entry set changes
+  h->inv_ready = false; h->ph_ready = false; h->index_gen++;   // the entry set changes
   h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
   for (int64_t i = 0; i < n; i++) {
     h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
@@ -1195,12 +1216,15 @@ int mhap_index_add_staged(mhap_handle* h) {
   // that was not announced to be larger, or the add that reaches the announced size): then it is built here, next to the ordered kernel
   const int64_t after = first + 2 * n;
   const bool likely_last = (first == 0 && 2 * h->reserve_reads <= after) || (h->reserve_reads > 0 && after == 2 * h->reserve_reads);
+  // (a rank of a multi-GPU job with the eager exchange on: the add is collective; only the first add of an empty index can gather)
+  const bool eager_exchange = h->dist != nullptr && dist_eager_wanted(h);
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W,
-                     likely_last ? after : 0);
+                     likely_last ? after : 0, eager_exchange, first == 0);
   if (rc != MHAP_OK) return rc;
   const bool built = h->inv_ready && h->inv_ne == after;
   rc = finish_add(h, first, h->st_ids.data(), n);
   if (rc == MHAP_OK && built) h->inv_ready = true;      // (finish_add drops the index of the OLD entry set; this one covers the new one)
+  if (rc == MHAP_OK && eager_exchange) dist_eager_commit(h);
   return rc;
 }
 
@@ -1262,7 +1286,7 @@ int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* i
   HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)m * 8, hipMemcpyHostToDevice));
   rc = mirror_meta(h, h->d_meta, first, m);
   if (rc != MHAP_OK) return rc;
-  h->n_entries = first + m; h->inv_ready = false; h->ph_ready = false;
+  h->n_entries = first + m; h->inv_ready = false; h->ph_ready = false; h->index_gen++;
   h->stats.strands_indexed += m;
   return MHAP_OK;
 }
@@ -1297,7 +1321,7 @@ int mhap_index_export(mhap_handle* h, int64_t first, int64_t count, int64_t* ids
 
 int mhap_index_clear(mhap_handle* h) {
   if (!h) return MHAP_E_INVALID;
-  h->n_entries = 0; h->external = false; h->inv_ready = false; h->ph_ready = false; h->reserve_reads = 0;
+  h->n_entries = 0; h->external = false; h->inv_ready = false; h->ph_ready = false; h->reserve_reads = 0; h->index_gen++;
   h->ids.clear(); h->fwd.clear(); h->seqlen.clear(); h->status.clear();
   h->d_minhash = h->own_minhash.as<int32_t>(); h->d_ordered = h->own_ordered.as<int32_t>(); h->d_meta = h->own_meta.as<int32_t>();
   h->stats = mhap_stats{};
@@ -1335,7 +1359,7 @@ int mhap_index_set_device(mhap_handle* h, const int64_t* ids, const uint8_t* is_
   HIPCHK(h, h->d_ids.ensure((size_t)std::max<int64_t>(m, 1) * 8));
   if (m > 0) HIPCHK(h, hipMemcpy(h->d_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
   if (m > 0) { int rc = mirror_meta(h, h->d_meta, 0, m); if (rc != MHAP_OK) return rc; }
-  h->n_entries = m; h->inv_ready = false; h->ph_ready = false;
+  h->n_entries = m; h->inv_ready = false; h->ph_ready = false; h->index_gen++;
   for (int64_t e = 0; e < m; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
   return MHAP_OK;
 }

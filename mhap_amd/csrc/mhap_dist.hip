@@ -248,12 +248,20 @@ struct DistState {
   double t_small = 0, t_wait_big = 0, t_total = 0;
   bool gate_ran = false;
   std::string gate_err;
+  // eager exchange: eager = the host asked for it; eager_go = the add in progress gathers eagerly (every rank agreed); eager_valid = g_*
+  // hold the forward rows of the index as it is now (eager_rows local rows, eager_npad per rank)
+  bool eager = false, eager_go = false, eager_done = false, eager_valid = false;
+  uint64_t eager_gen = 0;
+  int64_t eager_searches = 0;    // searches that found their rows gathered by the add
+  int64_t eager_rows = 0, eager_npad = 0;
+  hipEvent_t ev_prod = nullptr;
   ~DistState() {
     DevBuf* bufs[] = {&s_mh, &s_od, &s_mt, &s_ids, &g_mh, &g_od, &g_mt, &g_ids, &q_mh, &q_od, &q_mt};
     for (DevBuf* b : bufs) b->release();
     if (ev_pack) (void)hipEventDestroy(ev_pack);
     if (ev_small) (void)hipEventDestroy(ev_small);
     if (ev_big) (void)hipEventDestroy(ev_big);
+    if (ev_prod) (void)hipEventDestroy(ev_prod);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     delete tr;
   }
@@ -276,7 +284,8 @@ int attach(mhap_handle* h, Transport* tr) {
   DistState* d = new DistState();
   d->tr = tr;
   if (hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&d->ev_pack, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&d->ev_small, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_big, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&d->ev_small, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&d->ev_big, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&d->ev_prod, hipEventDisableTiming) != hipSuccess) {
     delete d;
     return dfail(v, MHAP_E_HIP, "cannot create the exchange stream");
   }
@@ -306,12 +315,21 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   bool finished = false;
   struct Guard { Transport* t; bool* ok; ~Guard() { if (!*ok) t->abort(); } } guard{tr, &finished};   // an error return must not strand the other ranks of this process
   d->t_small = d->t_wait_big = 0; d->gate_ran = false;
+  // the rows were gathered while the add was still computing (eager exchange): nothing to send — every rank knows this from the
+  // add's rendezvous, so all of them take this branch together
+  const bool use_eager = d->eager_valid && d->eager_gen == v.index_gen && to_self && stride == 2 && d_mh == v.d_minhash && rows == d->eager_rows &&
+                         2 * rows == v.n_entries;
+  if (!use_eager) d->eager_valid = false;       // (the gather below overwrites the buffers)
+  else d->eager_searches++;
   // equal shard size for the gather: the largest row count of any rank (shorter shards are padded with skipped rows)
-  std::vector<int64_t> counts((size_t)N, 0);
-  rc = tr->allgather_host(&rows, counts.data(), sizeof(int64_t), *v.err);
-  if (rc != MHAP_OK) return rc;
   int64_t n_pad = 0, total = 0;
-  for (int64_t c : counts) { n_pad = std::max(n_pad, c); total += c; }
+  if (use_eager) { n_pad = d->eager_npad; total = 1; }
+  else {
+    std::vector<int64_t> counts((size_t)N, 0);
+    rc = tr->allgather_host(&rows, counts.data(), sizeof(int64_t), *v.err);
+    if (rc != MHAP_OK) return rc;
+    for (int64_t c : counts) { n_pad = std::max(n_pad, c); total += c; }
+  }
   if (total == 0) { finished = true; tr->quiesce(); return MHAP_OK; }
   if ((int64_t)N * n_pad > (int64_t)INT32_MAX / 2) return dfail(v, MHAP_E_INVALID, "too many query rows for one gather");
   const size_t mh_row = (size_t)v.Hrow * 4, od_row = (size_t)v.S * 8, mt_row = (size_t)META_W * 4;
@@ -320,6 +338,7 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   DCHK(v, d->g_mh.ensure((size_t)N * np * mh_row)); DCHK(v, d->g_od.ensure((size_t)N * np * od_row));
   DCHK(v, d->g_mt.ensure((size_t)N * np * mt_row)); DCHK(v, d->g_ids.ensure((size_t)N * np * 8));
   hipStream_t st = v.stream, cs = d->comm_stream;
+  if (!use_eager) {
   // pack: every `stride`-th row of the tables; padding rows get status -1 (skipped as queries)
   if (rows > 0) {
     DCHK(v, hipMemcpy2DAsync(d->s_mh.p, mh_row, d_mh, mh_row * (size_t)stride, mh_row, (size_t)rows, hipMemcpyDeviceToDevice, st));
@@ -341,6 +360,7 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   DCHK(v, hipEventRecord(d->ev_small, cs));
   rc = tr->allgather(d->s_od.p, d->g_od.p, np * od_row, cs, *v.err); if (rc != MHAP_OK) return rc;
   DCHK(v, hipEventRecord(d->ev_big, cs));
+  }
   // meanwhile: this rank's inverted index (a no-op when the add built it eagerly)
   rc = mhap_index_prepare(h); if (rc != MHAP_OK) return rc;
   rc = tr->wait_event(d->ev_small, *v.err); if (rc != MHAP_OK) return rc;
@@ -360,6 +380,90 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
 }
 
 }  // namespace
+
+// ---- eager exchange hooks (declared in mhap_internal.hpp; called by the add path in mhap_capi.hip) ---------------------------------
+namespace mhap {
+bool dist_eager_wanted(mhap_handle* h) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  return d && d->eager;
+}
+int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool eligible) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d || !d->eager) return 0;
+  Transport* tr = d->tr;
+  const int N = tr->nranks;
+  d->eager_go = false; d->eager_done = false; d->eager_valid = false;
+  // rendezvous: every rank's row count, negative = "I cannot" (not the first add of an empty index, or more than one launch group)
+  const int64_t mine = eligible ? rows : -1;
+  std::vector<int64_t> counts((size_t)N, 0);
+  int rc = tr->allgather_host(&mine, counts.data(), sizeof(int64_t), *v.err);
+  if (rc != MHAP_OK) { tr->abort(); return rc; }
+  int64_t n_pad = 0, total = 0;
+  for (int64_t c : counts) { if (c < 0) return 0; n_pad = std::max(n_pad, c); total += c; }
+  if (total == 0 || (int64_t)N * n_pad > (int64_t)INT32_MAX / 2) return 0;
+  const size_t mh_row = (size_t)v.Hrow * 4, od_row = (size_t)v.S * 8, mt_row = (size_t)META_W * 4, np = (size_t)n_pad;
+  auto chk = [&](hipError_t e) { return e == hipSuccess; };
+  if (!chk(d->s_mh.ensure(np * mh_row)) || !chk(d->s_od.ensure(np * od_row)) || !chk(d->s_mt.ensure(np * mt_row)) || !chk(d->s_ids.ensure(np * 8)) ||
+      !chk(d->g_mh.ensure((size_t)N * np * mh_row)) || !chk(d->g_od.ensure((size_t)N * np * od_row)) || !chk(d->g_mt.ensure((size_t)N * np * mt_row)) ||
+      !chk(d->g_ids.ensure((size_t)N * np * 8))) { *v.err = "out of device memory (exchange buffers)"; tr->abort(); return MHAP_E_NOMEM; }
+  d->ids_local.assign(ids, ids + rows);
+  d->eager_rows = rows; d->eager_npad = n_pad; d->eager_go = true;
+  return 1;
+}
+// the ordered rows of this add exist once `producer` has run what it holds now: pack the forward ones and start their all-gather
+int dist_eager_ordered(mhap_handle* h, hipStream_t producer, const int32_t* d_od) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d || !d->eager_go) return MHAP_OK;
+  const size_t od_row = (size_t)v.S * 8, np = (size_t)d->eager_npad;
+  const int64_t rows = d->eager_rows;
+  hipStream_t cs = d->comm_stream;
+  DCHK(v, hipEventRecord(d->ev_prod, producer));
+  DCHK(v, hipStreamWaitEvent(cs, d->ev_prod, 0));
+  if (rows > 0) DCHK(v, hipMemcpy2DAsync(d->s_od.p, od_row, d_od, od_row * 2, od_row, (size_t)rows, hipMemcpyDeviceToDevice, cs));
+  const int rc = d->tr->allgather(d->s_od.p, d->g_od.p, np * od_row, cs, *v.err);
+  if (rc != MHAP_OK) { d->eager_go = false; d->tr->abort(); return rc; }
+  DCHK(v, hipEventRecord(d->ev_big, cs));
+  return MHAP_OK;
+}
+// ... and the MinHash rows, the meta rows (sizes by the ordered kernel, statuses by the MinHash kernel: both done) and the ids
+int dist_eager_minhash(mhap_handle* h, hipStream_t producer, const int32_t* d_mh, const int32_t* d_mt) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d || !d->eager_go) return MHAP_OK;
+  const size_t mh_row = (size_t)v.Hrow * 4, mt_row = (size_t)META_W * 4, np = (size_t)d->eager_npad;
+  const int64_t rows = d->eager_rows, n_pad = d->eager_npad;
+  hipStream_t cs = d->comm_stream;
+  DCHK(v, hipEventRecord(d->ev_prod, producer));
+  DCHK(v, hipStreamWaitEvent(cs, d->ev_prod, 0));
+  if (rows > 0) {
+    DCHK(v, hipMemcpy2DAsync(d->s_mh.p, mh_row, d_mh, mh_row * 2, mh_row, (size_t)rows, hipMemcpyDeviceToDevice, cs));
+    DCHK(v, hipMemcpy2DAsync(d->s_mt.p, mt_row, d_mt, mt_row * 2, mt_row, (size_t)rows, hipMemcpyDeviceToDevice, cs));
+    DCHK(v, hipMemcpyAsync(d->s_ids.p, d->ids_local.data(), (size_t)rows * 8, hipMemcpyHostToDevice, cs));
+  }
+  if (n_pad > rows) {
+    DCHK(v, hipMemsetAsync(d->s_mt.as<char>() + (size_t)rows * mt_row, 0xFF, (size_t)(n_pad - rows) * mt_row, cs));
+    DCHK(v, hipMemsetAsync(d->s_ids.as<char>() + (size_t)rows * 8, 0, (size_t)(n_pad - rows) * 8, cs));
+    DCHK(v, hipMemsetAsync(d->s_mh.as<char>() + (size_t)rows * mh_row, 0, (size_t)(n_pad - rows) * mh_row, cs));
+  }
+  Transport* tr = d->tr;
+  int rc = tr->allgather(d->s_mh.p, d->g_mh.p, np * mh_row, cs, *v.err);
+  if (rc == MHAP_OK) rc = tr->allgather(d->s_mt.p, d->g_mt.p, np * mt_row, cs, *v.err);
+  if (rc == MHAP_OK) rc = tr->allgather(d->s_ids.p, d->g_ids.p, np * 8, cs, *v.err);
+  if (rc != MHAP_OK) { d->eager_go = false; tr->abort(); return rc; }
+  DCHK(v, hipEventRecord(d->ev_small, cs));
+  d->eager_go = false; d->eager_done = true;
+  return MHAP_OK;
+}
+void dist_eager_commit(mhap_handle* h) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d || !d->eager_done) return;
+  d->eager_done = false; d->eager_valid = true; d->eager_gen = v.index_gen;
+}
+}  // namespace mhap
 
 namespace mhap {
 void mhap_dist_release(void* dist_state) { delete (DistState*)dist_state; }
@@ -435,6 +539,22 @@ int mhap_dist_find_matches_reads(mhap_handle* h, const char* bases, const int64_
     if (rc != MHAP_OK) return rc;
   }
   return exchange_and_search(h, d, d->q_mh.as<int32_t>(), d->q_od.as<int32_t>(), d->q_mt.as<int32_t>(), 2, ids, n, 0, sink, user);
+}
+
+int mhap_dist_set_eager(mhap_handle* h, int32_t on) {
+  if (!h) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job (mhap_dist_init / mhap_group_create first)");
+  d->eager = on != 0; d->eager_go = false; d->eager_done = false; d->eager_valid = false;
+  return MHAP_OK;
+}
+
+int64_t mhap_dist_eager_searches(mhap_handle* h) {
+  if (!h) return 0;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  return d ? d->eager_searches : 0;
 }
 
 int mhap_dist_last_timing(mhap_handle* h, double* out3) {
@@ -584,7 +704,10 @@ int mhap_group_add_reads(mhap_group* g, const char* bases, const int64_t* offset
     std::vector<int64_t> off, id; std::vector<int32_t> len;
     const int64_t i0 = ((r - first) % N + N) % N;
     for (int64_t i = i0; i < n; i += N) { off.push_back(offsets[i]); len.push_back(lengths[i]); id.push_back(ids[i]); }
-    if (off.empty()) return (int)MHAP_OK;
+    if (off.empty()) {   // (no read for this rank — with the eager exchange on it still joins the add's rendezvous, to say "not this time")
+      if (dist_eager_wanted(g->h[(size_t)r])) { const int rx = dist_eager_begin(g->h[(size_t)r], 0, nullptr, false); return rx < 0 ? rx : (int)MHAP_OK; }
+      return (int)MHAP_OK;
+    }
     return mhap_index_add_reads(g->h[(size_t)r], bases, off.data(), len.data(), id.data(), (int64_t)off.size());
   });
   if (rc == MHAP_OK) g->reads_added += n;
@@ -599,7 +722,10 @@ int mhap_group_add_scan(mhap_group* g, const mhap_fasta_scan* s) {
   const int64_t first = g->reads_added;
   const int rc = on_ranks(g, [&](int r) {
     const int64_t i0 = ((r - first) % N + N) % N;          // rank r takes the records whose ordinal in the data set is congruent to r
-    if (i0 >= n) return (int)MHAP_OK;
+    if (i0 >= n) {
+      if (dist_eager_wanted(g->h[(size_t)r])) { const int rx = dist_eager_begin(g->h[(size_t)r], 0, nullptr, false); return rx < 0 ? rx : (int)MHAP_OK; }
+      return (int)MHAP_OK;
+    }
     int64_t entries = 0;
     (void)mhap_index_size(g->h[(size_t)r], &entries);
     if (entries == 0) { const int rr = mhap_index_reserve(g->h[(size_t)r], (n - i0 + N - 1) / N); if (rr != MHAP_OK) return rr; }

@@ -62,6 +62,7 @@ struct HandleView {
   int device; hipStream_t stream;
   int Hrow, S, k, min_olap_length;
   int64_t n_entries;
+  uint64_t index_gen;      // bumped by every change of the entry set
   const int32_t *d_minhash, *d_ordered, *d_meta;
   const int64_t* h_ids; const uint8_t* h_fwd;
   std::string* err;
@@ -69,6 +70,16 @@ struct HandleView {
 };
 HandleView handle_view(mhap_handle* h);
 void mhap_dist_release(void* dist_state);
+// Eager exchange (mhap_dist.hip; mhap_dist_set_eager): an add on a rank of a multi-GPU job gathers its forward rows while the add is
+// still computing — the ordered rows (6/7 of the bytes) as soon as the ordered-sketch kernel has written them, under the MinHash
+// kernel; the MinHash rows, meta and ids right behind the MinHash kernel, under the index build — so that the collective search
+// that follows finds every rank's rows in place.  dist_eager_begin is a COLLECTIVE rendezvous (row counts and whether every rank
+// can take part): 1 = this add is eager on every rank, 0 = it is not, < 0 an error code.
+int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool eligible);
+int dist_eager_ordered(mhap_handle* h, hipStream_t producer, const int32_t* d_ordered_rows);   // rows of this add: [2 rows][S][2], forward = even
+int dist_eager_minhash(mhap_handle* h, hipStream_t producer, const int32_t* d_minhash_rows, const int32_t* d_meta_rows);
+bool dist_eager_wanted(mhap_handle* h);
+void dist_eager_commit(mhap_handle* h);   // the add is complete (host mirrors included): what was gathered describes the index as it is now
 // install a group of reads that the caller packed itself (2 bits per base / raw bytes, laid out like stage_reads does) as the handle's
 // staged reads: descs[i] = {base_off, length, flags (MHAP_RD_SKIP / MHAP_RD_RAW)}, packed = `bytes` bytes of host memory (pinned: the
 // upload then runs at PCIe speed)

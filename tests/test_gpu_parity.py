@@ -313,6 +313,52 @@ def test_rccl_rank_of_one_and_errors_of_the_sharded_search():
             ms.dist_find_matches()
 
 
+def test_eager_exchange_gathers_during_the_add(monkeypatch):
+    """mhap_dist_set_eager on the ranks of a group (three ranks sharing this box's GPU, peer copies): the add that fills the empty
+    index gathers every rank's forward rows while it computes (ordered rows behind the ordered kernel, which runs first; MinHash rows,
+    meta and ids behind the MinHash kernel) and the search finds them in place — same records as the oracle; a second search reuses
+    them; an index filled by two adds, a group with an empty rank, and a one-rank RCCL job all fall back or take part correctly."""
+    from mhap_amd import MinHashSearchGroup
+    fa = mhap_amd.synth_reads(600, 3000, seed=211, error_rate=0.07)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=512, device=0)
+    want = O.record_lines(O.run_self(fa, H=128, S=512, nthreads=8)["records"])
+    assert len(want) > 200
+    for force_peer in ("0", "1"):
+        monkeypatch.setenv("MHAP_GROUP_FORCE_PEER", force_peer)
+        with MinHashSearchGroup(p, n=3, devices=[0, 0, 0]) as g:
+            for r in range(3):
+                g.rank(r).dist_set_eager(True)
+            g.add_data(fa)
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want
+            assert [g.rank(r).dist_eager_searches() for r in range(3)] == [1, 1, 1]
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want            # the gathered rows are still those of the index
+            assert g.rank(0).dist_eager_searches() == 2
+            g.clear()                                                                     # two adds: the second cannot gather eagerly
+            g.add_data(fa.subset(np.arange(0, 250)))
+            g.add_data(fa.subset(np.arange(250, len(fa))))
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want
+            assert g.rank(0).dist_eager_searches() == 2
+            g.clear()
+            g.add_data(fa)                                                                # ... and eager again
+            assert sorted(mhap_amd.records_to_lines(g.find_matches())) == want
+            assert g.rank(1).dist_eager_searches() == 3
+            g.clear()
+            two = fa.subset(np.arange(2))                                                 # rank 2 gets no read: everybody falls back
+            g.add_data(two)
+            assert len(g.find_matches()) == len(O.run_self(two, H=128, S=512, nthreads=2)["records"])
+    monkeypatch.delenv("MHAP_GROUP_FORCE_PEER")
+    with MinHashSearch(p) as ms:                                                          # one RCCL rank
+        ms.dist_init(0, 1, MinHashSearch.dist_unique_id())
+        ms.dist_set_eager(True)
+        ms.add_data(fa)
+        assert sorted(mhap_amd.records_to_lines(ms.dist_find_matches())) == want and ms.dist_eager_searches() == 1
+        ms.clear()
+        monkeypatch.setenv("MHAP_BATCH_BASES", "400000")                                  # several launch groups: not eligible
+        ms.add_data(fa)
+        monkeypatch.delenv("MHAP_BATCH_BASES")
+        assert sorted(mhap_amd.records_to_lines(ms.dist_find_matches())) == want and ms.dist_eager_searches() == 1
+
+
 def test_group_survives_a_failing_rank_and_reports_its_reason(monkeypatch):
     """One rank of a group of three fails BEFORE it reaches the exchange (its shard is not made of sketched reads): the other ranks,
     already at the hub's barrier, are released instead of waiting for ever; the group reports the failing rank's reason, not a
