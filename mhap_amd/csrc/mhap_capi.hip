@@ -90,8 +90,7 @@ struct mhap_handle {
   int oj_per_cu[3] = {0, 0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (per shape) at ordered sketch size oj_per_cu_S
   int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = alone, 2 = pair, 3 = team
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
-  hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr, ev_ix_fork = nullptr, ev_ix_join = nullptr, ev_ord_join = nullptr;
-  hipStream_t ord_stream = nullptr, ord_stream_lo = nullptr;   // the ordered-sketch kernel next to the MinHash launch (MHAP_ORDERED_OVERLAP)
+  hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr, ev_ix_fork = nullptr, ev_ix_join = nullptr;
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
   bool inv_ready = false; int64_t inv_ne = 0;
   uint64_t index_gen = 0;   // bumped by every change of the entry set (the eager exchange's rows describe one generation)
@@ -471,16 +470,11 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     unsigned long long lens[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(lens, ctr + 4, 16, hipMemcpyDeviceToHost, h->stream));
     { const int rs = sync_stream(h); if (rs != MHAP_OK) return rs; }
-    // MHAP_ORDERED_OVERLAP=1|2: the ordered-sketch kernel (independent of the MinHash rows: it reads the strands only) on a side
-    // stream of its own (2: of the lowest priority), launched right behind the persistent MinHash grid instead of after it
-    int ord_mode = 0;
-    if (const char* e = getenv("MHAP_ORDERED_OVERLAP")) ord_mode = atoi(e);
-    hipStream_t ost = h->stream;
-    if (ord_mode == 1) ost = h->ord_stream;
-    if (ord_mode == 2) {
-      if (!h->ord_stream_lo) { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIPCHK(h, hipStreamCreateWithPriority(&h->ord_stream_lo, hipStreamNonBlocking, lo)); }
-      ost = h->ord_stream_lo;
-    }
+    // (Round 4 measured the ordered-sketch kernel — it only reads the strands — on a side stream next to the MinHash launch, with equal
+    //  and with lowest priority, and next to the weight kernel: 107.4 -> 107.6-108.4 and 108.1 -> 110-111.6 ms at C2.  It trickles
+    //  through the persistent MinHash grid's slots for 60-90 ms and slows that kernel by what it gains; the weight kernel and it both
+    //  live on the LDS pipe.  One stream it is.)
+    const hipStream_t ost = h->stream;
     auto do_ordered = [&]() -> int {
       time_begin(h, MHAP_K_ORDERED, ost);
       launch_ordered(ost, dd, nstr, max_len_codes, B.max_len, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
@@ -492,7 +486,6 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     if (eager_x) {
       // eager exchange: the ordered rows first (they do not depend on the MinHash rows), so that their all-gather — 6/7 of the bytes
       // a rank sends — runs under the MinHash kernel; its copy engines / RCCL workgroups are in place before the persistent grid starts
-      ost = h->stream;
       (void)do_ordered();
       ordered_done = true;
       const int rxo = dist_eager_ordered(h, h->stream, ord_rows);
@@ -503,7 +496,6 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
                    h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
                    meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(), h->jump_w1_tbl.as<uint64_t>(),
                    h->mhmerge.as<unsigned long long>(), std::max(0, B.max_len - k + 1));
-    if (ost != h->stream && !ordered_done) { (void)do_ordered(); HIPCHK(h, hipEventRecord(h->ev_ord_join, ost)); }   // (the stream was idle: the host waited for the weight kernel)
     HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
     HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
     time_end_at(h, t_mh);
@@ -519,9 +511,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       HIPCHK(h, hipEventRecord(h->ev_ix_join, h->mh_stream));
       eager_launched = true;
     }
-    if (ordered_done) { }
-    else if (ost == h->stream) (void)do_ordered();
-    else HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ord_join, 0));
+    if (!ordered_done) (void)do_ordered();
     DBGSYNC(h, "ordered");
     HIPCHK(h, hipGetLastError());
     if (eager_launched) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ix_join, 0));
@@ -1012,8 +1002,7 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (hipStreamCreateWithFlags(&h->mh_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_mh_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&h->ev_mh_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_ix_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&h->ev_ix_join, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_ord_join, hipEventDisableTiming) != hipSuccess ||
-      hipStreamCreateWithFlags(&h->ord_stream, hipStreamNonBlocking) != hipSuccess) { seterr("cannot create the side streams"); mhap_destroy(h); return MHAP_E_HIP; }
+      hipEventCreateWithFlags(&h->ev_ix_join, hipEventDisableTiming) != hipSuccess) { seterr("cannot create the side streams"); mhap_destroy(h); return MHAP_E_HIP; }
   h->Hrow = std::max(1, P.num_hashes);
   int cap = 1; while (cap < P.ordered_sketch_size) cap <<= 1;
   h->ord_cap = cap;
@@ -1077,9 +1066,6 @@ void mhap_destroy(mhap_handle* h) {
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev_mh_fork) (void)hipEventDestroy(h->ev_mh_fork);
   if (h->ev_mh_join) (void)hipEventDestroy(h->ev_mh_join);
-  if (h->ev_ord_join) (void)hipEventDestroy(h->ev_ord_join);
-  if (h->ord_stream) (void)hipStreamDestroy(h->ord_stream);
-  if (h->ord_stream_lo) (void)hipStreamDestroy(h->ord_stream_lo);
   if (h->ev_ix_fork) (void)hipEventDestroy(h->ev_ix_fork);
   if (h->ev_ix_join) (void)hipEventDestroy(h->ev_ix_join);
   if (h->mh_stream) (void)hipStreamDestroy(h->mh_stream);

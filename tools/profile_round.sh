@@ -1,30 +1,35 @@
-# final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload (run on the GPU box); ROUND=r03 bash tools/profile_round.sh
+# final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload, the other configurations' bench lines, one rank of an
+# N-GPU job, the native driver end to end (run on the GPU box); ROUND=r04 bash tools/profile_round.sh
 export TMPDIR=/tmp
-R=${ROUND:-r03}
-mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix
+R=${ROUND:-r04}
+mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix gpurun_out/$R
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o prof --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_final/bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace -d gpurun_out/pmc_$c -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$c/bench.log 2>&1
 done
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d gpurun_out/pmc_mix -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_mix/bench.log 2>&1
-mkdir -p gpurun_out/$R
 cp $(find gpurun_out/prof_final -name "prof_kernel_stats.csv" | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats.csv
 python tools/pmc_summary.py $(find gpurun_out/pmc_FETCH_SIZE -name "pmc_counter_collection.csv" | head -1) $(find gpurun_out/pmc_WRITE_SIZE -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_traffic.json
-grep -h "minhash_" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) | cut -c1-60,400- | head -20 > /dev/null
 head -1 $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_minhash_instmix.csv
 grep -h "minhash_" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) >> gpurun_out/$R/${R}_pmc_minhash_instmix.csv
 cp gpurun_out/$R/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json   # bench.py reads the byte counts from profiles/ (same source digest)
-timeout 600 python bench.py > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
+timeout 900 python bench.py > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
 tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
 MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
 for c in c1 c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_out/$R/${R}_bench_$c.json 2>/dev/null; done
-ls -la gpurun_out/$R
-# round 3 additions: the whole of configs[3] on one GPU, one rank of an N-GPU job, the native driver end to end, the C5 slice's kernels
+# configs[3] in full and one rank's share of configs[4] on one GPU, one rank of an N-GPU job (gathered rows of the other ranks in HBM), the native driver end to end
 timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c4.json 2>/dev/null
-for n in 2 4 8; do python tools/emulate_rank.py $n 2>/dev/null | tail -1; done > gpurun_out/$R/${R}_emulate_rank.txt
+timeout 1200 python bench.py --config c5rank --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c5rank.json 2>/dev/null
+(for n in 2 4 8; do python tools/emulate_rank.py $n c2 4 2>/dev/null | tail -1; done; python tools/emulate_rank.py 8 c4 3 2>/dev/null | tail -1; python tools/emulate_rank.py 8 c5 1 2>/dev/null | tail -1) > gpurun_out/$R/${R}_emulate_rank.txt
 (bash tools/e2e_probe.sh c2; bash tools/e2e_probe.sh c4) > gpurun_out/$R/${R}_e2e_probe.txt 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 2 --warmup 1 --config c5slice > /dev/null 2>&1
-cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats_c5slice.csv
-[ -x tools/bin/vgpr_bank ] && tools/bin/vgpr_bank > gpurun_out/$R/${R}_vgpr_bank_probe.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 1 --config c5rank > /dev/null 2>&1
+cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats_c5rank.csv
+# the planted family at 1 % and at 5 % divergence, one rank's size, first 40 000 queries (what the c5rank configuration was chosen from)
+(python tools/c5_probe.py 625000 40000 0.01 2>/dev/null | tail -1; python tools/c5_probe.py 625000 40000 0.05 2>/dev/null | tail -1; python tools/c5_probe.py 160000 160000 0.01 2>/dev/null | tail -1) > gpurun_out/$R/${R}_c5_probe.txt
+# where the pairs of the second stage end (diagnostic build of the join kernel)
+if [ -f mhap_amd/lib/variants/libmhaphip_ojstats.so ]; then
+  (MHAP_LIB_PATH=mhap_amd/lib/variants/libmhaphip_ojstats.so python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -1 | sed 's/^/c2: /'
+   MHAP_LIB_PATH=mhap_amd/lib/variants/libmhaphip_ojstats.so python bench.py --config c5slice --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -1 | sed 's/^/c5slice: /') > gpurun_out/$R/${R}_join_exit_stats.txt
+fi
 timeout 400 python tools/check_elements.py c5slice 2>/dev/null | tail -1 > gpurun_out/$R/${R}_check_elements_c5slice.txt
 ls -la gpurun_out/$R
