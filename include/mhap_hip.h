@@ -356,6 +356,9 @@ int mhap_selftest_hash_windows(const char* seq, int32_t len, int32_t k, int32_t 
 int mhap_selftest_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, const int64_t* probes, int64_t np, uint8_t* out_flags,
                         int64_t* out2);
 int mhap_selftest_transpose32(uint32_t* a32);
+/* the (inter, k) identity table (J/sketch/BottomOverlapSketch.java:391-395; scores[k (k + 1) / 2 + inter], k <= S; may be NULL) and the
+ * second stage's early-reject table derived from it: pass_min[k] = smallest inter with score >= threshold for any k' >= k (S + 2 entries) */
+int mhap_selftest_pass_min(int32_t S, int32_t k2, double threshold, double* scores, int32_t* pass_min);
 int mhap_selftest_xorshift_jump(uint64_t key, int32_t nsteps, uint64_t* out);
 int mhap_selftest_xorshift_unjump(uint64_t x, int32_t nsteps, uint64_t* out);   /* the key nsteps steps before chain value x */
 /* out8 = {empty, valid(rawScore), a1, a2, b1, b2, inter, k} */

@@ -59,7 +59,7 @@ EXPORTED_SYMBOLS = [
     "mhap_get_stats", "mhap_get_kernel_times", "mhap_reset_kernel_times", "mhap_set_stream", "mhap_synchronize",
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
-    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_xorshift_jump", "mhap_selftest_xorshift_unjump", "mhap_find_matches_sketches",
+    "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_pass_min", "mhap_selftest_xorshift_jump", "mhap_selftest_xorshift_unjump", "mhap_find_matches_sketches",
     "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
     "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing", "mhap_dist_set_eager", "mhap_dist_eager_searches",
     "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",

@@ -193,11 +193,21 @@ int sync_stream(mhap_handle* h) {
 
 // identity score for every reachable (inter, k): BottomOverlapSketch.jaccardToIdentity
 // (J/sketch/BottomOverlapSketch.java:391-395) evaluated on the host so libm lives in one place.
-int build_score_table(mhap_handle* h) {
-  const int S = h->P.ordered_sketch_size;
+// pass_min[kk] = the smallest number of shared k-mers that reaches the threshold for ANY k' >= kk, read off the score table itself
+// (no monotonicity assumed): a pair with fewer joined k-mers than pass_min[lower bound of its k] cannot be accepted
+// (search_kernels.hip, poshist_kernel).  MinHashSearch.java:229 accepts score >= acceptScore.
+void build_pass_min(const std::vector<double>& tbl, int S, double threshold, std::vector<int32_t>& pm) {
+  pm.assign((size_t)S + 2, INT32_MAX);
+  for (int kk = S; kk >= 0; kk--) {
+    int32_t best = kk < S ? pm[(size_t)kk + 1] : INT32_MAX;
+    for (int it = 0; it <= kk; it++)
+      if (tbl[(size_t)score_index(it, kk)] >= threshold) { best = std::min<int32_t>(best, it); break; }
+    pm[(size_t)kk] = best;
+  }
+}
+void fill_score_table(int S, int k2, std::vector<double>& tbl) {
   const int64_t n = score_index(S, S) + 1;
-  std::vector<double> tbl((size_t)n);
-  const int k2 = h->P.ordered_kmer_size;
+  tbl.resize((size_t)n);
   parallel_for(S + 1, host_threads(), [&](int64_t lo, int64_t hi) {
     for (int64_t kk = lo; kk < hi; kk++)
       for (int64_t it = 0; it <= kk; it++) {
@@ -206,18 +216,17 @@ int build_score_table(mhap_handle* h) {
         tbl[(size_t)score_index((int)it, (int)kk)] = std::exp(-d);
       }
   }, 8);
+}
+
+int build_score_table(mhap_handle* h) {
+  const int S = h->P.ordered_sketch_size;
+  const int64_t n = score_index(S, S) + 1;
+  std::vector<double> tbl;
+  fill_score_table(S, h->P.ordered_kmer_size, tbl);
   HIPCHK(h, h->score_tbl.ensure((size_t)n * 8));
   HIPCHK(h, hipMemcpy(h->score_tbl.p, tbl.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-  // pass_min[kk] = the smallest number of shared k-mers that reaches the threshold for ANY k' >= kk, read off the table itself
-  // (no monotonicity assumed): a pair with fewer joined k-mers than pass_min[lower bound of its k] cannot be accepted
-  // (search_kernels.hip, poshist_kernel).  MinHashSearch.java:229 accepts score >= acceptScore.
-  std::vector<int32_t> pm((size_t)S + 2, INT32_MAX);
-  for (int kk = S; kk >= 0; kk--) {
-    int32_t best = kk < S ? pm[(size_t)kk + 1] : INT32_MAX;
-    for (int it = 0; it <= kk; it++)
-      if (tbl[(size_t)score_index(it, kk)] >= h->P.threshold) { best = std::min<int32_t>(best, it); break; }
-    pm[(size_t)kk] = best;
-  }
+  std::vector<int32_t> pm;
+  build_pass_min(tbl, S, h->P.threshold, pm);
   HIPCHK(h, h->pass_min_tbl.ensure(pm.size() * 4));
   HIPCHK(h, hipMemcpy(h->pass_min_tbl.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
   return MHAP_OK;
@@ -458,7 +467,8 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     DBGSYNC(h, "kmer_weights");
     int per_cu = minhash_wgs_per_cu(H);   // the launch is persistent: exactly the workgroups that can be resident
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
-    const int mblocks = h->num_cus * per_cu;   // (each launch is trimmed to the workgroups its work list can feed)
+    int mblocks = h->num_cus * per_cu;   // (each launch is trimmed to the workgroups its work list can feed)
+    if (eager_x) mblocks = std::max(per_cu, mblocks - dist_eager_reserve_wgs(h));   // (room for the all-gather's own kernels: mhap_dist.hip)
     HIPCHK(h, h->mhq.ensure(minhash_queue_bytes(2 * std::max(mblocks, 1)) * 4));   // (x4: one wave per workgroup when --num-hashes is huge)
     HIPCHK(h, h->mhmerge.ensure(minhash_merge_bytes(std::max(mblocks, 1), H)));
     // The strands with weighted k-mers are a second launch (own instantiation).  On the same stream a handful of such strands (C2:
@@ -1587,6 +1597,18 @@ int mhap_selftest_bloom(const int64_t* hashes, int64_t n, int64_t size_bloom, co
 }
 
 // in-place 32x32 bit-matrix transpose used by the bit-sliced MinHash rows (device_common.hpp: transpose32)
+// host-side: the identity table of (inter, k) and the early-reject table derived from it (GPU-less unit tests): scores[(k (k + 1) / 2) + inter]
+// for k <= S, pass_min[0 .. S + 1]
+int mhap_selftest_pass_min(int32_t S, int32_t k2, double threshold, double* scores, int32_t* pass_min) {
+  if (S < 1 || S > 8192 || k2 < 1 || !pass_min) return MHAP_E_INVALID;
+  std::vector<double> tbl; std::vector<int32_t> pm;
+  fill_score_table(S, k2, tbl);
+  build_pass_min(tbl, S, threshold, pm);
+  if (scores) memcpy(scores, tbl.data(), tbl.size() * 8);
+  memcpy(pass_min, pm.data(), pm.size() * 4);
+  return MHAP_OK;
+}
+
 int mhap_selftest_transpose32(uint32_t* a32) {
   if (!a32) return MHAP_E_INVALID;
   uint32_t a[32];

@@ -388,6 +388,17 @@ bool dist_eager_wanted(mhap_handle* h) {
   DistState* d = (DistState*)*v.dist;
   return d && d->eager;
 }
+// The ordered rows' all-gather and the persistent MinHash grid become runnable at the same moment (both wait for the ordered kernel).
+// A grid that takes every workgroup slot of every CU leaves an RCCL kernel nothing to run on until it ends — the gather would simply
+// follow the MinHash kernel.  So the grid is launched a few workgroups short (MHAP_EAGER_RESERVE_WGS, default 48 of 1024: those CUs
+// keep a free slot of four wave64s and 128 VGPRs each).  Peer copies run on the copy engines and need none.
+int dist_eager_reserve_wgs(mhap_handle* h) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d || !d->eager_go || strcmp(d->tr->name(), "rccl") != 0 || d->tr->nranks < 2) return 0;
+  if (const char* e = getenv("MHAP_EAGER_RESERVE_WGS")) { const int x = atoi(e); if (x >= 0 && x <= 512) return x; }
+  return 48;
+}
 int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool eligible) {
   HandleView v = handle_view(h);
   DistState* d = (DistState*)*v.dist;

@@ -1190,6 +1190,10 @@ constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN) + MH_OJ_P
 #ifndef MH_OJ_KEEP
 #define MH_OJ_KEEP 1
 #endif
+// (Also tried in round 4, on top of this: the WHOLE row of the other sketch loaded at once — 24 loads per lane in flight — and looked up
+//  in groups of eight blocks: one memory round trip and six LDS round trips per pair instead of eight and sixteen.  168 VGPRs, three
+//  waves per SIMD: C2 4.78 -> 6.63 ms, C5 slice 69 -> 91; capped at 128 VGPRs (four waves): 5.24 / 74.8; at two waves 9.0 / 126.  The
+//  kernel's time stays inversely proportional to the waves a CU holds; instruction-level parallelism inside a wave does not replace them.)
 constexpr int OJ_KB = 24;              // blocks of the other sketch whose positions are kept (S <= 64 * OJ_KB)
 constexpr int OJ_KIT = (OJ_KB + OJ_U - 1) / OJ_U;
 

@@ -436,3 +436,36 @@ def test_bench_preflight_without_a_gpu_reports_instead_of_hanging():
     if not torch.cuda.is_available():
         assert r.returncode == 1 and not rep["ready"] and not rep["checks"]["devices"]["ok"]
     assert set(rep["checks"]) >= {"devices", "torch_rccl_backend", "library_rccl_entry_points", "peer_access", "ipc_mode"}
+
+
+def test_early_reject_table_of_the_second_stage_is_exact():
+    """The join kernel ends a pair early when its joined k-mers inside both windows (an upper bound of the intersection) are fewer than
+    pass_min[lower bound of its k]: pass_min[k] must be the smallest intersection that reaches --threshold for ANY k' >= k, read off the
+    identity table the kernel scores with — and that table must be the oracle's jaccardToIdentity bit for bit (BottomOverlapSketch.java:391-395)."""
+    lib = api.load_library()
+    S, k2 = 200, 12
+    f = O.lib().orc_jaccard_to_identity
+    f.restype = C.c_double
+    for thr in (0.0, 0.3, 0.78, 0.95, 1.0):
+        scores = np.zeros((S + 1) * (S + 2) // 2, dtype=np.float64)
+        pm = np.zeros(S + 2, dtype=np.int32)
+        assert lib.mhap_selftest_pass_min(C.c_int32(S), C.c_int32(k2), C.c_double(thr), scores.ctypes.data_as(C.c_void_p), pm.ctypes.data_as(C.c_void_p)) == 0
+        first = np.full(S + 1, np.iinfo(np.int32).max, dtype=np.int64)         # per k: the smallest inter with score >= thr (brute force)
+        for k in range(S + 1):
+            row = scores[k * (k + 1) // 2:k * (k + 1) // 2 + k + 1]
+            if k in (0, 1, 7, 64, S):
+                want = [f(C.c_double(0.0 if k == 0 else i / k), C.c_int(k2)) for i in range(k + 1)]
+                assert np.array_equal(row.view(np.uint64), np.array(want, dtype=np.float64).view(np.uint64)), k
+            ok = np.nonzero(row >= thr)[0]
+            if len(ok):
+                first[k] = ok[0]
+        suffix = np.minimum.accumulate(first[::-1])[::-1]                      # min over k' >= k
+        assert np.array_equal(pm[:S + 1].astype(np.int64), suffix), thr
+        # the property the kernel relies on: an accepted (inter, k) is never below pass_min of any lower bound of k
+        for k in range(S + 1):
+            row = scores[k * (k + 1) // 2:k * (k + 1) // 2 + k + 1]
+            acc = np.nonzero(row >= thr)[0]
+            if len(acc):
+                assert acc.min() >= pm[:k + 1].max() or acc.min() >= pm[k], (thr, k)
+                assert all(acc.min() >= pm[kl] for kl in range(0, k + 1, max(1, k // 7)))
+    assert pm[S + 1] == np.iinfo(np.int32).max
