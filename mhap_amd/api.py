@@ -380,9 +380,9 @@ def _collect_records(call, chk):
         n, buf = state["n"], state["buf"]
         need = n + cnt
         if need > buf.shape[0]:
-            nb = np.empty(max(need, 2 * buf.shape[0]), dtype=RECORD_DTYPE)
-            nb[:n] = buf[:n]
-            state["buf"] = buf = nb
+            # grow in place: realloc of a large block is a remap of its pages, not a copy (a fresh array + copy moved gigabytes
+            # per doubling on one rank's share of BASELINE configs[4] and made the library's sink thread wait)
+            buf.resize(max(need, 2 * buf.shape[0]), refcheck=False)
         src = np.ctypeslib.as_array(C.cast(recs, C.POINTER(C.c_uint8)), shape=(cnt * RECORD_DTYPE.itemsize,))
         buf[n:need] = src.view(RECORD_DTYPE)
         state["n"] = need

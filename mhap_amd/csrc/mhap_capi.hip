@@ -139,7 +139,8 @@ struct mhap_handle {
   hipStream_t copy_stream = nullptr;
   uint8_t* pin_rec[2] = {nullptr, nullptr};
   size_t pin_rec_cap[2] = {0, 0};
-  std::vector<mhap_record> out_recs2[2];
+  mhap_record* out_recs2[2] = {nullptr, nullptr};   // (grow-only raw buffers: a vector's resize would zero-fill hundreds of MB per chunk)
+  size_t out_recs2_cap[2] = {0, 0};
   InvIndex inv{};   // device view of the inverted index in inv_ends / inv_items
   mhap_stage_gate gate = nullptr; void* gate_user = nullptr;   // mhap_set_second_stage_gate
   void* dist = nullptr;   // multi-GPU state (mhap_dist.hip)
@@ -637,8 +638,13 @@ struct PostStage {
     if (hipMemcpyAsync((void*)hrecs, src, bytes, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) {
       err = "record read-back failed"; return MHAP_E_HIP;
     }
-    std::vector<mhap_record>& out = h->out_recs2[sl];
-    out.resize((size_t)n);
+    if (h->out_recs2_cap[sl] < (size_t)n) {
+      free(h->out_recs2[sl]);
+      h->out_recs2_cap[sl] = (size_t)n + (size_t)n / 4 + 1024;
+      h->out_recs2[sl] = (mhap_record*)malloc(h->out_recs2_cap[sl] * sizeof(mhap_record));
+      if (!h->out_recs2[sl]) { h->out_recs2_cap[sl] = 0; err = "out of host memory (record buffer)"; return MHAP_E_NOMEM; }
+    }
+    mhap_record* out = h->out_recs2[sl];
     const QuerySide& q = *qs;
     parallel_for((int64_t)n, host_threads(), [&](int64_t lo, int64_t hi) {
       for (int64_t i = lo; i < hi; i++) {
@@ -655,7 +661,7 @@ struct PostStage {
       }
     });
     matches += (int64_t)n;
-    if (sink && sink(out.data(), (int64_t)n, user) != 0) { err = "record sink aborted the search"; return MHAP_E_STATE; }
+    if (sink && sink(out, (int64_t)n, user) != 0) { err = "record sink aborted the search"; return MHAP_E_STATE; }
     return MHAP_OK;
   }
   void loop() {
@@ -1072,7 +1078,7 @@ void mhap_destroy(mhap_handle* h) {
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->pin_io) (void)hipHostFree(h->pin_io);
-  for (int i = 0; i < 2; i++) if (h->pin_rec[i]) (void)hipHostFree(h->pin_rec[i]);
+  for (int i = 0; i < 2; i++) { if (h->pin_rec[i]) (void)hipHostFree(h->pin_rec[i]); free(h->out_recs2[i]); }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev_mh_fork) (void)hipEventDestroy(h->ev_mh_fork);
   if (h->ev_mh_join) (void)hipEventDestroy(h->ev_mh_join);

@@ -960,7 +960,14 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
       if (threadIdx.x < nseg) segpre[threadIdx.x] = wbase + incl - len;
       if (threadIdx.x == 0) segpre[nseg] = total;
       __syncthreads();
-      uint32_t g = 0;   // queue entry of this lane's current posting (its postings come in ascending order)
+      // this lane's current queue entry, cached in registers: its span of the index space, where its postings start, the query's mix there.
+      // (The first version looked all of that up in LDS for every posting — five dependent LDS reads in front of each load, eight
+      //  postings per trip one after the other: the address arithmetic took as long as the memory round trip it was meant to keep busy.)
+      uint32_t g = 0;
+      unsigned long long seg_beg = 0, seg_end = 0;
+      const uint2* seg_base = nullptr;
+      uint32_t seg_want = 1u;
+      bool seg_fresh = false;
       for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += DQ2_THREADS * 8) {
         uint2 e[8];
         uint32_t want[8];
@@ -970,13 +977,19 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
           const unsigned long long i = i0 + (unsigned long long)DQ2_THREADS * u;
           e[u] = make_uint2(0u, 0u); want[u] = 1u; fresh[u] = false;              // (never equal)
           if (i < total) {
-            while (i >= segpre[g + 1]) g++;
-            const uint2 key = segkey[g];
-            const uint32_t grp = key.x >> 16;
-            const uint32_t off = grp == DQ2_NOGRP ? 0u : bounds[grp * per + pass];
-            e[u] = ix.items[(size_t)(key.x & 0xFFFFu) * ix.slot_stride + (size_t)seglist[g].x + (size_t)off + (size_t)(i - segpre[g])];
-            want[u] = key.y;
-            fresh[u] = grp != DQ2_NOGRP || pass == 0;
+            if (i >= seg_end) {                                                    // (its postings come in ascending order)
+              while (i >= segpre[g + 1]) g++;
+              seg_beg = segpre[g]; seg_end = segpre[g + 1];
+              const uint2 key = segkey[g];
+              const uint32_t grp = key.x >> 16;
+              const uint32_t off = grp == DQ2_NOGRP ? 0u : bounds[grp * per + pass];
+              seg_base = ix.items + (size_t)(key.x & 0xFFFFu) * ix.slot_stride + (size_t)seglist[g].x + (size_t)off;
+              seg_want = key.y;
+              seg_fresh = grp != DQ2_NOGRP || pass == 0;
+            }
+            e[u] = seg_base[(size_t)(i - seg_beg)];
+            want[u] = seg_want;
+            fresh[u] = seg_fresh;
           }
         }
 #pragma unroll

@@ -313,6 +313,37 @@ def test_rccl_rank_of_one_and_errors_of_the_sharded_search():
             ms.dist_find_matches()
 
 
+def test_record_sink_can_abort_a_search_and_the_handle_survives(monkeypatch):
+    """The sink's return value ends the search (include/mhap_hip.h: non-zero aborts): with 128-query chunks the post stage runs on the
+    library's worker thread, one chunk behind the kernels — the abort must surface as MHAP_E_STATE without a hang, whichever chunk's
+    sink call asks for it, and the same handle must search correctly afterwards.  Also with the tails inline (MHAP_SEARCH_PIPELINE=0)."""
+    import ctypes as C
+    from mhap_amd import api
+    fa = mhap_amd.synth_reads(500, 2500, seed=77, error_rate=0.05)
+    p = MhapParams(num_hashes=64, ordered_sketch_size=256)
+    monkeypatch.setenv("MHAP_QUERY_CHUNK", "128")
+    for pipeline in ("1", "0"):
+        monkeypatch.setenv("MHAP_SEARCH_PIPELINE", pipeline)
+        with MinHashSearch(p) as ms:
+            ms.add_data(fa)
+            want = _sorted_records(ms.find_matches())
+            assert len(want) > 300
+            for stop_at in (1, 2, 3):
+                calls = {"n": 0, "recs": 0}
+
+                def sink(recs, n, user):
+                    calls["n"] += 1
+                    calls["recs"] += n
+                    return 1 if calls["n"] == stop_at else 0
+
+                cb = api._SINK(sink)
+                rc = ms._lib.mhap_find_matches_self(ms._h, C.c_int64(0), C.c_int64(-1), cb, None)
+                assert rc == -4 and b"sink aborted" in ms._lib.mhap_last_error(ms._h), (pipeline, stop_at, rc)
+                assert calls["n"] == stop_at and 0 < calls["recs"] < len(want)
+                assert np.array_equal(_sorted_records(ms.find_matches()), want)
+    monkeypatch.delenv("MHAP_SEARCH_PIPELINE")
+
+
 def test_eager_exchange_gathers_during_the_add(monkeypatch):
     """mhap_dist_set_eager on the ranks of a group (three ranks sharing this box's GPU, peer copies): the add that fills the empty
     index gathers every rank's forward rows while it computes (ordered rows behind the ordered kernel, which runs first; MinHash rows,
