@@ -1302,6 +1302,48 @@ __device__ __forceinline__ int oj_group_merge(const int32_t* pa, int m, const in
   return cnt;
 }
 
+// The same replay run by ONE LANE for its own group (STORE = false: only count the records).  A pair of repeat-rich reads has half a
+// dozen groups; replayed one after the other by the whole wave (above) they were a third of the join kernel's time on the C5 slice
+// (-DMH_OJ_NO_GROUPS timing build: 69.0 -> 44.9 ms).  With three groups or more, lane g replays group g: once to count, an exclusive
+// prefix over the lanes gives every group the place the serial order would have given it, once more to store.
+template <bool STORE>
+__device__ __forceinline__ int oj_group_merge_lane(const int32_t* pa, int m, const int32_t* pb, int n, const OjWindows& w, int32_t* o1, int32_t* o2) {
+  int i1 = 0, i2 = 0, cnt = 0;
+  while (i1 < m && i2 < n) {
+    const int p1 = pa[i1], p2 = pb[i2];
+    if (p1 < w.v1lo || p1 >= w.v1hi) { i1++; continue; }
+    if (p2 < w.v2lo || p2 >= w.v2hi) { i2++; continue; }
+    const int diff = (p2 - p1) - w.med;
+    if (diff > w.absmax) { i1++; continue; }
+    if (diff < -w.absmax) { i2++; continue; }
+    if (STORE) { o1[cnt] = p1; o2[cnt] = p2; }
+    cnt++;
+    int i1Last = i1, p1Last = p1;
+    for (int t = i1 + 1; t < m; t++) {
+      const int pt = pa[t];
+      if (!(pt >= w.v1lo && pt < w.v1hi)) break;
+      i1Last = t; p1Last = pt;
+    }
+    int i2Last = i2, p2Last = p2;
+    for (int t = i2 + 1; t < n; t++) {
+      const int pt = pb[t];
+      if (!(pt >= w.v2lo && pt < w.v2hi)) break;
+      i2Last = t; p2Last = pt;
+    }
+    if (i1 != i1Last || i2 != i2Last) {
+      if (STORE) { o1[cnt] = p1Last; o2[cnt] = p2Last; }
+      cnt++;
+      i1 = i1Last + 1; i2 = i2Last + 1;
+    } else { i1++; i2++; }
+  }
+  return cnt;
+}
+#ifndef MH_OJ_GPAR
+#define MH_OJ_GPAR 3
+#endif
+constexpr int OJ_GPAR = MH_OJ_GPAR;   // groups of a pair from which on the lanes replay them side by side
+static_assert(OJ_GCAP <= 16, "the group offsets are a prefix sum over sixteen lanes");
+
 // One recordMatchingKmers pass over the join.  Entries [0, nj) are the unique-hash joined k-mers (kept if they pass the
 // pass's windows), the groups' records are appended behind them at [nj, nj + nx).  Bit r of the result = entry r*64+lane is a
 // record of this pass; count = number of records.
@@ -1309,10 +1351,27 @@ __device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, 
                                            int len1, int len2, ShiftStats st, int lane, int& count, int& nx_out) {
   const OjWindows w = oj_windows(st, len1, len2);
   int nx = 0;
-  for (int g = 0; g < ng; g++) {
-    const int k = oj_group_merge(gpa + g * OJ_GLEN, gi[g * 6 + 2], gpb + g * OJ_GLEN, gi[g * 6 + 3], w, jp1 + nj + nx, jp2 + nj + nx, lane);
-    if (lane == 0) { gi[g * 6 + 4] = nj + nx; gi[g * 6 + 5] = k; }
-    nx += k;
+  if (ng >= OJ_GPAR) {
+    const bool mine = lane < ng;
+    const int32_t* pa = gpa + (mine ? lane : 0) * OJ_GLEN;
+    const int32_t* pb = gpb + (mine ? lane : 0) * OJ_GLEN;
+    const int m = mine ? gi[lane * 6 + 2] : 0, n = mine ? gi[lane * 6 + 3] : 0;
+    const int k = oj_group_merge_lane<false>(pa, m, pb, n, w, nullptr, nullptr);
+    int incl = k;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }   // (OJ_GCAP <= 16 groups)
+    const int at = nj + incl - k;
+    if (mine) {
+      (void)oj_group_merge_lane<true>(pa, m, pb, n, w, jp1 + at, jp2 + at);
+      gi[lane * 6 + 4] = at; gi[lane * 6 + 5] = k;
+    }
+    nx = __builtin_amdgcn_readlane(incl, 15);
+  } else {
+    for (int g = 0; g < ng; g++) {
+      const int k = oj_group_merge(gpa + g * OJ_GLEN, gi[g * 6 + 2], gpb + g * OJ_GLEN, gi[g * 6 + 3], w, jp1 + nj + nx, jp2 + nj + nx, lane);
+      if (lane == 0) { gi[g * 6 + 4] = nj + nx; gi[g * 6 + 5] = k; }
+      nx += k;
+    }
   }
   if (ng) oj_lds_sync();
   uint32_t fl = 0;
@@ -1472,8 +1531,10 @@ static_assert(OJ_KIT <= 13, "OJ_KEEP_SWITCH covers 13 trips");
 //                 by one from an LDS counter.
 // SHARED = false: every wave works alone — pulls its own chunks, keeps its own hashes.
 // (the shapes in use and what each is for: OJ_ALONE / OJ_PAIR / OJ_TEAM below)
+// (the TEAM shape — candidate-rich queries, pairs with many duplicated-hash groups — collects three groups per round, which costs it
+//  registers: it is held at 96 VGPRs = five waves per SIMD, 8-16 B of scratch; the other shapes keep the one-group loop and their 93)
 template <bool SHARED, int WAVES, bool TABLE>
-__global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABLE ? 5 : 4, 8))) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                                      unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                                      int64_t ord_stride, const int32_t* __restrict__ meta,
                                                                      const int32_t* __restrict__ qordered, int64_t qord_stride,
@@ -1631,7 +1692,37 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
         }
       }
       oj_lds_sync();
+#ifdef MH_OJ_NO_GROUPS
+      ng = 0;   // (timing experiment: the duplicated-hash groups are dropped; results are wrong)
+#endif
       int gtot = 0;
+      if constexpr (TABLE) {
+      // collect the groups' entries, THREE groups per round (each round waits for a load from the other sketch's row): lanes 20 t .. 20 t + 8
+      // read the query's entries of the round's t-th group, lanes 20 t + 10 .. 20 t + 18 the other sketch's
+      for (int g0 = 0; g0 < ng && !bad; g0 += 3) {
+        const int t = lane / 20, r = lane - 20 * t;           // lanes 60..63: t = 3, idle
+        const int g = g0 + t;
+        const bool live = t < 3 && g < ng;
+        const int x = r < 10 ? r : r - 10;
+        const int lo = live ? gi[g * 6 + 0] : 0, j = live ? gi[g * 6 + 1] : 0;
+        const int h = ah[lo];
+        const bool a_ok = live && r <= OJ_GLEN && lo + x < nA && ah[lo + x] == h;
+        uint2 be = make_uint2(0u, 0u);
+        const bool b_in = live && r >= 10 && r <= 10 + OJ_GLEN && j + x < nB;
+        if (b_in) be = brow[j + x];
+        const bool b_ok = b_in && (int)be.x == h;
+        const unsigned long long bala = __ballot(a_ok), balb = __ballot(b_ok);
+        const int sh = 20 * (t < 3 ? t : 0);
+        const int m = __popcll((bala >> sh) & 0x3FFULL), nn = __popcll((balb >> (sh + 10)) & 0x3FFULL);
+        if (__any(live && (m > OJ_GLEN || nn > OJ_GLEN))) { bad = true; break; }
+        if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
+        if (b_ok) gpb[g * OJ_GLEN + x] = (int)be.y;
+        if (live && r == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; }
+#pragma unroll
+        for (int tt = 0; tt < 3; tt++)
+          if (g0 + tt < ng) gtot += __popcll((bala >> (20 * tt)) & 0x3FFULL) + __popcll((balb >> (20 * tt + 10)) & 0x3FFULL);
+      }
+      } else {
       for (int g = 0; g < ng && !bad; g++) {   // collect the groups' entries: lanes 0..8 the query's, lanes 16..24 the other sketch's
         const int lo = gi[g * 6 + 0], j = gi[g * 6 + 1];
         const int h = ah[lo];
@@ -1644,6 +1735,7 @@ __global__ __launch_bounds__(64 * WAVES) void overlap_join_kernel(const Candidat
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)brow[j + x].y;
         if (lane == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; }
         gtot += m + nn;
+      }
       }
       if (nj + gtot > OJ_JCAP) bad = true;
       if (bad) {
