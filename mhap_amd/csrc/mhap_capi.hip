@@ -866,7 +866,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
       // (C2: 4.5 candidates per query — alone 4.94, pair 4.83, team 5.03 ms; C5 slice: 79 — alone 93, pair 87, team 77; a rank of eight,
       //  0.56 per query: alone 0.86, pair 1.24)
-      int shape = (int64_t)ncand >= 16LL * nq ? 2 : ((int64_t)ncand >= 2LL * nq ? 1 : 0);
+      int shape = (int64_t)ncand >= 4LL * nq ? 2 : ((int64_t)ncand >= 2LL * nq ? 1 : 0);
       if (h->join_mode > 0) shape = h->join_mode - 1;
       while (!fits[shape]) shape = (shape + 1) % 3;
       if (h->oj_per_cu_S != S) {
@@ -970,6 +970,10 @@ int internal_stage_packed(mhap_handle* h, const ReadDesc* descs, const int64_t* 
   h->st_bytes = (int64_t)need;
   return MHAP_OK;
 }
+
+// the sharded search's call of mhap_find_matches_device: the gathered ids are in device memory already
+int internal_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                                 const int64_t* d_ids_dev, int64_t m, int to_self, mhap_record_sink sink, void* user);
 
 // -q mode of the sharded search: sketch n query reads (forward strands only, AbstractMatchSearch.java:225,236) into caller tables
 // laid out like an index's (row 2i = read i's forward strand)
@@ -1459,26 +1463,41 @@ int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t
   return search_core(h, qs, ql, false, false, sink, user);
 }
 
-int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
-                             int64_t m, int to_self, mhap_record_sink sink, void* user) {
+// (d_ids_dev: the ids as they already sit in device memory — the sharded search has them from its gather — or NULL: uploaded here)
+static int find_matches_device_impl(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                                    const int64_t* d_ids_dev, int64_t m, int to_self, mhap_record_sink sink, void* user) {
   if (!h) return MHAP_E_INVALID;
   if (m <= 0) return MHAP_OK;
   if (!d_q_minhash || !d_q_ordered || !d_q_meta || !ids) return fail(h, MHAP_E_INVALID, "null argument");
   if (m > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "too many query rows");
   (void)hipSetDevice(h->device);
   const int S = h->P.ordered_sketch_size;
-  std::vector<int32_t> meta((size_t)m * META_W);
-  HIPCHK(h, hipMemcpy(meta.data(), d_q_meta, meta.size() * 4, hipMemcpyDeviceToHost));
+  // the rows' meta words come to the host through the pinned bounce buffer (lengths for the records, statuses for the query list), and
+  // the ids go up — unless they are on the device already — while the host walks them: on one rank of eight this preparation was
+  // 0.4 ms of a 3.9 ms search
+  const size_t mbytes = (size_t)m * META_W * 4;
+  const int32_t* meta = (const int32_t*)pinned_io(h, mbytes);
+  if (!meta) return fail(h, MHAP_E_HIP, "cannot allocate pinned host memory");
+  if (!d_ids_dev) {
+    HIPCHK(h, h->q_ids.ensure((size_t)m * 8));
+    HIPCHK(h, hipMemcpyAsync(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));   // (ordered before the search's kernels)
+  }
+  HIPCHK(h, hipMemcpyAsync((void*)meta, d_q_meta, mbytes, hipMemcpyDeviceToHost, h->copy_stream));
+  HIPCHK(h, hipStreamSynchronize(h->copy_stream));
   std::vector<int32_t> qlen((size_t)m), ql;
+  ql.reserve((size_t)m);
   for (int64_t e = 0; e < m; e++) {
     qlen[(size_t)e] = meta[(size_t)e * META_W + 2];
     if (meta[(size_t)e * META_W + 3] == 0) ql.push_back((int32_t)e);
   }
-  HIPCHK(h, h->q_ids.ensure((size_t)m * 8));
-  HIPCHK(h, hipMemcpy(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice));
-  QuerySide qs{(const int32_t*)d_q_minhash, h->Hrow, (const int32_t*)d_q_ordered, 2LL * S, (const int32_t*)d_q_meta, h->q_ids.as<int64_t>(), ids,
-               qlen.data(), m};
+  QuerySide qs{(const int32_t*)d_q_minhash, h->Hrow, (const int32_t*)d_q_ordered, 2LL * S, (const int32_t*)d_q_meta,
+               d_ids_dev ? d_ids_dev : h->q_ids.as<int64_t>(), ids, qlen.data(), m};
   return search_core(h, qs, ql, to_self != 0, false, sink, user);
+}
+
+int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                             int64_t m, int to_self, mhap_record_sink sink, void* user) {
+  return find_matches_device_impl(h, d_q_minhash, d_q_ordered, d_q_meta, ids, nullptr, m, to_self, sink, user);
 }
 
 int mhap_set_second_stage_gate(mhap_handle* h, mhap_stage_gate gate, void* user) {
@@ -1638,3 +1657,10 @@ int mhap_selftest_overlap_lane(const int32_t* A, int32_t nA, int32_t lenA, const
 }
 
 }  // extern "C"
+
+namespace mhap {
+int internal_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                                 const int64_t* d_ids_dev, int64_t m, int to_self, mhap_record_sink sink, void* user) {
+  return find_matches_device_impl(h, d_q_minhash, d_q_ordered, d_q_meta, ids, d_ids_dev, m, to_self, sink, user);
+}
+}  // namespace mhap

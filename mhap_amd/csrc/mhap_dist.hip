@@ -368,7 +368,7 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   DCHK(v, hipMemcpy(d->ids_all.data(), d->g_ids.p, (size_t)N * np * 8, hipMemcpyDeviceToHost));
   d->t_small = now_ms() - t0;
   rc = mhap_set_second_stage_gate(h, gate_cb, d); if (rc != MHAP_OK) return rc;
-  rc = mhap_find_matches_device(h, d->g_mh.p, d->g_od.p, d->g_mt.p, d->ids_all.data(), (int64_t)N * n_pad, to_self, sink, user);
+  rc = internal_find_matches_device(h, d->g_mh.p, d->g_od.p, d->g_mt.p, d->ids_all.data(), d->g_ids.as<int64_t>(), (int64_t)N * n_pad, to_self, sink, user);
   (void)mhap_set_second_stage_gate(h, nullptr, nullptr);
   if (rc != MHAP_OK && !d->gate_err.empty()) *v.err = d->gate_err;   // (the gate's reason, not "the gate aborted the search")
   d->gate_err.clear();

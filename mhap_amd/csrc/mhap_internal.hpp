@@ -90,6 +90,8 @@ int internal_stage_packed(mhap_handle* h, const ReadDesc* descs, const int64_t* 
 struct FastaScanImpl;
 int ingest_add_subset(mhap_handle* h, const FastaScanImpl* scan, int64_t start, int64_t stride);
 const FastaScanImpl* scan_impl(const mhap_fasta_scan* s);
+int internal_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,
+                                 const int64_t* d_ids_dev, int64_t m, int to_self, mhap_record_sink sink, void* user);
 int internal_sketch_queries(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, int64_t n, void* d_mh, void* d_od, void* d_mt);
 
 }  // namespace mhap

@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
 // hashes (the two-pointer merge has no run there), and record ORDER only matters to optimizeShifts, which merges
 // neighbouring records of one query position, i.e. of one hash.  A hash that is duplicated in either sketch forms a
 // "group": the merge's run logic (:460-496), optimizeShifts and the one-to-one pairing of the Jaccard walk are replayed
-// literally on the group's few entries (oj_group_merge etc., wave-uniform), and its records join the others.  Pairs
+// literally on the group's few entries (oj_group_merge_lane etc.), and its records join the others.  Pairs
 // beyond the caps below (joined k-mers, groups, group length) are appended to `slow` for overlap_kernel's literal merge.
 // =============================================================================================
 #ifndef MH_OJ_WAVES
@@ -1249,7 +1249,7 @@ __device__ __forceinline__ ShiftStats oj_shift_stats(bool have, int med, int len
 #ifdef MH_OJ_STATS
 // (diagnostic build: where the pairs of the join kernel end — {nj < 3, no record in pass 1, in pass 2, < 3 valid, below the threshold,
 //  accepted, sum of nj, sum of in-window joined k-mers of the scored pairs}; printed by launch_overlap_join's caller through oj_stats_dump)
-__device__ unsigned long long g_oj_stats[8];
+__device__ unsigned long long g_oj_stats[16];
 #define OJ_STAT(k, v) do { if (lane == 0) atomicAdd(&g_oj_stats[k], (unsigned long long)(v)); } while (0)
 #else
 #define OJ_STAT(k, v) do { } while (0)
@@ -1267,46 +1267,10 @@ __device__ __forceinline__ OjWindows oj_windows(ShiftStats st, int len1, int len
 
 // recordMatchingKmers restricted to one hash value that is duplicated in at least one sketch: pa[0..m) / pb[0..n) are the
 // positions of ALL entries with that hash (ascending), and the loop below is the reference's, run on just those entries
-// (entries of other hashes end a run exactly like the end of these arrays does).  Wave-uniform: every lane walks the same
-// few LDS words; lane 0 stores the records.  Returns the number of records written to o1/o2.
-__device__ __forceinline__ int oj_group_merge(const int32_t* pa, int m, const int32_t* pb, int n, const OjWindows& w, int32_t* o1, int32_t* o2,
-                                              int lane) {
-  int i1 = 0, i2 = 0, cnt = 0;
-  while (i1 < m && i2 < n) {
-    const int p1 = pa[i1], p2 = pb[i2];
-    if (p1 < w.v1lo || p1 >= w.v1hi) { i1++; continue; }
-    if (p2 < w.v2lo || p2 >= w.v2hi) { i2++; continue; }
-    const int diff = (p2 - p1) - w.med;
-    if (diff > w.absmax) { i1++; continue; }
-    if (diff < -w.absmax) { i2++; continue; }
-    if (lane == 0) { o1[cnt] = p1; o2[cnt] = p2; }
-    cnt++;
-    int i1Last = i1, p1Last = p1;
-    for (int t = i1 + 1; t < m; t++) {
-      const int pt = pa[t];
-      if (!(pt >= w.v1lo && pt < w.v1hi)) break;
-      i1Last = t; p1Last = pt;
-    }
-    int i2Last = i2, p2Last = p2;
-    for (int t = i2 + 1; t < n; t++) {
-      const int pt = pb[t];
-      if (!(pt >= w.v2lo && pt < w.v2hi)) break;
-      i2Last = t; p2Last = pt;
-    }
-    if (i1 != i1Last || i2 != i2Last) {
-      if (lane == 0) { o1[cnt] = p1Last; o2[cnt] = p2Last; }
-      cnt++;
-      i1 = i1Last + 1; i2 = i2Last + 1;
-    } else { i1++; i2++; }
-  }
-  return cnt;
-}
-
-// The same replay run by ONE LANE for its own group (STORE = false: only count the records).  A pair of repeat-rich reads has half a
-// dozen groups; replayed one after the other by the whole wave (above) they were a third of the join kernel's time on the C5 slice
-// (-DMH_OJ_NO_GROUPS timing build: 69.0 -> 44.9 ms).  With three groups or more, lane g replays group g: once to count, an exclusive
-// prefix over the lanes gives every group the place the serial order would have given it, once more to store.
-template <bool STORE>
+// (entries of other hashes end a run exactly like the end of these arrays does).  Run by ONE LANE for its own group: a pair of
+// repeat-rich reads has half a dozen groups, and replayed one after the other by the whole wave they were a third of the join
+// kernel's time on the C5 slice (-DMH_OJ_NO_GROUPS timing build: 69.0 -> 44.9 ms).  Returns the number of records written to o1/o2:
+// at most two for every three entries the walk consumes, so a group's records fit the m + n words its entries reserve (oj_pass).
 __device__ __forceinline__ int oj_group_merge_lane(const int32_t* pa, int m, const int32_t* pb, int n, const OjWindows& w, int32_t* o1, int32_t* o2) {
   int i1 = 0, i2 = 0, cnt = 0;
   while (i1 < m && i2 < n) {
@@ -1316,7 +1280,7 @@ __device__ __forceinline__ int oj_group_merge_lane(const int32_t* pa, int m, con
     const int diff = (p2 - p1) - w.med;
     if (diff > w.absmax) { i1++; continue; }
     if (diff < -w.absmax) { i2++; continue; }
-    if (STORE) { o1[cnt] = p1; o2[cnt] = p2; }
+    o1[cnt] = p1; o2[cnt] = p2;
     cnt++;
     int i1Last = i1, p1Last = p1;
     for (int t = i1 + 1; t < m; t++) {
@@ -1331,49 +1295,33 @@ __device__ __forceinline__ int oj_group_merge_lane(const int32_t* pa, int m, con
       i2Last = t; p2Last = pt;
     }
     if (i1 != i1Last || i2 != i2Last) {
-      if (STORE) { o1[cnt] = p1Last; o2[cnt] = p2Last; }
+      o1[cnt] = p1Last; o2[cnt] = p2Last;
       cnt++;
       i1 = i1Last + 1; i2 = i2Last + 1;
     } else { i1++; i2++; }
   }
   return cnt;
 }
-#ifndef MH_OJ_GPAR
-#define MH_OJ_GPAR 3
-#endif
-constexpr int OJ_GPAR = MH_OJ_GPAR;   // groups of a pair from which on the lanes replay them side by side
-static_assert(OJ_GCAP <= 16, "the group offsets are a prefix sum over sixteen lanes");
+static_assert(OJ_GCAP <= 64, "lane g replays group g");
 
 // One recordMatchingKmers pass over the join.  Entries [0, nj) are the unique-hash joined k-mers (kept if they pass the
-// pass's windows), the groups' records are appended behind them at [nj, nj + nx).  Bit r of the result = entry r*64+lane is a
-// record of this pass; count = number of records.
-__device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, int ng, int32_t* gi, const int32_t* gpa, const int32_t* gpb,
-                                           int len1, int len2, ShiftStats st, int lane, int& count, int& nx_out) {
+// pass's windows); behind them every group owns as many words as it has entries ([gi[4], gi[4] + m + n), nx words in all: laid out
+// when the groups were collected), lane g replays group g into the first of them and marks the rest unused — the order of the
+// records matters inside a group only (optimizeShifts), so nothing has to be counted or compacted first.  (Round 4's first version
+// replayed every group twice — to count, then, after a prefix sum over the lanes, to store contiguously — and groups of fewer than
+// three one after the other by the whole wave.)  Bit r of the result = entry r*64+lane is a record of this pass; count = their number.
+__device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, int ng, int nx, int32_t* gi, const int32_t* gpa, const int32_t* gpb,
+                                           int len1, int len2, ShiftStats st, int lane, int& count) {
   const OjWindows w = oj_windows(st, len1, len2);
-  int nx = 0;
-  if (ng >= OJ_GPAR) {
-    const bool mine = lane < ng;
-    const int32_t* pa = gpa + (mine ? lane : 0) * OJ_GLEN;
-    const int32_t* pb = gpb + (mine ? lane : 0) * OJ_GLEN;
-    const int m = mine ? gi[lane * 6 + 2] : 0, n = mine ? gi[lane * 6 + 3] : 0;
-    const int k = oj_group_merge_lane<false>(pa, m, pb, n, w, nullptr, nullptr);
-    int incl = k;
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }   // (OJ_GCAP <= 16 groups)
-    const int at = nj + incl - k;
-    if (mine) {
-      (void)oj_group_merge_lane<true>(pa, m, pb, n, w, jp1 + at, jp2 + at);
-      gi[lane * 6 + 4] = at; gi[lane * 6 + 5] = k;
+  if (ng) {
+    if (lane < ng) {
+      const int m = gi[lane * 6 + 2], n = gi[lane * 6 + 3], at = gi[lane * 6 + 4];
+      const int k = oj_group_merge_lane(gpa + lane * OJ_GLEN, m, gpb + lane * OJ_GLEN, n, w, jp1 + at, jp2 + at);
+      for (int x = k; x < m + n; x++) jp1[at + x] = INT32_MIN;
+      gi[lane * 6 + 5] = k;
     }
-    nx = __builtin_amdgcn_readlane(incl, 15);
-  } else {
-    for (int g = 0; g < ng; g++) {
-      const int k = oj_group_merge(gpa + g * OJ_GLEN, gi[g * 6 + 2], gpb + g * OJ_GLEN, gi[g * 6 + 3], w, jp1 + nj + nx, jp2 + nj + nx, lane);
-      if (lane == 0) { gi[g * 6 + 4] = nj + nx; gi[g * 6 + 5] = k; }
-      nx += k;
-    }
+    oj_lds_sync();
   }
-  if (ng) oj_lds_sync();
   uint32_t fl = 0;
   int cnt = 0;
 #pragma unroll
@@ -1385,53 +1333,111 @@ __device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, 
         const int p1 = jp1[t], p2 = jp2[t];
         const int diff = (p2 - p1) - w.med;
         ok = p1 >= w.v1lo && p1 < w.v1hi && p2 >= w.v2lo && p2 < w.v2hi && !(diff > w.absmax) && !(diff < -w.absmax);
-      } else if (t < nj + nx) ok = true;
+      } else if (t < nj + nx) ok = jp1[t] != INT32_MIN;
       fl |= (ok ? 1u : 0u) << r;
       cnt += __popcll(__ballot(ok));
     }
   }
   count = cnt;
-  nx_out = nx;
   return fl;
 }
 
-// k-th smallest (k = count / 2) of the records' shifts = Utils.quickSelect(shifts, count / 2, count)
-__device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t* jp2, int32_t* sh, uint32_t fl, int ntot, int count, int lane) {
-  int myv[OJ_R], myidx[OJ_R], less[OJ_R];
-  int base = 0;
+// k-th smallest (k = count / 2) of the records' shifts = Utils.quickSelect(shifts, count / 2, count): the value, bit by bit from the
+// top — of the records still in the running, those with a 0 in the bit are the smaller ones; the k-th is among them or k moves past
+// them.  The records' lanes are scalar masks, so a bit costs two vector instructions per round of 64 records and a handful of scalar
+// ones: 15 bits for 10-kb reads.  (Round 3 counted, for every record, the records below it — one LDS broadcast and four vector
+// instructions per record and round: with the 40 records of a typical C2 pair, three times the instructions; and this kernel is
+// bound by the instructions it issues — at five waves per SIMD more resident waves no longer help it.  That way stays for pairs
+// of a dozen records or fewer, where it is the shorter one.)
+// A shift is p2 - p1 with 0 <= p1 < len1, 0 <= p2 < len2: biased by 2^lb > max(len1, len2) it is a positive (lb + 1)-bit number.
+constexpr int OJ_MED_SMALL = 12;   // up to this many records the median is found by counting (below)
+__device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t* jp2, int32_t* sh, uint32_t fl, int ntot, int count, int lane, int lb) {
+  if (count <= OJ_MED_SMALL) {
+    // a handful of records (a pair that shares a repeat's k-mers and nothing else): every record counts the records below it —
+    // one LDS broadcast and a few instructions per record, fewer than the lb + 1 bit steps
+    int myv[OJ_R], myidx[OJ_R], less[OJ_R];
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < OJ_R; r++) {
+      myv[r] = 0; myidx[r] = 0; less[r] = 0;
+      if (r * 64 < ntot) {
+        const bool ok = (fl >> r) & 1u;
+        const unsigned long long bal = __ballot(ok);
+        if (ok) {
+          const int t = r * 64 + lane;
+          myv[r] = jp2[t] - jp1[t];
+          myidx[r] = base + oj_mbcnt(bal);
+          sh[myidx[r]] = myv[r];
+        }
+        base += __popcll(bal);
+      }
+    }
+    oj_lds_sync();
+    for (int u = 0; u < count; u++) {
+      const int v = sh[u];   // same address in every lane: LDS broadcast
+#pragma unroll
+      for (int r = 0; r < OJ_R; r++)
+        if (r * 64 < ntot) less[r] += (v < myv[r] || (v == myv[r] && u < myidx[r])) ? 1 : 0;
+    }
+    const int k = count / 2;
+    int med = 0;
+#pragma unroll
+    for (int r = 0; r < OJ_R; r++) {
+      if (r * 64 < ntot) {
+        const unsigned long long bal = __ballot(((fl >> r) & 1u) && less[r] == k);
+        if (bal) med = __builtin_amdgcn_readlane(myv[r], __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return med;
+  }
+  uint32_t key[OJ_R];
+  unsigned long long in[OJ_R];
+  const uint32_t bias = 1u << lb;
 #pragma unroll
   for (int r = 0; r < OJ_R; r++) {
-    myv[r] = 0; myidx[r] = 0; less[r] = 0;
+    key[r] = 0u; in[r] = 0ULL;
     if (r * 64 < ntot) {
       const bool ok = (fl >> r) & 1u;
-      const unsigned long long bal = __ballot(ok);
-      if (ok) {
-        const int t = r * 64 + lane;
-        myv[r] = jp2[t] - jp1[t];
-        myidx[r] = base + oj_mbcnt(bal);
-        sh[myidx[r]] = myv[r];
-      }
-      base += __popcll(bal);
+      if (ok) { const int t = r * 64 + lane; key[r] = (uint32_t)(jp2[t] - jp1[t]) + bias; }
+      in[r] = __builtin_amdgcn_ballot_w64(ok);
     }
   }
-  oj_lds_sync();
-  for (int u = 0; u < count; u++) {
-    const int v = sh[u];   // same address in every lane: LDS broadcast
+  int k = count / 2;
+  uint32_t res = 0u;
+  for (int b = lb; b >= 0; b--) {
+    const uint32_t bit = 1u << b;
+    unsigned long long one[OJ_R];
+    int c0 = 0;
 #pragma unroll
-    for (int r = 0; r < OJ_R; r++)
-      if (r * 64 < ntot) less[r] += (v < myv[r] || (v == myv[r] && u < myidx[r])) ? 1 : 0;
-  }
-  const int k = count / 2;
-  int med = 0;
+    for (int r = 0; r < OJ_R; r++) {
+      one[r] = 0ULL;
+      if (r * 64 < ntot) { one[r] = __builtin_amdgcn_ballot_w64((key[r] & bit) != 0u); c0 += __popcll(in[r] & ~one[r]); }
+    }
+    if (k < c0) {
 #pragma unroll
-  for (int r = 0; r < OJ_R; r++) {
-    if (r * 64 < ntot) {
-      const unsigned long long bal = __ballot(((fl >> r) & 1u) && less[r] == k);
-      if (bal) med = __builtin_amdgcn_readlane(myv[r], __builtin_amdgcn_readfirstlane(__builtin_ctzll(bal)));
+      for (int r = 0; r < OJ_R; r++) in[r] &= ~one[r];
+    } else {
+      k -= c0; res |= bit;
+#pragma unroll
+      for (int r = 0; r < OJ_R; r++) in[r] &= one[r];
     }
   }
-  __builtin_amdgcn_wave_barrier();
-  return med;
+  return (int)(res - bias);
+}
+
+// Rank of entry idx (of the current chunk of OJ_RCH blocks) among the in-window entries ahead of it: lane b of the wave holds block
+// b's in-window mask and the in-window count of the blocks before it.
+extern "C" __device__ int oj_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");   // v_writelane_b32 (this clang has no builtin for it)
+constexpr int OJ_CQ = 256;              // ring of entry indices that passed the query's filter (FILTER shapes; it lives in jp1's words during the join)
+static_assert(OJ_CQ * 2 <= OJ_JCAP * 4 && OJ_CQ >= 64 * OJ_U + 64, "the ring takes a trip's entries on top of an unhandled rest");
+constexpr int OJ_RCH = (64 / OJ_U) * OJ_U;   // blocks of a chunk: whole trips of OJ_U blocks, one block per lane
+__device__ __forceinline__ int oj_rank_from(uint32_t mlo, uint32_t mhi, int mpre, int idx) {
+  const int src = (idx >> 6) & 63;
+  const uint32_t lo = (uint32_t)__shfl((int)mlo, src), hi = (uint32_t)__shfl((int)mhi, src);
+  const int pre = __shfl(mpre, src);
+  const unsigned long long m = (((unsigned long long)hi << 32) | (unsigned long long)lo) & ((1ULL << (idx & 63)) - 1ULL);
+  return pre + __popcll(m);
 }
 
 // Lookup of a hash among the query's sorted hashes, in LDS.  The hashes of a bottom-S sketch are uniform order statistics of
@@ -1505,6 +1511,14 @@ __device__ __forceinline__ OjBuckets oj_buckets(int first, int last, int nb) {
 }
 __device__ __forceinline__ int oj_bucket_of(const OjBuckets& k, int h) { return (int)__umulhi((uint32_t)(h - k.first), k.mult); }
 int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; return t; }
+// bits of a query's filter: 8 per entry where LDS bounds the resident waves (PAIR: 9 % of the other sketch's entries pass), 32 where registers do (TEAM: 2.3 %)
+int overlap_join_filter_bits(int S, int waves) {
+  int per = waves == 4 ? 32 : 8;   // (TEAM, C5 slice: 8 / 16 / 32 bits per entry 57.3 / 55.3 / 53.2 ms; PAIR, C2: 4 / 8 / 16: 4.04 / 3.75 / 3.95)
+  if (const char* e = getenv("MHAP_OJ_FILTER_BPE")) { const int x = atoi(e); if (x >= 1 && x <= 64) per = x; }   // (experiments)
+  int t = 1024;
+  while (t < per * S) t <<= 1;
+  return t;
+}
 
 template <int IT>
 __device__ __forceinline__ void oj_keep_store(int (&pbk)[OJ_KB], const uint2 (&e)[OJ_U]) {
@@ -1533,8 +1547,11 @@ static_assert(OJ_KIT <= 13, "OJ_KEEP_SWITCH covers 13 trips");
 // (the shapes in use and what each is for: OJ_ALONE / OJ_PAIR / OJ_TEAM below)
 // (the TEAM shape — candidate-rich queries, pairs with many duplicated-hash groups — collects three groups per round, which costs it
 //  registers: it is held at 96 VGPRs = five waves per SIMD, 8-16 B of scratch; the other shapes keep the one-group loop and their 93)
-template <bool SHARED, int WAVES, bool TABLE>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABLE ? 5 : 4, 8))) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
+#ifndef MH_OJ_MINW
+#define MH_OJ_MINW 4   // waves per SIMD the shapes without the table are compiled for
+#endif
+template <bool SHARED, int WAVES, bool TABLE, bool FILTER>
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 5 : MH_OJ_MINW, 8))) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                                      unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                                      int64_t ord_stride, const int32_t* __restrict__ meta,
                                                                      const int32_t* __restrict__ qordered, int64_t qord_stride,
@@ -1550,15 +1567,19 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr bool APOS = SHARED && MH_OJ_KEEP;                          // the shared query's positions are staged too
   const bool keepb = MH_OJ_KEEP && sp.S <= 64 * OJ_KB;                 // the other sketch's positions stay in registers
-  const int spad = (sp.S + 3) & ~3, own = (TABLE ? spad + ts / 2 + 2 : spad) + (APOS ? spad : 0);   // ints of the hashes (+ the table: ts + 1 shorts, padded) (+ the positions)
+  static_assert(!(TABLE && FILTER) && (!FILTER || SHARED), "one lookup aid per shape; the filter is built by a workgroup");
+  const int tabw = TABLE ? ts / 2 + 2 : (FILTER ? ts / 32 : 0);        // ints of the table (ts + 1 shorts, padded) / of the filter (ts bits)
+  const int spad = (sp.S + 3) & ~3, own = spad + tabw + (APOS ? spad : 0);   // ints of the hashes (+ the table / the filter) (+ the positions)
   int32_t* ah = SHARED ? oj_lds : oj_lds + (size_t)wv * (own + OJ_LDS_EXTRA);   // the query sketch's hashes,
-  uint16_t* st = (uint16_t*)(ah + spad);                               // ... the bucket starts over them,
-  int32_t* ap = ah + (TABLE ? spad + ts / 2 + 2 : spad);               // ... (APOS) its positions,
+  uint16_t* st = (uint16_t*)(ah + spad);                               // ... (TABLE) the bucket starts over them,
+  uint32_t* bm = (uint32_t*)(ah + spad);                               // ... (FILTER) a bit per hash value mod ts,
+  int32_t* ap = ah + spad + tabw;                                      // ... (APOS) its positions,
   int32_t* svar = oj_lds + own;                                        // (SHARED) {-, next candidate of the run, chunk start lo, hi}
   int32_t* jp1 = SHARED ? svar + 4 + (size_t)wv * OJ_LDS_EXTRA : ah + own;   // per wave — join: position in the query / in the other sketch,
   int32_t* jp2 = jp1 + OJ_JCAP;
+  uint16_t* cq = (uint16_t*)jp1;                                       // (FILTER, during the join: jp1 is filled after it) ring of OJ_CQ entry indices that passed the filter
   uint32_t* jij = (uint32_t*)(jp2 + OJ_JCAP);                          // ... entry indices (i | j << 16)
-  int32_t* sh = (int32_t*)jij;                                         // (later) shifts of the current records, median selection
+  int32_t* sh = (int32_t*)jij;                                         // (later) shifts of the current records, median by counting
   int32_t* gi = (int32_t*)(jij + OJ_JCAP);                             // groups: {first i, first j, m, n, first record, records}
   int32_t* gpa = gi + OJ_GCAP * 6;                                     // ... positions of the group's entries in the query
   int32_t* gpb = gpa + OJ_GCAP * OJ_GLEN;                              // ... and in the other sketch
@@ -1580,6 +1601,92 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
       bool bad = false;
       int pbk[OJ_KB];    // (keepb) positions of the other sketch: entry blk * 64 + lane in pbk[blk]
       if (nA > 0 && nB > 0) {
+        if constexpr (FILTER) {
+        // Filter, compact, look up.  1 entry in 40 of the other sketch has a partner in the query (a true overlap; a handful for a pair that
+        // shares a repeat), but a wave looked all 64 entries of a block up and went through the found-entry code for nearly every block.
+        // Now a block costs one LDS word per entry — the query's filter, a bit per hash value mod ts: 5-9 % of the entries pass — and
+        // the indices of those that pass are queued (a ring of OJ_CQ 16-bit words); whenever 64 are waiting they are handled as ONE
+        // dense block: entry and neighbours re-read (L2), bisection among the query's hashes, run / group detection.  At S = 1536 that
+        // is three or four dense blocks per pair instead of twenty-four sparse ones.
+        const uint32_t bmask = (uint32_t)ts - 1u;
+        const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
+        int qn = 0, qd = 0, kit = 0;   // entries queued / handled (wave-uniform)
+        uint2 en[OJ_U];
+#pragma unroll
+        for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = make_uint2(0u, 0u); if (j < nB) en[u] = brow[j]; }
+        for (int j0 = 0;; j0 += 64 * OJ_U) {
+          const bool more = j0 < nB && !bad;
+          if (more) {
+            uint2 e[OJ_U];
+            uint32_t w[OJ_U];
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              e[u] = en[u];
+              const int jn = j0 + (u + OJ_U) * 64 + lane;
+              en[u] = make_uint2(0u, 0u);
+              if (jn < nB) en[u] = brow[jn];
+            }
+            if (keepb) { OJ_KEEP_SWITCH(kit, oj_keep_store, pbk, e) kit++; }
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) w[u] = bm[(e[u].x & bmask) >> 5];
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              const int jb = j0 + u * 64;
+              if (jb < nB) {
+                bool c = ((w[u] >> (e[u].x & 31u)) & 1u) != 0u;
+                if (jb + 64 > nB) c = c && jb + lane < nB;   // (the last block's lanes past the sketch)
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(c);
+                if (bal) {
+                  if (c) cq[(qn + oj_mbcnt(bal)) & (OJ_CQ - 1)] = (uint16_t)(jb + lane);
+                  qn += __popcll(bal);
+                }
+              }
+            }
+          }
+          // whole blocks of queued entries — at the row's end whatever is left.  (A trip adds at most 64 OJ_U entries to at most 63.)
+          while (!bad && (qn - qd >= 64 || (!more && qn > qd))) {
+            oj_lds_sync();
+            const int cnt = qn - qd < 64 ? qn - qd : 64;
+            const bool act = lane < cnt;
+            int j = 0, hb = 0, pb = 0, hprev = 0, hnext = 0;
+            if (act) {
+              j = cq[(qd + lane) & (OJ_CQ - 1)];
+              const uint2 be = brow[j];
+              hb = (int)be.x; pb = (int)be.y;
+              if (j > 0) hprev = (int)brow[j - 1].x;
+              if (j + 1 < nB) hnext = (int)brow[j + 1].x;
+            }
+            qd += cnt;
+            int l = (ah[p2 - 1] < hb) ? nA - p2 : -1;   // lower bound by bisection: fixed probe sequence for a sorted array of any length
+            for (int q = p2 >> 1; q > 0; q >>= 1) l = (ah[l + q] < hb) ? l + q : l;
+            l += 1;
+            const bool found = act && l < nA && ah[l < nA ? l : 0] == hb;
+            if (__builtin_amdgcn_ballot_w64(found)) {
+              // the first entry of a run of equal hashes in the other sketch speaks for the run
+              const bool leader = found && !(j > 0 && hprev == hb);
+              bool grp = false;
+              if (leader) grp = (l + 1 < nA && ah[l + 1] == hb) || (j + 1 < nB && hnext == hb);
+              const bool reg = leader && !grp;
+              const unsigned long long balr = __builtin_amdgcn_ballot_w64(reg), balg = __builtin_amdgcn_ballot_w64(grp);
+              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) bad = true;
+              else {
+                if (reg) {
+                  const int idx = nj + oj_mbcnt(balr);
+                  jp2[idx] = pb;
+                  jij[idx] = (uint32_t)l | ((uint32_t)j << 16);
+                }
+                if (grp) {
+                  const int idx = ng + oj_mbcnt(balg);
+                  gi[idx * 6 + 0] = l; gi[idx * 6 + 1] = j;
+                }
+                nj += __popcll(balr);
+                ng += __popcll(balg);
+              }
+            }
+          }
+          if (!more) break;
+        }
+        } else {
         int carry = 0;   // hash of the last entry of the previous OJ_U blocks (run detection across blocks)
         int kit = 0;
         uint2 en[OJ_U];
@@ -1655,6 +1762,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
               anyf |= found[u];
             }
           }
+#ifdef MH_OJ_NO_FOUND
+          { int acc = 0;   // (timing experiment: the lookups are done, what they find is dropped; results are wrong)
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) acc ^= l[u] + (found[u] ? 7 : 0);
+            if (acc == 0x12345678) bad = true;
+            anyf = false; }
+#endif
           if (__any(anyf)) {
 #pragma unroll
             for (int u = 0; u < OJ_U; u++) {
@@ -1690,13 +1804,14 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
           }
           carry = __builtin_amdgcn_readlane((int)e[OJ_U - 1].x, 63);
         }
+        }
       }
       oj_lds_sync();
 #ifdef MH_OJ_NO_GROUPS
       ng = 0;   // (timing experiment: the duplicated-hash groups are dropped; results are wrong)
 #endif
       int gtot = 0;
-      if constexpr (TABLE) {
+      if constexpr (WAVES == 4) {
       // collect the groups' entries, THREE groups per round (each round waits for a load from the other sketch's row): lanes 20 t .. 20 t + 8
       // read the query's entries of the round's t-th group, lanes 20 t + 10 .. 20 t + 18 the other sketch's
       for (int g0 = 0; g0 < ng && !bad; g0 += 3) {
@@ -1717,10 +1832,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
         if (__any(live && (m > OJ_GLEN || nn > OJ_GLEN))) { bad = true; break; }
         if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)be.y;
-        if (live && r == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; }
+        int sz[3];   // entries of the round's groups (wave-uniform)
 #pragma unroll
         for (int tt = 0; tt < 3; tt++)
-          if (g0 + tt < ng) gtot += __popcll((bala >> (20 * tt)) & 0x3FFULL) + __popcll((balb >> (20 * tt + 10)) & 0x3FFULL);
+          sz[tt] = g0 + tt < ng ? __popcll((bala >> (20 * tt)) & 0x3FFULL) + __popcll((balb >> (20 * tt + 10)) & 0x3FFULL) : 0;
+        // (gi[4]: where the group's records go — behind the joined k-mers, every group as many words as it has entries: oj_pass)
+        if (live && r == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; gi[g * 6 + 4] = nj + gtot + (t >= 1 ? sz[0] : 0) + (t >= 2 ? sz[1] : 0); }
+        gtot += sz[0] + sz[1] + sz[2];
       }
       } else {
       for (int g = 0; g < ng && !bad; g++) {   // collect the groups' entries: lanes 0..8 the query's, lanes 16..24 the other sketch's
@@ -1733,7 +1851,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
         if (m > OJ_GLEN || nn > OJ_GLEN) { bad = true; break; }
         if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)brow[j + x].y;
-        if (lane == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; }
+        if (lane == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; gi[g * 6 + 4] = nj + gtot; }
         gtot += m + nn;
       }
       }
@@ -1750,7 +1868,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
 #ifdef MH_OJ_JOIN_ONLY
         if (nj >= 0) break;   // (timing experiment: everything after the join skipped; results are wrong)
 #endif
-        OJ_STAT(6, nj);
+        OJ_STAT(6, nj); OJ_STAT(8, ng); OJ_STAT(9, ng > 0 ? 1 : 0); OJ_STAT(10, ng >= 3 ? 1 : 0); OJ_STAT(11, gtot);
         if (ng == 0 && nj < 3) { OJ_STAT(0, 1); break; }   // computeEdges needs three valid records (:126): fewer joined k-mers can only end EMPTY
         int iA[OJ_R], jB[OJ_R];   // the joined k-mers' entry indices move to registers, their LDS words become `sh`
 #pragma unroll
@@ -1762,14 +1880,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
         }
         oj_lds_sync();
         // ---- recordMatchingKmers twice (:600-606), median shift after each ----
-        int count = 0, nx = 0;
+        const int shift_lb = 32 - __builtin_clz((unsigned)((len1 > len2 ? len1 : len2) | 1));   // (2^shift_lb > either length)
+        int count = 0;
+        const int nx = gtot;   // words behind the joined k-mers that the groups' records may take
         ShiftStats st = oj_shift_stats(false, 0, len1, len2, sp.max_shift);
-        uint32_t fl = oj_pass(jp1, jp2, nj, ng, gi, gpa, gpb, len1, len2, st, lane, count, nx);
+        uint32_t fl = oj_pass(jp1, jp2, nj, ng, nx, gi, gpa, gpb, len1, len2, st, lane, count);
         if (count <= 0) { OJ_STAT(1, 1); break; }
-        st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
-        fl = oj_pass(jp1, jp2, nj, ng, gi, gpa, gpb, len1, len2, st, lane, count, nx);
+        st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane, shift_lb), len1, len2, sp.max_shift);
+        fl = oj_pass(jp1, jp2, nj, ng, nx, gi, gpa, gpb, len1, len2, st, lane, count);
         if (count <= 0) { OJ_STAT(2, 1); break; }
-        st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
+        st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane, shift_lb), len1, len2, sp.max_shift);
         // optimizeShifts (:156-189): neighbouring records of one query position exist only inside a group
         int removed = 0;
         for (int g = 0; g < ng; g++) {
@@ -1786,9 +1906,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
             if (drop >= 0) { removed++; if ((drop & 63) == lane) fl &= ~(1u << (drop >> 6)); }
           }
         }
+        OJ_STAT(12, nx); OJ_STAT(13, removed);
         if (removed) {
           count -= removed;
-          st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane), len1, len2, sp.max_shift);
+          st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane, shift_lb), len1, len2, sp.max_shift);
         }
         // computeEdges (:90-137)
         int le1 = INT32_MAX, le2 = INT32_MAX, re1 = INT32_MIN, re2 = INT32_MIN, nvalid = 0;
@@ -1854,72 +1975,94 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
         }
         const int jrounds = (nj + 63) >> 6;
         int s1 = 0, s2 = 0;
-        int pan[OJ_U], pbn[OJ_U];   // next OJ_U blocks of positions of either sketch, in flight while the current ones are ranked
+        // One pass over the positions of either sketch: a block of 64 entries costs its in-window test, the ballot and three
+        // v_writelane — lane b of the wave collects block b's mask and the count ahead of it — and the joined k-mers fetch
+        // their block's words from that lane afterwards (three shuffles per round of 64 joined k-mers and sketch).  Round 3
+        // handed every block's ranks to the joined k-mers as it went: two or three shuffles and ten more instructions per BLOCK.
+        int pan[OJ_U], pbn[OJ_U];   // next OJ_U blocks of positions of either sketch, in flight while the current ones are tested
 #pragma unroll
         for (int u = 0; u < OJ_U; u++) {
           const int i = u * 64 + lane;
           pan[u] = (!APOS && i < nA) ? qrow[2 * i + 1] : INT32_MIN;
           pbn[u] = (!keepb && i < nB) ? (int)brow[i].y : INT32_MIN;
         }
-        for (int ib = 0; ib < nA; ib += 64 * OJ_U) {
-          int posv[OJ_U];
-#pragma unroll
-          for (int u = 0; u < OJ_U; u++) {
-            if (APOS) { const int i = ib + u * 64 + lane; posv[u] = i < nA ? ap[i] : INT32_MIN; }
-            else {
-              posv[u] = pan[u];
-              const int i = ib + (u + OJ_U) * 64 + lane;
-              pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < OJ_U; u++) {
-            const int i0 = ib + u * 64;
-            if (i0 < nA) {
-              const bool in = i0 + lane < nA && posv[u] >= a1 && posv[u] <= a2;
-              const unsigned long long bal = __ballot(in);
-              const int rank = s1 + oj_mbcnt(bal);
-#pragma unroll
-              for (int r = 0; r < OJ_R; r++) {
-                if (r < jrounds) {
-                  const int v = __shfl(rank, iA[r] & 63);
-                  if ((iA[r] & ~63) == i0) rA[r] = v;
-                }
-              }
-              if (ng) { const int v = __shfl(rank, giA & 63); if ((giA & ~63) == i0) grA = v; }
-              s1 += __popcll(bal);
-            }
-          }
-        }
-        for (int jb = 0, kit2 = 0; jb < nB; jb += 64 * OJ_U, kit2++) {
-          int posv[OJ_U];
-          if (keepb) { OJ_KEEP_SWITCH(kit2, oj_keep_load, pbk, posv) }
-          else {
+        for (int cb = 0; cb < nA; cb += 64 * OJ_RCH) {
+          uint32_t mlo = 0u, mhi = 0u;
+          int mpre = 0;
+          const int cend = cb + 64 * OJ_RCH < nA ? cb + 64 * OJ_RCH : nA;
+          for (int ib = cb; ib < cend; ib += 64 * OJ_U) {
+            int posv[OJ_U];
 #pragma unroll
             for (int u = 0; u < OJ_U; u++) {
-              posv[u] = pbn[u];
-              const int j = jb + (u + OJ_U) * 64 + lane;
-              pbn[u] = j < nB ? (int)brow[j].y : INT32_MIN;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < OJ_U; u++) {
-            const int j0 = jb + u * 64;
-            if (j0 < nB) {
-              const bool in = j0 + lane < nB && posv[u] >= b1 && posv[u] <= b2;
-              const unsigned long long bal = __ballot(in);
-              const int rank = s2 + oj_mbcnt(bal);
-#pragma unroll
-              for (int r = 0; r < OJ_R; r++) {
-                if (r < jrounds) {
-                  const int v = __shfl(rank, jB[r] & 63);
-                  if ((jB[r] & ~63) == j0) rB[r] = v;
-                }
+              if (APOS) posv[u] = ap[ib + u * 64 + lane];   // (past the sketch: whatever follows in LDS — the last block's ballot is trimmed below)
+              else {
+                posv[u] = pan[u];
+                const int i = ib + (u + OJ_U) * 64 + lane;
+                pan[u] = i < nA ? qrow[2 * i + 1] : INT32_MIN;
               }
-              if (ng) { const int v = __shfl(rank, gjB & 63); if ((gjB & ~63) == j0) grB = v; }
-              s2 += __popcll(bal);
+            }
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              const int i0 = ib + u * 64;
+              if (i0 < nA) {
+                // (read from memory, entries past the sketch hold INT32_MIN, and a1 >= 0; a ballot per comparison: the compiler turns a ballot of their conjunction into
+                // two more vector instructions)
+                unsigned long long bal = __builtin_amdgcn_ballot_w64(posv[u] >= a1) & __builtin_amdgcn_ballot_w64(posv[u] <= a2);
+                if (APOS && i0 + 64 > nA) bal &= (1ULL << (nA - i0)) - 1ULL;
+                const int blk = (i0 - cb) >> 6;
+                mlo = (uint32_t)oj_writelane((int)(uint32_t)bal, blk, (int)mlo);
+                mhi = (uint32_t)oj_writelane((int)(uint32_t)(bal >> 32), blk, (int)mhi);
+                mpre = oj_writelane(s1, blk, mpre);
+                s1 += __popcll(bal);
+              }
             }
           }
+#pragma unroll
+          for (int r = 0; r < OJ_R; r++) {
+            if (r < jrounds) {
+              const int v = oj_rank_from(mlo, mhi, mpre, iA[r] - cb);
+              if (iA[r] >= cb && iA[r] < cend) rA[r] = v;
+            }
+          }
+          if (ng) { const int v = oj_rank_from(mlo, mhi, mpre, giA - cb); if (giA >= cb && giA < cend) grA = v; }
+        }
+        for (int cb = 0, kit2 = 0; cb < nB; cb += 64 * OJ_RCH) {
+          uint32_t mlo = 0u, mhi = 0u;
+          int mpre = 0;
+          const int cend = cb + 64 * OJ_RCH < nB ? cb + 64 * OJ_RCH : nB;
+          for (int jb = cb; jb < cend; jb += 64 * OJ_U, kit2++) {
+            int posv[OJ_U];
+            if (keepb) { OJ_KEEP_SWITCH(kit2, oj_keep_load, pbk, posv) }
+            else {
+#pragma unroll
+              for (int u = 0; u < OJ_U; u++) {
+                posv[u] = pbn[u];
+                const int j = jb + (u + OJ_U) * 64 + lane;
+                pbn[u] = j < nB ? (int)brow[j].y : INT32_MIN;
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) {
+              const int j0 = jb + u * 64;
+              if (j0 < nB) {
+                unsigned long long bal = __builtin_amdgcn_ballot_w64(posv[u] >= b1) & __builtin_amdgcn_ballot_w64(posv[u] <= b2);
+                if (j0 + 64 > nB) bal &= (1ULL << (nB - j0)) - 1ULL;   // (the last block's lanes past the sketch)
+                const int blk = (j0 - cb) >> 6;
+                mlo = (uint32_t)oj_writelane((int)(uint32_t)bal, blk, (int)mlo);
+                mhi = (uint32_t)oj_writelane((int)(uint32_t)(bal >> 32), blk, (int)mhi);
+                mpre = oj_writelane(s2, blk, mpre);
+                s2 += __popcll(bal);
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < OJ_R; r++) {
+            if (r < jrounds) {
+              const int v = oj_rank_from(mlo, mhi, mpre, jB[r] - cb);
+              if (jB[r] >= cb && jB[r] < cend) rB[r] = v;
+            }
+          }
+          if (ng) { const int v = oj_rank_from(mlo, mhi, mpre, gjB - cb); if (gjB >= cb && gjB < cend) grB = v; }
         }
         const int kk = s1 < s2 ? s1 : s2;
         // a joined k-mer counts if its index in the merged union (in-window entries of both, joined ones once) is below k:
@@ -2005,8 +2148,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
           }
         } else __builtin_amdgcn_wave_barrier();
         if (APOS) for (int i = tid; i < nA; i += NT) ap[i] = qrow[2 * i + 1];
+        if (FILTER) {
+          for (int i = tid; i < tabw; i += NT) bm[i] = 0u;
+          __syncthreads();
+        }
         if (!TABLE) {
-          for (int i = tid; i < nA; i += NT) ah[i] = qrow[2 * i];
+          for (int i = tid; i < nA; i += NT) {
+            const int h = qrow[2 * i];
+            ah[i] = h;
+            if (FILTER) atomicOr(&bm[((uint32_t)h & (uint32_t)(ts - 1)) >> 5], 1u << ((uint32_t)h & 31u));   // (the low bits of a hash value are uniform whatever the sketch keeps)
+          }
         } else if (nA > 0) {
           bk = oj_buckets(__builtin_amdgcn_readfirstlane(qrow[0]), __builtin_amdgcn_readfirstlane(qrow[2 * (nA - 1)]), ts);
           for (int i = tid; i < nA; i += NT) {   // entry i starts every bucket after its predecessor's up to its own
@@ -2051,6 +2202,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(TABL
 //          4.83 ms against 4.94 alone).  For a few candidates per query.
 //   TEAM   four waves share the query and a bucket table over its hashes (two LDS round trips per lookup instead of eleven).
 //          For tens of candidates per query (repeat-rich reads).
+#ifndef MH_OJ_FILTER
+#define MH_OJ_FILTER 1   // the shared shapes filter the other sketch's entries through a bitmap of the query's hashes (0: round 3's lookups of every entry)
+#endif
 enum { OJ_ALONE = 0, OJ_PAIR = 1, OJ_TEAM = 2 };
 constexpr int OJ_SHAPE_WAVES[3] = {2, 2, OJ_WAVES};
 int overlap_join_waves_per_block(int shape) { return OJ_SHAPE_WAVES[shape]; }
@@ -2058,12 +2212,13 @@ int overlap_join_waves_per_block(int shape) { return OJ_SHAPE_WAVES[shape]; }
 size_t overlap_join_lds_bytes(int S, int shape) {
   const size_t sp = (size_t)((S + 3) & ~3), w = (size_t)OJ_SHAPE_WAVES[shape];
   if (shape == OJ_ALONE) return w * (sp + OJ_LDS_EXTRA) * 4;
-  return (sp + (MH_OJ_KEEP ? sp : 0) + (shape == OJ_TEAM ? (size_t)overlap_join_table_slots(S) / 2 + 2 : 0) + 4 + w * OJ_LDS_EXTRA) * 4;
+  const size_t aid = MH_OJ_FILTER ? (size_t)overlap_join_filter_bits(S, (int)w) / 32 : (shape == OJ_TEAM ? (size_t)overlap_join_table_slots(S) / 2 + 2 : 0);
+  return (sp + (MH_OJ_KEEP ? sp : 0) + aid + 4 + w * OJ_LDS_EXTRA) * 4;
 }
 template <class F> static auto oj_dispatch(int shape, F f) {
-  if (shape == OJ_TEAM) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_TEAM], true>);
-  if (shape == OJ_PAIR) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_PAIR], false>);
-  return f(overlap_join_kernel<false, OJ_SHAPE_WAVES[OJ_ALONE], false>);
+  if (shape == OJ_TEAM) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_TEAM], !MH_OJ_FILTER, MH_OJ_FILTER != 0>);
+  if (shape == OJ_PAIR) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_PAIR], false, MH_OJ_FILTER != 0>);
+  return f(overlap_join_kernel<false, OJ_SHAPE_WAVES[OJ_ALONE], false, false>);
 }
 // workgroups of the join kernel one CU holds at this sketch size
 int overlap_join_blocks_per_cu(int S, int shape) {
@@ -2078,7 +2233,7 @@ void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, cons
                          int64_t qord_stride, const int32_t* qmeta, const SearchParams& sp, const double* score_table, DevRecord* recs,
                          unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, Candidate* slow,
                          unsigned long long* slow_count, unsigned long long* work, const uint16_t* ph, const uint16_t* qph, const int32_t* pass_min) {
-  const int ts = overlap_join_table_slots(sp.S);
+  const int ts = (MH_OJ_FILTER && shape != OJ_ALONE) ? overlap_join_filter_bits(sp.S, OJ_SHAPE_WAVES[shape]) : overlap_join_table_slots(sp.S);
   oj_dispatch(shape, [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(64 * OJ_SHAPE_WAVES[shape]), overlap_join_lds_bytes(sp.S, shape), st, cand, cand_count, cand_cap, ordered,
                        ord_stride, meta, qordered, qord_stride, qmeta, sp, score_table, recs, rec_count, rec_cap, compared, slow, slow_count, chunk, work, ts,
@@ -2089,10 +2244,13 @@ void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, cons
 
 void oj_stats_dump() {
 #ifdef MH_OJ_STATS
-  unsigned long long h[8];
+  unsigned long long h[16];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_oj_stats), sizeof h) != hipSuccess) return;
+  const double np = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + 1);
   fprintf(stderr, "[oj stats] pairs: nj<3 %llu, no record in pass 1 %llu, in pass 2 %llu, <3 valid %llu, below threshold %llu, accepted %llu; mean nj %.2f, mean in-window joined of scored %.2f\n",
-          h[0], h[1], h[2], h[3], h[4], h[5], (double)h[6] / (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + 1), (double)h[7] / (double)(h[4] + h[5] + 1));
+          h[0], h[1], h[2], h[3], h[4], h[5], (double)h[6] / np, (double)h[7] / (double)(h[4] + h[5] + 1));
+  fprintf(stderr, "[oj stats] groups: per pair %.2f, pairs with groups %llu, with >= 3 %llu, entries in groups per pair %.2f, group records in pass 2 per pair %.2f, removed by optimizeShifts per pair %.2f\n",
+          (double)h[8] / np, h[9], h[10], (double)h[11] / np, (double)h[12] / np, (double)h[13] / np);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_oj_stats), h, sizeof h);
 #endif
