@@ -1271,34 +1271,43 @@ __device__ __forceinline__ OjWindows oj_windows(ShiftStats st, int len1, int len
 // repeat-rich reads has half a dozen groups, and replayed one after the other by the whole wave they were a third of the join
 // kernel's time on the C5 slice (-DMH_OJ_NO_GROUPS timing build: 69.0 -> 44.9 ms).  Returns the number of records written to o1/o2:
 // at most two for every three entries the walk consumes, so a group's records fit the m + n words its entries reserve (oj_pass).
+// (Which of a group's positions — eight words per sketch, 16-byte aligned, read as vectors — lie in the pass's windows becomes a bit
+// mask per sketch, so the walk's skips and its runs of consecutive in-window entries are bit scans; only the positions the walk
+// stops at are read again.  The literal loop read one LDS word per step, every read waiting for the one before: two replays per
+// pair were 13 % of the kernel on the C5 slice.  Keeping all sixteen positions in registers and picking them by index was tried:
+// 114 VGPRs in the PAIR shape, 92 bytes of scratch in TEAM, slower everywhere.)
+__device__ __forceinline__ uint32_t oj_mask4(const int4 v, int lo, uint32_t width) {
+  return (((uint32_t)(v.x - lo) < width) ? 1u : 0u) | (((uint32_t)(v.y - lo) < width) ? 2u : 0u) | (((uint32_t)(v.z - lo) < width) ? 4u : 0u) |
+         (((uint32_t)(v.w - lo) < width) ? 8u : 0u);
+}
+__device__ __forceinline__ uint32_t oj_mask8(const int32_t* p, int cnt, int lo, int hi) {   // bit x: entry x < cnt lies in [lo, hi)
+  const uint32_t width = hi > lo ? (uint32_t)(hi - lo) : 0u;
+  uint32_t m = oj_mask4(*(const int4*)p, lo, width);
+  if (cnt > 4) m |= oj_mask4(*(const int4*)(p + 4), lo, width) << 4;
+  return m & ((1u << cnt) - 1u);
+}
+static_assert(OJ_GLEN == 8, "a group's positions are two int4 per sketch");
 __device__ __forceinline__ int oj_group_merge_lane(const int32_t* pa, int m, const int32_t* pb, int n, const OjWindows& w, int32_t* o1, int32_t* o2) {
+  const uint32_t w1 = oj_mask8(pa, m, w.v1lo, w.v1hi), w2 = oj_mask8(pb, n, w.v2lo, w.v2hi);
   int i1 = 0, i2 = 0, cnt = 0;
-  while (i1 < m && i2 < n) {
+  for (;;) {
+    const uint32_t r1 = w1 >> i1, r2 = w2 >> i2;
+    if (r1 == 0u || r2 == 0u) break;                    // (entries outside their window are stepped over one by one in the reference: no record on the way)
+    i1 += __builtin_ctz(r1); i2 += __builtin_ctz(r2);
     const int p1 = pa[i1], p2 = pb[i2];
-    if (p1 < w.v1lo || p1 >= w.v1hi) { i1++; continue; }
-    if (p2 < w.v2lo || p2 >= w.v2hi) { i2++; continue; }
     const int diff = (p2 - p1) - w.med;
     if (diff > w.absmax) { i1++; continue; }
     if (diff < -w.absmax) { i2++; continue; }
     o1[cnt] = p1; o2[cnt] = p2;
     cnt++;
-    int i1Last = i1, p1Last = p1;
-    for (int t = i1 + 1; t < m; t++) {
-      const int pt = pa[t];
-      if (!(pt >= w.v1lo && pt < w.v1hi)) break;
-      i1Last = t; p1Last = pt;
-    }
-    int i2Last = i2, p2Last = p2;
-    for (int t = i2 + 1; t < n; t++) {
-      const int pt = pb[t];
-      if (!(pt >= w.v2lo && pt < w.v2hi)) break;
-      i2Last = t; p2Last = pt;
-    }
-    if (i1 != i1Last || i2 != i2Last) {
-      o1[cnt] = p1Last; o2[cnt] = p2Last;
+    // the in-window entries that follow without a gap (:476-490): the last of either run makes a second record
+    const int e1 = __builtin_ctz(~(w1 >> (i1 + 1))), e2 = __builtin_ctz(~(w2 >> (i2 + 1)));
+    if (e1 | e2) {
+      i1 += e1; i2 += e2;
+      o1[cnt] = pa[i1]; o2[cnt] = pb[i2];
       cnt++;
-      i1 = i1Last + 1; i2 = i2Last + 1;
-    } else { i1++; i2++; }
+    }
+    i1++; i2++;
   }
   return cnt;
 }
@@ -1310,13 +1319,18 @@ static_assert(OJ_GCAP <= 64, "lane g replays group g");
 // records matters inside a group only (optimizeShifts), so nothing has to be counted or compacted first.  (Round 4's first version
 // replayed every group twice — to count, then, after a prefix sum over the lanes, to store contiguously — and groups of fewer than
 // three one after the other by the whole wave.)  Bit r of the result = entry r*64+lane is a record of this pass; count = their number.
+template <bool FIRST>
 __device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, int ng, int nx, int32_t* gi, const int32_t* gpa, const int32_t* gpb,
                                            int len1, int len2, ShiftStats st, int lane, int& count) {
   const OjWindows w = oj_windows(st, len1, len2);
   if (ng) {
     if (lane < ng) {
       const int m = gi[lane * 6 + 2], n = gi[lane * 6 + 3], at = gi[lane * 6 + 4];
+#ifdef MH_OJ_NO_GMERGE
+      const int k = 0;   // (timing experiment; results are wrong)
+#else
       const int k = oj_group_merge_lane(gpa + lane * OJ_GLEN, m, gpb + lane * OJ_GLEN, n, w, jp1 + at, jp2 + at);
+#endif
       for (int x = k; x < m + n; x++) jp1[at + x] = INT32_MIN;
       gi[lane * 6 + 5] = k;
     }
@@ -1330,9 +1344,13 @@ __device__ __forceinline__ uint32_t oj_pass(int32_t* jp1, int32_t* jp2, int nj, 
       const int t = r * 64 + lane;
       bool ok = false;
       if (t < nj) {
-        const int p1 = jp1[t], p2 = jp2[t];
-        const int diff = (p2 - p1) - w.med;
-        ok = p1 >= w.v1lo && p1 < w.v1hi && p2 >= w.v2lo && p2 < w.v2hi && !(diff > w.absmax) && !(diff < -w.absmax);
+        // (the first pass's windows are the whole strands and its shift bound max(len1, len2) + 1: every position pair of [0, len1) x [0, len2) passes)
+        if (FIRST) ok = true;
+        else {
+          const int p1 = jp1[t], p2 = jp2[t];
+          const int diff = (p2 - p1) - w.med;
+          ok = p1 >= w.v1lo && p1 < w.v1hi && p2 >= w.v2lo && p2 < w.v2hi && !(diff > w.absmax) && !(diff < -w.absmax);
+        }
       } else if (t < nj + nx) ok = jp1[t] != INT32_MIN;
       fl |= (ok ? 1u : 0u) << r;
       cnt += __popcll(__ballot(ok));
@@ -1568,7 +1586,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
   constexpr bool APOS = SHARED && MH_OJ_KEEP;                          // the shared query's positions are staged too
   const bool keepb = MH_OJ_KEEP && sp.S <= 64 * OJ_KB;                 // the other sketch's positions stay in registers
   static_assert(!(TABLE && FILTER) && (!FILTER || SHARED), "one lookup aid per shape; the filter is built by a workgroup");
-  const int tabw = TABLE ? ts / 2 + 2 : (FILTER ? ts / 32 : 0);        // ints of the table (ts + 1 shorts, padded) / of the filter (ts bits)
+  const int tabw = TABLE ? (ts / 2 + 4) & ~3 : (FILTER ? ts / 32 : 0);  // ints of the table (ts + 1 shorts, padded: what follows stays 16-byte aligned) / of the filter (ts bits)
   const int spad = (sp.S + 3) & ~3, own = spad + tabw + (APOS ? spad : 0);   // ints of the hashes (+ the table / the filter) (+ the positions)
   int32_t* ah = SHARED ? oj_lds : oj_lds + (size_t)wv * (own + OJ_LDS_EXTRA);   // the query sketch's hashes,
   uint16_t* st = (uint16_t*)(ah + spad);                               // ... (TABLE) the bucket starts over them,
@@ -1884,26 +1902,41 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         int count = 0;
         const int nx = gtot;   // words behind the joined k-mers that the groups' records may take
         ShiftStats st = oj_shift_stats(false, 0, len1, len2, sp.max_shift);
-        uint32_t fl = oj_pass(jp1, jp2, nj, ng, nx, gi, gpa, gpb, len1, len2, st, lane, count);
+        uint32_t fl = oj_pass<true>(jp1, jp2, nj, ng, nx, gi, gpa, gpb, len1, len2, st, lane, count);
         if (count <= 0) { OJ_STAT(1, 1); break; }
         st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane, shift_lb), len1, len2, sp.max_shift);
-        fl = oj_pass(jp1, jp2, nj, ng, nx, gi, gpa, gpb, len1, len2, st, lane, count);
+        fl = oj_pass<false>(jp1, jp2, nj, ng, nx, gi, gpa, gpb, len1, len2, st, lane, count);
         if (count <= 0) { OJ_STAT(2, 1); break; }
         st = oj_shift_stats(true, oj_median_shift(jp1, jp2, sh, fl, nj + nx, count, lane, shift_lb), len1, len2, sp.max_shift);
         // optimizeShifts (:156-189): neighbouring records of one query position exist only inside a group
+        // (lane g walks group g's records and marks the dropped ones, then every lane looks at its own entries)
         int removed = 0;
-        for (int g = 0; g < ng; g++) {
-          const int start = gi[g * 6 + 4], k = gi[g * 6 + 5];
-          int red = -1;
-          for (int x = 0; x < k; x++) {
-            const int t = start + x;
-            const int p1 = jp1[t], p2 = jp2[t];
-            int drop = -1;
-            if (red >= 0 && jp1[red] == p1) {
-              const int sr = jp2[red] - jp1[red];
-              if (iabs32(sr - st.med) > iabs32((p2 - p1) - st.med)) { drop = red; red = t; } else drop = t;
-            } else red = t;
-            if (drop >= 0) { removed++; if ((drop & 63) == lane) fl &= ~(1u << (drop >> 6)); }
+        if (ng) {
+          int rem = 0;
+          if (lane < ng) {
+            const int start = gi[lane * 6 + 4], k = gi[lane * 6 + 5];
+            int red = -1, rp1 = 0, rp2 = 0;
+            for (int x = 0; x < k; x++) {
+              const int t = start + x;
+              const int p1 = jp1[t], p2 = jp2[t];
+              if (red >= 0 && rp1 == p1) {
+                if (iabs32((rp2 - rp1) - st.med) > iabs32((p2 - p1) - st.med)) { jp1[red] = INT32_MIN; red = t; rp1 = p1; rp2 = p2; }
+                else jp1[t] = INT32_MIN;
+                rem++;
+              } else { red = t; rp1 = p1; rp2 = p2; }
+            }
+          }
+          if (__builtin_amdgcn_ballot_w64(rem != 0)) {
+            oj_lds_sync();
+#pragma unroll
+            for (int r = 0; r < OJ_R; r++) {
+              if (r * 64 < nj + nx) {
+                const int t = r * 64 + lane;
+                const bool gone = ((fl >> r) & 1u) && t >= nj && jp1[t] == INT32_MIN;
+                if (gone) fl &= ~(1u << r);
+                removed += __popcll(__builtin_amdgcn_ballot_w64(gone));
+              }
+            }
           }
         }
         OJ_STAT(12, nx); OJ_STAT(13, removed);
@@ -1968,9 +2001,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         int giA = 0xffff, gjB = 0xffff, grA = 0, grB = 0, gmin = 0;
         if (lane < ng) {
           giA = gi[lane * 6 + 0]; gjB = gi[lane * 6 + 1];
-          int ca = 0, cb = 0;
-          for (int x = 0; x < gi[lane * 6 + 2]; x++) { const int p = gpa[lane * OJ_GLEN + x]; ca += (p >= a1 && p <= a2) ? 1 : 0; }
-          for (int x = 0; x < gi[lane * 6 + 3]; x++) { const int p = gpb[lane * OJ_GLEN + x]; cb += (p >= b1 && p <= b2) ? 1 : 0; }
+          const int32_t *pa = gpa + lane * OJ_GLEN, *pb = gpb + lane * OJ_GLEN;
+          const int ca = __popc(oj_mask8(pa, gi[lane * 6 + 2], a1, a2 + 1)), cb = __popc(oj_mask8(pb, gi[lane * 6 + 3], b1, b2 + 1));
           gmin = ca < cb ? ca : cb;   // equal hashes pair up one to one in the union walk
         }
         const int jrounds = (nj + 63) >> 6;
@@ -2212,7 +2244,7 @@ int overlap_join_waves_per_block(int shape) { return OJ_SHAPE_WAVES[shape]; }
 size_t overlap_join_lds_bytes(int S, int shape) {
   const size_t sp = (size_t)((S + 3) & ~3), w = (size_t)OJ_SHAPE_WAVES[shape];
   if (shape == OJ_ALONE) return w * (sp + OJ_LDS_EXTRA) * 4;
-  const size_t aid = MH_OJ_FILTER ? (size_t)overlap_join_filter_bits(S, (int)w) / 32 : (shape == OJ_TEAM ? (size_t)overlap_join_table_slots(S) / 2 + 2 : 0);
+  const size_t aid = MH_OJ_FILTER ? (size_t)overlap_join_filter_bits(S, (int)w) / 32 : (shape == OJ_TEAM ? (size_t)((overlap_join_table_slots(S) / 2 + 4) & ~3) : 0);
   return (sp + (MH_OJ_KEEP ? sp : 0) + aid + 4 + w * OJ_LDS_EXTRA) * 4;
 }
 template <class F> static auto oj_dispatch(int shape, F f) {
