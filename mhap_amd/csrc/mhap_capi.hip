@@ -856,16 +856,17 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
     // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
     if (h->gate && h->gate(h->gate_user) != 0) return fail(h, MHAP_E_STATE, "second-stage gate aborted the search");
-    // the join kernel's three shapes (search_kernels.hip): every wave alone, pairs of waves sharing a staged query, teams of four with
-    // a bucket table — by the candidates per query.  MHAP_JOIN_MODE=alone|pair|team pins one.
+    // the join kernel's three shapes (search_kernels.hip): every wave alone, pairs of waves or teams of four sharing a staged query and
+    // its filter — by the candidates per query.  MHAP_JOIN_MODE=alone|pair|team pins one.
     bool fits[3];
     for (int i = 0; i < 3; i++) fits[i] = overlap_join_lds_bytes(S, i) <= 64 * 1024;
     const bool use_join = !lane_only && S <= OJ_MAX_S && (fits[0] || fits[1] || fits[2]);
     unsigned long long nslow = use_join ? 0 : ncand;
     if (use_join) {
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
-      // (C2: 4.5 candidates per query — alone 4.94, pair 4.83, team 5.03 ms; C5 slice: 79 — alone 93, pair 87, team 77; a rank of eight,
-      //  0.56 per query: alone 0.86, pair 1.24)
+      // (round 3, every entry looked up — C2, 4.5 candidates per query: alone 4.94, pair 4.83, team 5.03 ms; C5 slice, 79: alone 93, pair 87,
+      //  team 77; a rank of eight, 0.56 per query: alone 0.86, pair 1.24.  Round 4, the shared shapes with the filter — C2: pair 3.74, team 3.65;
+      //  C5 slice: pair 66.8, team 49.8; ranks of two / four / eight: alone 2.29 / 1.19 / 0.69, pair 2.09 / 1.29 / 0.83, team 2.29 / 1.69 / 1.33)
       int shape = (int64_t)ncand >= 4LL * nq ? 2 : ((int64_t)ncand >= 2LL * nq ? 1 : 0);
       if (h->join_mode > 0) shape = h->join_mode - 1;
       while (!fits[shape]) shape = (shape + 1) % 3;
@@ -881,7 +882,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       const int64_t want = ((int64_t)ncand + (int64_t)wpb * chunk - 1) / ((int64_t)wpb * chunk);
       const int jblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * per_cu, want));
       // Early "below the threshold" from position histograms (search_kernels.hip, poshist_kernel): pays when the joined k-mers of a pair
-      // are few next to its windows — repeat-induced candidates, i.e. many candidates per query (the TEAM shape's regime); at C2 (40
+      // are few next to its windows — repeat-induced candidates, i.e. many candidates per query (sixteen and more); at C2 (40
       // joined k-mers per pair) it rejects nothing and the histograms would cost a pass over the ordered table.  MHAP_OVERLAP_PRUNE=0|1.
       const char* pe = getenv("MHAP_OVERLAP_PRUNE");
       const bool prune = pe ? pe[0] == '1' : (int64_t)ncand >= 16LL * nq;

@@ -1565,11 +1565,14 @@ static_assert(OJ_KIT <= 13, "OJ_KEEP_SWITCH covers 13 trips");
 // (the shapes in use and what each is for: OJ_ALONE / OJ_PAIR / OJ_TEAM below)
 // (the TEAM shape — candidate-rich queries, pairs with many duplicated-hash groups — collects three groups per round, which costs it
 //  registers: it is held at 96 VGPRs = five waves per SIMD, 8-16 B of scratch; the other shapes keep the one-group loop and their 93)
+#ifndef MH_OJ_TEAM_MINW
+#define MH_OJ_TEAM_MINW 5
+#endif
 #ifndef MH_OJ_MINW
 #define MH_OJ_MINW 4   // waves per SIMD the shapes without the table are compiled for
 #endif
 template <bool SHARED, int WAVES, bool TABLE, bool FILTER>
-__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? 5 : MH_OJ_MINW, 8))) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVES == 4 ? MH_OJ_TEAM_MINW : MH_OJ_MINW, 8))) void overlap_join_kernel(const Candidate* __restrict__ cand, const unsigned long long* __restrict__ cand_count,
                                                                      unsigned long long cand_cap, const int32_t* __restrict__ ordered,
                                                                      int64_t ord_stride, const int32_t* __restrict__ meta,
                                                                      const int32_t* __restrict__ qordered, int64_t qord_stride,
@@ -1651,7 +1654,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int u = 0; u < OJ_U; u++) {
               const int jb = j0 + u * 64;
               if (jb < nB) {
+#ifdef MH_OJ_NO_SEARCH
+                bool c = (e[u].x ^ e[u].y) == 0x7ffffffeu && w[u] == 0x12345u;   // (timing experiment: the rows are streamed, nothing passes the filter; results are wrong)
+#else
                 bool c = ((w[u] >> (e[u].x & 31u)) & 1u) != 0u;
+#endif
                 if (jb + 64 > nB) c = c && jb + lane < nB;   // (the last block's lanes past the sketch)
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(c);
                 if (bal) {
@@ -2281,7 +2288,7 @@ void oj_stats_dump() {
   const double np = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + 1);
   fprintf(stderr, "[oj stats] pairs: nj<3 %llu, no record in pass 1 %llu, in pass 2 %llu, <3 valid %llu, below threshold %llu, accepted %llu; mean nj %.2f, mean in-window joined of scored %.2f\n",
           h[0], h[1], h[2], h[3], h[4], h[5], (double)h[6] / np, (double)h[7] / (double)(h[4] + h[5] + 1));
-  fprintf(stderr, "[oj stats] groups: per pair %.2f, pairs with groups %llu, with >= 3 %llu, entries in groups per pair %.2f, group records in pass 2 per pair %.2f, removed by optimizeShifts per pair %.2f\n",
+  fprintf(stderr, "[oj stats] groups: per pair %.2f, pairs with groups %llu, with >= 3 %llu, entries in groups per pair %.2f, words reserved for group records per pair %.2f, removed by optimizeShifts per pair %.2f\n",
           (double)h[8] / np, h[9], h[10], (double)h[11] / np, (double)h[12] / np, (double)h[13] / np);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_oj_stats), h, sizeof h);

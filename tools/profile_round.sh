@@ -26,10 +26,21 @@ timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o p --output-forma
 cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats_c5rank.csv
 # the planted family at 1 % and at 5 % divergence, one rank's size, first 40 000 queries (what the c5rank configuration was chosen from)
 (python tools/c5_probe.py 625000 40000 0.01 2>/dev/null | tail -1; python tools/c5_probe.py 625000 40000 0.05 2>/dev/null | tail -1; python tools/c5_probe.py 160000 160000 0.01 2>/dev/null | tail -1) > gpurun_out/$R/${R}_c5_probe.txt
-# where the pairs of the second stage end (diagnostic build of the join kernel)
-if [ -f mhap_amd/lib/variants/libmhaphip_ojstats.so ]; then
-  (MHAP_LIB_PATH=mhap_amd/lib/variants/libmhaphip_ojstats.so python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -1 | sed 's/^/c2: /'
-   MHAP_LIB_PATH=mhap_amd/lib/variants/libmhaphip_ojstats.so python bench.py --config c5slice --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -1 | sed 's/^/c5slice: /') > gpurun_out/$R/${R}_join_exit_stats.txt
+# where the pairs of the second stage end (diagnostic build of the join kernel: bash tools/build_variant.sh ojstats -DMH_OJ_STATS)
+V=mhap_amd/lib/variants
+if [ -f $V/libmhaphip_ojstats.so ]; then
+  (MHAP_LIB_PATH=$V/libmhaphip_ojstats.so python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -2 | sed 's/^/c2: /'
+   MHAP_LIB_PATH=$V/libmhaphip_ojstats.so python bench.py --config c5slice --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -2 | sed 's/^/c5slice: /') > gpurun_out/$R/${R}_join_exit_stats.txt
+fi
+# what the parts of the join kernel cost (timing builds, results wrong by construction): rows streamed only / + filter, lookups, groups collected /
+# everything but the duplicated-hash groups / the shipped kernel
+#   bash tools/build_variant.sh oj_stream -DMH_OJ_NO_SEARCH -DMH_OJ_JOIN_ONLY; bash tools/build_variant.sh oj_join -DMH_OJ_JOIN_ONLY; bash tools/build_variant.sh oj_nogroups -DMH_OJ_NO_GROUPS
+if [ -f $V/libmhaphip_oj_stream.so ]; then
+  (for c in c2 c5slice; do for v in $V/libmhaphip_oj_stream.so $V/libmhaphip_oj_join.so $V/libmhaphip_oj_nogroups.so mhap_amd/lib/libmhaphip.so; do
+     MHAP_LIB_PATH=$v timeout 600 python bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline --soak-seconds 0 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$c', '$v'.split('/')[-1], 'overlap kernel ms', d['kernel_ms_per_step'].get('overlap'))"
+   done; done) > gpurun_out/$R/${R}_join_timing_builds.txt
 fi
 timeout 400 python tools/check_elements.py c5slice 2>/dev/null | tail -1 > gpurun_out/$R/${R}_check_elements_c5slice.txt
 ls -la gpurun_out/$R
