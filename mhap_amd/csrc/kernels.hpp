@@ -142,7 +142,7 @@ void oj_stats_dump();   // -DMH_OJ_STATS builds: print and reset the join kernel
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
                     const int32_t* qmeta, const SearchParams& sp, const double* score_table, int32_t* scratch, int64_t scratch_per_lane,
-                    DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared);
+                    DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, int spread);
 // Second stage: one wavefront per candidate (equal-hash join); pairs it cannot decide exactly are appended to `slow`.
 constexpr int OJ_MAX_S = 8192;   // largest ordered sketch the join path stages in LDS
 size_t overlap_join_lds_bytes(int S, int shape);     // shape: 0 every wave alone, 1 pairs of waves share a query, 2 teams of four + bucket table

@@ -919,13 +919,18 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       h->stats.slow_pairs += (int64_t)nslow;
     }
     if (nslow > 0) {
-      const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)nslow + OVL_THREADS - 1) / OVL_THREADS));
-      HIPCHK(h, h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS * (size_t)per_lane * 4));
+      // (few pairs — what the join kernel hands over — are spread over more wavefronts while there is at most one per SIMD: 600 pairs of a
+      //  c5rank chunk, one per wave, 9 -> 3.5 ms; the 76 000 of the C5 slice at sixteen per wave instead of 64: 3 ms SLOWER — four times
+      //  the instructions on a machine that is then full: search_kernels.hip, overlap_kernel)
+      int spread = 1;
+      while (spread < 64 && (int64_t)nslow * spread * 2 <= (int64_t)h->num_cus * 4 * 64) spread *= 2;
+      const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)nslow * spread + OVL_THREADS - 1) / OVL_THREADS));
+      HIPCHK(h, h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS / (size_t)spread * (size_t)per_lane * 4));
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap(h->stream, oblocks, use_join ? h->slow_cand.as<Candidate>() : h->cand.as<Candidate>(), use_join ? ctr + 5 : ctr + 0,
                      use_join ? (unsigned long long)ncand : (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                      qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
-                     recbuf.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2);
+                     recbuf.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2, spread);
       time_end(h);
       HIPCHK(h, hipGetLastError());
     }

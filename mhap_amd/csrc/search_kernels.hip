@@ -854,7 +854,7 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
                                                                          unsigned long long* __restrict__ cand_count, unsigned long long cand_cap,
                                                                          unsigned long long* __restrict__ split_count, unsigned long long* __restrict__ elements,
                                                                          const uint32_t range_log /* <= DQ2_RANGE_LOG: entries per pass (tests shrink it) */) {
-  __shared__ uint32_t cnt[DQ2_WORDS];                   // eight 4-bit thermometers per word
+  __shared__ __align__(16) uint32_t cnt[DQ2_WORDS];    // eight 4-bit thermometers per word
   __shared__ uint2 seglist[DQ2_THREADS];                // queued buckets (longer than IQ_INLINE): (first posting within the slot, length),
   __shared__ uint2 segkey[DQ2_THREADS];                 // ... (slot | bounds row << 16, the query's mix there)
   __shared__ unsigned long long segpre[DQ2_THREADS + 1];
@@ -919,12 +919,28 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
         if (p && bounds[g * per + p + 1] > bounds[g * per + p]) atomicOr(&rmask[p >> 5], 1u << (p & 31));
       }
   }
+  // a short bucket (read by the lane that looked it up) is read ONCE: its postings with the query's value — none, one or two, nearly
+  // always — stay in registers for the passes.  (Every pass read the bucket again, posting after posting, each load waiting for the
+  // one before: with ten passes over 1.25 M entries that was a fifth of this kernel.)
+  uint32_t in_me0 = 0, in_me1 = 0;
+  int in_cnt = 0;
+  if (n && n <= (uint32_t)IQ_INLINE) {
+    const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
+    for (uint32_t u0 = 0; u0 < n; u0 += 4) {
+      uint2 x[4];
+#pragma unroll
+      for (int c = 0; c < 4; c++) { x[c] = make_uint2(~hv, 0u); if (u0 + (uint32_t)c < n) x[c] = P[u0 + (uint32_t)c]; }
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        if (x[c].x == hv) { if (in_cnt == 0) in_me0 = x[c].y; else if (in_cnt == 1) in_me1 = x[c].y; in_cnt++; }
+    }
+  }
   unsigned long long mine = 0;
   for (uint32_t pass = 0; pass < npass; pass++) {
     __syncthreads();
     if (pass > 0 && npass <= (uint32_t)DQ2_MAX_RANGES && !((rmask[pass >> 5] >> (pass & 31)) & 1u)) continue;   // (uniform)
     const uint32_t span = min(1u << range_log, ix.ne - (pass << range_log));   // stored entries of this range (the last one is partial)
-    for (uint32_t j = threadIdx.x; j < (span + 7) / 8; j += DQ2_THREADS) cnt[j] = 0;
+    for (uint32_t j = threadIdx.x * 4; j < (span + 7) / 8; j += DQ2_THREADS * 4) *(uint4*)&cnt[j] = make_uint4(0u, 0u, 0u, 0u);   // (16 bytes per lane: whole vectors, the last one past the span's words too)
     if (threadIdx.x == 0) s_emit = 0;
     __syncthreads();
     // one hit of stored entry `me` (celem: this posting has not been seen by an earlier pass — "table elements processed", :173)
@@ -940,8 +956,13 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
       }                                                                                                               \
     } while (0)
     if (n && n <= (uint32_t)IQ_INLINE) {
-      const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
-      for (uint32_t u = 0; u < n; u++) { const uint2 x = P[u]; if (x.x == hv) DQ2_HIT(x.y, pass == 0); }
+      if (in_cnt <= 2) {
+        if (in_cnt > 0) DQ2_HIT(in_me0, pass == 0);
+        if (in_cnt > 1) DQ2_HIT(in_me1, pass == 0);
+      } else {
+        const uint2* P = ix.items + (size_t)s * ix.slot_stride + lo;
+        for (uint32_t u = 0; u < n; u++) { const uint2 x = P[u]; if (x.x == hv) DQ2_HIT(x.y, pass == 0); }
+      }
     }
     if (nseg) {
       // the queued buckets — of a grouped one this pass's part — as ONE index space (exclusive prefix of the lengths in segpre)
@@ -1000,21 +1021,31 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
 #undef DQ2_HIT
     __syncthreads();
     if (pass > 0 && threadIdx.x == 0) atomicAdd(split_count, 1ULL);   // a pass beyond the first = the hit set was split
-    // emit this range's candidates as ONE contiguous block (one global atomic).  Lane t owns words t, t + 512, ... of the counters
-    // (conflict-free); entries that reached numMinMatches but fail the id / length rules lose their top bit in the first sweep, so
-    // the second one only enumerates bits.
+    // emit this range's candidates as ONE contiguous block (one global atomic).  Lane t owns the four-word vectors t, t + 512, ... of the
+    // counters (16-byte LDS accesses, conflict-free; a pass of a repeat-carrying query touches a few thousand of the 131 072 entries, so
+    // nearly every vector is skipped on one test: zeroing and sweeping word by word cost a query more LDS instructions than its postings);
+    // entries that reached numMinMatches but fail the id / length rules lose their top bit in the first sweep, so the second one only
+    // enumerates bits.
     const uint32_t nwords = (span + 7) / 8;
     int mycount = 0;
-    for (uint32_t wi = threadIdx.x; wi < nwords; wi += DQ2_THREADS) {
-      uint32_t w = cnt[wi], m = w & topmask;
-      while (m) {
-        const int b = __builtin_ctz(m);
-        m &= m - 1;
-        const uint32_t me = (pass << range_log) + wi * 8 + (uint32_t)(b >> 2);
-        if (me < ix.ne && pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) mycount++;   // MinHashSearch.java:200-225
-        else w &= ~(1u << b);
+    for (uint32_t w4 = threadIdx.x * 4; w4 < nwords; w4 += DQ2_THREADS * 4) {
+      const uint4 v = *(const uint4*)&cnt[w4];
+      if (((v.x | v.y | v.z | v.w) & topmask) == 0u) continue;
+      const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        uint32_t w = vw[c], m = w & topmask;
+        if (!m) continue;
+        const uint32_t wi = w4 + (uint32_t)c;
+        while (m) {
+          const int b = __builtin_ctz(m);
+          m &= m - 1;
+          const uint32_t me = (pass << range_log) + wi * 8 + (uint32_t)(b >> 2);
+          if (me < ix.ne && pair_passes(sp, qid, ids[me], qlen, meta[(int64_t)me * META_W + 2])) mycount++;   // MinHashSearch.java:200-225
+          else w &= ~(1u << b);
+        }
+        cnt[wi] = w;
       }
-      cnt[wi] = w;
     }
     uint32_t local = 0;
     if (mycount) local = atomicAdd(&s_emit, (uint32_t)mycount);
@@ -1023,13 +1054,19 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
     __syncthreads();
     unsigned long long slot = s_base + local;
     if (mycount)
-      for (uint32_t wi = threadIdx.x; wi < nwords; wi += DQ2_THREADS) {
-        uint32_t m = cnt[wi] & topmask;
-        while (m) {
-          const int b = __builtin_ctz(m);
-          m &= m - 1;
-          if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)((pass << range_log) + wi * 8 + (uint32_t)(b >> 2)); }
-          slot++;
+      for (uint32_t w4 = threadIdx.x * 4; w4 < nwords; w4 += DQ2_THREADS * 4) {
+        const uint4 v = *(const uint4*)&cnt[w4];
+        if (((v.x | v.y | v.z | v.w) & topmask) == 0u) continue;
+        const uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          uint32_t m = vw[c] & topmask;
+          while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            if (slot < cand_cap) { cand[slot].q = qe; cand[slot].m = (int)((pass << range_log) + (w4 + (uint32_t)c) * 8 + (uint32_t)(b >> 2)); }
+            slot++;
+          }
         }
       }
   }
@@ -1124,12 +1161,17 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
                                                               const double* __restrict__ score_table, int32_t* __restrict__ scratch,
                                                               int64_t scratch_per_lane, DevRecord* __restrict__ recs,
                                                               unsigned long long* __restrict__ rec_count, unsigned long long rec_cap,
-                                                              unsigned long long* __restrict__ compared) {
+                                                              unsigned long long* __restrict__ compared, int spread) {
   __shared__ uint2 lines[2][8 * OVL_THREADS];
   unsigned long long n = *cand_count;
   if (n > cand_cap) n = cand_cap;
-  const int64_t G = (int64_t)gridDim.x * OVL_THREADS;
-  const int64_t g = (int64_t)blockIdx.x * OVL_THREADS + threadIdx.x;
+  // spread (a power of two <= 64): only every spread-th lane takes pairs.  A handful of pairs — the few the join kernel hands over —
+  // packed 64 to a wavefront run in lockstep through each other's branches (4 147 pairs of a c5rank step: 63 ms, on 65 waves of a
+  // machine that holds 20 000); one pair per wavefront, they take as long as the longest of them.
+  const int64_t gl = (int64_t)blockIdx.x * OVL_THREADS + threadIdx.x;
+  if (gl & (int64_t)(spread - 1)) return;
+  const int64_t G = (int64_t)gridDim.x * OVL_THREADS / spread;
+  const int64_t g = gl / spread;
   LaneScratch sc;
   sc.base = scratch + g;
   sc.stride = G;
@@ -1184,7 +1226,7 @@ constexpr int OJ_WAVES = MH_OJ_WAVES;
 constexpr int OJ_JCAP = 128;           // joined k-mers + group records kept per pair
 constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
 #ifndef MH_OJ_GCAP
-#define MH_OJ_GCAP 12
+#define MH_OJ_GCAP 16   // 12 / 16 with the 6-KB filter: C5 slice 50.6 / 46.9 ms (75 928 / 3 739 pairs handed to the per-lane kernel), c5rank 1004 / 996, C2 3.64 / 3.63
 #endif
 constexpr int OJ_GCAP = MH_OJ_GCAP;    // duplicated-hash groups per pair
 constexpr int OJ_GLEN = 8;             // entries of one sketch in a group
@@ -1249,7 +1291,7 @@ __device__ __forceinline__ ShiftStats oj_shift_stats(bool have, int med, int len
 #ifdef MH_OJ_STATS
 // (diagnostic build: where the pairs of the join kernel end — {nj < 3, no record in pass 1, in pass 2, < 3 valid, below the threshold,
 //  accepted, sum of nj, sum of in-window joined k-mers of the scored pairs}; printed by launch_overlap_join's caller through oj_stats_dump)
-__device__ unsigned long long g_oj_stats[16];
+__device__ unsigned long long g_oj_stats[20];
 #define OJ_STAT(k, v) do { if (lane == 0) atomicAdd(&g_oj_stats[k], (unsigned long long)(v)); } while (0)
 #else
 #define OJ_STAT(k, v) do { } while (0)
@@ -1447,6 +1489,9 @@ __device__ __forceinline__ int oj_median_shift(const int32_t* jp1, const int32_t
 // Rank of entry idx (of the current chunk of OJ_RCH blocks) among the in-window entries ahead of it: lane b of the wave holds block
 // b's in-window mask and the in-window count of the blocks before it.
 extern "C" __device__ int oj_writelane(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");   // v_writelane_b32 (this clang has no builtin for it)
+// bit of a hash value in a filter of ts <= 65 536 bits: the low 16 bits of the value (uniform, whatever end of the hash range the sketch keeps)
+// scaled onto [0, ts) — ts need not be a power of two, so the filter can take exactly the LDS a workgroup has to spare
+__device__ __forceinline__ uint32_t oj_filter_bit(uint32_t h, uint32_t ts) { return (uint32_t)__umul24(h & 0xFFFFu, ts) >> 16; }   // (HIP declares __umul24 as int)
 constexpr int OJ_CQ = 256;              // ring of entry indices that passed the query's filter (FILTER shapes; it lives in jp1's words during the join)
 static_assert(OJ_CQ * 2 <= OJ_JCAP * 4 && OJ_CQ >= 64 * OJ_U + 64, "the ring takes a trip's entries on top of an unhandled rest");
 constexpr int OJ_RCH = (64 / OJ_U) * OJ_U;   // blocks of a chunk: whole trips of OJ_U blocks, one block per lane
@@ -1529,13 +1574,15 @@ __device__ __forceinline__ OjBuckets oj_buckets(int first, int last, int nb) {
 }
 __device__ __forceinline__ int oj_bucket_of(const OjBuckets& k, int h) { return (int)__umulhi((uint32_t)(h - k.first), k.mult); }
 int overlap_join_table_slots(int S) { int t = 1024; while (t < 2 * S) t <<= 1; return t; }
-// bits of a query's filter: 8 per entry where LDS bounds the resident waves (PAIR: 9 % of the other sketch's entries pass), 32 where registers do (TEAM: 2.3 %)
+// bits of a query's filter: 8 per entry where LDS bounds the resident waves (PAIR: 12 % of the other sketch's entries pass), 32 where registers do (TEAM: 3 %)
 int overlap_join_filter_bits(int S, int waves) {
-  int per = waves == 4 ? 32 : 8;   // (TEAM, C5 slice: 8 / 16 / 32 bits per entry 57.3 / 55.3 / 53.2 ms; PAIR, C2: 4 / 8 / 16: 4.04 / 3.75 / 3.95)
+  int per = waves == 4 ? 32 : 8;   // (power-of-two filters — TEAM, C5 slice: 16 384 / 32 768 / 65 536 bits 57.3 / 55.3 / 53.2 ms; PAIR, C2: 8 192 / 16 384 / 32 768: 4.04 / 3.75 /
+                                   //  3.95.  TEAM's 49 152 bits = 6 KB leave the LDS that sixteen groups per pair need with five workgroups on a CU)
   if (const char* e = getenv("MHAP_OJ_FILTER_BPE")) { const int x = atoi(e); if (x >= 1 && x <= 64) per = x; }   // (experiments)
-  int t = 1024;
-  while (t < per * S) t <<= 1;
-  return t;
+  long long t = ((long long)per * S + 127) & ~127LL;   // (whole 16-byte vectors of LDS)
+  if (t < 1024) t = 1024;
+  if (t > 65536) t = 65536;                            // (oj_filter_bit maps sixteen bits of the hash)
+  return (int)t;
 }
 
 template <int IT>
@@ -1629,7 +1676,6 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         // the indices of those that pass are queued (a ring of OJ_CQ 16-bit words); whenever 64 are waiting they are handled as ONE
         // dense block: entry and neighbours re-read (L2), bisection among the query's hashes, run / group detection.  At S = 1536 that
         // is three or four dense blocks per pair instead of twenty-four sparse ones.
-        const uint32_t bmask = (uint32_t)ts - 1u;
         const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
         int qn = 0, qd = 0, kit = 0;   // entries queued / handled (wave-uniform)
         uint2 en[OJ_U];
@@ -1648,8 +1694,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               if (jn < nB) en[u] = brow[jn];
             }
             if (keepb) { OJ_KEEP_SWITCH(kit, oj_keep_store, pbk, e) kit++; }
+            uint32_t fb[OJ_U];
 #pragma unroll
-            for (int u = 0; u < OJ_U; u++) w[u] = bm[(e[u].x & bmask) >> 5];
+            for (int u = 0; u < OJ_U; u++) { fb[u] = oj_filter_bit(e[u].x, (uint32_t)ts); w[u] = bm[fb[u] >> 5]; }
 #pragma unroll
             for (int u = 0; u < OJ_U; u++) {
               const int jb = j0 + u * 64;
@@ -1657,7 +1704,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
 #ifdef MH_OJ_NO_SEARCH
                 bool c = (e[u].x ^ e[u].y) == 0x7ffffffeu && w[u] == 0x12345u;   // (timing experiment: the rows are streamed, nothing passes the filter; results are wrong)
 #else
-                bool c = ((w[u] >> (e[u].x & 31u)) & 1u) != 0u;
+                bool c = ((w[u] >> (fb[u] & 31u)) & 1u) != 0u;
 #endif
                 if (jb + 64 > nB) c = c && jb + lane < nB;   // (the last block's lanes past the sketch)
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(c);
@@ -1693,7 +1740,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               if (leader) grp = (l + 1 < nA && ah[l + 1] == hb) || (j + 1 < nB && hnext == hb);
               const bool reg = leader && !grp;
               const unsigned long long balr = __builtin_amdgcn_ballot_w64(reg), balg = __builtin_amdgcn_ballot_w64(grp);
-              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) bad = true;
+              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) { bad = true; OJ_STAT(ng + __popcll(balg) > OJ_GCAP ? 15 : 14, 1); }
               else {
                 if (reg) {
                   const int idx = nj + oj_mbcnt(balr);
@@ -1854,7 +1901,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         const unsigned long long bala = __ballot(a_ok), balb = __ballot(b_ok);
         const int sh = 20 * (t < 3 ? t : 0);
         const int m = __popcll((bala >> sh) & 0x3FFULL), nn = __popcll((balb >> (sh + 10)) & 0x3FFULL);
-        if (__any(live && (m > OJ_GLEN || nn > OJ_GLEN))) { bad = true; break; }
+        if (__any(live && (m > OJ_GLEN || nn > OJ_GLEN))) { bad = true; OJ_STAT(16, 1); break; }
         if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)be.y;
         int sz[3];   // entries of the round's groups (wave-uniform)
@@ -1880,7 +1927,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         gtot += m + nn;
       }
       }
-      if (nj + gtot > OJ_JCAP) bad = true;
+      if (!bad && nj + gtot > OJ_JCAP) { bad = true; OJ_STAT(17, 1); }
       if (bad) {
         if (lane == 0) { const unsigned long long slot = atomicAdd(slow_count, 1ULL); slow[slot] = cd; }
         return;
@@ -2195,7 +2242,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
           for (int i = tid; i < nA; i += NT) {
             const int h = qrow[2 * i];
             ah[i] = h;
-            if (FILTER) atomicOr(&bm[((uint32_t)h & (uint32_t)(ts - 1)) >> 5], 1u << ((uint32_t)h & 31u));   // (the low bits of a hash value are uniform whatever the sketch keeps)
+            if (FILTER) { const uint32_t fb = oj_filter_bit((uint32_t)h, (uint32_t)ts); atomicOr(&bm[fb >> 5], 1u << (fb & 31u)); }
           }
         } else if (nA > 0) {
           bk = oj_buckets(__builtin_amdgcn_readfirstlane(qrow[0]), __builtin_amdgcn_readfirstlane(qrow[2 * (nA - 1)]), ts);
@@ -2283,13 +2330,15 @@ void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, cons
 
 void oj_stats_dump() {
 #ifdef MH_OJ_STATS
-  unsigned long long h[16];
+  unsigned long long h[20];
   if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_oj_stats), sizeof h) != hipSuccess) return;
   const double np = (double)(h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + 1);
   fprintf(stderr, "[oj stats] pairs: nj<3 %llu, no record in pass 1 %llu, in pass 2 %llu, <3 valid %llu, below threshold %llu, accepted %llu; mean nj %.2f, mean in-window joined of scored %.2f\n",
           h[0], h[1], h[2], h[3], h[4], h[5], (double)h[6] / np, (double)h[7] / (double)(h[4] + h[5] + 1));
   fprintf(stderr, "[oj stats] groups: per pair %.2f, pairs with groups %llu, with >= 3 %llu, entries in groups per pair %.2f, words reserved for group records per pair %.2f, removed by optimizeShifts per pair %.2f\n",
           (double)h[8] / np, h[9], h[10], (double)h[11] / np, (double)h[12] / np, (double)h[13] / np);
+  fprintf(stderr, "[oj stats] handed to the per-lane kernel: more than %d joined k-mers %llu, more than %d groups %llu, a group of more than %d entries %llu, joined k-mers + group entries > %d: %llu\n",
+          OJ_JCAP, h[14], OJ_GCAP, h[15], OJ_GLEN, h[16], OJ_JCAP, h[17]);
   memset(h, 0, sizeof h);
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_oj_stats), h, sizeof h);
 #endif
@@ -2298,9 +2347,9 @@ void oj_stats_dump() {
 void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const unsigned long long* cand_count, unsigned long long cand_cap,
                     const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered, int64_t qord_stride,
                     const int32_t* qmeta, const SearchParams& sp, const double* score_table, int32_t* scratch, int64_t scratch_per_lane,
-                    DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared) {
+                    DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, int spread) {
   hipLaunchKernelGGL(overlap_kernel, dim3(nblocks), dim3(OVL_THREADS), 0, st, cand, cand_count, cand_cap, ordered, ord_stride, meta,
-                     qordered, qord_stride, qmeta, sp, score_table, scratch, scratch_per_lane, recs, rec_count, rec_cap, compared);
+                     qordered, qord_stride, qmeta, sp, score_table, scratch, scratch_per_lane, recs, rec_count, rec_cap, compared, spread);
 }
 
 }  // namespace mhap

@@ -29,8 +29,8 @@ cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_r
 # where the pairs of the second stage end (diagnostic build of the join kernel: bash tools/build_variant.sh ojstats -DMH_OJ_STATS)
 V=mhap_amd/lib/variants
 if [ -f $V/libmhaphip_ojstats.so ]; then
-  (MHAP_LIB_PATH=$V/libmhaphip_ojstats.so python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -2 | sed 's/^/c2: /'
-   MHAP_LIB_PATH=$V/libmhaphip_ojstats.so python bench.py --config c5slice --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -2 | sed 's/^/c5slice: /') > gpurun_out/$R/${R}_join_exit_stats.txt
+  (MHAP_LIB_PATH=$V/libmhaphip_ojstats.so python bench.py --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -3 | sed 's/^/c2: /'
+   MHAP_LIB_PATH=$V/libmhaphip_ojstats.so python bench.py --config c5slice --steps 1 --warmup 0 --no-cpu-baseline 2>&1 | grep "oj stats" | tail -3 | sed 's/^/c5slice: /') > gpurun_out/$R/${R}_join_exit_stats.txt
 fi
 # what the parts of the join kernel cost (timing builds, results wrong by construction): rows streamed only / + filter, lookups, groups collected /
 # everything but the duplicated-hash groups / the shipped kernel
@@ -42,5 +42,7 @@ import sys, json
 d = json.loads(sys.stdin.read()); print('$c', '$v'.split('/')[-1], 'overlap kernel ms', d['kernel_ms_per_step'].get('overlap'))"
    done; done) > gpurun_out/$R/${R}_join_timing_builds.txt
 fi
+# instruction mix of the join kernel (PMC pass of its own)
+(bash tools/pmc_kernel.sh overlap_join_kernel; CONFIG=c5slice bash tools/pmc_kernel.sh overlap_join_kernel) > gpurun_out/$R/${R}_pmc_join_instmix.txt 2>&1
 timeout 400 python tools/check_elements.py c5slice 2>/dev/null | tail -1 > gpurun_out/$R/${R}_check_elements_c5slice.txt
 ls -la gpurun_out/$R
