@@ -562,10 +562,11 @@ class MinHashSearch:
         return self._collect(lambda cb: self._lib.mhap_find_matches_sketches(self._h, _ptr(ids), _ptr(sl), _ptr(mh), _ptr(od), _ptr(osz),
                                                                             _ptr(osl), C.c_int64(len(ids)), cb, None))
 
-    def find_matches_device(self, d_q_minhash_ptr, d_q_ordered_ptr, d_q_meta_ptr, ids, to_self=True, before_second_stage=None):
+    def find_matches_device(self, d_q_minhash_ptr, d_q_ordered_ptr, d_q_meta_ptr, ids, to_self=True, before_second_stage=None, count_only=False):
         """Device-resident query sketches (forward rows of the ranks' tables) against this handle's index.
         before_second_stage: callable run once the candidates are known and before the ordered rows are read (e.g. the wait
-        for their asynchronous all-gather)."""
+        for their asynchronous all-gather).  count_only: no sink — the library reads the records back and converts them as always,
+        nobody keeps them; returns their number (10^8 records and more per search: what a driver would stream to a file)."""
         ids = np.ascontiguousarray(ids, dtype=np.int64)
         gate = None
         if before_second_stage is not None:
@@ -579,9 +580,14 @@ class MinHashSearch:
             gate = _GATE(_gate)
             self._chk(self._lib.mhap_set_second_stage_gate(self._h, gate, None))
         try:
-            return self._collect(lambda cb: self._lib.mhap_find_matches_device(self._h, C.c_void_p(d_q_minhash_ptr), C.c_void_p(d_q_ordered_ptr),
-                                                                              C.c_void_p(d_q_meta_ptr), _ptr(ids), C.c_int64(len(ids)),
-                                                                              C.c_int(1 if to_self else 0), cb, None))
+            def call(cb):
+                return self._lib.mhap_find_matches_device(self._h, C.c_void_p(d_q_minhash_ptr), C.c_void_p(d_q_ordered_ptr), C.c_void_p(d_q_meta_ptr),
+                                                          _ptr(ids), C.c_int64(len(ids)), C.c_int(1 if to_self else 0), cb, None)
+            if count_only:
+                before = self.stats()["matches_found"]
+                self._chk(call(_SINK(0)))
+                return self.stats()["matches_found"] - before
+            return self._collect(call)
         finally:
             if gate is not None:
                 self._chk(self._lib.mhap_set_second_stage_gate(self._h, _GATE(0), None))

@@ -245,6 +245,27 @@ def test_index_export_roundtrip_and_query_sharding():
     assert kt["index_build"]["launches"] == 1 and kt["index_query"]["launches"] == 3
 
 
+def test_search_with_query_sketches_already_in_device_memory():
+    """mhap_find_matches_device — what one rank of a sharded search runs after its all-gather, and what tools/emulate_rank.py times: the
+    forward rows of every read, sketched into caller-owned device buffers, against the index of the same reads under the toSelf id
+    rules = the self overlap; with no sink the records are counted, not delivered."""
+    import torch
+    fa = mhap_amd.synth_reads(300, 3000, seed=77, error_rate=0.06)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=512, device=0)
+    n, H, S = len(fa), 128, 512
+    dev = torch.device("cuda", 0)
+    mh = torch.empty((2 * n, H), dtype=torch.int32, device=dev); od = torch.empty((2 * n, S, 2), dtype=torch.int32, device=dev)
+    mt = torch.empty((2 * n, 4), dtype=torch.int32, device=dev)
+    with MinHashSearch(p) as ms:
+        ms.stage(fa); ms.sketch_staged_device(mh.data_ptr(), od.data_ptr(), mt.data_ptr()); ms.synchronize()
+        q_mh, q_od, q_mt = mh[0::2].contiguous(), od[0::2].contiguous(), mt[0::2].contiguous()
+        ms.add_staged()
+        want = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+        got = sorted(mhap_amd.records_to_lines(ms.find_matches_device(q_mh.data_ptr(), q_od.data_ptr(), q_mt.data_ptr(), fa.ids, to_self=True)))
+        cnt = ms.find_matches_device(q_mh.data_ptr(), q_od.data_ptr(), q_mt.data_ptr(), fa.ids, to_self=True, count_only=True)
+    assert len(want) > 100 and got == want and cnt == len(want)
+
+
 def test_group_of_ranks_on_one_device_matches_the_oracle(monkeypatch):
     """The multi-GPU path inside the library (mhap_group_*: reads dealt round-robin, one index shard per rank, forward query rows
     gathered by peer copies, every rank scoring all queries against its shard under the toSelf id rules) with 2, 3 and 4 ranks

@@ -3,7 +3,7 @@
 toSelf id rules — exactly what mhap_dist_find_matches_self runs after its all-gather).  The other ranks' rows are sketched
 beforehand, untimed, straight into the buffers an all-gather would have filled (DESIGN.md §5's memory plan, allocated for real:
 `hbm_gb` in the output).  Prints the per-phase wall times: the compute side of DESIGN.md §5's model.
-  python tools/emulate_rank.py [N=8] [config=c2|c4|c5|c5rank|...] [iterations=4]"""
+  python tools/emulate_rank.py [N=8] [config=c2|c4|c5|c5rank|...] [iterations=4] [count|keep]"""
 import json, os, sys, tempfile, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -57,12 +57,16 @@ for it in range(iters):
     t0 = time.perf_counter()
     ms.add_staged(); ms.synchronize()
     t1 = time.perf_counter()
-    nrec = len(ms.find_matches_device(g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr(), all_ids, to_self=True))
+    # (10^8 records and more per rank — all of configs[4] — are counted, not kept: the mirror's array of them would be what is measured)
+    count_only = (sys.argv[4] == "count") if len(sys.argv) > 4 else n_total >= 2_000_000
+    r = ms.find_matches_device(g_mh.data_ptr(), g_od.data_ptr(), g_mt.data_ptr(), all_ids, to_self=True, count_only=count_only)
+    nrec = int(r) if count_only else len(r)
     t2 = time.perf_counter()
     kt = ms.kernel_times(); ms.reset_kernel_times(); st = ms.stats()
     free, total = torch.cuda.mem_get_info()
     res = {"world": world, "config": cfgname, "reads_per_rank": len(fa0), "queries_all_ranks": tot, "sketch_and_index_ms": round((t1 - t0) * 1e3, 2),
            "search_all_queries_ms": round((t2 - t1) * 1e3, 2), "rank_step_ms_without_comm": round((t2 - t0) * 1e3, 2), "records_this_rank": nrec,
+           "records_kept_by_the_caller": not count_only,
            "candidates_this_rank": int(st["candidates_compared"]), "slow_pairs": int(st["slow_pairs"]),
            "kernel_ms": {k: round(v["ms"], 3) for k, v in kt.items() if v["ms"] > 0},
            "gathered_row_bytes": int(sum(x.numel() * 4 for x in (g_mh, g_od, g_mt))),

@@ -17,7 +17,7 @@ for r in csv.DictReader(open(f)):
             seen.add(r["Dispatch_Id"]); dur += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 import json
 try:
-    b = json.loads(open("gpurun_out/pmc_k/bench.log").read().strip().splitlines()[-1]); pairs = b.get("candidates_per_step")
+    b = json.loads([l for l in open("gpurun_out/pmc_k/bench.log").read().splitlines() if l.startswith("{")][-1]); pairs = b.get("candidates_per_step")
 except Exception: pairs = None
 print("$C", "candidate pairs per step", pairs, "(the counters are sums over every launch of the run: the timed step and the fenced extra one)")
 print("$K", "dispatches", len(seen), "ns", dur, {k: "%.3e" % v for k, v in sorted(acc.items())})

@@ -20,7 +20,7 @@ for c in c1 c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun
 # configs[3] in full and one rank's share of configs[4] on one GPU, one rank of an N-GPU job (gathered rows of the other ranks in HBM), the native driver end to end
 timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c4.json 2>/dev/null
 timeout 1200 python bench.py --config c5rank --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c5rank.json 2>/dev/null
-(for n in 2 4 8; do python tools/emulate_rank.py $n c2 4 2>/dev/null | tail -1; done; python tools/emulate_rank.py 8 c4 3 2>/dev/null | tail -1; python tools/emulate_rank.py 8 c5 1 2>/dev/null | tail -1) > gpurun_out/$R/${R}_emulate_rank.txt
+(for n in 2 4 8; do python tools/emulate_rank.py $n c2 4 2>/dev/null | tail -1; done; python tools/emulate_rank.py 8 c4 3 2>/dev/null | tail -1; python tools/emulate_rank.py 8 c5 1 count 2>/dev/null | tail -1) > gpurun_out/$R/${R}_emulate_rank.txt
 (bash tools/e2e_probe.sh c2; bash tools/e2e_probe.sh c4) > gpurun_out/$R/${R}_e2e_probe.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 1 --config c5rank > /dev/null 2>&1
 cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats_c5rank.csv
