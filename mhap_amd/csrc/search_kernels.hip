@@ -1585,17 +1585,23 @@ int overlap_join_filter_bits(int S, int waves) {
   return (int)t;
 }
 
+typedef int oj_keep_t __attribute__((ext_vector_type(12)));   // (vectors, not an array: with a dynamic index an array of this size goes to scratch in this kernel; two of
+                                                              //  twelve: a vector of 24 takes 32 registers, and up to eight elements the compiler picks by compare and select)
+static_assert(OJ_KB == 24 && 12 % OJ_U == 0, "two vectors of twelve blocks, whole trips each");
 template <int IT>
-__device__ __forceinline__ void oj_keep_store(int (&pbk)[OJ_KB], const uint2 (&e)[OJ_U]) {
+__device__ __forceinline__ void oj_keep_store(oj_keep_t (&pbk)[2], const uint2 (&e)[OJ_U]) {
 #pragma unroll
-  for (int u = 0; u < OJ_U; u++) if (IT * OJ_U + u < OJ_KB) pbk[IT * OJ_U + u] = (int)e[u].y;
+  for (int u = 0; u < OJ_U; u++) if (IT * OJ_U + u < OJ_KB) pbk[(IT * OJ_U + u) / 12][(IT * OJ_U + u) % 12] = (int)e[u].y;
 }
 template <int IT>
-__device__ __forceinline__ void oj_keep_load(const int (&pbk)[OJ_KB], int (&posv)[OJ_U]) {
+__device__ __forceinline__ void oj_keep_load(const oj_keep_t (&pbk)[2], int (&posv)[OJ_U]) {
 #pragma unroll
-  for (int u = 0; u < OJ_U; u++) posv[u] = IT * OJ_U + u < OJ_KB ? pbk[IT * OJ_U + u] : INT32_MIN;
+  for (int u = 0; u < OJ_U; u++) posv[u] = IT * OJ_U + u < OJ_KB ? pbk[(IT * OJ_U + u) / 12][(IT * OJ_U + u) % 12] : INT32_MIN;
 }
 // (a wave-uniform switch over static indices: the array stays in registers, no indirect addressing)
+#ifndef MH_OJ_KEEP_IDX
+#define MH_OJ_KEEP_IDX 1
+#endif
 #define OJ_KEEP_SWITCH(it, OP, ...)                                                                                              \
   switch (it) {                                                                                                                  \
     case 0: OP<0>(__VA_ARGS__); break; case 1: OP<1>(__VA_ARGS__); break; case 2: OP<2>(__VA_ARGS__); break; case 3: OP<3>(__VA_ARGS__); break;   \
@@ -1604,6 +1610,22 @@ __device__ __forceinline__ void oj_keep_load(const int (&pbk)[OJ_KB], int (&posv
     default: OP<12>(__VA_ARGS__); break;                                                                                         \
   }
 static_assert(OJ_KIT <= 13, "OJ_KEEP_SWITCH covers 13 trips");
+// The kept positions are addressed by a wave-uniform trip number.  As a switch over static indices the array stayed in registers, but the
+// compiler merged the cases through copies of the WHOLE array — a dozen to two dozen v_mov per trip of the streaming loop (found in the ISA
+// when a probe showed that loop at 3.5 TB/s where bare row gathers reach 6.1: tools/row_gather_probe.hip).  A dynamic uniform index
+// compiles to s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off: three instructions per element.
+#if MH_OJ_KEEP_IDX
+#define OJ_KEEP_STORE(it, pbk, e) { const int b_ = (it) * OJ_U;                                                                 \
+    if (b_ < 12) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) pbk[0][b_ + u_] = (int)e[u_].y; }                          \
+    else if (b_ < 24) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) pbk[1][b_ - 12 + u_] = (int)e[u_].y; } }
+#define OJ_KEEP_LOAD(it, pbk, posv) { const int b_ = (it) * OJ_U;                                                               \
+    if (b_ < 12) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) posv[u_] = pbk[0][b_ + u_]; }                              \
+    else if (b_ < 24) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) posv[u_] = pbk[1][b_ - 12 + u_]; }                    \
+    else { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) posv[u_] = INT32_MIN; } }
+#else
+#define OJ_KEEP_STORE(it, pbk, e) OJ_KEEP_SWITCH(it, oj_keep_store, pbk, e)
+#define OJ_KEEP_LOAD(it, pbk, posv) OJ_KEEP_SWITCH(it, oj_keep_load, pbk, posv)
+#endif
 
 // SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its WAVES waves stage the
 //                 query's hashes (and, TABLE, build the bucket table) together — one copy in LDS — then take the run's candidates one
@@ -1667,7 +1689,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
       // ---- join ----
       int nj = 0, ng = 0;
       bool bad = false;
-      int pbk[OJ_KB];    // (keepb) positions of the other sketch: entry blk * 64 + lane in pbk[blk]
+      oj_keep_t pbk[2];      // (keepb) positions of the other sketch: entry blk * 64 + lane in pbk[blk / 12][blk % 12]
       if (nA > 0 && nB > 0) {
         if constexpr (FILTER) {
         // Filter, compact, look up.  1 entry in 40 of the other sketch has a partner in the query (a true overlap; a handful for a pair that
@@ -1678,9 +1700,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         // is three or four dense blocks per pair instead of twenty-four sparse ones.
         const int p2 = 1 << (31 - __builtin_clz((unsigned)nA));   // largest power of two <= nA
         int qn = 0, qd = 0, kit = 0;   // entries queued / handled (wave-uniform)
+        // (loads past the sketch's end read its last entry again — no bounds branch around a load; what such lanes queue is dropped when the
+        //  queue is handled, and the rank pass trims the last block's mask)
         uint2 en[OJ_U];
 #pragma unroll
-        for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = make_uint2(0u, 0u); if (j < nB) en[u] = brow[j]; }
+        for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = brow[j < nB ? j : nB - 1]; }
         for (int j0 = 0;; j0 += 64 * OJ_U) {
           const bool more = j0 < nB && !bad;
           if (more) {
@@ -1690,10 +1714,9 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int u = 0; u < OJ_U; u++) {
               e[u] = en[u];
               const int jn = j0 + (u + OJ_U) * 64 + lane;
-              en[u] = make_uint2(0u, 0u);
-              if (jn < nB) en[u] = brow[jn];
+              en[u] = brow[jn < nB ? jn : nB - 1];
             }
-            if (keepb) { OJ_KEEP_SWITCH(kit, oj_keep_store, pbk, e) kit++; }
+            if (keepb) { OJ_KEEP_STORE(kit, pbk, e) kit++; }
             uint32_t fb[OJ_U];
 #pragma unroll
             for (int u = 0; u < OJ_U; u++) { fb[u] = oj_filter_bit(e[u].x, (uint32_t)ts); w[u] = bm[fb[u] >> 5]; }
@@ -1702,11 +1725,10 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               const int jb = j0 + u * 64;
               if (jb < nB) {
 #ifdef MH_OJ_NO_SEARCH
-                bool c = (e[u].x ^ e[u].y) == 0x7ffffffeu && w[u] == 0x12345u;   // (timing experiment: the rows are streamed, nothing passes the filter; results are wrong)
+                const bool c = (e[u].x ^ e[u].y) == 0x7ffffffeu && w[u] == 0x12345u;   // (timing experiment: the rows are streamed, nothing passes the filter; results are wrong)
 #else
-                bool c = ((w[u] >> (fb[u] & 31u)) & 1u) != 0u;
+                const bool c = ((w[u] >> (fb[u] & 31u)) & 1u) != 0u;
 #endif
-                if (jb + 64 > nB) c = c && jb + lane < nB;   // (the last block's lanes past the sketch)
                 const unsigned long long bal = __builtin_amdgcn_ballot_w64(c);
                 if (bal) {
                   if (c) cq[(qn + oj_mbcnt(bal)) & (OJ_CQ - 1)] = (uint16_t)(jb + lane);
@@ -1719,10 +1741,11 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
           while (!bad && (qn - qd >= 64 || (!more && qn > qd))) {
             oj_lds_sync();
             const int cnt = qn - qd < 64 ? qn - qd : 64;
-            const bool act = lane < cnt;
+            bool act = lane < cnt;
             int j = 0, hb = 0, pb = 0, hprev = 0, hnext = 0;
+            if (act) j = cq[(qd + lane) & (OJ_CQ - 1)];
+            act = act && j < nB;                       // (the last block's lanes past the sketch's end queue themselves too)
             if (act) {
-              j = cq[(qd + lane) & (OJ_CQ - 1)];
               const uint2 be = brow[j];
               hb = (int)be.x; pb = (int)be.y;
               if (j > 0) hprev = (int)brow[j - 1].x;
@@ -1786,7 +1809,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             en[u] = make_uint2(0u, 0u);
             if (jn < nB) en[u] = brow[jn];
           }
-          if (keepb) { OJ_KEEP_SWITCH(kit, oj_keep_store, pbk, e) kit++; }
+          if (keepb) { OJ_KEEP_STORE(kit, pbk, e) kit++; }
           bool found[OJ_U];
           bool anyf = false;
           if constexpr (TABLE) {
@@ -2118,7 +2141,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
           const int cend = cb + 64 * OJ_RCH < nB ? cb + 64 * OJ_RCH : nB;
           for (int jb = cb; jb < cend; jb += 64 * OJ_U, kit2++) {
             int posv[OJ_U];
-            if (keepb) { OJ_KEEP_SWITCH(kit2, oj_keep_load, pbk, posv) }
+            if (keepb) { OJ_KEEP_LOAD(kit2, pbk, posv) }
             else {
 #pragma unroll
               for (int u = 0; u < OJ_U; u++) {
