@@ -1495,6 +1495,15 @@ __device__ __forceinline__ uint32_t oj_filter_bit(uint32_t h, uint32_t ts) { ret
 constexpr int OJ_CQ = 256;              // ring of entry indices that passed the query's filter (FILTER shapes; it lives in jp1's words during the join)
 static_assert(OJ_CQ * 2 <= OJ_JCAP * 4 && OJ_CQ >= 64 * OJ_U + 64, "the ring takes a trip's entries on top of an unhandled rest");
 constexpr int OJ_RCH = (64 / OJ_U) * OJ_U;   // blocks of a chunk: whole trips of OJ_U blocks, one block per lane
+// The last block of a sketch whose length is no multiple of 64: its lanes past the end took part in the ballot with whatever they held.
+// Trimmed once after the pass (the block's mask sits in lane `blk`; no later block's prefix depends on it) instead of tested in every block.
+__device__ __forceinline__ void oj_trim_last_block(uint32_t& mlo, uint32_t& mhi, int& total, int blk, int valid) {
+  const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mhi, blk) << 32) | (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mlo, blk);
+  const unsigned long long keep = m & ((1ULL << valid) - 1ULL);
+  total -= __popcll(m ^ keep);
+  mlo = (uint32_t)oj_writelane((int)(uint32_t)keep, blk, (int)mlo);
+  mhi = (uint32_t)oj_writelane((int)(uint32_t)(keep >> 32), blk, (int)mhi);
+}
 __device__ __forceinline__ int oj_rank_from(uint32_t mlo, uint32_t mhi, int mpre, int idx) {
   const int src = (idx >> 6) & 63;
   const uint32_t lo = (uint32_t)__shfl((int)mlo, src), hi = (uint32_t)__shfl((int)mhi, src);
@@ -2116,8 +2125,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               if (i0 < nA) {
                 // (read from memory, entries past the sketch hold INT32_MIN, and a1 >= 0; a ballot per comparison: the compiler turns a ballot of their conjunction into
                 // two more vector instructions)
-                unsigned long long bal = __builtin_amdgcn_ballot_w64(posv[u] >= a1) & __builtin_amdgcn_ballot_w64(posv[u] <= a2);
-                if (APOS && i0 + 64 > nA) bal &= (1ULL << (nA - i0)) - 1ULL;
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(posv[u] >= a1) & __builtin_amdgcn_ballot_w64(posv[u] <= a2);
                 const int blk = (i0 - cb) >> 6;
                 mlo = (uint32_t)oj_writelane((int)(uint32_t)bal, blk, (int)mlo);
                 mhi = (uint32_t)oj_writelane((int)(uint32_t)(bal >> 32), blk, (int)mhi);
@@ -2126,6 +2134,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               }
             }
           }
+          if (APOS && cend == nA && (nA & 63)) oj_trim_last_block(mlo, mhi, s1, (nA - 1 - cb) >> 6, nA & 63);   // (what the LDS words behind the positions happened to hold)
 #pragma unroll
           for (int r = 0; r < OJ_R; r++) {
             if (r < jrounds) {
@@ -2154,8 +2163,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             for (int u = 0; u < OJ_U; u++) {
               const int j0 = jb + u * 64;
               if (j0 < nB) {
-                unsigned long long bal = __builtin_amdgcn_ballot_w64(posv[u] >= b1) & __builtin_amdgcn_ballot_w64(posv[u] <= b2);
-                if (j0 + 64 > nB) bal &= (1ULL << (nB - j0)) - 1ULL;   // (the last block's lanes past the sketch)
+                const unsigned long long bal = __builtin_amdgcn_ballot_w64(posv[u] >= b1) & __builtin_amdgcn_ballot_w64(posv[u] <= b2);
                 const int blk = (j0 - cb) >> 6;
                 mlo = (uint32_t)oj_writelane((int)(uint32_t)bal, blk, (int)mlo);
                 mhi = (uint32_t)oj_writelane((int)(uint32_t)(bal >> 32), blk, (int)mhi);
@@ -2164,6 +2172,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               }
             }
           }
+          if (keepb && cend == nB && (nB & 63)) oj_trim_last_block(mlo, mhi, s2, (nB - 1 - cb) >> 6, nB & 63);   // (the kept registers of lanes past the sketch's end)
 #pragma unroll
           for (int r = 0; r < OJ_R; r++) {
             if (r < jrounds) {
