@@ -638,6 +638,7 @@ struct PostStage {
     if (hipMemcpyAsync((void*)hrecs, src, bytes, hipMemcpyDeviceToHost, h->copy_stream) != hipSuccess || hipStreamSynchronize(h->copy_stream) != hipSuccess) {
       err = "record read-back failed"; return MHAP_E_HIP;
     }
+    HPROF("tail: records on the host");
     if (h->out_recs2_cap[sl] < (size_t)n) {
       free(h->out_recs2[sl]);
       h->out_recs2_cap[sl] = (size_t)n + (size_t)n / 4 + 1024;
@@ -659,9 +660,11 @@ struct PostStage {
         else { r.b1 = d.b1; r.b2 = d.b2; }
         r.pad = 0;
       }
-    });
+    }, 65536);   // (spawning threads for C2's 41 915 records took longer than converting them)
     matches += (int64_t)n;
+    HPROF("tail: records converted");
     if (sink && sink(out, (int64_t)n, user) != 0) { err = "record sink aborted the search"; return MHAP_E_STATE; }
+    HPROF("tail: sink returned");
     return MHAP_OK;
   }
   void loop() {
@@ -826,6 +829,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
           rc = sync_stream(h);
           if (rc != MHAP_OK) return rc;
         }
+        HPROF("candidates known");
         ncand = c5[0];
         if (ncand <= cand_cap) { h->stats.table_elements += (int64_t)c5[4]; h->stats.index_splits += (int64_t)c5[3]; }
       } else {
@@ -862,6 +866,8 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     for (int i = 0; i < 3; i++) fits[i] = overlap_join_lds_bytes(S, i) <= 64 * 1024;
     const bool use_join = !lane_only && S <= OJ_MAX_S && (fits[0] || fits[1] || fits[2]);
     unsigned long long nslow = use_join ? 0 : ncand;
+    unsigned long long cj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool have_counts = false;
     if (use_join) {
       HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
       // (round 3, every entry looked up — C2, 4.5 candidates per query: alone 4.94, pair 4.83, team 5.03 ms; C5 slice, 79: alone 93, pair 87,
@@ -913,9 +919,12 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
                           (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7, ph, qph, h->pass_min_tbl.as<int32_t>());
       time_end(h);
       HIPCHK(h, hipGetLastError());
-      HIPCHK(h, hipMemcpyAsync(&nslow, ctr + 5, 8, hipMemcpyDeviceToHost, h->stream));
+      // (one read-back for the pairs handed over and for the counts the tail needs: nothing else changes them when none were)
+      HIPCHK(h, hipMemcpyAsync(cj, ctr, 64, hipMemcpyDeviceToHost, h->stream));
       int rcj = sync_stream(h);
       if (rcj != MHAP_OK) return rcj;
+      nslow = cj[5];
+      have_counts = nslow == 0;
       h->stats.slow_pairs += (int64_t)nslow;
     }
     if (nslow > 0) {
@@ -934,10 +943,12 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       time_end(h);
       HIPCHK(h, hipGetLastError());
     }
-    unsigned long long counts[3] = {0, 0, 0};
-    HIPCHK(h, hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
-    int rc = sync_stream(h);
-    if (rc != MHAP_OK) return rc;
+    unsigned long long counts[3] = {cj[0], cj[1], cj[2]};
+    if (!have_counts) {
+      HIPCHK(h, hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
+      int rc = sync_stream(h);
+      if (rc != MHAP_OK) return rc;
+    }
     HPROF("overlap done");
     oj_stats_dump();
     const unsigned long long nrec = counts[1];
