@@ -496,9 +496,9 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       const uint32_t* E = ix.ends + (size_t)s * eper + (hvp >> ix.shift);
       const uint32_t e0 = E[0], e1 = E[1];
       tot += e1 - e0;
-      if (SPT == 1 && itp < IQ_PRE) { pre_hv[itp] = (int)hvp; pre_lo[itp] = (int)e0; pre_n[itp] = (int)(e1 - e0); }
+      if (itp < IQ_PRE) { pre_hv[itp] = (int)hvp; pre_lo[itp] = (int)e0; pre_n[itp] = (int)(e1 - e0); }
     }
-    pre_ok = SPT == 1;
+    pre_ok = true;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
@@ -561,8 +561,8 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       for (int u = 0; u < SPT; u++) {
         const int s = s0 + u * IQ_THREADS + (int)threadIdx.x;
         hv[u] = 0; lo[u] = 0; n[u] = 0;
-        if (pre_ok && it < IQ_PRE) {
-          if (s < sp.H) { hv[u] = (uint32_t)pre_hv[it]; lo[u] = (uint32_t)pre_lo[it]; n[u] = (uint32_t)pre_n[it]; }
+        if (pre_ok && it * SPT + u < IQ_PRE) {
+          if (s < sp.H) { hv[u] = (uint32_t)pre_hv[it * SPT + u]; lo[u] = (uint32_t)pre_lo[it * SPT + u]; n[u] = (uint32_t)pre_n[it * SPT + u]; }
         } else if (s < sp.H) {
           hv[u] = inv_mix((uint32_t)qrow[s]);
           const uint32_t* E = ix.ends + (size_t)s * eper + (hv[u] >> ix.shift);
