@@ -1741,11 +1741,19 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
         if (!dprof1) (void)hipMalloc(&dprof1, 8 * sizeof(unsigned long long));
         (void)hipMemsetAsync(dprof1, 0, 8 * sizeof(unsigned long long), st);
         a.prof = dprof1;
+        static hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        if (!pe0) { (void)hipEventCreate(&pe0); (void)hipEventCreate(&pe1); }
+        (void)hipEventRecord(pe0, st);
         hipLaunchKernelGGL(minhash_w1_kernel<true>, dim3(nb), dim3(256), lds1, st, a);
+        (void)hipEventRecord(pe1, st);
         unsigned long long hp[8];
         (void)hipMemcpyAsync(hp, dprof1, sizeof(hp), hipMemcpyDeviceToHost, st);
         (void)hipStreamSynchronize(st);
         const double tot = (double)hp[7];
+        float pms = 0.f; (void)hipEventElapsedTime(&pms, pe0, pe1);
+        // shader clock the chip held: every resident wave counts its own s_memtime ticks from start to end of the persistent loop
+        fprintf(stderr, "[minhash w1 prof] launch %.3f ms, %d waves: mean shader clock %.0f MHz (wave-clocks / waves / time)\n", pms, nb * 4,
+                pms > 0.f ? tot / ((double)nb * 4.0) / ((double)pms * 1e3) : 0.0);
         fprintf(stderr, "[minhash w1 prof] rows %llu (first-type %llu)  wave-clocks: total %.3g  key load+transpose %.1f%%  first-row slots %.1f%% (%.0f clocks/step)  "
                         "later-row slots %.1f%% (%.0f clocks/step)  drains %.1f%%  candidates/row %.0f\n", hp[4], hp[5], tot, 100.0 * hp[0] / tot, 100.0 * hp[1] / tot,
                 hp[5] ? (double)hp[1] / ((double)hp[5] * H) : 0.0, 100.0 * hp[2] / tot, hp[4] > hp[5] ? (double)hp[2] / ((double)(hp[4] - hp[5]) * H) : 0.0,

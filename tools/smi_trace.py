@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Clock / power / temperature trace of GPU 0 while something else runs.
+
+    python tools/smi_trace.py OUT.txt [seconds] &      # samples until killed (SIGTERM) or `seconds` have passed
+Start it while the load is ALREADY running: the card to trace is picked by its gpu_busy_percent over the first 1.5 s.
+
+Two sources, both logged with a monotonic timestamp:
+  * sysfs (hwmon freq1_input / power1_average|power1_input / temp*_input, pp_dpm_sclk, gpu_busy_percent) at ~20 Hz when the
+    files exist on the box;
+  * `rocm-smi --showclocks --showpower --showtemp --showuse --json` once a second (the tool's own view; its start-up is slow).
+The summary at the end gives min / mean / max per quantity over the samples with gpu_busy >= 50 % (or all samples when the
+busy figure is absent).
+"""
+import glob
+import json
+import os
+import signal
+import subprocess
+import sys
+import threading
+import time
+
+out = sys.argv[1] if len(sys.argv) > 1 else "smi_trace.txt"
+limit = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
+stop = threading.Event()
+signal.signal(signal.SIGTERM, lambda *_: stop.set())
+signal.signal(signal.SIGINT, lambda *_: stop.set())
+
+
+def rd(p):
+    try:
+        with open(p) as fh:
+            return fh.read().strip()
+    except OSError:
+        return None
+
+
+def cards():
+    return [os.path.join(c, "device") for c in sorted(glob.glob("/sys/class/drm/card[0-9]*"))
+            if os.path.exists(os.path.join(c, "device", "gpu_busy_percent"))]
+
+
+def busiest_card(seconds=1.5):
+    """The box has eight GPUs in sysfs and ONE visible to the job: the card to trace is the one that is busy (ROCR_VISIBLE_DEVICES /
+    the cgroup say nothing here).  Sampled for a moment; falls back to the first card."""
+    cs = cards()
+    if not cs:
+        return None
+    tot = {c: 0.0 for c in cs}
+    t_end = time.monotonic() + seconds
+    while time.monotonic() < t_end:
+        for c in cs:
+            try:
+                tot[c] += float(rd(os.path.join(c, "gpu_busy_percent")) or 0)
+            except ValueError:
+                pass
+        time.sleep(0.05)
+    return max(cs, key=lambda c: tot[c])
+
+
+dev = busiest_card()
+hw = (glob.glob(os.path.join(dev, "hwmon", "hwmon*")) or [None])[0] if dev else None
+files = {}
+if hw:
+    for name in ("freq1_input", "freq2_input", "power1_average", "power1_input", "power1_cap", "temp1_input", "temp2_input", "temp3_input"):
+        p = os.path.join(hw, name)
+        if os.path.exists(p):
+            files[name] = p
+if dev:
+    for name in ("gpu_busy_percent", "pp_dpm_sclk", "pp_dpm_mclk"):
+        p = os.path.join(dev, name)
+        if os.path.exists(p):
+            files[name] = p
+
+rows = []
+smi_rows = []
+
+
+def cur_dpm(txt):
+    if not txt:
+        return None
+    for ln in txt.splitlines():
+        if ln.rstrip().endswith("*"):
+            try:
+                return float(ln.split(":")[1].replace("Mhz", "").replace("MHz", "").replace("*", "").strip())
+            except (IndexError, ValueError):
+                return None
+    return None
+
+
+def smi_loop():
+    while not stop.is_set():
+        t = time.monotonic()
+        try:
+            r = subprocess.run(["rocm-smi", "-d", os.path.basename(os.path.dirname(dev)).replace("card", "") if dev else "0", "--showclocks", "--showpower", "--showtemp", "--showuse", "--json"], capture_output=True, text=True, timeout=20)
+            smi_rows.append((t, r.stdout.strip()))
+        except Exception as e:   # noqa: BLE001
+            smi_rows.append((t, "rocm-smi failed: %r" % (e,)))
+        stop.wait(1.0)
+
+
+th = threading.Thread(target=smi_loop, daemon=True)
+th.start()
+t0 = time.monotonic()
+while not stop.is_set() and time.monotonic() - t0 < limit:
+    t = time.monotonic() - t0
+    row = {"t": round(t, 3)}
+    for k, p in files.items():
+        v = rd(p)
+        if k.startswith("pp_dpm"):
+            row[k] = cur_dpm(v)
+        else:
+            try:
+                row[k] = float(v)
+            except (TypeError, ValueError):
+                row[k] = None
+    rows.append(row)
+    stop.wait(0.05)
+stop.set()
+th.join(timeout=25)
+
+
+def stats(key, scale=1.0, busy_only=True):
+    vals = [r[key] * scale for r in rows if r.get(key) is not None and (not busy_only or r.get("gpu_busy_percent") is None or r["gpu_busy_percent"] >= 50)]
+    if not vals:
+        return None
+    return {"n": len(vals), "min": round(min(vals), 2), "mean": round(sum(vals) / len(vals), 2), "max": round(max(vals), 2)}
+
+
+with open(out, "w") as fh:
+    fh.write("# sysfs device %s hwmon %s files %s\n" % (dev, hw, sorted(files)))
+    summ = {"sclk_MHz_hwmon": stats("freq1_input", 1e-6), "mclk_MHz_hwmon": stats("freq2_input", 1e-6), "sclk_MHz_dpm": stats("pp_dpm_sclk"),
+            "power_W_average": stats("power1_average", 1e-6), "power_W_input": stats("power1_input", 1e-6),
+            "power_cap_W": stats("power1_cap", 1e-6, busy_only=False), "temp1_C": stats("temp1_input", 1e-3), "temp2_C": stats("temp2_input", 1e-3),
+            "busy_pct_all_samples": stats("gpu_busy_percent", 1.0, busy_only=False)}
+    fh.write("# summary over the samples with gpu_busy >= 50 %%: %s\n" % json.dumps(summ))
+    for r in rows:
+        fh.write(json.dumps(r) + "\n")
+    fh.write("# rocm-smi, once a second\n")
+    for t, s in smi_rows:
+        fh.write("%.3f %s\n" % (t - t0, s.replace("\n", " ")))
+print(json.dumps(summ))
