@@ -1480,6 +1480,188 @@ __device__ __forceinline__ void w1_row(int64_t* best, uint32_t* __restrict__ q, 
   if (PROF) { tp[0] += t1 - t0; tp[first ? 1 : 2] += t2 - t1; tp[3] += MHAP_TICK() - t2; tp[4]++; tp[5] += first ? 1 : 0; tp[6] += (unsigned long long)qn; }
 }
 
+
+// ---- round 5: the row loop priced by what its instructions COST (tools/issue_probe.hip, profiles/r05_issue_probe.txt) -----------
+// A VALU-dense kernel on this chip runs at a constant number of lane-operations per second per instruction kind, whatever the
+// occupancy and whatever clock results (more waves per SIMD = fewer clocks per instruction AND a lower shader clock): what it pays
+// is the SUM of its instructions' prices.  In units of one v_xor_b32_e32: a three-VGPR v_bitop3_b32 1.2, ANY VALU instruction with
+// an SGPR source 1.7, v_readlane / v_mbcnt / v_ffbl / ds_write 3.2-3.9, a global store 6.6, a scalar instruction 0.65 and more.
+// The xorshift step is 114 of those units; the round-3 loop around it cost 19 (filter: five of its ten v_bitop3 took scalar enable
+// words, + v_readlane + five s_bfe) and a triggered step 40 more (second ballot, four v_mbcnt, v_ffbl, bounds compare, the
+// per-bit loop) plus up to eight scalar-operand v_bitop3 of the second look — on two steps in three.  This version:
+//   * the slot's filter depth selects CODE, not operands: the planes 1..8 are OR-ed unconditionally (four three-VGPR ops; inactive
+//     chains carry key 0 = chain value 0 for ever = never negative, so no mask of active chains is needed), and a scalar switch on the
+//     slot's depth class (one v_readlane per step) adds the planes 9..13 its depth allows with one to three more VGPR-only ops;
+//     a slot without a usable minimum (fewer than eight leading zero bits) takes the exact masked filter — rare;
+//   * a triggered step appends ONE 8-byte entry per lane that has candidates — its whole 32-chain candidate mask + (slot, lane) —
+//     at the position the trigger's own ballot gives it (two v_mbcnt on the scalar fill count); no per-bit loop, no v_ffbl, no
+//     second ballot, no bounds branch (the index is clamped to a spare last entry and the running count says "overflow");
+//   * the drain takes the lowest chain of every entry and re-queues what is left of a multi-chain mask (one entry in a hundred).
+// MH_W1_V2=0 builds the round-3/4 loop (A/B).
+#ifndef MH_W1_V2
+#define MH_W1_V2 1
+#endif
+constexpr int W1_QCAP = BS_QCAP / 2 - 1;  // 8-byte entries in the same 16 KB per wave; entry W1_QCAP (the last of the 16 KB) is the spare one overflowing appends land in
+constexpr int W1_CLS_BASE = 8;            // class c >= 1 filters down to depth W1_CLS_BASE + c - 1; class 0 = the exact masked filter
+constexpr int W1_CLS_MAX = 6;             // depth 13: 2048 x 2^-14 = one false candidate per eight steps at worst
+
+// class of a slot from the high dword of its minimum
+__device__ __forceinline__ int w1_class_of(int32_t bhs) {
+  const int z = bs_depth(bhs);
+  if (z < W1_CLS_BASE) return 0;
+  const int c = z - W1_CLS_BASE + 1;
+  return c > W1_CLS_MAX ? W1_CLS_MAX : c;
+}
+
+// append the lanes' candidate masks (cand != 0 somewhere in the wave, m = its ballot)
+__device__ __forceinline__ void w1_enqueue(uint2* __restrict__ q, int& qn, uint32_t head, uint32_t cand, unsigned long long m) {
+  if (cand) {
+    uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qn));
+    idx = idx < (uint32_t)W1_QCAP ? idx : (uint32_t)W1_QCAP;
+    uint32_t lanehi;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 16, %0" : "=&v"(lanehi));   // (computed here: a value kept across the slot loop is a spill)
+    ((__attribute__((address_space(1))) unsigned long long*)q)[idx] = (unsigned long long)cand | ((unsigned long long)(head | lanehi) << 32);
+  }
+  qn += __popcll(m);
+}
+
+// drain: entry = (candidate mask of one lane, slot | lane << 16); chain value recomputed from the key, slot minimum lowered
+__device__ __forceinline__ void w1_flush2(int64_t* best, uint2* __restrict__ q, int qn, int rb, const KeySrc& ks,
+                                          const uint64_t* __restrict__ jump, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores have left the wave before its lanes read each other's entries
+  __builtin_amdgcn_wave_barrier();
+  int qend = qn < W1_QCAP ? qn : W1_QCAP;
+  for (int b0 = 0; b0 < qend; b0 += 64) {
+    const bool valid = b0 + lane < qend;
+    uint32_t rest = 0u, ehi = 0u;
+    if (valid) {
+      const uint2 e = q[b0 + lane];
+      ehi = e.y;
+      const int j = __builtin_ctz(e.x), l = (int)(e.y >> 16), s = (int)(e.y & 0xFFFFu);
+      rest = e.x & (e.x - 1u);
+      const int nsteps = s + 1;
+      int a = nsteps >> XS_JUMP_LOG2;
+      const int r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
+      const int qa = a > W1_JUMP_NA ? (a - 1) / W1_JUMP_NA : 0;      // two levels of tables, as in w1_flush
+      a -= qa * W1_JUMP_NA;
+      uint64_t x = ks_key(ks, rb + j * 64 + l);
+      if (qa > 0) {
+        const uint32_t tb = (uint32_t)(W1_JUMP_NA + qa - 1) * 2048u;
+        uint64_t y = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+        x = y;
+      }
+      if (a > 0) {
+        const uint32_t tb = (uint32_t)(a - 1) * 2048u;
+        uint64_t y = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
+        x = y;
+      }
+#pragma unroll
+      for (int t = 0; t < (1 << XS_JUMP_LOG2) - 1; t++) { const uint64_t nx = xorshift_step(x); x = (t < r) ? nx : x; }
+      atomicMin((long long*)&best[s], (long long)x);
+    }
+    // what is left of a multi-chain mask goes to the end of the queue (rare: two candidates of one step in one lane)
+    const unsigned long long m2 = __ballot(rest != 0u);
+    if (m2) {
+      // (behind the entries this trip covers: an append into the last, partly filled trip would land on lanes that have already run)
+      const int base = b0 + 64 > qend ? b0 + 64 : qend;
+      if (rest) {
+        const uint32_t idx = (uint32_t)base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+        if (idx < (uint32_t)W1_QCAP) q[idx] = make_uint2(rest, ehi);
+      }
+      qend = base + __popcll(m2);
+      if (qend > W1_QCAP) qend = W1_QCAP;      // (cannot happen when the row's count fitted: a mask re-queues at most 31 times, and the caller checked qn)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// the planes 1..8 of the magnitude and the sign: a chain that is not negative or has a one among them is out (bit = 1)
+__device__ __forceinline__ uint32_t w1_base_filter(const uint32_t (&P)[64]) {
+  const uint32_t t0 = __builtin_amdgcn_bitop3_b32(P[62], P[61], P[60], BS_TT_OR3);
+  const uint32_t t1 = __builtin_amdgcn_bitop3_b32(P[59], P[58], P[57], BS_TT_OR3);
+  const uint32_t t2 = __builtin_amdgcn_bitop3_b32(P[56], P[55], P[63], 0xFD);     // a | b | ~c   (table index = 4a + 2b + c)
+  return __builtin_amdgcn_bitop3_b32(t0, t1, t2, BS_TT_OR3);
+}
+
+template <bool PROF>
+__device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, int rb, int nk, bool first, int H, const KeySrc& ks,
+                                        const uint64_t* __restrict__ jump, int lane, bool& ok, unsigned long long* tp) {
+  const unsigned long long t0 = MHAP_TICK();
+  uint32_t P[64];
+  uint32_t ACT = 0;
+#pragma unroll
+  for (int j = 0; j < 32; j++) {
+    const int i = rb + j * 64 + lane;
+    uint64_t key = 0;                                      // (an inactive chain stays 0 for ever: never negative, never a candidate)
+    if (i < nk) { key = ks_key(ks, i); ACT |= 1u << j; }
+    P[j] = (uint32_t)key;
+    P[32 + j] = (uint32_t)(key >> 32);
+    if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 keys in flight at a time
+  }
+  transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
+  transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
+  int qn = 0;   // queue fill (wave-uniform)
+  const unsigned long long t1 = MHAP_TICK();
+  if (first) {
+    for (int s = 0; s < H; s++) {
+      bs_step(P);
+      const uint32_t cand = bs_argmin(P, ACT);
+      w1_enqueue(q, qn, (uint32_t)s, cand, __ballot(cand != 0u));
+    }
+  } else {
+    const int32_t* besthi = (const int32_t*)best;
+    for (int s0 = 0; s0 < H; s0 += 64) {
+      int vcls;
+      {
+        uint32_t ln;   // (the lane id where it is used: a value kept across the slot loop is one more register the allocator spills around)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(ln));
+        vcls = w1_class_of(besthi[2 * (s0 + (int)ln < H ? s0 + (int)ln : H - 1) + 1]);   // classes of 64 slots, one per lane
+      }
+      int send = s0 + 64;   // (scalar loop bound: written as a select it became v_med3 and a VALU compare per step)
+      if (send > H) send = H;
+      send = __builtin_amdgcn_readfirstlane(send);
+      for (int sl = s0; sl < send; sl++) {
+        const int t = sl - s0;
+        const int cls = __builtin_amdgcn_readlane(vcls, t);
+        bs_step(P);
+        uint32_t n = w1_base_filter(P);
+        switch (cls) {
+          case 1: break;
+          case 2: n |= P[54]; break;
+          case 3: n = __builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3); break;
+          case 4: n = __builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3) | P[52]; break;
+          case 5: n = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3), P[52], P[51], BS_TT_OR3); break;
+          case 6: n = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3), P[52], P[51], BS_TT_OR3) | P[50]; break;
+          default: {   // no usable minimum yet: the exact filter of the slot's depth (every active chain when there is no negative minimum)
+            const uint32_t sm = bs_mask_of(besthi[2 * sl + 1]);
+            uint32_t ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(ln));
+            const int left = nk - rb - (int)ln;                                  // chains j with rb + 64 j + lane < nk
+            const int na_ = left <= 0 ? 0 : (left + 63) >> 6;
+            const uint32_t act = na_ >= 32 ? 0xFFFFFFFFu : ((1u << na_) - 1u);
+            n = __builtin_amdgcn_bitop3_b32(P[63], bs_sbit(sm, 0), ~act, 0xBA);   // (~sign & enable) | inactive
+#pragma unroll
+            for (int b = 1; b < W1_CLS_BASE; b++) n = __builtin_amdgcn_bitop3_b32(P[63 - b], bs_sbit(sm, b), n, BS_TT_ANDOR);
+          } break;
+        }
+        const unsigned long long m = __ballot(n != 0xFFFFFFFFu);
+        if (__builtin_expect(m != 0ULL, 0)) w1_enqueue(q, qn, (uint32_t)sl, ~n, m);
+      }
+    }
+  }
+  if (qn > W1_QCAP) ok = false;
+  const unsigned long long t2 = MHAP_TICK();
+  w1_flush2(best, q, qn, rb, ks, jump, lane);
+  if (PROF) { tp[0] += t1 - t0; tp[first ? 1 : 2] += t2 - t1; tp[3] += MHAP_TICK() - t2; tp[4]++; tp[5] += first ? 1 : 0; tp[6] += (unsigned long long)qn; }
+}
+
 template <bool PROF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES_EU, 8))) void minhash_w1_kernel(W1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1533,7 +1715,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES
         __builtin_amdgcn_wave_barrier();
         bool ok = true;
         const int r0 = whole ? 0 : row, r1 = whole ? nrows : row + 1;
+#if MH_W1_V2
+        for (int r = r0; r < r1; r++) w1_row2<PROF>(best, (uint2*)q, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
+#else
         for (int r = r0; r < r1; r++) w1_row<PROF>(best, q, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
+#endif
         // (a row whose candidates overflowed the queue — never seen — is redone one k-mer at a time: exact, slow)
         if (!ok) {
           for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;
