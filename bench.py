@@ -93,9 +93,16 @@ def main():
     ap.add_argument("--preflight", action="store_true",
                     help="check what an N-GPU run needs (devices, RCCL entry points, peer access, rendezvous variables) and print why "
                          "it cannot run instead of hanging in a collective; exit code 0 = ready")
+    ap.add_argument("--dry-collective", action="store_true",
+                    help="form the N-rank communicator exactly as the timed run does (torch only carries the unique id), all-gather 1 MB "
+                         "per rank through the library's transport, check every rank's block and peer access, print one JSON line with "
+                         "every rank's view (ncclCommCount / ncclCommUserRank / device PCI id) and exit: a fabric or rendezvous problem "
+                         "shows here, not as a hang of the compute step.  Launch like the timed run (torch.distributed.run for N > 1)")
     args = ap.parse_args()
     if args.preflight:
         raise SystemExit(preflight(args.gpus))
+    if args.dry_collective:
+        raise SystemExit(dry_collective(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +171,9 @@ def main():
         os.environ.setdefault("MHAP_DIST_TIMEOUT_S", "600")   # (a rank that never arrives makes the others give up, not hang: mhap_dist.hip)
         # the ranks form their communicator inside the library (ncclCommInitRank); the host only hands rank 0's id round
         ms.dist_init(rank, world, mdist.broadcast_unique_id(dist, rank, MinHashSearch.dist_unique_id))
+    rank_views = None
+    if force_dist:
+        rank_views = gather_rank_views(ms, dist, rank, world, local_rank)
     phase = {"sketch": 0.0, "exchange": 0.0, "search": 0.0}
 
     def step(timed_phases=False):
@@ -401,6 +411,7 @@ def main():
             "hbm_traffic_by_kernel": hbm_by_kernel,
             "roofline": roofline, "valu": valu, "roofline_stage2": roofline_stage2,
             "eager_exchange": eager_note,
+            "ranks": rank_views,
             "soak": soak,
             "input_gen_s": round(t_gen, 2),
             "staging_ms_untimed": round(t_stage * 1e3, 1),
@@ -408,6 +419,11 @@ def main():
             "c3": "C3 skipped: MHAP_C3_FASTA is not set" if (args.config != "c3" and W.c3_fasta_path() is None) else
                   ("this run" if args.config == "c3" else "available: run --config c3"),
         }
+        if not args.no_cpu_baseline and world == 1 and not force_dist:
+            # the N > 1 code path (collective add + sharded search through a ONE-rank RCCL communicator) timed on the same staged reads,
+            # after the timed region: the N = 1 point of a scaling curve takes the plain path above — this says what the other path
+            # costs on one GPU, so that the two are never confused (round 4: 7.1 vs 5.1 ms of ordered kernel between them)
+            out["dist_path_1rank"] = dist_path_leg(ms, args, recs, mhap_amd.KERNEL_NAMES)
         if not args.no_cpu_baseline and world == 1:
             out.update(host_legs(args, cfg, p, flt, filter_path, fa_bench, L, H, S, k, k2, total_records, sha, tmpdir))
         print(json.dumps(out), flush=True)
@@ -416,6 +432,108 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def gather_rank_views(ms, dist, rank, world, local_rank):
+    """Every rank's own view of the job, gathered to all ranks: what RCCL says (ncclCommCount, ncclCommUserRank, the communicator's
+    device), the device's PCI bus id, and what the launcher said (RANK / LOCAL_RANK).  `consistent` = N ranks, each counting N, user
+    ranks 0..N-1, N distinct PCI ids."""
+    mine = dict(ms.dist_info(), rank=rank, local_rank=local_rank, pid=os.getpid(),
+                device_name=torch.cuda.get_device_name(local_rank) if torch.cuda.is_available() else None)
+    views = [mine]
+    if dist is not None and world > 1:
+        views = [None] * world
+        dist.all_gather_object(views, mine)
+    ok = (len(views) == world and all(v["comm_count"] == world for v in views) and sorted(v["comm_user_rank"] for v in views) == list(range(world))
+          and len({v["pci_bus_id"] for v in views}) == world and all(v["comm_device"] == v["handle_device"] for v in views))
+    return {"world": world, "consistent": bool(ok), "per_rank": views}
+
+
+def dry_collective(n):
+    """`bench.py --gpus N --dry-collective`: the communicator and one checked all-gather, nothing else (see --help)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n:
+        raise SystemExit(f"--dry-collective --gpus {n}: launch with torch.distributed.run --nproc-per-node {n} (WORLD_SIZE is {world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ.setdefault("MHAP_DIST_TIMEOUT_S", "120")
+    rep = {"dry_collective": True, "n_gpus": world}
+    t0 = time.perf_counter()
+    ms = MinHashSearch(MhapParams(num_hashes=64, ordered_sketch_size=64, device=local_rank))
+    err = None
+    try:
+        ms.dist_init(rank, world, mdist.broadcast_unique_id(dist, rank, MinHashSearch.dist_unique_id))
+        t_init = time.perf_counter() - t0
+        gather_ms = [ms.dist_selftest(1 << 20) for _ in range(3)]       # 1 MB per rank, three times (the first one warms the channels up)
+        big_ms = ms.dist_selftest(64 << 20)                             # and 64 MB per rank once: a bandwidth figure
+        views = gather_rank_views(ms, dist, rank, world, local_rank)
+    except Exception as e:   # noqa: BLE001
+        err = repr(e)
+    peers_bad = []
+    have = torch.cuda.device_count()
+    for b in range(min(world, have)):
+        if b != local_rank and not torch.cuda.can_device_access_peer(local_rank, b):
+            peers_bad.append(b)
+    mine = {"rank": rank, "error": err, "no_peer_access_to": peers_bad}
+    if err is None:
+        mine.update(init_s=round(t_init, 3), allgather_1MB_ms=[round(x, 3) for x in gather_ms], allgather_64MB_ms=round(big_ms, 3),
+                    allgather_64MB_GBps_per_rank_received=round((world - 1) * 64 * 2**20 / (big_ms / 1e3) / 1e9, 2) if world > 1 and big_ms > 0 else None)
+    alls = [mine]
+    if dist is not None:
+        alls = [None] * world
+        try:
+            dist.all_gather_object(alls, mine)
+        except Exception as e:   # noqa: BLE001
+            alls = [mine, {"error": "all_gather_object: " + repr(e)}]
+    ok = all(a and a.get("error") is None and not a.get("no_peer_access_to") for a in alls) and (err is None and views["consistent"])
+    if rank == 0:
+        rep.update(ready=bool(ok), ranks=views if err is None else None, per_rank_results=alls)
+        print(json.dumps(rep), flush=True)
+    ms.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def dist_path_leg(ms, args, recs_plain, kernel_names):
+    """world == 1 only: K steps through the N > 1 entry points (collective add with the eager exchange, mhap_dist_find_matches_self) on a
+    communicator of one rank, on the reads already staged; same fences as the timed region."""
+    try:
+        ms.dist_init(0, 1, MinHashSearch.dist_unique_id())
+
+        def dstep():
+            ms.clear()
+            ms.add_staged()
+            return ms.dist_find_matches()
+        dstep()
+        ms.dist_set_eager(True)
+        dstep()
+        ms.reset_kernel_times()
+        ms.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        K = max(args.steps, 1)
+        for _ in range(K):
+            r = dstep()
+        ms.synchronize(); torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / K
+        kt = ms.kernel_times()
+        same = len(r) == len(recs_plain) and sorted(mhap_amd.records_to_lines(r)) == sorted(mhap_amd.records_to_lines(recs_plain)) if len(r) < 4_000_000 else len(r) == len(recs_plain)
+        view = ms.dist_info()
+        ms.dist_finalize()
+        return {"ms_per_step": round(dt * 1e3, 3), "records_equal_to_the_plain_path": bool(same), "eager_exchange": True,
+                "kernel_ms_per_step": {kk: round(kt[kk]["ms"] / K, 3) for kk in kernel_names}, "rccl": view,
+                "what": "the same step through mhap_dist_* (collective add, sharded search) on a one-rank RCCL communicator; `value` is the plain path's"}
+    except Exception as e:   # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def preflight(n):

@@ -285,6 +285,14 @@ int mhap_dist_find_matches_reads(mhap_handle* h, const char* bases, const int64_
 int mhap_dist_set_eager(mhap_handle* h, int32_t on);
 int64_t mhap_dist_eager_searches(mhap_handle* h);   /* searches of this rank that found every rank's rows already gathered by the add */
 int mhap_dist_last_timing(mhap_handle* h, double* out3);
+/* The transport's own view of this rank (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion), for a launcher that
+ * wants to confirm that its N processes formed ONE communicator over N devices — the reference has nothing to compare: one JVM, one index
+ * (AbstractMatchSearch.java:67-117).  out5 = {ranks, this rank, communicator's device, handle's device, RCCL version code};
+ * pci = PCI bus id of the device ("0000:05:00.0"). */
+int mhap_dist_info(mhap_handle* h, int32_t* out5, char* pci, size_t pci_cap);
+/* The exchange by itself: all-gathers `bytes` (<= 1 GiB) of a known pattern per rank through the handle's transport, under the same
+ * watchdog as a search, and checks every rank's block.  Collective over the ranks.  ms_out: wall time of the gather (may be NULL). */
+int mhap_dist_selftest(mhap_handle* h, size_t bytes, double* ms_out);
 
 typedef struct mhap_group mhap_group;
 /* N handles on the given devices (NULL: devices 0..n-1; repeats allowed — several ranks may share a device, which is how a

@@ -320,6 +320,11 @@ JNIEXPORT jbyteArray JNICALL Java_edu_umd_marbl_mhap_impl_HipMinHashSearch_nativ
   e->parked -= got;
   pthread_cond_broadcast(&e->space);
   pthread_mutex_unlock(&e->mu);
+  if (got == 0) {   /* records are parked but the split block could not be allocated: raise, a zero-length array would make Java's take() loop spin */
+    jclass oom = (*env)->FindClass(env, "java/lang/OutOfMemoryError");
+    if (oom) (*env)->ThrowNew(env, oom, "mhap_jni: cannot allocate a record block");
+    return NULL;
+  }
   out = (*env)->NewByteArray(env, (jsize)(got * (int64_t)sizeof(mhap_record)));   /* <= 64 MB: fits a jsize */
   got = 0;
   while (first) {

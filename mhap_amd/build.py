@@ -1,8 +1,8 @@
 """Build libmhaphip.so (gfx950) and the mhap-hip CLI in-tree with hipcc.
 
-No CMake: four translation units, one hipcc command.  The built artefacts live under
-mhap_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).  An artefact is rebuilt whenever the SHA-256 of its
-sources + build command differs from the stamp written next to it.
+No CMake: six translation units, each compiled to an object of its own (side by side) and linked with one hipcc command.  The built
+artefacts live under mhap_amd/lib/ (git-ignored, but shipped to the GPU box by gpurun).  An object is rebuilt whenever the SHA-256
+of its source + the headers + its command differs from the stamp written next to it, the library whenever an object changed.
 """
 import hashlib
 import os
@@ -64,27 +64,73 @@ def _stamp(target, digest):
         fh.write(digest + "\n")
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS]
-    try:
-        hipcc = _hipcc()
-    except RuntimeError:
-        if os.path.exists(LIB) and not force:   # a box without a compiler: the shipped artefact is all there is — but say so if it is stale
-            cmd = ["hipcc", f"--offload-arch={ARCH}", *CFLAGS, *srcs, "-o", LIB, "-lz", "-ldl"]
-            if _stale(LIB, _digest(deps, cmd[1:])):
-                print(f"warning: {LIB} does not match the sources next to it (no hipcc here to rebuild it); "
-                      "mhap_amd.load_library() checks its ABI version and struct sizes", file=sys.stderr)
-            return LIB
-        raise
-    cmd = [hipcc, f"--offload-arch={ARCH}", *CFLAGS, *srcs, "-o", LIB, "-lz", "-ldl"]
-    dg = _digest(deps, cmd[1:])
-    if force or _stale(LIB, dg):
+OBJDIR = os.path.join(LIBDIR, "obj")
+# variant builds that tests need next to the shipped library: NAME -> (extra flags, the translation units they change)
+VARIANTS = {
+    # the weight-1 MinHash kernel with a 31-entry candidate queue per wave: every row overflows it, so the exact redo path
+    # (sketch_kernels.hip, `if (!ok)` in minhash_w1_kernel) is EXECUTED against the oracle (tests/test_gpu_parity.py)
+    "qcap64": (["-DMH_QCAP=64"], ["sketch_kernels.hip"]),
+}
+
+
+def variant_path(name):
+    return os.path.join(LIBDIR, "variants", f"libmhaphip_{name}.so")
+
+
+def _compile_objects(hipcc, flags, only, tag, force, verbose):
+    """One object per translation unit (compiled side by side), reused while the digest of (source, headers, command) holds."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs, objs = [], []
+    for s in SOURCES:
+        variant = bool(flags) and s in only
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + (f".{tag}" if variant else "") + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}", *[f for f in CFLAGS if f != "-shared"], *(flags if variant else []), "-c", os.path.join(CSRC, s), "-o", obj]
+        dg = _digest([os.path.join(CSRC, s)] + hdrs, cmd[1:])
+        objs.append(obj)
+        if force or _stale(obj, dg):
+            jobs.append((cmd, obj, dg))
+
+    def run(job):
+        cmd, obj, dg = job
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True, cwd=CSRC)
-        _stamp(LIB, dg)
+        _stamp(obj, dg)
+    with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1, 6))) as ex:
+        list(ex.map(run, jobs))
+    return objs, bool(jobs)
+
+
+def _link(hipcc, objs, target, force, verbose):
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-pthread", *objs, "-o", target, "-lz", "-ldl"]
+    h = hashlib.sha256(" ".join(cmd[1:]).encode())
+    for o in objs:
+        with open(o + ".sha256") as fh:
+            h.update(fh.read().encode())
+    dg = h.hexdigest()
+    if force or _stale(target, dg):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        os.makedirs(os.path.dirname(target), exist_ok=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+        _stamp(target, dg)
+    return dg
+
+
+def build(force=False, verbose=False, variants=()):
+    """libmhaphip.so + mhap-hip; `variants`: names from VARIANTS to build as mhap_amd/lib/variants/libmhaphip_NAME.so as well."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    try:
+        hipcc = _hipcc()
+    except RuntimeError:
+        if os.path.exists(LIB) and not force:   # a box without a compiler: the shipped artefact is all there is
+            print(f"note: no hipcc here; using the shipped {LIB} (mhap_amd.load_library() checks its ABI version and struct sizes)", file=sys.stderr)
+            return LIB
+        raise
+    objs, _ = _compile_objects(hipcc, [], [], "", force, verbose)
+    dg = _link(hipcc, objs, LIB, force, verbose)
     cli_src = os.path.join(CSRC, "mhap_cli.cpp")
     if os.path.exists(cli_src):
         cmd = [hipcc, "-O2", "-std=c++17", "-pthread", cli_src, "-o", CLI, f"-L{LIBDIR}", "-lmhaphip",
@@ -95,8 +141,29 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True, cwd=CSRC)
             _stamp(CLI, dg_cli)
+    for name in variants:
+        flags, only = VARIANTS[name]
+        vobjs, _ = _compile_objects(hipcc, flags, only, name, force, verbose)
+        _link(hipcc, vobjs, variant_path(name), force, verbose)
     return LIB
 
 
+def build_variant(name, flags, only=None, verbose=False):
+    """An ad-hoc variant (tools/build_variant.sh): extra -D flags on the given translation units (default: the two kernel files)."""
+    hipcc = _hipcc()
+    vobjs, _ = _compile_objects(hipcc, list(flags), only or ["sketch_kernels.hip", "search_kernels.hip"], name, False, verbose)
+    _link(hipcc, vobjs, variant_path(name), False, verbose)
+    return variant_path(name)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":      # python -m mhap_amd.build --variant NAME -DX=1 ... [--only file.hip,...]
+        rest = sys.argv[3:]
+        only = None
+        if "--only" in rest:
+            i = rest.index("--only")
+            only = rest[i + 1].split(",")
+            rest = rest[:i] + rest[i + 2:]
+        print(build_variant(sys.argv[2], rest, only, verbose=True))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True, variants=list(VARIANTS) if "--variants" in sys.argv else ()))

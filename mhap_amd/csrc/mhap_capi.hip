@@ -209,25 +209,25 @@ void build_pass_min(const std::vector<double>& tbl, int S, double threshold, std
 void fill_score_table(int S, int k2, std::vector<double>& tbl) {
   const int64_t n = score_index(S, S) + 1;
   tbl.resize((size_t)n);
-  parallel_for(S + 1, host_threads(), [&](int64_t lo, int64_t hi) {
-    for (int64_t kk = lo; kk < hi; kk++)
+  // row kk has kk + 1 entries: the rows are dealt to the threads in pairs (kk, S - kk) of equal total length — contiguous chunks of a
+  // triangle gave the last thread a third of the work (42 ms of mhap_create at S = 1536 on a 16-thread box)
+  const int64_t half = (S + 2) / 2;
+  parallel_for(half, host_threads(), [&](int64_t lo, int64_t hi) {
+    auto row = [&](int64_t kk) {
       for (int64_t it = 0; it <= kk; it++) {
         double j = (kk == 0) ? 0.0 : (double)it / (double)kk;
         double d = -1.0 / (double)k2 * std::log(2.0 * j / (1.0 + j));
         tbl[(size_t)score_index((int)it, (int)kk)] = std::exp(-d);
       }
-  }, 8);
+    };
+    for (int64_t a = lo; a < hi; a++) { row(a); if (S - a != a && S - a >= half) row(S - a); }
+  }, 4);
 }
 
-int build_score_table(mhap_handle* h) {
-  const int S = h->P.ordered_sketch_size;
-  const int64_t n = score_index(S, S) + 1;
-  std::vector<double> tbl;
-  fill_score_table(S, h->P.ordered_kmer_size, tbl);
-  HIPCHK(h, h->score_tbl.ensure((size_t)n * 8));
-  HIPCHK(h, hipMemcpy(h->score_tbl.p, tbl.data(), (size_t)n * 8, hipMemcpyHostToDevice));
-  std::vector<int32_t> pm;
-  build_pass_min(tbl, S, h->P.threshold, pm);
+// (the two tables are computed on the host — mhap_create starts that before it touches the device — and uploaded here)
+int upload_score_table(mhap_handle* h, const std::vector<double>& tbl, const std::vector<int32_t>& pm) {
+  HIPCHK(h, h->score_tbl.ensure(tbl.size() * 8));
+  HIPCHK(h, hipMemcpy(h->score_tbl.p, tbl.data(), tbl.size() * 8, hipMemcpyHostToDevice));
   HIPCHK(h, h->pass_min_tbl.ensure(pm.size() * 4));
   HIPCHK(h, hipMemcpy(h->pass_min_tbl.p, pm.data(), pm.size() * 4, hipMemcpyHostToDevice));
   return MHAP_OK;
@@ -351,7 +351,7 @@ int ensure_inverted_index(mhap_handle* h, hipStream_t st = nullptr, int64_t ne_o
 int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t* d_ordered, int64_t ord_stride, int32_t* d_meta,
                   int64_t eager_index_entries = 0, bool eager_exchange = false, bool eager_first = false) {
   const int64_t n = h->st_n;
-  if (n <= 0) return MHAP_OK;
+  if (n <= 0) { if (eager_exchange) { const int rx = dist_eager_begin(h, 0, nullptr, false); if (rx < 0) return rx; } return MHAP_OK; }
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
   int64_t batch_bases = 1LL << 30;   // bases per launch group: 16 B of scratch per base (weights + class lists of both strands) = 16 GB of the 288 GB;
                                      // fewer, larger launches = fewer drain tails of the persistent MinHash waves (a strand takes ~2 ms)
@@ -740,7 +740,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   h->iq_start_mid = false;   // decided anew by the first chunks of every search
   bool q_ph_done = false;    // the query side's position histograms exist (second stage, early "below the threshold")
   PostStage post; post.h = h; post.qs = &qs; post.sink = sink; post.user = user;
-  // every error return below leaves through here: the worker is drained first (its buffers belong to the handle)
+#define SCHK(expr) do { const hipError_t _e = (expr); if (_e != hipSuccess) return leave(fail(h, _e == hipErrorOutOfMemory ? MHAP_E_NOMEM : MHAP_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+  // every error return below leaves through here: the worker is drained first (its buffers belong to the handle), the records it has
+  // already delivered are credited, and — if the search itself was fine — the worker's own error is the one reported
   auto leave = [&](int code) { const int pr = post.drain(); h->stats.matches_found += post.matches; post.matches = 0;
                                if (code == MHAP_OK && pr != MHAP_OK) return fail(h, pr, post.err); return code; };
   int64_t chunk_no = 0;
@@ -762,18 +764,18 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         acc += std::min<long long>(ntu, ((long long)maxq + CAND_TM - 1) / CAND_TM);
       }
       rs[(size_t)ntq] = acc; nblocks_tri = acc;
-      HIPCHK(h, h->rowstart.ensure(rs.size() * 8));
-      HIPCHK(h, hipMemcpyAsync(h->rowstart.p, rs.data(), rs.size() * 8, hipMemcpyHostToDevice, h->stream));
-      HIPCHK(h, hipStreamSynchronize(h->stream));  // rs is a stack vector
+      SCHK(h->rowstart.ensure(rs.size() * 8));
+      SCHK(hipMemcpyAsync(h->rowstart.p, rs.data(), rs.size() * 8, hipMemcpyHostToDevice, h->stream));
+      SCHK(hipStreamSynchronize(h->stream));  // rs is a stack vector
       d_rowstart = h->rowstart.as<long long>();
       if (nblocks_tri == 0) { h->stats.queries_searched += nq; continue; }
     }
     unsigned long long ncand = 0;
     for (;;) {
-      HIPCHK(h, h->cand.ensure(cand_cap * sizeof(Candidate)));
-      HIPCHK(h, hipMemsetAsync(ctr, 0, 80, h->stream));
+      SCHK(h->cand.ensure(cand_cap * sizeof(Candidate)));
+      SCHK(hipMemsetAsync(ctr, 0, 80, h->stream));
       if (use_index) {
-        HIPCHK(h, h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
+        SCHK(h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
         const bool tiers = index_query_tiers() && !(tv && tv[0] == '1');
         // (an index or a numMinMatches the first tier's packed hit-count words cannot hold: every query takes the dense tier)
@@ -795,11 +797,11 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
                            (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && t0 < 2 ? listA : nullptr, ctr + 6, t0);
         time_end(h);
-        HIPCHK(h, hipGetLastError());
+        SCHK(hipGetLastError());
         unsigned long long c5[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
+        SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
         int rc = sync_stream(h);
-        if (rc != MHAP_OK) return rc;
+        if (rc != MHAP_OK) return leave(rc);
         const int32_t* dense_list = listA;
         unsigned long long n_dense = c5[6];
         if (t0 == 0 && use_mid && c5[0] <= cand_cap) {
@@ -811,10 +813,10 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
             launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,
                                h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, ctr + 3, ctr + 4, listB, ctr + 8, 1);
             time_end(h);
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
+            SCHK(hipGetLastError());
+            SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
             rc = sync_stream(h);
-            if (rc != MHAP_OK) return rc;
+            if (rc != MHAP_OK) return leave(rc);
             dense_list = listB; n_dense = c5[8];
           }
         }
@@ -824,10 +826,10 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
                              h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
                              (unsigned long long)cand_cap, ctr + 3, ctr + 4, nullptr, nullptr, 2);
           time_end(h);
-          HIPCHK(h, hipGetLastError());
-          HIPCHK(h, hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
+          SCHK(hipGetLastError());
+          SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
           rc = sync_stream(h);
-          if (rc != MHAP_OK) return rc;
+          if (rc != MHAP_OK) return leave(rc);
         }
         HPROF("candidates known");
         ncand = c5[0];
@@ -838,10 +840,10 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
                           h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, d_rowstart, nblocks_tri, h->cand.as<Candidate>(),
                           ctr + 0, (unsigned long long)cand_cap);
         time_end(h);
-        HIPCHK(h, hipGetLastError());
-        HIPCHK(h, hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
+        SCHK(hipGetLastError());
+        SCHK(hipMemcpyAsync(&ncand, ctr + 0, 8, hipMemcpyDeviceToHost, h->stream));
         int rc = sync_stream(h);
-        if (rc != MHAP_OK) return rc;
+        if (rc != MHAP_OK) return leave(rc);
         if (ncand <= cand_cap) {
           const long long tiles = d_rowstart ? nblocks_tri : (long long)ntq * ntu;
           h->stats.slot_compares += tiles * (long long)CAND_TQ * CAND_TM * sp.H;
@@ -856,10 +858,10 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     // (read-back, conversion, sink: PostStage) hides behind the next chunk's kernels, so less of it is left over at the end
     if (chunk_no == 0 && (int64_t)ncand >= 64LL * nq && !getenv("MHAP_QUERY_CHUNK")) qchunk = 65536;
     DevBuf& recbuf = slot ? h->recs2 : h->recs;
-    HIPCHK(h, recbuf.ensure((size_t)ncand * sizeof(DevRecord)));
+    SCHK(recbuf.ensure((size_t)ncand * sizeof(DevRecord)));
     // second stage: one wavefront per candidate from the equal-hash join (MHAP_OVERLAP=lane: the literal per-lane merge for
     // every pair); pairs the join cannot decide exactly come back in slow_cand and take the per-lane merge
-    if (h->gate && h->gate(h->gate_user) != 0) return fail(h, MHAP_E_STATE, "second-stage gate aborted the search");
+    if (h->gate && h->gate(h->gate_user) != 0) return leave(fail(h, MHAP_E_STATE, "second-stage gate aborted the search"));
     // the join kernel's three shapes (search_kernels.hip): every wave alone, pairs of waves or teams of four sharing a staged query and
     // its filter — by the candidates per query.  MHAP_JOIN_MODE=alone|pair|team pins one.
     bool fits[3];
@@ -869,7 +871,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     unsigned long long cj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool have_counts = false;
     if (use_join) {
-      HIPCHK(h, h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
+      SCHK(h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
       // (round 3, every entry looked up — C2, 4.5 candidates per query: alone 4.94, pair 4.83, team 5.03 ms; C5 slice, 79: alone 93, pair 87,
       //  team 77; a rank of eight, 0.56 per query: alone 0.86, pair 1.24.  Round 4, the shared shapes with the filter — C2: pair 3.74, team 3.65;
       //  C5 slice: pair 66.8, team 49.8; ranks of two / four / eight: alone 2.29 / 1.19 / 0.69, pair 2.09 / 1.29 / 0.83, team 2.29 / 1.69 / 1.33)
@@ -896,7 +898,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       if (prune) {
         time_begin(h, MHAP_K_OVERLAP);
         if (!(h->ph_ready && h->ph_ne == h->n_entries)) {
-          HIPCHK(h, h->poshist.ensure((size_t)h->n_entries * POSHIST_BINS * 2));
+          SCHK(h->poshist.ensure((size_t)h->n_entries * POSHIST_BINS * 2));
           launch_poshist(h->stream, h->d_ordered, 2LL * S, h->d_meta, h->n_entries, h->poshist.as<uint16_t>());
           h->ph_ready = true; h->ph_ne = h->n_entries;
         }
@@ -904,25 +906,25 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         if (qs.d_ordered == h->d_ordered && qs.d_meta == h->d_meta) qph = ph;
         else {
           if (!q_ph_done) {      // (after the gate: the query rows of a sharded search have all arrived)
-            HIPCHK(h, h->q_poshist.ensure((size_t)qs.n_rows * POSHIST_BINS * 2));
+            SCHK(h->q_poshist.ensure((size_t)qs.n_rows * POSHIST_BINS * 2));
             launch_poshist(h->stream, qs.d_ordered, qs.ord_stride, qs.d_meta, qs.n_rows, h->q_poshist.as<uint16_t>());
             q_ph_done = true;
           }
           qph = h->q_poshist.as<uint16_t>();
         }
         time_end(h);
-        HIPCHK(h, hipGetLastError());
+        SCHK(hipGetLastError());
       }
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap_join(h->stream, shape, jblocks, chunk, h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                           qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), recbuf.as<DevRecord>(), ctr + 1,
                           (unsigned long long)ncand, ctr + 2, h->slow_cand.as<Candidate>(), ctr + 5, ctr + 7, ph, qph, h->pass_min_tbl.as<int32_t>());
       time_end(h);
-      HIPCHK(h, hipGetLastError());
+      SCHK(hipGetLastError());
       // (one read-back for the pairs handed over and for the counts the tail needs: nothing else changes them when none were)
-      HIPCHK(h, hipMemcpyAsync(cj, ctr, 64, hipMemcpyDeviceToHost, h->stream));
+      SCHK(hipMemcpyAsync(cj, ctr, 64, hipMemcpyDeviceToHost, h->stream));
       int rcj = sync_stream(h);
-      if (rcj != MHAP_OK) return rcj;
+      if (rcj != MHAP_OK) return leave(rcj);
       nslow = cj[5];
       have_counts = nslow == 0;
       h->stats.slow_pairs += (int64_t)nslow;
@@ -934,20 +936,20 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       int spread = 1;
       while (spread < 64 && (int64_t)nslow * spread * 2 <= (int64_t)h->num_cus * 4 * 64) spread *= 2;
       const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)nslow * spread + OVL_THREADS - 1) / OVL_THREADS));
-      HIPCHK(h, h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS / (size_t)spread * (size_t)per_lane * 4));
+      SCHK(h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS / (size_t)spread * (size_t)per_lane * 4));
       time_begin(h, MHAP_K_OVERLAP);
       launch_overlap(h->stream, oblocks, use_join ? h->slow_cand.as<Candidate>() : h->cand.as<Candidate>(), use_join ? ctr + 5 : ctr + 0,
                      use_join ? (unsigned long long)ncand : (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                      qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
                      recbuf.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2, spread);
       time_end(h);
-      HIPCHK(h, hipGetLastError());
+      SCHK(hipGetLastError());
     }
     unsigned long long counts[3] = {cj[0], cj[1], cj[2]};
     if (!have_counts) {
-      HIPCHK(h, hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
+      SCHK(hipMemcpyAsync(counts, ctr, 24, hipMemcpyDeviceToHost, h->stream));
       int rc = sync_stream(h);
-      if (rc != MHAP_OK) return rc;
+      if (rc != MHAP_OK) return leave(rc);
     }
     HPROF("overlap done");
     oj_stats_dump();
@@ -957,11 +959,12 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     // the chunk's tail: inline when it is the last chunk with no worker running (nothing left to hide it behind), else on the worker
     const bool last = c0 + nq >= (int64_t)ql.size();
     const int rp = post.submit(slot, nrec, !pipeline || last);
-    if (rp != MHAP_OK) return fail(h, rp, post.err);
+    if (rp != MHAP_OK) return leave(fail(h, rp, post.err));
     slot ^= 1;
     HPROF("chunk tail handed over");
   }
   return leave(MHAP_OK);
+#undef SCHK
 }
 
 }  // namespace
@@ -1022,6 +1025,26 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   if (P.max_shift < -1.0) { seterr("The minimum shift must be greater than -1."); return MHAP_E_INVALID; }
   if (P.threshold < 0.0 || P.threshold > 1.0) { seterr("The second stage filter threshold must be 0<=threshold<=1.0."); return MHAP_E_INVALID; }
   HPROF("create begin");
+  // The handle's constant tables are functions of the flags alone (S, k2, threshold, H): they are computed on host threads WHILE the HIP
+  // runtime and the device come up (0.18 s in a fresh process, the larger part of mhap_create), and uploaded afterwards.
+  struct HostTables { std::vector<double> score; std::vector<int32_t> pass_min; std::vector<uint64_t> jump, jump_w1, unjump, luts; int na = 0; } ht;
+  std::thread th_score([&]() {
+    fill_score_table(P.ordered_sketch_size, P.ordered_kmer_size, ht.score);
+    build_pass_min(ht.score, P.ordered_sketch_size, P.threshold, ht.pass_min);
+  });
+  std::thread th_jump([&]() {
+    ht.na = ((P.num_hashes + 1) >> XS_JUMP_LOG2) + 1;
+    ht.jump.resize((size_t)(ht.na + XS_JUMP_NQ) * 2048);
+    build_xorshift_jump_tables(ht.na, XS_JUMP_NQ, ht.jump.data());
+  });
+  std::thread th_jump2([&]() {
+    const int nt = w1_jump_tables(P.num_hashes);
+    ht.jump_w1.resize((size_t)nt * 2048); ht.unjump.resize((size_t)nt * 2048); ht.luts.resize(768);
+    build_xorshift_jump_tables(W1_JUMP_NA, nt - W1_JUMP_NA, ht.jump_w1.data());
+    build_xorshift_unjump_tables(W1_JUMP_NA, nt - W1_JUMP_NA, ht.unjump.data());
+    build_kmer_hash_luts(ht.luts.data());
+  });
+  struct Join { std::thread& a; std::thread& b; std::thread& c; ~Join() { if (a.joinable()) a.join(); if (b.joinable()) b.join(); if (c.joinable()) c.join(); } } join_tables{th_score, th_jump, th_jump2};
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) { seterr(std::string("no HIP device available: ") + hipGetErrorString(e)); return MHAP_E_HIP; }
@@ -1045,42 +1068,21 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   h->ord_cap = cap;
   h->ft = FilterTable{nullptr, nullptr, 0, 0, 0, 0, 3.0};
   HPROF("create: device + streams");
-  int rc = build_score_table(h);
+  th_score.join(); th_jump.join(); th_jump2.join();
+  HPROF("create: host tables joined");
+  int rc = upload_score_table(h, ht.score, ht.pass_min);
   if (rc != MHAP_OK) { seterr(h->err); mhap_destroy(h); return rc; }
   HPROF("create: score table");
-  {   // xorshift jump-ahead tables for slots up to H (MinHash kernel's deferred-candidate drain)
-    const int na = ((P.num_hashes + 1) >> XS_JUMP_LOG2) + 1;
-    std::vector<uint64_t> jt((size_t)(na + XS_JUMP_NQ) * 2048);
-    build_xorshift_jump_tables(na, XS_JUMP_NQ, jt.data());
-    h->jump_na = na;
-    if (h->jump_tbl.ensure(jt.size() * 8) != hipSuccess || hipMemcpy(h->jump_tbl.p, jt.data(), jt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
-      seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
+  // xorshift jump-ahead tables for slots up to H (the general MinHash kernel's deferred-candidate drain); the weight-1 kernel's own small
+  // two-level set (its drains look tables up a thousand times per strand: they must stay in L2) and their inverses (a slot's minimal
+  // chain value back into the winning key); the block-mix tables of the k = 16 / k2 = 12 hash path
+  h->jump_na = ht.na;
+  struct Up { DevBuf* b; const std::vector<uint64_t>* v; } ups[] = {{&h->jump_tbl, &ht.jump}, {&h->jump_w1_tbl, &ht.jump_w1}, {&h->unjump_tbl, &ht.unjump}, {&h->hash_luts, &ht.luts}};
+  for (const Up& u : ups)
+    if (u.b->ensure(u.v->size() * 8) != hipSuccess || hipMemcpy(u.b->p, u.v->data(), u.v->size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+      seterr("cannot allocate the jump / hash tables"); mhap_destroy(h); return MHAP_E_HIP;
     }
-  }
-  {   // the weight-1 MinHash kernel's own small two-level set (its drains look tables up a thousand times per strand: they must stay in L2)
-    const int nt = w1_jump_tables(P.num_hashes);
-    std::vector<uint64_t> jt((size_t)nt * 2048);
-    build_xorshift_jump_tables(W1_JUMP_NA, nt - W1_JUMP_NA, jt.data());
-    if (h->jump_w1_tbl.ensure(jt.size() * 8) != hipSuccess || hipMemcpy(h->jump_w1_tbl.p, jt.data(), jt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
-      seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
-    }
-  }
-  {   // ... and their inverses (the weight-1 MinHash kernel turns a slot's minimal chain value back into the winning key)
-    const int nt = w1_jump_tables(P.num_hashes);
-    std::vector<uint64_t> ut((size_t)nt * 2048);
-    build_xorshift_unjump_tables(W1_JUMP_NA, nt - W1_JUMP_NA, ut.data());
-    if (h->unjump_tbl.ensure(ut.size() * 8) != hipSuccess || hipMemcpy(h->unjump_tbl.p, ut.data(), ut.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
-      seterr("cannot allocate jump tables"); mhap_destroy(h); return MHAP_E_HIP;
-    }
-  }
   HPROF("create: jump tables");
-  {   // block-mix tables of the k-mer hash kernel's k = 16 / k2 = 12 path
-    std::vector<uint64_t> lt(768);
-    build_kmer_hash_luts(lt.data());
-    if (h->hash_luts.ensure(lt.size() * 8) != hipSuccess || hipMemcpy(h->hash_luts.p, lt.data(), lt.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
-      seterr("cannot allocate hash tables"); mhap_destroy(h); return MHAP_E_HIP;
-    }
-  }
   *out = h;
   return MHAP_OK;
 }
@@ -1170,16 +1172,31 @@ int mhap_set_filter_whitelist(mhap_handle* h, const int64_t* hashes, int64_t n, 
 
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n);
 
+// With the eager exchange on (mhap_dist_set_eager) an add is a COLLECTIVE call: its rendezvous (dist_eager_begin, inside sketch_staged)
+// is where the ranks agree whether this add gathers its rows.  A rank that leaves the add before it gets there — nothing to add, a bad
+// argument, no memory for the tables — must still take part, saying "not this time": otherwise the other ranks wait in the rendezvous
+// until the watchdog's time-out (MHAP_DIST_TIMEOUT_S).  Returns `code`, or the rendezvous' own error if it failed.
+static int leave_collective_add(mhap_handle* h, int code) {
+  if (h->dist != nullptr && dist_eager_wanted(h)) {
+    const std::string keep = h->err;
+    const int rx = dist_eager_begin(h, 0, nullptr, false);
+    if (code != MHAP_OK) h->err = keep;                 // (the caller's reason, not the rendezvous')
+    else if (rx < 0) return rx;
+  }
+  return code;
+}
+
 int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offsets, const int32_t* lengths, const int64_t* ids, int64_t n) {
-  if (!h || (n > 0 && (!bases || !offsets || !lengths || !ids))) return h ? fail(h, MHAP_E_INVALID, "null argument") : MHAP_E_INVALID;
-  if (n <= 0) return MHAP_OK;
+  if (!h) return MHAP_E_INVALID;
   (void)hipSetDevice(h->device);
-  if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
-  for (int64_t i = 0; i < n; i++) if (lengths[i] < 0) return fail(h, MHAP_E_INVALID, "negative read length");
+  if (n > 0 && (!bases || !offsets || !lengths || !ids)) return leave_collective_add(h, fail(h, MHAP_E_INVALID, "null argument"));
+  if (n <= 0) return leave_collective_add(h, MHAP_OK);
+  if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return leave_collective_add(h, fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices"));
+  for (int64_t i = 0; i < n; i++) if (lengths[i] < 0) return leave_collective_add(h, fail(h, MHAP_E_INVALID, "negative read length"));
   // = mhap_stage_reads + mhap_index_add_staged (a fresh index is filled while its reads are being sketched), staging released afterwards
   int rc = mhap_stage_reads(h, bases, offsets, lengths, ids, n);
-  if (rc != MHAP_OK) return rc;
-  rc = mhap_index_add_staged(h);
+  if (rc != MHAP_OK) return leave_collective_add(h, rc);
+  rc = mhap_index_add_staged(h);      // (from here on the add takes care of the rendezvous itself)
   h->st_n = 0;
   return rc;
 }
@@ -1226,13 +1243,14 @@ int mhap_index_add_staged(mhap_handle* h) {
   if (!h) return MHAP_E_INVALID;
   (void)hipSetDevice(h->device);
   const int64_t n = h->st_n;
-  if (n <= 0 || (int64_t)h->st_ids.size() != n) return fail(h, MHAP_E_STATE, "no staged reads (call mhap_stage_reads first)");
-  if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
+  // (every exit in front of sketch_staged's rendezvous goes through leave_collective_add: the add is collective under the eager exchange)
+  if (n <= 0 || (int64_t)h->st_ids.size() != n) return leave_collective_add(h, fail(h, MHAP_E_STATE, "no staged reads (call mhap_stage_reads first)"));
+  if (h->n_entries + 2 * n > (int64_t)INT32_MAX / 2) return leave_collective_add(h, fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices"));
   const int64_t first = h->n_entries;
   // mhap_index_reserve: the tables are sized once for every read that is still to come
   const int64_t want_entries = std::max<int64_t>(first + 2 * n, first == 0 ? 2 * h->reserve_reads : 0);
   int rc = ensure_index_capacity(h, want_entries);
-  if (rc != MHAP_OK) return rc;
+  if (rc != MHAP_OK) return leave_collective_add(h, rc);
   const int S = h->P.ordered_sketch_size;
   h->ph_ready = false; h->inv_ready = false;
   // The inverted index is built by the first search — unless this add very likely completes the index (the first add of an index
@@ -1282,6 +1300,26 @@ int mhap_sketch_batch(mhap_handle* h, const char* bases, const int64_t* offsets,
   return MHAP_OK;
 }
 
+// Sketches that did not come from this library's kernels (a `.dat` file, a caller's arrays): the second stage ranks and medians positions
+// by their bits and keeps no per-entry window test in its first pass (search_kernels.hip: FIRST => ok), which is only the reference's
+// arithmetic for 0 <= pos < seqLength (J/sketch/BottomOverlapSketch.java:246-276: valid1Upper = seqLength; :548-558 writes pos = an
+// index into the hash array).  A position outside that range is therefore refused here instead of being silently mis-ranked.
+static bool ordered_positions_ok(const int32_t* ordered, const int32_t* ordered_size, const int32_t* ordered_seqlen, int64_t m, int S, int64_t* bad_entry) {
+  std::atomic<int64_t> bad{-1};
+  parallel_for(m, host_threads(), [&](int64_t lo, int64_t hi) {
+    for (int64_t e = lo; e < hi && bad.load(std::memory_order_relaxed) < 0; e++) {
+      const int32_t n = ordered_size[e], len = ordered_seqlen[e];
+      if (n < 0 || n > S) continue;                       // (reported by the caller's own size check)
+      const int32_t* row = ordered + (size_t)e * (size_t)S * 2;
+      uint32_t out = 0;
+      for (int32_t i = 0; i < n; i++) out |= (uint32_t)((uint32_t)row[2 * i + 1] >= (uint32_t)len);   // (one unsigned compare: pos < 0 or pos >= len)
+      if (out) { int64_t want = -1; bad.compare_exchange_strong(want, e); }
+    }
+  }, 256);
+  *bad_entry = bad.load();
+  return *bad_entry < 0;
+}
+
 int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* is_fwd, const int32_t* seq_length, const int32_t* minhash,
                             const int32_t* ordered, const int32_t* ordered_size, const int32_t* ordered_seqlen, int64_t m) {
   if (!h) return MHAP_E_INVALID;
@@ -1291,6 +1329,11 @@ int mhap_index_add_sketches(mhap_handle* h, const int64_t* ids, const uint8_t* i
   if (h->n_entries + m > (int64_t)INT32_MAX / 2) return fail(h, MHAP_E_INVALID, "index too large for 32-bit entry indices");
   for (int64_t e = 0; e < m; e++)
     if (seq_length[e] < 0 || ordered_seqlen[e] < 0) return fail(h, MHAP_E_INVALID, "negative sequence length in a precomputed sketch");
+  {
+    int64_t bad = -1;
+    if (!ordered_positions_ok(ordered, ordered_size, ordered_seqlen, m, h->P.ordered_sketch_size, &bad))
+      return fail(h, MHAP_E_INVALID, "precomputed sketch " + std::to_string(bad) + ": an ordered-sketch position outside [0, its sequence's k-mer count)");
+  }
   int rc = ensure_index_capacity(h, h->n_entries + m);
   if (rc != MHAP_OK) return rc;
   const int64_t first = h->n_entries;
@@ -1459,6 +1502,13 @@ int mhap_find_matches_sketches(mhap_handle* h, const int64_t* ids, const int32_t
   if (!ids || !seq_length || !minhash || !ordered || !ordered_size || !ordered_seqlen) return fail(h, MHAP_E_INVALID, "null argument");
   (void)hipSetDevice(h->device);
   const int S = h->P.ordered_sketch_size;
+  for (int64_t e = 0; e < m; e++)
+    if (seq_length[e] < 0 || ordered_seqlen[e] < 0) return fail(h, MHAP_E_INVALID, "negative sequence length in a precomputed sketch");
+  {
+    int64_t bad = -1;
+    if (!ordered_positions_ok(ordered, ordered_size, ordered_seqlen, m, S, &bad))
+      return fail(h, MHAP_E_INVALID, "query sketch " + std::to_string(bad) + ": an ordered-sketch position outside [0, its sequence's k-mer count)");
+  }
   std::vector<int32_t> meta((size_t)m * META_W);
   std::vector<int32_t> ql((size_t)m);
   for (int64_t e = 0; e < m; e++) {

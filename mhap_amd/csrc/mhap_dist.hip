@@ -60,6 +60,10 @@ struct RcclApi {
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;   // optional (watchdog)
   ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                          // optional (watchdog)
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;              // optional (mhap_dist_info)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;           // optional
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;           // optional
+  ncclResult_t (*GetVersion)(int*) = nullptr;                               // optional
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
 };
@@ -85,6 +89,10 @@ RcclApi& rccl() {
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
     api.CommGetAsyncError = (decltype(api.CommGetAsyncError))dlsym(api.lib, "ncclCommGetAsyncError");
     api.CommAbort = (decltype(api.CommAbort))dlsym(api.lib, "ncclCommAbort");
+    api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+    api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
+    api.CommCuDevice = (decltype(api.CommCuDevice))dlsym(api.lib, "ncclCommCuDevice");
+    api.GetVersion = (decltype(api.GetVersion))dlsym(api.lib, "ncclGetVersion");
     if (!api.why.empty()) { api.lib = nullptr; }
   });
   return api;
@@ -102,6 +110,11 @@ struct Transport {
   virtual void quiesce() {}
   // this rank gives up: ranks of the same process waiting for it must not wait for ever
   virtual void abort() {}
+  // this rank leaves a collective call with a LOCAL error (its sink said stop, it ran out of memory in the search) after it has
+  // enqueued everything the other ranks need from it.  In-process peers still wait for it at the hub's barriers, so the default is
+  // abort(); an RCCL communicator stays usable — tearing it down for a recoverable local error would kill the rank for good, and the
+  // peers, who are owed nothing more by this call, would only learn of it in their next collective's time-out
+  virtual void local_failure() { abort(); }
   // false (+ why): a peer of this exchange has failed or left — nothing it was to send will arrive
   virtual bool healthy(std::string&) { return true; }
   virtual const char* name() const = 0;
@@ -150,6 +163,7 @@ struct RcclTransport : Transport {
   void abort() override {
     if (comm && rccl().CommAbort) { (void)rccl().CommAbort(comm); comm = nullptr; }   // (aborted communicators are not destroyed again)
   }
+  void local_failure() override {}   // (the communicator is kept: see Transport::local_failure)
   int allgather(const void* send, void* recv, size_t bytes, hipStream_t st, std::string& err) override {
     if (!comm) { err = "the RCCL communicator was aborted"; return MHAP_E_STATE; }
     const ncclResult_t r = rccl().AllGather(send, recv, bytes, ncclChar, comm, st);
@@ -312,33 +326,57 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   const int N = tr->nranks;
   const double t0 = now_ms();
   int rc = MHAP_OK;
-  bool finished = false;
-  struct Guard { Transport* t; bool* ok; ~Guard() { if (!*ok) t->abort(); } } guard{tr, &finished};   // an error return must not strand the other ranks of this process
+  // How an error return treats the transport.  ABORT: the other ranks are owed something this rank will never send (a failed collective,
+  // a HIP error between the rendezvous and the last gather) — in-process peers are released from the hub, an RCCL communicator is torn
+  // down so that nobody hangs in a gather.  LOCAL: everything the others need is enqueued and the error is this rank's own (sink, out
+  // of memory in the search): Transport::local_failure — the RCCL communicator survives.  NONE: every rank returns together (success,
+  // or an error all of them computed from the same gathered numbers).
+  enum { LEAVE_ABORT, LEAVE_LOCAL, LEAVE_NONE } leave = LEAVE_ABORT;
+  struct Guard { Transport* t; decltype(leave)* how; ~Guard() { if (*how == LEAVE_ABORT) t->abort(); else if (*how == LEAVE_LOCAL) t->local_failure(); } } guard{tr, &leave};
   d->t_small = d->t_wait_big = 0; d->gate_ran = false;
-  // the rows were gathered while the add was still computing (eager exchange): nothing to send — every rank knows this from the
-  // add's rendezvous, so all of them take this branch together
-  const bool use_eager = d->eager_valid && d->eager_gen == v.index_gen && to_self && stride == 2 && d_mh == v.d_minhash && rows == d->eager_rows &&
-                         2 * rows == v.n_entries;
+  // The rows may have been gathered while the add was still computing (eager exchange).  Whether THIS rank's gathered rows describe its
+  // index as it is now is rank-local knowledge (a failed commit, an add of precomputed sketches, a clear on one rank only), so the ranks
+  // agree on the branch here: one small rendezvous carries every rank's row count and its "my rows are in place" flag, and the eager
+  // branch is taken only if all of them say so — otherwise some ranks would enter the gathers below and others would not.
+  const bool eager_mine = d->eager_valid && d->eager_gen == v.index_gen && to_self && stride == 2 && d_mh == v.d_minhash && rows == d->eager_rows &&
+                          2 * rows == v.n_entries;
+  int64_t n_pad = 0, total = 0;
+  bool use_eager = eager_mine;
+  {
+    const int64_t mine[2] = {rows, eager_mine ? 1 : 0};
+    std::vector<int64_t> all((size_t)N * 2, 0);
+    rc = tr->allgather_host(mine, all.data(), sizeof mine, *v.err);
+    if (rc != MHAP_OK) return rc;                         // (a failed rendezvous: ABORT)
+    for (int r = 0; r < N; r++) { n_pad = std::max(n_pad, all[(size_t)r * 2]); total += all[(size_t)r * 2]; use_eager = use_eager && all[(size_t)r * 2 + 1] != 0; }
+  }
+  if (use_eager && n_pad != d->eager_npad) use_eager = false;   // (cannot happen: every rank's count is the one its add announced)
   if (!use_eager) d->eager_valid = false;       // (the gather below overwrites the buffers)
   else d->eager_searches++;
-  // equal shard size for the gather: the largest row count of any rank (shorter shards are padded with skipped rows)
-  int64_t n_pad = 0, total = 0;
-  if (use_eager) { n_pad = d->eager_npad; total = 1; }
-  else {
-    std::vector<int64_t> counts((size_t)N, 0);
-    rc = tr->allgather_host(&rows, counts.data(), sizeof(int64_t), *v.err);
-    if (rc != MHAP_OK) return rc;
-    for (int64_t c : counts) { n_pad = std::max(n_pad, c); total += c; }
-  }
-  if (total == 0) { finished = true; tr->quiesce(); return MHAP_OK; }
-  if ((int64_t)N * n_pad > (int64_t)INT32_MAX / 2) return dfail(v, MHAP_E_INVALID, "too many query rows for one gather");
+  if (total == 0) { leave = LEAVE_NONE; tr->quiesce(); return MHAP_OK; }
+  if ((int64_t)N * n_pad > (int64_t)INT32_MAX / 2) { leave = LEAVE_NONE; tr->quiesce(); return dfail(v, MHAP_E_INVALID, "too many query rows for one gather"); }
   const size_t mh_row = (size_t)v.Hrow * 4, od_row = (size_t)v.S * 8, mt_row = (size_t)META_W * 4;
   const size_t np = (size_t)n_pad;
-  DCHK(v, d->s_mh.ensure(np * mh_row)); DCHK(v, d->s_od.ensure(np * od_row)); DCHK(v, d->s_mt.ensure(np * mt_row)); DCHK(v, d->s_ids.ensure(np * 8));
-  DCHK(v, d->g_mh.ensure((size_t)N * np * mh_row)); DCHK(v, d->g_od.ensure((size_t)N * np * od_row));
-  DCHK(v, d->g_mt.ensure((size_t)N * np * mt_row)); DCHK(v, d->g_ids.ensure((size_t)N * np * 8));
   hipStream_t st = v.stream, cs = d->comm_stream;
   if (!use_eager) {
+  // the exchange buffers; a rank that cannot allocate them says so in a second rendezvous, and all ranks return together with the
+  // communicator intact (without it the others would sit in the gathers until the watchdog's time-out)
+  {
+    const bool got = d->s_mh.ensure(np * mh_row) == hipSuccess && d->s_od.ensure(np * od_row) == hipSuccess && d->s_mt.ensure(np * mt_row) == hipSuccess &&
+                     d->s_ids.ensure(np * 8) == hipSuccess && d->g_mh.ensure((size_t)N * np * mh_row) == hipSuccess &&
+                     d->g_od.ensure((size_t)N * np * od_row) == hipSuccess && d->g_mt.ensure((size_t)N * np * mt_row) == hipSuccess &&
+                     d->g_ids.ensure((size_t)N * np * 8) == hipSuccess;
+    if (!got) (void)hipGetLastError();
+    const int64_t mine = got ? 0 : 1;
+    std::vector<int64_t> all((size_t)N, 0);
+    rc = tr->allgather_host(&mine, all.data(), sizeof mine, *v.err);
+    if (rc != MHAP_OK) return rc;
+    int bad = -1;
+    for (int r = 0; r < N; r++) if (all[(size_t)r] != 0 && bad < 0) bad = r;
+    if (bad >= 0) {
+      leave = LEAVE_NONE; tr->quiesce();
+      return dfail(v, MHAP_E_NOMEM, got ? "rank " + std::to_string(bad) + " is out of device memory for the exchange buffers" : std::string("out of device memory (exchange buffers)"));
+    }
+  }
   // pack: every `stride`-th row of the tables; padding rows get status -1 (skipped as queries)
   if (rows > 0) {
     DCHK(v, hipMemcpy2DAsync(d->s_mh.p, mh_row, d_mh, mh_row * (size_t)stride, mh_row, (size_t)rows, hipMemcpyDeviceToDevice, st));
@@ -361,20 +399,31 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   rc = tr->allgather(d->s_od.p, d->g_od.p, np * od_row, cs, *v.err); if (rc != MHAP_OK) return rc;
   DCHK(v, hipEventRecord(d->ev_big, cs));
   }
+  // From here on the other ranks are owed nothing more by this call: an error below is this rank's own.  It still waits for the
+  // gathers it takes part in (they write this rank's buffers) before it returns.
+  leave = LEAVE_LOCAL;
+  auto leave_local = [&](int code) {
+    if (!d->gate_ran) { std::string why; if (tr->wait_event(d->ev_big, why) != MHAP_OK) leave = LEAVE_NONE; }   // (wait_event aborts by itself when the gather is dead)
+    d->t_total = now_ms() - t0;
+    return code;
+  };
   // meanwhile: this rank's inverted index (a no-op when the add built it eagerly)
-  rc = mhap_index_prepare(h); if (rc != MHAP_OK) return rc;
-  rc = tr->wait_event(d->ev_small, *v.err); if (rc != MHAP_OK) return rc;
+  rc = mhap_index_prepare(h); if (rc != MHAP_OK) return leave_local(rc);
+  rc = tr->wait_event(d->ev_small, *v.err); if (rc != MHAP_OK) { leave = LEAVE_NONE; return rc; }   // (a dead gather: wait_event has aborted the transport)
   d->ids_all.resize((size_t)N * np);
-  DCHK(v, hipMemcpy(d->ids_all.data(), d->g_ids.p, (size_t)N * np * 8, hipMemcpyDeviceToHost));
+  { const hipError_t e = hipMemcpy(d->ids_all.data(), d->g_ids.p, (size_t)N * np * 8, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return leave_local(dfail(v, MHAP_E_HIP, std::string("read-back of the gathered ids: ") + hipGetErrorString(e))); }
   d->t_small = now_ms() - t0;
-  rc = mhap_set_second_stage_gate(h, gate_cb, d); if (rc != MHAP_OK) return rc;
+  rc = mhap_set_second_stage_gate(h, gate_cb, d); if (rc != MHAP_OK) return leave_local(rc);
   rc = internal_find_matches_device(h, d->g_mh.p, d->g_od.p, d->g_mt.p, d->ids_all.data(), d->g_ids.as<int64_t>(), (int64_t)N * n_pad, to_self, sink, user);
   (void)mhap_set_second_stage_gate(h, nullptr, nullptr);
-  if (rc != MHAP_OK && !d->gate_err.empty()) *v.err = d->gate_err;   // (the gate's reason, not "the gate aborted the search")
+  const bool gate_failed = !d->gate_err.empty();
+  if (rc != MHAP_OK && gate_failed) *v.err = d->gate_err;   // (the gate's reason, not "the gate aborted the search")
   d->gate_err.clear();
-  if (rc == MHAP_OK && !d->gate_ran) rc = tr->wait_event(d->ev_big, *v.err);   // no candidates here: the gather still has to finish before the buffers are reused
-  finished = rc == MHAP_OK;
-  if (finished) tr->quiesce();
+  if (rc != MHAP_OK) { if (gate_failed) { leave = LEAVE_NONE; d->t_total = now_ms() - t0; return rc; } return leave_local(rc); }
+  if (!d->gate_ran) { rc = tr->wait_event(d->ev_big, *v.err); if (rc != MHAP_OK) { leave = LEAVE_NONE; return rc; } }   // no candidates here: the gather still has to finish before the buffers are reused
+  leave = LEAVE_NONE;
+  tr->quiesce();
   d->t_total = now_ms() - t0;
   return rc;
 }
@@ -416,9 +465,19 @@ int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool elig
   if (total == 0 || (int64_t)N * n_pad > (int64_t)INT32_MAX / 2) return 0;
   const size_t mh_row = (size_t)v.Hrow * 4, od_row = (size_t)v.S * 8, mt_row = (size_t)META_W * 4, np = (size_t)n_pad;
   auto chk = [&](hipError_t e) { return e == hipSuccess; };
-  if (!chk(d->s_mh.ensure(np * mh_row)) || !chk(d->s_od.ensure(np * od_row)) || !chk(d->s_mt.ensure(np * mt_row)) || !chk(d->s_ids.ensure(np * 8)) ||
-      !chk(d->g_mh.ensure((size_t)N * np * mh_row)) || !chk(d->g_od.ensure((size_t)N * np * od_row)) || !chk(d->g_mt.ensure((size_t)N * np * mt_row)) ||
-      !chk(d->g_ids.ensure((size_t)N * np * 8))) { *v.err = "out of device memory (exchange buffers)"; tr->abort(); return MHAP_E_NOMEM; }
+  // A rank that cannot allocate its exchange buffers says so in a second rendezvous and ALL ranks fall back to the exchange at search
+  // time together (which reports the shortage properly); tearing the transport down here left the others in their gathers.
+  const bool got = chk(d->s_mh.ensure(np * mh_row)) && chk(d->s_od.ensure(np * od_row)) && chk(d->s_mt.ensure(np * mt_row)) && chk(d->s_ids.ensure(np * 8)) &&
+                   chk(d->g_mh.ensure((size_t)N * np * mh_row)) && chk(d->g_od.ensure((size_t)N * np * od_row)) && chk(d->g_mt.ensure((size_t)N * np * mt_row)) &&
+                   chk(d->g_ids.ensure((size_t)N * np * 8));
+  if (!got) (void)hipGetLastError();
+  {
+    const int64_t flag = got ? 0 : 1;
+    std::vector<int64_t> all((size_t)N, 0);
+    rc = tr->allgather_host(&flag, all.data(), sizeof flag, *v.err);
+    if (rc != MHAP_OK) { tr->abort(); return rc; }
+    for (int64_t f : all) if (f != 0) return 0;
+  }
   d->ids_local.assign(ids, ids + rows);
   d->eager_rows = rows; d->eager_npad = n_pad; d->eager_go = true;
   return 1;
@@ -566,6 +625,66 @@ int64_t mhap_dist_eager_searches(mhap_handle* h) {
   HandleView v = handle_view(h);
   DistState* d = (DistState*)*v.dist;
   return d ? d->eager_searches : 0;
+}
+
+// What the transport itself says about this rank: out[0] = ranks in the communicator (ncclCommCount), out[1] = this rank's number in
+// it (ncclCommUserRank), out[2] = the device the communicator is bound to (ncclCommCuDevice), out[3] = the handle's device, out[4] =
+// RCCL's version code (0 for the in-process peer transport, whose numbers come from the hub); pci = that device's PCI bus id.
+// A driver that launched N processes can check that N ranks on N different devices were really seen.
+int mhap_dist_info(mhap_handle* h, int32_t* out5, char* pci, size_t pci_cap) {
+  if (!h || !out5) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job (mhap_dist_init / mhap_group_create first)");
+  out5[0] = d->tr->nranks; out5[1] = d->tr->rank; out5[2] = v.device; out5[3] = v.device; out5[4] = 0;
+  if (strcmp(d->tr->name(), "rccl") == 0) {
+    RcclTransport* rt = (RcclTransport*)d->tr;
+    RcclApi& api = rccl();
+    if (!rt->comm) return dfail(v, MHAP_E_STATE, "the RCCL communicator was aborted");
+    int x = 0;
+    if (api.CommCount && api.CommCount(rt->comm, &x) == ncclSuccess) out5[0] = x;
+    if (api.CommUserRank && api.CommUserRank(rt->comm, &x) == ncclSuccess) out5[1] = x;
+    if (api.CommCuDevice && api.CommCuDevice(rt->comm, &x) == ncclSuccess) out5[2] = x;
+    if (api.GetVersion && api.GetVersion(&x) == ncclSuccess) out5[4] = x;
+  }
+  if (pci && pci_cap) { pci[0] = 0; if (hipDeviceGetPCIBusId(pci, (int)pci_cap, v.device) != hipSuccess) { (void)hipGetLastError(); pci[0] = 0; } }
+  return MHAP_OK;
+}
+
+// The collective by itself, no sketching and no search: every rank fills `bytes` bytes with (rank + 1), all-gathers them on the
+// exchange stream through the handle's transport (the watchdog applies), reads the result back and checks every rank's block.
+// ms_out = wall time of the gather.  A fabric or rendezvous problem shows here, separately from any compute kernel.
+int mhap_dist_selftest(mhap_handle* h, size_t bytes, double* ms_out) {
+  if (!h || bytes == 0 || bytes > ((size_t)1 << 30)) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job (mhap_dist_init / mhap_group_create first)");
+  (void)hipSetDevice(v.device);
+  Transport* tr = d->tr;
+  const int N = tr->nranks;
+  DevBuf sb, rb;
+  DCHK(v, sb.ensure(bytes)); DCHK(v, rb.ensure(bytes * (size_t)N));
+  struct Rel { DevBuf& a; DevBuf& b; ~Rel() { a.release(); b.release(); } } rel{sb, rb};
+  hipStream_t cs = d->comm_stream;
+  DCHK(v, hipMemsetAsync(sb.p, (tr->rank + 1) & 0xFF, bytes, cs));
+  DCHK(v, hipMemsetAsync(rb.p, 0, bytes * (size_t)N, cs));
+  const double t0 = now_ms();
+  int rc = tr->allgather(sb.p, rb.p, bytes, cs, *v.err);
+  if (rc != MHAP_OK) { tr->abort(); return rc; }
+  DCHK(v, hipEventRecord(d->ev_small, cs));
+  rc = tr->wait_event(d->ev_small, *v.err);
+  if (rc != MHAP_OK) return rc;
+  if (ms_out) *ms_out = now_ms() - t0;
+  std::vector<unsigned char> host(bytes * (size_t)N);
+  DCHK(v, hipMemcpy(host.data(), rb.p, host.size(), hipMemcpyDeviceToHost));
+  for (int r = 0; r < N; r++) {
+    const unsigned char want = (unsigned char)((r + 1) & 0xFF);
+    for (size_t i = 0; i < bytes; i += (bytes > 4096 ? 509 : 1))
+      if (host[(size_t)r * bytes + i] != want) return dfail(v, MHAP_E_STATE, "all-gather self-test: rank " + std::to_string(r) + "'s block arrived damaged (byte " + std::to_string(i) + ")");
+    if (host[(size_t)r * bytes + bytes - 1] != want) return dfail(v, MHAP_E_STATE, "all-gather self-test: rank " + std::to_string(r) + "'s block arrived short");
+  }
+  tr->quiesce();
+  return MHAP_OK;
 }
 
 int mhap_dist_last_timing(mhap_handle* h, double* out3) {

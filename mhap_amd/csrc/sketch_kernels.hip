@@ -1782,9 +1782,11 @@ __global__ __launch_bounds__(256) void minhash_w1_finish_kernel(W1Args a) {
 void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
   uint64_t col[64], nxt[64];
   auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
-  auto emit = [&](const uint64_t* c, uint64_t* T) {
-    for (int i = 0; i < 8; i++)
-      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(c, (uint64_t)v << (8 * i));
+  auto emit = [&](const uint64_t* c, uint64_t* T) {   // (one xor per entry: the entry without v's lowest set bit, plus that bit's column)
+    for (int i = 0; i < 8; i++) {
+      T[i * 256] = 0;
+      for (int v = 1; v < 256; v++) T[i * 256 + v] = T[i * 256 + (v & (v - 1))] ^ c[8 * i + __builtin_ctz((unsigned)v)];
+    }
   };
   for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < (1 << XS_JUMP_LOG2); t++) x = xorshift_step(x); col[j] = x; }   // M^g
   uint64_t base[64], big[64];
@@ -1806,9 +1808,11 @@ void build_xorshift_jump_tables(int na, int nq, uint64_t* out) {
 void build_xorshift_unjump_tables(int na, int nq, uint64_t* out) {
   uint64_t col[64], nxt[64], base[64], big[64];
   auto apply = [](const uint64_t* c, uint64_t x) { uint64_t y = 0; while (x) { const int b = __builtin_ctzll(x); x &= x - 1; y ^= c[b]; } return y; };
-  auto emit = [&](const uint64_t* c, uint64_t* T) {
-    for (int i = 0; i < 8; i++)
-      for (int v = 0; v < 256; v++) T[i * 256 + v] = apply(c, (uint64_t)v << (8 * i));
+  auto emit = [&](const uint64_t* c, uint64_t* T) {   // (one xor per entry: the entry without v's lowest set bit, plus that bit's column)
+    for (int i = 0; i < 8; i++) {
+      T[i * 256] = 0;
+      for (int v = 1; v < 256; v++) T[i * 256 + v] = T[i * 256 + (v & (v - 1))] ^ c[8 * i + __builtin_ctz((unsigned)v)];
+    }
   };
   for (int j = 0; j < 64; j++) { uint64_t x = 1ULL << j; for (int t = 0; t < (1 << XS_JUMP_LOG2); t++) x = xorshift_unstep(x); col[j] = base[j] = x; }
   for (int a = 1; a <= na; a++) {

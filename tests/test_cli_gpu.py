@@ -258,6 +258,8 @@ def test_bench_distributed_path_through_the_library_one_rccl_rank():
     assert r2["records_per_step"] == r1["records_per_step"] and r1["records_per_step"] > 1000
     assert r2["records_checksum"] == r1["records_checksum"] and r1["records_sha256_sorted_lines"]
     assert r2["phase_wall_ms"]["exchange"] >= 0.0
+    # the per-rank view the driver can check an N-GPU run against: N ranks, each counting N, distinct devices
+    assert r2["ranks"]["consistent"] and r2["ranks"]["world"] == 1 and r2["ranks"]["per_rank"][0]["comm_count"] == 1 and r1["ranks"] is None
 
 
 def test_bench_preflight_says_what_an_n_gpu_run_needs():
@@ -272,6 +274,24 @@ def test_bench_preflight_says_what_an_n_gpu_run_needs():
         many = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight", "--gpus", "8"], capture_output=True, text=True, timeout=300)
         r8 = json.loads(many.stdout.strip().split("\n")[-1])
         assert many.returncode == 1 and not r8["ready"] and not r8["checks"]["devices"]["ok"] and "torch.distributed.run" in r8["launch"]
+
+
+def test_bench_dry_collective_and_rank_views():
+    """bench.py --gpus 1 --dry-collective: the communicator the timed run would form (one rank here), a checked 1 MB and 64 MB all-gather
+    through the library's transport, and the per-rank view — RCCL's count / user rank / device and the PCI bus id — in ONE JSON line,
+    without any compute step; a world size that does not match the launch is refused before any collective."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-collective"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    assert d["dry_collective"] and d["ready"] and d["n_gpus"] == 1
+    v = d["ranks"]
+    assert v["consistent"] and v["world"] == 1 and v["per_rank"][0]["comm_count"] == 1 and v["per_rank"][0]["comm_user_rank"] == 0
+    assert v["per_rank"][0]["pci_bus_id"] and v["per_rank"][0]["rccl_version"]
+    res = d["per_rank_results"][0]
+    assert res["error"] is None and len(res["allgather_1MB_ms"]) == 3 and res["allgather_64MB_ms"] > 0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-collective"], capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "torch.distributed.run" in (bad.stdout + bad.stderr)
 
 
 def test_cli_gpus_flag_shards_the_index_and_keeps_the_records(tmp_path):
