@@ -426,12 +426,24 @@ def main():
             out["dist_path_1rank"] = dist_path_leg(ms, args, recs, mhap_amd.KERNEL_NAMES)
         if not args.no_cpu_baseline and world == 1:
             out.update(host_legs(args, cfg, p, flt, filter_path, fa_bench, L, H, S, k, k2, total_records, sha, tmpdir))
-        print(json.dumps(out), flush=True)
+        emit(out)
     ms.close()
     shutil.rmtree(tmpdir, ignore_errors=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def emit(obj):
+    """The JSON line is the LAST line of stdout: whatever native libraries have printed through C stdio (RCCL's banner at the first
+    communicator) sits in a buffer that would otherwise be flushed at exit, after the line the driver parses."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    print(json.dumps(obj), flush=True)
 
 
 def gather_rank_views(ms, dist, rank, world, local_rank):
@@ -496,7 +508,7 @@ def dry_collective(n):
     ok = all(a and a.get("error") is None and not a.get("no_peer_access_to") for a in alls) and (err is None and views["consistent"])
     if rank == 0:
         rep.update(ready=bool(ok), ranks=views if err is None else None, per_rank_results=alls)
-        print(json.dumps(rep), flush=True)
+        emit(rep)
     ms.close()
     if dist is not None:
         dist.barrier()

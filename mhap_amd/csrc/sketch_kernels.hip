@@ -1969,6 +1969,13 @@ __device__ unsigned long long g_ord_prof[8];
 #else
 #define ORD_TICK(k) do { } while (0)
 #endif
+// h * 5 + 0xe6546b64 of the murmur3_x86_32 body as a shift-add and an add: the compiler turns the multiply-add into v_mad_u64_u32
+// (quarter rate; 48 of them per eight hashes in the pass below)
+__device__ __forceinline__ uint32_t mm3_mul5c(uint32_t h) {
+  uint32_t t;
+  asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(t) : "v"(h));
+  return t + 0xe6546b64U;
+}
 constexpr uint32_t ORD_BUCKET_MAX = 32;   // keys per first-level bin the bucket path sorts by insertion
 __device__ inline uint64_t okey(int32_t h, int pos) { return ((uint64_t)((uint32_t)h ^ 0x80000000u) << 32) | (uint32_t)pos; }
 
@@ -1985,7 +1992,12 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint16_t* bstart = (uint16_t*)(buf + cap);              // bucket path: first buffer slot of every first-level bin (+1 end marker)
   uint32_t* stage = (uint32_t*)(bstart + ORD_BINS + 2);   // one-pass path: positions of the keys below the guessed cut (16-bit unless the
   uint16_t* stage16 = (uint16_t*)stage;                   // launch has a strand with more than 65535 k-mers: 4 KB instead of 8 at S = 1536)
-  uint64_t* lut = (uint64_t*)(((uintptr_t)stage + (size_t)cap * (stage_wide ? 4 : 2) + 7) & ~(uintptr_t)7);   // murmur3_x86_32 block-mix table (256 words), then the strand's base codes
+  // murmur3_x86_32 block-mix table (256 words), then the strand's base codes.  The offset is computed as a NUMBER and added to the
+  // shared-memory base: rounding the pointer itself up through uintptr_t (round 1-4) cost the compiler the address space — every read of
+  // the table and of the codes was a flat_load (85 of them in the kernel, 7.2e7 wave-level VMEM reads per C2 launch in the PMC pass),
+  // which goes through the vector-memory path and its address check instead of a ds_read
+  const size_t lut_off = ((size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)cap * (stage_wide ? 4 : 2) + 7) & ~(size_t)7;
+  uint64_t* lut = (uint64_t*)(smem + lut_off);
   uint32_t* codes = (uint32_t*)(lut + 256);
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
   const int64_t strand = blockIdx.x;
@@ -2019,8 +2031,8 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const uint64_t kk = lut[(cw >> (8 * q)) & 255u];
-      h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
-      h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+      h ^= (uint32_t)kk;         h = rotl32(h, 13); h = mm3_mul5c(h);
+      h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = mm3_mul5c(h);
     }
     h ^= 24u;
     return (int32_t)fmix32(h);
@@ -2068,8 +2080,8 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
 #pragma unroll
           for (int q = 0; q < 3; q++) {
             const uint64_t kk = g[u + q];
-            h ^= (uint32_t)kk;         h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
-            h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = h * 5 + 0xe6546b64U;
+            h ^= (uint32_t)kk;         h = rotl32(h, 13); h = mm3_mul5c(h);
+            h ^= (uint32_t)(kk >> 32); h = rotl32(h, 13); h = mm3_mul5c(h);
           }
           h ^= 24u;
           hv[u] = (int32_t)fmix32(h);
@@ -2125,30 +2137,51 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
     if (ok) {
       for (uint32_t b = threadIdx.x; b <= cutbin; b += ORD_THREADS) hist[b] = 0;   // becomes the bins' fill counters
       __syncthreads();
-      for (uint32_t t = threadIdx.x; t < m; t += ORD_THREADS) {
-        const int i = stage_wide ? (int)stage[t] : (int)stage16[t];
-        const uint64_t key = okey(hget(i), i);
-        const uint32_t b = (uint32_t)(key >> 53);
-        buf[(uint32_t)bstart[b] + atomicAdd(&hist[b], 1u)] = key;
+      // (four kept keys per lane and trip: a lane has about seven of them, and one at a time the chain position -> codes -> table ->
+      //  hash -> bin counter -> store ran seven times back to back with nothing to overlap it)
+      for (uint32_t t0 = threadIdx.x; t0 < m; t0 += 4 * ORD_THREADS) {
+        int ii[4]; uint64_t key[4]; uint32_t slot[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t t = t0 + (uint32_t)u * ORD_THREADS; ii[u] = t < m ? (stage_wide ? (int)stage[t] : (int)stage16[t]) : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) key[u] = okey(hget(ii[u]), ii[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t b = (uint32_t)(key[u] >> 53); slot[u] = t0 + (uint32_t)u * ORD_THREADS < m ? (uint32_t)bstart[b] + atomicAdd(&hist[b], 1u) : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (slot[u] != 0xFFFFFFFFu) buf[slot[u]] = key[u];
       }
       __syncthreads();
       ORD_TICK(3);
       // every key finds its rank inside its bin (<= ORD_BUCKET_MAX keys, all reads independent) and goes straight to its place in
       // the output row: one key per lane instead of one bin per lane walking a serial insertion sort
       int32_t* orow = out_rows + strand * out_stride;
-      for (uint32_t t = threadIdx.x; t < m; t += ORD_THREADS) {
-        const uint64_t key = buf[t];
-        const uint32_t b = (uint32_t)(key >> 53), s0 = bstart[b], c = hist[b];
-        uint32_t rank = 0;
-        for (uint32_t q = 0; q < c; q += 4) {   // four independent reads per trip (the bin's slice is followed by valid buffer words)
-          uint64_t o[4];
+      // (two keys per lane and trip, their bins walked side by side: eight independent reads in flight instead of four)
+      for (uint32_t t0 = threadIdx.x; t0 < m; t0 += 2 * ORD_THREADS) {
+        uint64_t key[2]; uint32_t s0[2], c[2], rank[2] = {0u, 0u};
 #pragma unroll
-          for (int x = 0; x < 4; x++) o[x] = buf[s0 + q + (uint32_t)x < (uint32_t)cap ? s0 + q + (uint32_t)x : s0];
-#pragma unroll
-          for (int x = 0; x < 4; x++) rank += (q + (uint32_t)x < c && o[x] < key) ? 1u : 0u;
+        for (int u = 0; u < 2; u++) {
+          const uint32_t t = t0 + (uint32_t)u * ORD_THREADS;
+          key[u] = buf[t < m ? t : t0];
+          const uint32_t b = (uint32_t)(key[u] >> 53);
+          s0[u] = bstart[b]; c[u] = t < m ? hist[b] : 0u;
         }
-        const uint32_t j = s0 + rank;
-        if (j < (uint32_t)K) { orow[2 * j] = (int32_t)((uint32_t)(key >> 32) ^ 0x80000000u); orow[2 * j + 1] = (int32_t)(uint32_t)key; }
+        const uint32_t cmax = c[0] > c[1] ? c[0] : c[1];
+        for (uint32_t q = 0; q < cmax; q += 4) {   // (a bin's slice is followed by valid buffer words)
+          uint64_t o[2][4];
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) o[u][x] = buf[s0[u] + q + (uint32_t)x < (uint32_t)cap ? s0[u] + q + (uint32_t)x : s0[u]];
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) rank[u] += (q + (uint32_t)x < c[u] && o[u][x] < key[u]) ? 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const uint32_t j = s0[u] + rank[u];
+          if (t0 + (uint32_t)u * ORD_THREADS < m && j < (uint32_t)K) { orow[2 * j] = (int32_t)((uint32_t)(key[u] >> 32) ^ 0x80000000u); orow[2 * j + 1] = (int32_t)(uint32_t)key[u]; }
+        }
       }
       ORD_TICK(5);
 #ifdef MH_ORD_PROF
