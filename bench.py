@@ -409,6 +409,7 @@ def main():
             "records_sha256_sorted_lines": sha, "records_checksum": "%016x" % records_checksum,
             "records_checksum_kind": "binary fields (output too large for text lines in Python)" if big_output else "sha256 of text lines, summed",
             "hbm_traffic_by_kernel": hbm_by_kernel,
+            "kernel_ceilings": kernel_ceilings(args.config, n_total, L, world, kernel_ms_per_step, hbm_by_kernel),
             "roofline": roofline, "valu": valu, "roofline_stage2": roofline_stage2,
             "eager_exchange": eager_note,
             "ranks": rank_views,
@@ -580,6 +581,59 @@ def preflight(n):
                          f"bench.py --gpus {n} --steps K --warmup W")
     print(json.dumps(rep), flush=True)
     return 0 if rep["ready"] else 1
+
+
+VALU_WAVE_INSTR_PER_S = 6.7e13 / 64.0   # full-rate VALU wave-instructions per second the chip sustains at ANY occupancy (tools/issue_probe.hip)
+# bench.py kernel-time slot -> the kernels of the PMC summaries that run in it
+SLOT_KERNELS = {"kmer_weight": ("kmer_weight_kernel",), "minhash": ("minhash_w1_kernel", "minhash_kernel_weighted", "minhash_kernel", "minhash_w1_finish_kernel"),
+                "ordered": ("ordered_kernel",), "index_build": ("index_tile_kernel", "index_offsets_kernel", "index_bins_kernel", "index_group_kernel"),
+                "index_query": ("index_query_kernel", "index_query_dense_kernel", "index_query_dense4_kernel"), "overlap": ("overlap_join_kernel", "overlap_kernel", "poshist_kernel")}
+
+
+def kernel_ceilings(config, n_total, L, world, kernel_ms_per_step, hbm_by_kernel):
+    """One ceiling statement per kernel slot of a C2 step: which pipe bounds it and how close it runs to that pipe.
+    The counters come from the committed PMC summary of THIS source (profiles/rNN_pmc_pipes.json, tools/pmc_pipes.py; null when the
+    sources changed since), the times are this run's.  valu = VALU wave-instructions per second against the 1.05e12/s the chip sustains
+    on full-rate work (v_bitop3 / v_alignbit / multiplies cost more than one such unit, so a kernel can be VALU-bound below 1.0);
+    lds = share of the kernel's cycles the CUs' LDS pipes are busy (and how much of that is bank conflicts); hbm = PMC bytes over time
+    against 8 TB/s.  `bound` names the largest of the three."""
+    if not (config == "c2" and n_total == 100000 and L == 10000 and world == 1):
+        return None
+    from mhap_amd import build as mbuild
+    here = mbuild.source_digest()
+    doc = None
+    for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_pipes.json")), reverse=True):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if d.get("source_digest") == here:
+                doc = (name, d)
+                break
+        except Exception:   # noqa: BLE001
+            continue
+    if doc is None:
+        return {"note": "no profiles/*_pmc_pipes.json carries this source's digest (run tools/profile_round.sh on the GPU box)"}
+    out = {"source": "profiles/" + doc[0]}
+    for slot, members in SLOT_KERNELS.items():
+        ms = kernel_ms_per_step.get(slot, 0.0)
+        ks = [doc[1]["kernels"][m] for m in members if m in doc[1]["kernels"]]
+        if ms <= 0 or not ks:
+            continue
+        valu = sum(k["per_launch"].get("SQ_INSTS_VALU", 0.0) * k["launches"] for k in ks) / max(k["launches"] for k in ks[:1])
+        salu = sum(k["per_launch"].get("SQ_INSTS_SALU", 0.0) * k["launches"] for k in ks) / max(k["launches"] for k in ks[:1])
+        lds_busy = sum(k["per_launch"].get("SQ_LDS_IDX_ACTIVE", 0.0) * k["launches"] for k in ks)
+        gui = sum(k["per_launch"].get("GRBM_GUI_ACTIVE", 0.0) * k["launches"] for k in ks)
+        conf = sum(k["per_launch"].get("SQ_LDS_BANK_CONFLICT", 0.0) * k["launches"] for k in ks)
+        e = {"ms": round(ms, 3), "valu_instr_per_step": float("%.4g" % valu), "salu_instr_per_step": float("%.4g" % salu),
+             "valu_frac": round(valu / (ms / 1e3) / VALU_WAVE_INSTR_PER_S, 3),
+             "lds_pipe_frac": round(lds_busy / (256.0 * gui / 8.0), 3) if gui else None,
+             "lds_conflict_share": round(conf / lds_busy, 3) if lds_busy else None,
+             "hbm_frac": round(hbm_by_kernel[slot]["GB_per_s"] / HBM_PEAK_GBS, 3) if slot in hbm_by_kernel else None,
+             "vgpr": max(k["vgpr"] for k in ks), "scratch_bytes_per_lane": max(k["scratch_bytes_per_lane"] for k in ks)}
+        cands = {"valu": e["valu_frac"], "lds": e["lds_pipe_frac"] or 0.0, "hbm": e["hbm_frac"] or 0.0}
+        e["bound"] = max(cands, key=cands.get)
+        e["frac_of_bound"] = cands[e["bound"]]
+        out[slot] = e
+    return out
 
 
 def pmc_traffic(kernel, config, n_total, L, world):

@@ -1,7 +1,7 @@
 # final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload, the other configurations' bench lines, one rank of an
 # N-GPU job, the native driver end to end (run on the GPU box); ROUND=r04 bash tools/profile_round.sh
 export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix gpurun_out/$R
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o prof --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_final/bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -12,8 +12,21 @@ cp $(find gpurun_out/prof_final -name "prof_kernel_stats.csv" | head -1) gpurun_
 python tools/pmc_summary.py $(find gpurun_out/pmc_FETCH_SIZE -name "pmc_counter_collection.csv" | head -1) $(find gpurun_out/pmc_WRITE_SIZE -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_traffic.json
 head -1 $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_minhash_instmix.csv
 grep -h "minhash_" $(find gpurun_out/pmc_mix -name "pmc_counter_collection.csv" | head -1) >> gpurun_out/$R/${R}_pmc_minhash_instmix.csv
+# pipe counters of every kernel (LDS pipe, bank conflicts, VALU / SALU instructions): two more passes of eight counters
+for set in "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_ADDR_CONFLICT" "GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU"; do
+  tag=pipes_$(echo $set | cut -d' ' -f1)
+  rm -rf gpurun_out/pmc_$tag; mkdir -p gpurun_out/pmc_$tag
+  timeout 300 rocprofv3 --pmc $set --kernel-trace -d gpurun_out/pmc_$tag -o pmc --output-format csv -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_$tag/bench.log 2>&1
+done
+python tools/pmc_pipes.py $(find gpurun_out/pmc_pipes_SQ_INSTS_LDS -name "pmc_counter_collection.csv" | head -1) $(find gpurun_out/pmc_pipes_GRBM_GUI_ACTIVE -name "pmc_counter_collection.csv" | head -1) > gpurun_out/$R/${R}_pmc_pipes.json
+cp gpurun_out/$R/${R}_pmc_pipes.json profiles/${R}_pmc_pipes.json
 cp gpurun_out/$R/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json   # bench.py reads the byte counts from profiles/ (same source digest)
-timeout 900 python bench.py > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
+# the committed bench line, with a clock / power trace of the card under its soak leg (tools/smi_trace.py) and the MinHash kernel's own
+# wave-clock attribution + mean shader clock beside it
+(sleep 45; python tools/smi_trace.py gpurun_out/$R/smi_trace_raw.txt 60 > gpurun_out/$R/${R}_smi_trace_c2.txt 2>&1) &
+timeout 900 python bench.py --steps 20 --warmup 5 --soak-seconds 20 > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
+wait
+MHAP_MINHASH_PROF=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --soak-seconds 0 2>&1 >/dev/null | grep "w1 prof" | tail -4 > gpurun_out/$R/${R}_minhash_prof.txt
 tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
 MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
 for c in c1 c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_out/$R/${R}_bench_$c.json 2>/dev/null; done
