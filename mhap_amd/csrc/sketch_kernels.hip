@@ -1590,6 +1590,24 @@ __device__ __forceinline__ uint32_t w1_base_filter(const uint32_t (&P)[64]) {
   return __builtin_amdgcn_bitop3_b32(t0, t1, t2, BS_TT_OR3);
 }
 
+#ifndef MH_W1_CLS
+#define MH_W1_CLS 2     // how a step selects its class's filter code: 0 = `switch`, 1 = if-chain in C, 2 = the chain written out in assembly
+#endif
+// a slot without a usable minimum (fewer than eight leading zero bits, or none at all: every active chain is a candidate): the exact masked
+// filter of its depth.  left = k-mers of the strand from this row's first on (chains j with 64 j + lane < left are active)
+__device__ __forceinline__ uint32_t w1_exact_filter(const uint32_t (&P)[64], int32_t bhs, int left_row) {
+  const uint32_t sm = bs_mask_of(bhs);
+  uint32_t ln;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(ln));
+  const int left = left_row - (int)ln;
+  const int na_ = left <= 0 ? 0 : (left + 63) >> 6;
+  const uint32_t act = na_ >= 32 ? 0xFFFFFFFFu : ((1u << na_) - 1u);
+  uint32_t n = __builtin_amdgcn_bitop3_b32(P[63], bs_sbit(sm, 0), ~act, 0xBA);   // (~sign & enable) | inactive
+#pragma unroll
+  for (int b = 1; b < W1_CLS_BASE; b++) n = __builtin_amdgcn_bitop3_b32(P[63 - b], bs_sbit(sm, b), n, BS_TT_ANDOR);
+  return n;
+}
+
 template <bool PROF>
 __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, int rb, int nk, bool first, int H, const KeySrc& ks,
                                         const uint64_t* __restrict__ jump, int lane, bool& ok, unsigned long long* tp) {
@@ -1632,6 +1650,7 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
         const int cls = __builtin_amdgcn_readlane(vcls, t);
         bs_step(P);
         uint32_t n = w1_base_filter(P);
+#if MH_W1_CLS == 0
         switch (cls) {
           case 1: break;
           case 2: n |= P[54]; break;
@@ -1639,18 +1658,48 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
           case 4: n = __builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3) | P[52]; break;
           case 5: n = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3), P[52], P[51], BS_TT_OR3); break;
           case 6: n = __builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3), P[52], P[51], BS_TT_OR3) | P[50]; break;
-          default: {   // no usable minimum yet: the exact filter of the slot's depth (every active chain when there is no negative minimum)
-            const uint32_t sm = bs_mask_of(besthi[2 * sl + 1]);
-            uint32_t ln;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(ln));
-            const int left = nk - rb - (int)ln;                                  // chains j with rb + 64 j + lane < nk
-            const int na_ = left <= 0 ? 0 : (left + 63) >> 6;
-            const uint32_t act = na_ >= 32 ? 0xFFFFFFFFu : ((1u << na_) - 1u);
-            n = __builtin_amdgcn_bitop3_b32(P[63], bs_sbit(sm, 0), ~act, 0xBA);   // (~sign & enable) | inactive
-#pragma unroll
-            for (int b = 1; b < W1_CLS_BASE; b++) n = __builtin_amdgcn_bitop3_b32(P[63 - b], bs_sbit(sm, b), n, BS_TT_ANDOR);
-          } break;
+          default: n = w1_exact_filter(P, besthi[2 * sl + 1], nk - rb); break;
         }
+#elif MH_W1_CLS == 1
+        if (__builtin_expect(cls >= 3, 1)) {
+          n = __builtin_amdgcn_bitop3_b32(n, P[54], P[53], BS_TT_OR3);
+          if (cls >= 5) {
+            n = __builtin_amdgcn_bitop3_b32(n, P[52], P[51], BS_TT_OR3);
+            if (cls >= 6) n |= P[50];
+          } else if (cls == 4) n |= P[52];
+        } else if (cls == 2) n |= P[54];
+        else if (__builtin_expect(cls == 0, 0)) n = w1_exact_filter(P, besthi[2 * sl + 1], nk - rb);   // no usable minimum yet: the exact filter of the slot's depth
+#else
+        // The class selects code through a short chain of scalar compares, deepest classes first (the common ones from the third row on),
+        // written out in assembly: the compiler lowers the equivalent `switch` / if-chain through its control-flow structurizer — a compare
+        // tree with "which way did I come" flags in SGPR pairs, 11 to 16 scalar instructions a step (and selects in place of the
+        // innermost branches); this is 6 or 7.  (One asm statement, branches local to it; classes 1..6 add the planes 9..13.)
+        asm volatile(
+            "s_cmp_lt_i32 %[c], 3\n\t"
+            "s_cbranch_scc1 1f\n\t"
+            "v_bitop3_b32 %[n], %[n], %[p54], %[p53] bitop3:0xfe\n\t"
+            "s_cmp_lt_i32 %[c], 5\n\t"
+            "s_cbranch_scc1 2f\n\t"
+            "v_bitop3_b32 %[n], %[n], %[p52], %[p51] bitop3:0xfe\n\t"
+            "s_cmp_lt_i32 %[c], 6\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "v_or_b32 %[n], %[n], %[p50]\n\t"
+            "s_branch 3f\n"
+            "2:\n\t"
+            "s_cmp_lt_i32 %[c], 4\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "v_or_b32 %[n], %[n], %[p52]\n\t"
+            "s_branch 3f\n"
+            "1:\n\t"
+            "s_cmp_lt_i32 %[c], 2\n\t"
+            "s_cbranch_scc1 3f\n\t"
+            "v_or_b32 %[n], %[n], %[p54]\n"
+            "3:\n"
+            : [n] "+v"(n)
+            : [c] "s"(cls), [p54] "v"(P[54]), [p53] "v"(P[53]), [p52] "v"(P[52]), [p51] "v"(P[51]), [p50] "v"(P[50])
+            : "scc");
+        if (__builtin_expect(cls == 0, 0)) n = w1_exact_filter(P, besthi[2 * sl + 1], nk - rb);   // no usable minimum yet: the exact filter of the slot's depth
+#endif
         const unsigned long long m = __ballot(n != 0xFFFFFFFFu);
         if (__builtin_expect(m != 0ULL, 0)) w1_enqueue(q, qn, (uint32_t)sl, ~n, m);
       }
