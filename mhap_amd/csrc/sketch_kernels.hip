@@ -960,6 +960,24 @@ __device__ __forceinline__ uint32_t bs_cold_filter(const uint32_t (&P)[64], uint
 // about 2048 / 2^BS_ARGMIN_PLANES other chains still share its prefix, and the deferred exact update sorts those out,
 // so the walk stops there instead of testing for a single survivor.
 constexpr int BS_ARGMIN_PLANES = 11;   // measured 9 / 10 / 11 / 12 / 14 planes: 86.9 / 85.9 / 85.8 / 86.9 / 87.2 ms at C2
+__device__ __forceinline__ uint32_t bs_argmin_walk(const uint32_t (&P)[64], uint32_t ACT) {
+  uint32_t cand = ACT & P[63];                 // negative values first (signed compare)
+  if (!__any(cand != 0u)) cand = ACT;
+#pragma unroll
+  for (int b = 62; b > 62 - BS_ARGMIN_PLANES; b--) {
+    const uint32_t m = cand & ~P[b];
+    if (__any(m != 0u)) cand = m;
+  }
+  return cand;
+}
+// the shortcut alone (the callers that test its ballot themselves)
+__device__ __forceinline__ uint32_t bs_argmin_pre(const uint32_t (&P)[64], uint32_t ACT) {
+  uint32_t o = __builtin_amdgcn_bitop3_b32(P[62], P[61], P[60], BS_TT_OR3);
+  o = __builtin_amdgcn_bitop3_b32(o, P[59], P[58], BS_TT_OR3);
+  o = __builtin_amdgcn_bitop3_b32(o, P[57], P[56], BS_TT_OR3);
+  o = __builtin_amdgcn_bitop3_b32(o, P[55], P[54], BS_TT_OR3);
+  return __builtin_amdgcn_bitop3_b32(ACT, P[63], o, 0x40);   // ACT & sign & ~o
+}
 __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t ACT) {
   // shortcut: the chains that are negative with nine leading zero magnitude bits (two are expected among 2048, and if there is
   // any the minimum is among them); the plane-by-plane walk below only runs for the ~14 % of slots without one.  Measured with
@@ -971,16 +989,8 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
   o = __builtin_amdgcn_bitop3_b32(o, P[55], P[54], BS_TT_OR3);
   const uint32_t pre = __builtin_amdgcn_bitop3_b32(ACT, P[63], o, 0x40);   // ACT & sign & ~o   (table index = 4a + 2b + c)
   if (__any(pre != 0u)) return pre;
-  uint32_t cand = ACT & P[63];                 // negative values first (signed compare)
-  if (!__any(cand != 0u)) cand = ACT;
-#pragma unroll
-  for (int b = 62; b > 62 - BS_ARGMIN_PLANES; b--) {
-    const uint32_t m = cand & ~P[b];
-    if (__any(m != 0u)) cand = m;
-  }
-  return cand;
+  return bs_argmin_walk(P, ACT);
 }
-
 // Deferred candidates: pulling a candidate's 64-bit value out of the planes would cost 64 v_readlane + ~250 scalar ops
 // (~1600 issue cycles).  Instead a trigger only appends (slot, sub-step, lane, chain) words to the wave's queue (global memory,
 // fire-and-forget stores); slots are independent within a row, so the queue is drained at the end of the row, 64 entries at a
@@ -1591,7 +1601,7 @@ __device__ __forceinline__ uint32_t w1_base_filter(const uint32_t (&P)[64]) {
 }
 
 #ifndef MH_W1_CLS
-#define MH_W1_CLS 2     // how a step selects its class's filter code: 0 = `switch`, 1 = if-chain in C, 2 = the chain written out in assembly
+#define MH_W1_CLS 2     // how a step selects its class's filter code: 0 = `switch`, 1 = if-chain in C, 2 = the whole chain in assembly, 3 = classes 3..6 in assembly behind one C branch (fewer scalar instructions than 2 but more TAKEN branches: 1 ms slower)
 #endif
 // a slot without a usable minimum (fewer than eight leading zero bits, or none at all: every active chain is a candidate): the exact masked
 // filter of its depth.  left = k-mers of the strand from this row's first on (chains j with 64 j + lane < left are active)
@@ -1630,8 +1640,12 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
   if (first) {
     for (int s = 0; s < H; s++) {
       bs_step(P);
-      const uint32_t cand = bs_argmin(P, ACT);
-      w1_enqueue(q, qn, (uint32_t)s, cand, __ballot(cand != 0u));
+      // the nine-plane shortcut of bs_argmin in line, its ballot serving both the "anyone?" test and the enqueue; the plane walk (one
+      // step in seven) is the out-of-line side
+      uint32_t cand = bs_argmin_pre(P, ACT);
+      unsigned long long m = __ballot(cand != 0u);
+      if (__builtin_expect(m == 0ULL, 0)) { cand = bs_argmin_walk(P, ACT); m = __ballot(cand != 0u); }
+      w1_enqueue(q, qn, (uint32_t)s, cand, m);
     }
   } else {
     const int32_t* besthi = (const int32_t*)best;
@@ -1669,7 +1683,7 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
           } else if (cls == 4) n |= P[52];
         } else if (cls == 2) n |= P[54];
         else if (__builtin_expect(cls == 0, 0)) n = w1_exact_filter(P, besthi[2 * sl + 1], nk - rb);   // no usable minimum yet: the exact filter of the slot's depth
-#else
+#elif MH_W1_CLS == 2
         // The class selects code through a short chain of scalar compares, deepest classes first (the common ones from the third row on),
         // written out in assembly: the compiler lowers the equivalent `switch` / if-chain through its control-flow structurizer — a compare
         // tree with "which way did I come" flags in SGPR pairs, 11 to 16 scalar instructions a step (and selects in place of the
@@ -1699,9 +1713,41 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
             : [c] "s"(cls), [p54] "v"(P[54]), [p53] "v"(P[53]), [p52] "v"(P[52]), [p51] "v"(P[51]), [p50] "v"(P[50])
             : "scc");
         if (__builtin_expect(cls == 0, 0)) n = w1_exact_filter(P, besthi[2 * sl + 1], nk - rb);   // no usable minimum yet: the exact filter of the slot's depth
+#else
+        // as 2, with the deepest classes (from the third row on the most frequent) on the straightest path: one C branch sends the
+        // classes 0..2 out of line, the assembly takes 3..6 in four scalar instructions
+        if (__builtin_expect(cls < 3, 0)) {
+          if (cls == 2) n |= P[54];
+          else if (cls == 0) {   // no usable minimum yet: the exact filter of the slot's depth
+            int so;   // (the slot index through an opaque copy: otherwise the address of its minimum is strength-reduced into one more
+                      //  scalar add in EVERY step of the loop, for a path one step in a thousand takes)
+            asm volatile("s_mov_b32 %0, %1" : "=s"(so) : "s"(sl));
+            n = w1_exact_filter(P, besthi[2 * so + 1], nk - rb);
+          }
+        } else {
+          uint32_t o;   // (a result register of its own: tied to n the compiler copies n first, for the other path's sake)
+          asm volatile(
+              "v_bitop3_b32 %[o], %[n], %[p54], %[p53] bitop3:0xfe\n\t"
+              "s_cmp_lt_i32 %[c], 5\n\t"
+              "s_cbranch_scc0 4f\n\t"
+              "s_cmp_lt_i32 %[c], 4\n\t"
+              "s_cbranch_scc1 3f\n\t"
+              "v_or_b32 %[o], %[o], %[p52]\n\t"
+              "s_branch 3f\n"
+              "4:\n\t"
+              "v_bitop3_b32 %[o], %[o], %[p52], %[p51] bitop3:0xfe\n\t"
+              "s_cmp_lt_i32 %[c], 6\n\t"
+              "s_cbranch_scc1 3f\n\t"
+              "v_or_b32 %[o], %[o], %[p50]\n"
+              "3:\n"
+              : [o] "=&v"(o)
+              : [n] "v"(n), [c] "s"(cls), [p54] "v"(P[54]), [p53] "v"(P[53]), [p52] "v"(P[52]), [p51] "v"(P[51]), [p50] "v"(P[50])
+              : "scc");
+          n = o;
+        }
 #endif
         const unsigned long long m = __ballot(n != 0xFFFFFFFFu);
-        if (__builtin_expect(m != 0ULL, 0)) w1_enqueue(q, qn, (uint32_t)sl, ~n, m);
+        if (__builtin_expect(m != 0ULL, 1)) w1_enqueue(q, qn, (uint32_t)sl, ~n, m);   // (two steps in three trigger: the enqueue is the fall-through side)
       }
     }
   }
