@@ -1136,6 +1136,29 @@ __device__ __forceinline__ void perchain_row(int64_t* best, int32_t* bpos, const
 // pays most for) — plus the strands without a sketch (their zero rows / status).  WEIGHTED = true: a second launch takes
 // the other strands (class lists, a common weight > 1).  kmer_weight_kernel sorts the strands into the two work lists.
 // (amdgpu_waves_per_eu: the weighted instantiation needs 129 VGPRs left alone — one over four waves per SIMD.)
+// ---- depth classes of a slot (round 5, the weight-1 kernel): the filter a step needs is selected as CODE by the slot's class, not through
+// scalar enable operands (an SGPR source makes a v_bitop3 1.5 times as dear: profiles/r05_issue_probe.txt).  (The same selection in the
+// general kernel — seven copies of its step loop, one per class, switched per slot — ran 52 % SLOWER on the C5 slice, 181 against 119 ms:
+// the copies with their trigger paths no longer fit the instruction cache the slot loop lives in.) ----
+constexpr int W1_CLS_BASE = 8;            // class c >= 1 filters down to depth W1_CLS_BASE + c - 1; class 0 = the exact masked filter
+constexpr int W1_CLS_MAX = 6;             // depth 13: 2048 x 2^-14 = one false candidate per eight steps at worst
+
+// class of a slot from the high dword of its minimum
+__device__ __forceinline__ int w1_class_of(int32_t bhs) {
+  const int z = bs_depth(bhs);
+  if (z < W1_CLS_BASE) return 0;
+  const int c = z - W1_CLS_BASE + 1;
+  return c > W1_CLS_MAX ? W1_CLS_MAX : c;
+}
+
+// the planes 1..8 of the magnitude and the sign: a chain that is not negative or has a one among them is out (bit = 1)
+__device__ __forceinline__ uint32_t w1_base_filter(const uint32_t (&P)[64]) {
+  const uint32_t t0 = __builtin_amdgcn_bitop3_b32(P[62], P[61], P[60], BS_TT_OR3);
+  const uint32_t t1 = __builtin_amdgcn_bitop3_b32(P[59], P[58], P[57], BS_TT_OR3);
+  const uint32_t t2 = __builtin_amdgcn_bitop3_b32(P[56], P[55], P[63], 0xFD);     // a | b | ~c   (table index = 4a + 2b + c)
+  return __builtin_amdgcn_bitop3_b32(t0, t1, t2, BS_TT_OR3);
+}
+
 #ifndef MH_WAVES_EU
 #define MH_WAVES_EU 4
 #endif
@@ -1512,17 +1535,6 @@ __device__ __forceinline__ void w1_row(int64_t* best, uint32_t* __restrict__ q, 
 #define MH_W1_V2 1
 #endif
 constexpr int W1_QCAP = BS_QCAP / 2 - 1;  // 8-byte entries in the same 16 KB per wave; entry W1_QCAP (the last of the 16 KB) is the spare one overflowing appends land in
-constexpr int W1_CLS_BASE = 8;            // class c >= 1 filters down to depth W1_CLS_BASE + c - 1; class 0 = the exact masked filter
-constexpr int W1_CLS_MAX = 6;             // depth 13: 2048 x 2^-14 = one false candidate per eight steps at worst
-
-// class of a slot from the high dword of its minimum
-__device__ __forceinline__ int w1_class_of(int32_t bhs) {
-  const int z = bs_depth(bhs);
-  if (z < W1_CLS_BASE) return 0;
-  const int c = z - W1_CLS_BASE + 1;
-  return c > W1_CLS_MAX ? W1_CLS_MAX : c;
-}
-
 // append the lanes' candidate masks (cand != 0 somewhere in the wave, m = its ballot)
 __device__ __forceinline__ void w1_enqueue(uint2* __restrict__ q, int& qn, uint32_t head, uint32_t cand, unsigned long long m) {
   if (cand) {
@@ -1536,8 +1548,12 @@ __device__ __forceinline__ void w1_enqueue(uint2* __restrict__ q, int& qn, uint3
 }
 
 // drain: entry = (candidate mask of one lane, slot | lane << 16); chain value recomputed from the key, slot minimum lowered
-__device__ __forceinline__ void w1_flush2(int64_t* best, uint2* __restrict__ q, int qn, int rb, const KeySrc& ks,
+// Returns false when the re-queued rests of multi-chain masks did not fit the queue: the row's own count fitted (the caller checked it), but a
+// rest is appended BEHIND it — with the count close to the capacity (a first row at --num-hashes 1024 queues about 2 048 entries) rests were
+// dropped silently; found by the fuzz sweep on the 31-entry variant build (round 5).  The caller redoes the strand exactly.
+__device__ __forceinline__ bool w1_flush2(int64_t* best, uint2* __restrict__ q, int qn, int rb, const KeySrc& ks,
                                           const uint64_t* __restrict__ jump, int lane) {
+  bool fits = true;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores have left the wave before its lanes read each other's entries
   __builtin_amdgcn_wave_barrier();
   int qend = qn < W1_QCAP ? qn : W1_QCAP;
@@ -1583,21 +1599,14 @@ __device__ __forceinline__ void w1_flush2(int64_t* best, uint2* __restrict__ q, 
         if (idx < (uint32_t)W1_QCAP) q[idx] = make_uint2(rest, ehi);
       }
       qend = base + __popcll(m2);
-      if (qend > W1_QCAP) qend = W1_QCAP;      // (cannot happen when the row's count fitted: a mask re-queues at most 31 times, and the caller checked qn)
+      if (qend > W1_QCAP) { qend = W1_QCAP; fits = false; }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-}
-
-// the planes 1..8 of the magnitude and the sign: a chain that is not negative or has a one among them is out (bit = 1)
-__device__ __forceinline__ uint32_t w1_base_filter(const uint32_t (&P)[64]) {
-  const uint32_t t0 = __builtin_amdgcn_bitop3_b32(P[62], P[61], P[60], BS_TT_OR3);
-  const uint32_t t1 = __builtin_amdgcn_bitop3_b32(P[59], P[58], P[57], BS_TT_OR3);
-  const uint32_t t2 = __builtin_amdgcn_bitop3_b32(P[56], P[55], P[63], 0xFD);     // a | b | ~c   (table index = 4a + 2b + c)
-  return __builtin_amdgcn_bitop3_b32(t0, t1, t2, BS_TT_OR3);
+  return fits;
 }
 
 #ifndef MH_W1_CLS
@@ -1753,7 +1762,7 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
   }
   if (qn > W1_QCAP) ok = false;
   const unsigned long long t2 = MHAP_TICK();
-  w1_flush2(best, q, qn, rb, ks, jump, lane);
+  if (!w1_flush2(best, q, qn, rb, ks, jump, lane)) ok = false;
   if (PROF) { tp[0] += t1 - t0; tp[first ? 1 : 2] += t2 - t1; tp[3] += MHAP_TICK() - t2; tp[4]++; tp[5] += first ? 1 : 0; tp[6] += (unsigned long long)qn; }
 }
 

@@ -1149,7 +1149,7 @@ def test_minhash_queue_overflow_redo_path_against_the_oracle(tmp_path):
     lib = B.variant_path("qcap64")
     assert os.path.exists(lib), f"{lib} missing: __graft_entry__.build() builds it (python -m mhap_amd.build --variants)"
     rnd = random.Random(2105)
-    seqs = [_rand_seq(rnd, rnd.choice((900, 2063, 2100, 3000, 4111, 4200, 5300))) for _ in range(4200)]   # 8 400 strands > 4 096 resident waves
+    seqs = [_rand_seq(rnd, rnd.choice((900, 2063, 2100, 3000, 4111, 4200, 5300))) for _ in range(2300)]   # 4 600 strands > 4 096 resident waves
     fasta = tmp_path / "reads.fasta"
     with open(fasta, "w") as fh:
         for i, s in enumerate(seqs):
@@ -1159,20 +1159,43 @@ def test_minhash_queue_overflow_redo_path_against_the_oracle(tmp_path):
              "from mhap_amd import FastaData, MhapParams, MinHashSearch\n"
              "assert mhap_amd.api._LIB_PATH.endswith('libmhaphip_qcap64.so'), mhap_amd.api._LIB_PATH\n"
              "fa = FastaData.from_file(sys.argv[1])\n"
-             "with MinHashSearch(MhapParams(num_hashes=512, ordered_sketch_size=64)) as ms:\n"
+             "with MinHashSearch(MhapParams(num_hashes=int(sys.argv[3]), ordered_sketch_size=64)) as ms:\n"
              "    sk = ms.sketch(fa)\n"
              "    kt = ms.kernel_times()\n"
              "assert kt['minhash']['launches'] > 0\n"
              "np.save(sys.argv[2], sk['minhash']); np.save(sys.argv[2] + '.status.npy', sk['status'])\n")
     env = dict(os.environ, MHAP_LIB_PATH=lib, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
-    r = subprocess.run([sys.executable, "-c", child, str(fasta), str(out)], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout + r.stderr
-    mh, st = np.load(out), np.load(str(out) + ".status.npy")
-    assert (st == 0).all()
+    from concurrent.futures import ThreadPoolExecutor
+    # H = 512: every full row overflows on its own count.  H = 16 / 13: a first row queues about 2 x H entries — the count often FITS the 31
+    # entries and only the re-queued rests of multi-chain masks run over: the case that was dropped silently until round 5 (found by the
+    # fuzz sweep on this variant; with the shipped 2 047 entries it is a first row at --num-hashes 1024)
+    for H in (512, 16, 13):
+        r = subprocess.run([sys.executable, "-c", child, str(fasta), str(out), str(H)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout + r.stderr
+        mh, st = np.load(out), np.load(str(out) + ".status.npy")
+        assert (st == 0).all()
+
+        def differs(i):   # (the oracle call releases the GIL: ctypes)
+            return sum(int(mh[2 * i + strand].tolist() != O.minhash(s, 16, H)[1].tolist()) for strand, s in ((0, seqs[i]), (1, O.rc(seqs[i]))))
+        with ThreadPoolExecutor(16) as ex:
+            bad = sum(ex.map(differs, range(len(seqs))))
+        assert bad == 0, f"H = {H}: {bad} of {2 * len(seqs)} MinHash rows differ from the oracle on the queue-overflow path"
+
+
+def test_minhash_at_1024_hashes_where_a_first_row_fills_the_queue():
+    """--num-hashes 1024 with the shipped library: a strand's first row queues about two candidates per slot — 2 048 entries against the
+    queue's 2 047 — so some rows overflow on their count (exact redo) and some fit with their re-queued rests running over (redo since round 5,
+    silently dropped before).  MinHash rows against the oracle."""
+    rnd = random.Random(1024)
+    seqs = [_rand_seq(rnd, rnd.choice((2063, 2100, 2600, 4200))) for _ in range(260)]
+    fa = FastaData.from_strings(seqs)
+    with MinHashSearch(MhapParams(num_hashes=1024, ordered_sketch_size=64)) as ms:
+        sk = ms.sketch(fa)
+    assert (sk["status"] == 0).all()
     from concurrent.futures import ThreadPoolExecutor
 
-    def differs(i):   # (the oracle call releases the GIL: ctypes)
-        return sum(int(mh[2 * i + strand].tolist() != O.minhash(s, 16, 512)[1].tolist()) for strand, s in ((0, seqs[i]), (1, O.rc(seqs[i]))))
+    def differs(i):
+        return sum(int(sk["minhash"][2 * i + strand].tolist() != O.minhash(s, 16, 1024)[1].tolist()) for strand, s in ((0, seqs[i]), (1, O.rc(seqs[i]))))
     with ThreadPoolExecutor(16) as ex:
         bad = sum(ex.map(differs, range(len(seqs))))
-    assert bad == 0, f"{bad} of {2 * len(seqs)} MinHash rows differ from the oracle on the queue-overflow path"
+    assert bad == 0, f"{bad} of {2 * len(seqs)} MinHash rows differ from the oracle at --num-hashes 1024"

@@ -29,7 +29,8 @@ wait
 MHAP_MINHASH_PROF=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --soak-seconds 0 2>&1 >/dev/null | grep "w1 prof" | tail -4 > gpurun_out/$R/${R}_minhash_prof.txt
 tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
 MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
-for c in c1 c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_out/$R/${R}_bench_$c.json 2>/dev/null; done
+timeout 600 python bench.py --config c1 --steps 200 --warmup 20 > gpurun_out/$R/${R}_bench_c1.json 2>/dev/null   # (a 1.3-ms step: two steps are one hiccup away from any number)
+for c in c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_out/$R/${R}_bench_$c.json 2>/dev/null; done
 # configs[3] in full and one rank's share of configs[4] on one GPU, one rank of an N-GPU job (gathered rows of the other ranks in HBM), the native driver end to end
 timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c4.json 2>/dev/null
 timeout 1200 python bench.py --config c5rank --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c5rank.json 2>/dev/null
