@@ -3,7 +3,7 @@
 R=${ROUND:-r05}
 mkdir -p gpurun_out/$R
 OUT=gpurun_out/$R/${R}_fuzz_summary.txt
-echo "# tests/fuzz_parity.py against the round-5 kernels (MinHash class dispatch in assembly, class-selected first look of the weighted kernel, ordered kernel's LDS reads and batched fill / rank), run on an MI355X box:" > $OUT
+echo "# tests/fuzz_parity.py against the round-5 kernels (MinHash class dispatch in assembly + the re-queue overflow fix, ordered kernel with LDS reads and batched fill / rank, collective-call rendezvous), run on an MI355X box:" > $OUT
 run() {  # draws seed label env...
   n=$1; seed=$2; label=$3; shift 3
   f=$(env "$@" timeout 3000 python tests/fuzz_parity.py $n $seed 2>/dev/null | tail -1)
@@ -11,7 +11,7 @@ run() {  # draws seed label env...
 }
 run ${N1:-400} 50000 "default"
 run ${N2:-150} 51000 "queue-overflow variant of the MinHash kernel (qcap64: every full row takes the exact redo)" MHAP_LIB_PATH=mhap_amd/lib/variants/libmhaphip_qcap64.so
-run ${N3:-100} 52000 "MHAP_MINHASH=classic (the general kernel for the weight-1 strands too: its class-selected first look on every strand)" MHAP_MINHASH=classic
+run ${N3:-100} 52000 "MHAP_MINHASH=classic (the general kernel for the weight-1 strands too)" MHAP_MINHASH=classic
 run ${N4:-80} 53000 "MHAP_MINHASH=perchain" MHAP_MINHASH=perchain
 run ${N5:-100} 54000 "TEAM shape pinned + prune forced" MHAP_JOIN_MODE=team MHAP_OVERLAP_PRUNE=1
 run ${N6:-80} 55000 "128-query chunks (post stage on the worker thread)" MHAP_QUERY_CHUNK=128
