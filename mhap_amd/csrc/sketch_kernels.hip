@@ -2442,9 +2442,12 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
 }
 
 // code_words = dwords of base codes staged per strand (0: every strand of the launch is MHAP_RD_MAT)
+#ifndef MH_ORD_PAD
+#define MH_ORD_PAD 0   // unused LDS bytes per workgroup (occupancy experiments)
+#endif
 size_t ordered_lds_bytes(int cap, int code_words, int stage_wide) {
   return (size_t)ORD_BINS * 4 + (size_t)ORD_THREADS * 4 + 16 + (size_t)cap * 8 + (size_t)(ORD_BINS + 2) * 2 + (size_t)cap * (stage_wide ? 4 : 2) +
-         (code_words > 0 ? (size_t)256 * 8 + (size_t)code_words * 4 : 0) + 8;
+         (code_words > 0 ? (size_t)256 * 8 + (size_t)code_words * 4 : 0) + 8 + MH_ORD_PAD;
 }
 
 // A read whose forward sketch throws ZeroNGramsFoundException is dropped entirely
