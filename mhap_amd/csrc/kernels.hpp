@@ -79,7 +79,8 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
 size_t minhash_merge_bytes(int nblocks, int H);
 void build_xorshift_unjump_tables(int na, int nq, uint64_t* out);   // M^-(g a), a = 1..na, then M^-(g na q), q = 1..nq: laid out like the forward tables
 int minhash_wgs_per_cu(int H);   // resident MinHash workgroups per CU (LDS and register budget)
-size_t minhash_queue_bytes(int nblocks_total);
+size_t minhash_queue_bytes(int nblocks_total, int H);
+int minhash_queue_words(int H);
 // GF(2) jump-ahead tables of the xorshift64 step, two levels: na tables of 8x256 words for M^(g a), a = 1..na (g = 2^XS_JUMP_LOG2),
 // then nq tables for M^(g na q), q = 1..nq (weighted chains run past H steps: one coarse + one fine table application)
 constexpr int XS_JUMP_LOG2 = 2;   // measured 0 / 1 / 2 / 3 / 4: 86.9 / 84.3 / 83.9 / 84.5 / 85.8 ms MinHash at C2 (2 MB of tables at H = 512)

@@ -470,7 +470,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     int mblocks = h->num_cus * per_cu;   // (each launch is trimmed to the workgroups its work list can feed)
     if (eager_x) mblocks = std::max(per_cu, mblocks - dist_eager_reserve_wgs(h));   // (room for the all-gather's own kernels: mhap_dist.hip)
-    HIPCHK(h, h->mhq.ensure(minhash_queue_bytes(2 * std::max(mblocks, 1)) * 4));   // (x4: one wave per workgroup when --num-hashes is huge)
+    HIPCHK(h, h->mhq.ensure(minhash_queue_bytes(2 * std::max(mblocks, 1), H) * 4));   // (x4: one wave per workgroup when --num-hashes is huge)
     HIPCHK(h, h->mhmerge.ensure(minhash_merge_bytes(std::max(mblocks, 1), H)));
     // The strands with weighted k-mers are a second launch (own instantiation).  On the same stream a handful of such strands (C2:
     // under 1 %) hold the GPU for one strand's duration (3 ms) after the weight-1 launch has drained.  So the two list lengths are

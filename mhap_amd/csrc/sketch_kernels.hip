@@ -1001,12 +1001,12 @@ __device__ __forceinline__ uint32_t bs_argmin(const uint32_t (&P)[64], uint32_t 
 // fall back to the per-chain rows.
 #define MHAP_TICK() (PROF ? (unsigned long long)clock64() : 0ULL)
 template <bool PROF = false>
-__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int rb, int w, const KeySrc& ks,
+__device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uint32_t* q, int& qn_ref, int qcap, int rb, int w, const KeySrc& ks,
                                          const uint64_t* __restrict__ jump, int na, int lane, unsigned long long* tf = nullptr) {
   const unsigned long long t0 = MHAP_TICK();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores of this wave have left it (vmcnt(0)) before its lanes read each other's entries
   __builtin_amdgcn_wave_barrier();
-  const int qn = qn_ref < BS_QCAP ? qn_ref : BS_QCAP;
+  const int qn = qn_ref < qcap ? qn_ref : qcap;
   for (int b0 = 0; b0 < qn; b0 += 64) {
     const bool valid = b0 + lane < qn;
     const uint32_t e = valid ? q[b0 + lane] : 0u;
@@ -1054,7 +1054,7 @@ __device__ __forceinline__ void bs_flush(int64_t* best, int32_t* bpos, const uin
 // append this trigger's candidates: one entry per candidate chain (a lane's mask nearly always has a single bit; the loop
 // runs while any lane has bits left).  The fill count lives in a wave-uniform register and queue slots are handed out with
 // ballot + mbcnt (no atomic, no read-back).  Entries beyond the capacity are dropped; the count keeps running, so the drain sees it.
-__device__ __forceinline__ void bs_defer(uint32_t* __restrict__ q, int& qn, int s, int c, uint32_t cand) {
+__device__ __forceinline__ void bs_defer(uint32_t* __restrict__ q, int& qn, int qcap, int s, int c, uint32_t cand) {
   // Both MinHash kernels sit at their VGPR limit in the slot loop, and whatever this path keeps alive is spilled: the lane id, hoisted
   // out of the loop by the compiler (the mbcnt builtins are pure), and the queue's base as a VGPR pair were reloaded from scratch —
   // a memory round trip and an s_waitcnt vmcnt(0) each — in front of every queue store (later rows of the weight-1 kernel: 1387 ->
@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void bs_defer(uint32_t* __restrict__ q, int& qn, int 
   do {
     if (cand) {
       const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-      if (idx < BS_QCAP) {
+      if (idx < qcap) {
         uint32_t lane;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(lane));
         ((__attribute__((address_space(1))) uint32_t*)q)[idx] = shead | (lane << 5) | (uint32_t)__builtin_ctz(cand);   // (global_store with the scalar base)
@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
                                                       const uint64_t* __restrict__ jump, int jump_na, const int32_t* __restrict__ slist,
                                                       const unsigned long long* __restrict__ slist_count,
-                                                      uint32_t* __restrict__ qbuf, unsigned long long* __restrict__ prof = nullptr) {
+                                                      uint32_t* __restrict__ qbuf, int qcap, unsigned long long* __restrict__ prof = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar LDS / queue bases)
   // PROF: wave-clock attribution {strand total, first-row total, first-row argmin, first-row defer, later-row defer, key load+transpose,
@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
   char* wbase = smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * ((per_wave + 15) & ~(size_t)15);
   int64_t* best = (int64_t*)wbase;
   int32_t* bpos = (int32_t*)(best + H);
-  uint32_t* bsq = qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * BS_QCAP;   // this wave's deferred-candidate queue (global memory)
+  uint32_t* bsq = qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * (size_t)qcap;   // this wave's deferred-candidate queue (global memory)
   {   // the window's base as a scalar pair: the queue stores then take it as their SGPR base + a 32-bit lane offset (as a VGPR pair it
       // was spilled, and reloaded from scratch in front of every queue store)
     const unsigned long long qa = (unsigned long long)(uintptr_t)bsq;
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
                 const unsigned long long ta = MHAP_TICK();
                 const uint32_t cand = bs_argmin(P, ACT);
                 const unsigned long long tb = MHAP_TICK();
-                bs_defer(bsq, bsqn, s, c, cand);
+                bs_defer(bsq, bsqn, qcap, s, c, cand);
                 if (PROF) { tp[2] += tb - ta; tp[3] += MHAP_TICK() - tb; }
               }
           } else {
@@ -1282,15 +1282,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
                   if (__builtin_expect(__any(nacc != 0xFFFFFFFFu), 0)) {
                     const unsigned long long ta = MHAP_TICK();
                     nacc = bs_cold_filter(P, nacc, nACT, sm);
-                    if (__any(nacc != 0xFFFFFFFFu)) bs_defer(bsq, bsqn, s0 + t, c, ~nacc);
+                    if (__any(nacc != 0xFFFFFFFFu)) bs_defer(bsq, bsqn, qcap, s0 + t, c, ~nacc);
                     if (PROF) tp[4] += MHAP_TICK() - ta;
                   }
                 }
               }
             }
           }
-          if (bsqn > BS_QCAP) bs_ok = false;
-          bs_flush<PROF>(best, bpos, bsq, bsqn, base, w, ks, jump, jump_na, lane, tf);
+          if (bsqn > qcap) bs_ok = false;
+          bs_flush<PROF>(best, bpos, bsq, bsqn, qcap, base, w, ks, jump, jump_na, lane, tf);
           if (PROF && first) tp[1] += MHAP_TICK() - tr0;
           first = false;
         }
@@ -1392,7 +1392,7 @@ struct W1Args {
   unsigned long long* stat;          // strands sketched (statistics)
   int32_t* out_rows; long long out_stride; int32_t* out_status; long long status_stride;
   const uint64_t* jump; const uint64_t* unjump; int jump_na;
-  uint32_t* qbuf;                    // BS_QCAP words per wave
+  uint32_t* qbuf; int qcap;          // the waves' candidate queues: qcap words each (minhash_queue_words)
   unsigned long long* merge;         // n_tail x H words, filled with 0xFF: minima of the row items, sign bit flipped (unsigned order)
   unsigned long long* prof;          // MHAP_MINHASH_PROF: wave-clock sums {key load + transpose, first-row slots, later-row slots, drains, rows, first rows, candidates}
 };
@@ -1423,97 +1423,6 @@ __device__ __forceinline__ uint64_t w1_key_of(uint64_t x, int n, const uint64_t*
   return y;
 }
 
-// drain: every queue entry's chain value, recomputed from its key, lowers its slot's minimum (LDS atomic min; no winner bookkeeping)
-__device__ __forceinline__ void w1_flush(int64_t* best, const uint32_t* __restrict__ q, int qn, int rb, const KeySrc& ks,
-                                         const uint64_t* __restrict__ jump, int lane) {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores have left the wave before its lanes read each other's entries
-  __builtin_amdgcn_wave_barrier();
-  if (qn > BS_QCAP) qn = BS_QCAP;
-  for (int b0 = 0; b0 < qn; b0 += 64) {
-    if (b0 + lane < qn) {
-      const uint32_t e = q[b0 + lane];
-      const int j = (int)(e & 31u), l = (int)((e >> 5) & 63u), s = (int)(e >> 17);
-      const int nsteps = s + 1;
-      int a = nsteps >> XS_JUMP_LOG2;
-      const int r = nsteps & ((1 << XS_JUMP_LOG2) - 1);
-      // two levels of tables — M^(4 W1_JUMP_NA q), then M^(4 a), a <= W1_JUMP_NA: 24 tables of 16 KB at H = 512, which stay in the L2
-      // beside everything else the kernel touches.  One level (H/4 tables, 2 MB per XCD's L2) missed about one lookup in ten:
-      // 27 GB of fabric reads per C2 step for a kernel whose algorithmic traffic is 3 GB (r03 PMC pass)
-      const int qa = a > W1_JUMP_NA ? (a - 1) / W1_JUMP_NA : 0;
-      a -= qa * W1_JUMP_NA;
-      uint64_t x = ks_key(ks, rb + j * 64 + l);
-      if (qa > 0) {
-        const uint32_t tb = (uint32_t)(W1_JUMP_NA + qa - 1) * 2048u;
-        uint64_t y = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
-        x = y;
-      }
-      if (a > 0) {
-        const uint32_t tb = (uint32_t)(a - 1) * 2048u;
-        uint64_t y = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) y ^= jump[tb + (uint32_t)(i * 256) + ((uint32_t)(x >> (8 * i)) & 255u)];
-        x = y;
-      }
-#pragma unroll
-      for (int t = 0; t < (1 << XS_JUMP_LOG2) - 1; t++) { const uint64_t nx = xorshift_step(x); x = (t < r) ? nx : x; }
-      atomicMin((long long*)&best[s], (long long)x);
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// one row: k-mers [rb, rb + 2048) of the strand (key order), all H slots.  first: no minima exist yet.
-template <bool PROF>
-__device__ __forceinline__ void w1_row(int64_t* best, uint32_t* __restrict__ q, int rb, int nk, bool first, int H, const KeySrc& ks,
-                                       const uint64_t* __restrict__ jump, int lane, bool& ok, unsigned long long* tp) {
-  const unsigned long long t0 = MHAP_TICK();
-  uint32_t P[64];
-  uint32_t ACT = 0;
-#pragma unroll
-  for (int j = 0; j < 32; j++) {
-    const int i = rb + j * 64 + lane;
-    uint64_t key = 0;
-    if (i < nk) { key = ks_key(ks, i); ACT |= 1u << j; }
-    P[j] = (uint32_t)key;
-    P[32 + j] = (uint32_t)(key >> 32);
-    if ((j & 7) == 7) asm volatile("" ::: "memory");   // 8 keys in flight at a time
-  }
-  transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[0]));
-  transpose32(*reinterpret_cast<uint32_t(*)[32]>(&P[32]));
-  int qn = 0;   // queue fill (wave-uniform)
-  const unsigned long long t1 = MHAP_TICK();
-  if (first) {
-    for (int s = 0; s < H; s++) {
-      bs_step(P);
-      bs_defer(q, qn, s, 0, bs_argmin(P, ACT));
-    }
-  } else {
-    const int32_t* besthi = (const int32_t*)best;
-    const uint32_t nACT = ~ACT;
-    for (int s0 = 0; s0 < H; s0 += 64) {
-      const uint32_t vm = bs_mask_of(besthi[2 * (s0 + lane < H ? s0 + lane : H - 1) + 1]);   // depth masks of 64 slots, one per lane
-      const int tn = H - s0 < 64 ? H - s0 : 64;
-      for (int t = 0; t < tn; t++) {
-        const uint32_t sm = (uint32_t)__builtin_amdgcn_readlane((int)vm, t);
-        bs_step(P);
-        uint32_t nacc = bs_hot_filter(P, nACT, sm);
-        if (__builtin_expect(__any(nacc != 0xFFFFFFFFu), 0)) {
-          nacc = bs_cold_filter(P, nacc, nACT, sm);
-          if (__any(nacc != 0xFFFFFFFFu)) bs_defer(q, qn, s0 + t, 0, ~nacc);
-        }
-      }
-    }
-  }
-  if (qn > BS_QCAP) ok = false;
-  const unsigned long long t2 = MHAP_TICK();
-  w1_flush(best, q, qn, rb, ks, jump, lane);
-  if (PROF) { tp[0] += t1 - t0; tp[first ? 1 : 2] += t2 - t1; tp[3] += MHAP_TICK() - t2; tp[4]++; tp[5] += first ? 1 : 0; tp[6] += (unsigned long long)qn; }
-}
-
-
 // ---- round 5: the row loop priced by what its instructions COST (tools/issue_probe.hip, profiles/r05_issue_probe.txt) -----------
 // A VALU-dense kernel on this chip runs at a constant number of lane-operations per second per instruction kind, whatever the
 // occupancy and whatever clock results (more waves per SIMD = fewer clocks per instruction AND a lower shader clock): what it pays
@@ -1530,16 +1439,13 @@ __device__ __forceinline__ void w1_row(int64_t* best, uint32_t* __restrict__ q, 
 //     at the position the trigger's own ballot gives it (two v_mbcnt on the scalar fill count); no per-bit loop, no v_ffbl, no
 //     second ballot, no bounds branch (the index is clamped to a spare last entry and the running count says "overflow");
 //   * the drain takes the lowest chain of every entry and re-queues what is left of a multi-chain mask (one entry in a hundred).
-// MH_W1_V2=0 builds the round-3/4 loop (A/B).
-#ifndef MH_W1_V2
-#define MH_W1_V2 1
-#endif
-constexpr int W1_QCAP = BS_QCAP / 2 - 1;  // 8-byte entries in the same 16 KB per wave; entry W1_QCAP (the last of the 16 KB) is the spare one overflowing appends land in
+// (The round-3/4 loop this replaced is in the history of this file: commit e70836d keeps both.)
+// (8-byte entries in the wave's window of qcap words: wcap = qcap / 2 - 1 of them, entry wcap — the window's last — is the spare one overflowing appends land in)
 // append the lanes' candidate masks (cand != 0 somewhere in the wave, m = its ballot)
-__device__ __forceinline__ void w1_enqueue(uint2* __restrict__ q, int& qn, uint32_t head, uint32_t cand, unsigned long long m) {
+__device__ __forceinline__ void w1_enqueue(uint2* __restrict__ q, int& qn, int wcap, uint32_t head, uint32_t cand, unsigned long long m) {
   if (cand) {
     uint32_t idx = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, (uint32_t)qn));
-    idx = idx < (uint32_t)W1_QCAP ? idx : (uint32_t)W1_QCAP;
+    idx = idx < (uint32_t)wcap ? idx : (uint32_t)wcap;
     uint32_t lanehi;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 16, %0" : "=&v"(lanehi));   // (computed here: a value kept across the slot loop is a spill)
     ((__attribute__((address_space(1))) unsigned long long*)q)[idx] = (unsigned long long)cand | ((unsigned long long)(head | lanehi) << 32);
@@ -1551,12 +1457,12 @@ __device__ __forceinline__ void w1_enqueue(uint2* __restrict__ q, int& qn, uint3
 // Returns false when the re-queued rests of multi-chain masks did not fit the queue: the row's own count fitted (the caller checked it), but a
 // rest is appended BEHIND it — with the count close to the capacity (a first row at --num-hashes 1024 queues about 2 048 entries) rests were
 // dropped silently; found by the fuzz sweep on the 31-entry variant build (round 5).  The caller redoes the strand exactly.
-__device__ __forceinline__ bool w1_flush2(int64_t* best, uint2* __restrict__ q, int qn, int rb, const KeySrc& ks,
+__device__ __forceinline__ bool w1_flush2(int64_t* best, uint2* __restrict__ q, int qn, int wcap, int rb, const KeySrc& ks,
                                           const uint64_t* __restrict__ jump, int lane) {
   bool fits = true;
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the queue stores have left the wave before its lanes read each other's entries
   __builtin_amdgcn_wave_barrier();
-  int qend = qn < W1_QCAP ? qn : W1_QCAP;
+  int qend = qn < wcap ? qn : wcap;
   for (int b0 = 0; b0 < qend; b0 += 64) {
     const bool valid = b0 + lane < qend;
     uint32_t rest = 0u, ehi = 0u;
@@ -1596,10 +1502,10 @@ __device__ __forceinline__ bool w1_flush2(int64_t* best, uint2* __restrict__ q, 
       const int base = b0 + 64 > qend ? b0 + 64 : qend;
       if (rest) {
         const uint32_t idx = (uint32_t)base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
-        if (idx < (uint32_t)W1_QCAP) q[idx] = make_uint2(rest, ehi);
+        if (idx < (uint32_t)wcap) q[idx] = make_uint2(rest, ehi);
       }
       qend = base + __popcll(m2);
-      if (qend > W1_QCAP) { qend = W1_QCAP; fits = false; }
+      if (qend > wcap) { qend = wcap; fits = false; }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
     }
@@ -1628,7 +1534,7 @@ __device__ __forceinline__ uint32_t w1_exact_filter(const uint32_t (&P)[64], int
 }
 
 template <bool PROF>
-__device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, int rb, int nk, bool first, int H, const KeySrc& ks,
+__device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, int wcap, int rb, int nk, bool first, int H, const KeySrc& ks,
                                         const uint64_t* __restrict__ jump, int lane, bool& ok, unsigned long long* tp) {
   const unsigned long long t0 = MHAP_TICK();
   uint32_t P[64];
@@ -1654,7 +1560,7 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
       uint32_t cand = bs_argmin_pre(P, ACT);
       unsigned long long m = __ballot(cand != 0u);
       if (__builtin_expect(m == 0ULL, 0)) { cand = bs_argmin_walk(P, ACT); m = __ballot(cand != 0u); }
-      w1_enqueue(q, qn, (uint32_t)s, cand, m);
+      w1_enqueue(q, qn, wcap, (uint32_t)s, cand, m);
     }
   } else {
     const int32_t* besthi = (const int32_t*)best;
@@ -1756,17 +1662,19 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
         }
 #endif
         const unsigned long long m = __ballot(n != 0xFFFFFFFFu);
-        if (__builtin_expect(m != 0ULL, 1)) w1_enqueue(q, qn, (uint32_t)sl, ~n, m);   // (two steps in three trigger: the enqueue is the fall-through side)
+        if (__builtin_expect(m != 0ULL, 1)) w1_enqueue(q, qn, wcap, (uint32_t)sl, ~n, m);   // (two steps in three trigger: the enqueue is the fall-through side)
       }
     }
   }
-  if (qn > W1_QCAP) ok = false;
+  if (qn > wcap) ok = false;
   const unsigned long long t2 = MHAP_TICK();
-  if (!w1_flush2(best, q, qn, rb, ks, jump, lane)) ok = false;
+  if (!w1_flush2(best, q, qn, wcap, rb, ks, jump, lane)) ok = false;
   if (PROF) { tp[0] += t1 - t0; tp[first ? 1 : 2] += t2 - t1; tp[3] += MHAP_TICK() - t2; tp[4]++; tp[5] += first ? 1 : 0; tp[6] += (unsigned long long)qn; }
 }
 
-template <bool PROF>
+// FIXQ: the queue window has the default 4 096 words (every run up to --num-hashes 512): its capacity is then a literal in the enqueue and
+// the drain — as a kernel argument it cost the slot loops one more live scalar and 1.3 % (78.8 -> 79.8 ms at C2)
+template <bool PROF, bool FIXQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES_EU, 8))) void minhash_w1_kernel(W1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -1775,7 +1683,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES
   for (int i = threadIdx.x; i < MH_LUT_WORDS; i += blockDim.x) lut[i] = a.luts[i];
   __syncthreads();
   int64_t* best = (int64_t*)(smem + (size_t)MH_LUT_WORDS * 8 + (size_t)wv * (size_t)H * 8);
-  uint32_t* q = a.qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * BS_QCAP;
+  const int qcap = FIXQ ? BS_QCAP : a.qcap;
+  uint32_t* q = a.qbuf + ((size_t)blockIdx.x * (blockDim.x >> 6) + (size_t)wv) * (size_t)qcap;
   {   // the window's base as a scalar pair: the queue stores then take it as their SGPR base + a 32-bit lane offset (as a VGPR pair it
       // was spilled, and reloaded from scratch in front of every queue store)
     const unsigned long long qa = (unsigned long long)(uintptr_t)q;
@@ -1819,11 +1728,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES
         __builtin_amdgcn_wave_barrier();
         bool ok = true;
         const int r0 = whole ? 0 : row, r1 = whole ? nrows : row + 1;
-#if MH_W1_V2
-        for (int r = r0; r < r1; r++) w1_row2<PROF>(best, (uint2*)q, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
-#else
-        for (int r = r0; r < r1; r++) w1_row<PROF>(best, q, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
-#endif
+        for (int r = r0; r < r1; r++) w1_row2<PROF>(best, (uint2*)q, qcap / 2 - 1, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
         // (a row whose candidates overflowed the queue — never seen — is redone one k-mer at a time: exact, slow)
         if (!ok) {
           for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;
@@ -1942,7 +1847,16 @@ int minhash_wgs_per_cu(int H) {
   if (n > by_regs) n = by_regs;
   return n < 1 ? 1 : n;
 }
-size_t minhash_queue_bytes(int nblocks_total) { return (size_t)nblocks_total * 4 * (size_t)BS_QCAP * 4; }
+// Words of one wave's candidate queue.  A strand's FIRST row queues about two entries per slot (no minima to filter by yet): 4 096 words —
+// 2 047 eight-byte entries of the weight-1 kernel, 4 096 four-byte ones of the general kernel — hold that up to --num-hashes 512 with a
+// factor of two to spare; beyond, the window grows with H (8 H words), so that a run at --num-hashes 1024 or 2048 does not send every strand
+// through the exact one-k-mer-at-a-time redo (round 5).  A variant build with another MH_QCAP keeps its fixed size (tests).
+int minhash_queue_words(int H) {
+  if (BS_QCAP != 4096) return BS_QCAP;
+  const int want = ((8 * H + 63) / 64) * 64;
+  return want > BS_QCAP ? want : BS_QCAP;
+}
+size_t minhash_queue_bytes(int nblocks_total, int H) { return (size_t)nblocks_total * 4 * (size_t)minhash_queue_words(H) * 4; }
 
 // Strands of a weight-1 launch that are cut into row items (the others are taken whole): one strand's worth of rows per resident
 // wave at the end of the list evens the waves' finish times out to one row; a list shorter than that is all rows.
@@ -1970,7 +1884,8 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
   const size_t lds = per_wave * waves + lut_bytes;
   const dim3 block(64 * waves);
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);
-  uint32_t* qbuf_w = qbuf + (size_t)nblocks * (size_t)waves * BS_QCAP;
+  const int qcap = minhash_queue_words(H);
+  uint32_t* qbuf_w = qbuf + (size_t)nblocks * (size_t)waves * (size_t)qcap;
   static int profmode = -1;
   if (profmode < 0) { const char* e = getenv("MHAP_MINHASH_PROF"); profmode = (e && atoi(e)) ? 1 : 0; }
   unsigned long long* counter_u = counter + 1; unsigned long long* counter_w = counter + 2;
@@ -1982,10 +1897,10 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
       (void)hipMemsetAsync(dprof, 0, 16 * sizeof(unsigned long long), st);
       if (pass == 0)
         hipLaunchKernelGGL((minhash_kernel<MH_U, true, false, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                           counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, dprof);
+                           counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, qcap, dprof);
       else
         hipLaunchKernelGGL((minhash_kernel<MH_U, true, true, true>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                           counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, dprof);
+                           counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, qcap, dprof);
       unsigned long long hp[16];
       (void)hipMemcpyAsync(hp, dprof, sizeof(hp), hipMemcpyDeviceToHost, st);
       (void)hipStreamSynchronize(st);
@@ -2000,9 +1915,9 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
   }
   if (perchain) {
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, true>), dim3(nblocks), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w);
+                       counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, qcap);
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf);
+                       counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, qcap);
   } else {
     // n_unweighted / n_weighted >= 0: the lengths of the two work lists (the caller read them back): each launch gets only the
     // workgroups its list can feed, the weighted one first, on its own stream — its few workgroups take their slots, the weight-1
@@ -2012,10 +1927,10 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
     const int nb_u = n_unweighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, (n_unweighted + waves_wg - 1) / waves_wg);
     if (nb_w > 0)
       hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nb_w), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w);
+                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, qcap);
     if (nb_u > 0 && (classic || n_unweighted < 0 || waves_wg != 4)) {
       hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nb_u), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                         counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf);
+                         counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, qcap);
     } else if (nb_u > 0) {
       // the weight-1 strands: whole strands first, the last minhash_tail_strands() of the list row by row (see minhash_w1_kernel)
       W1Args a;
@@ -2024,7 +1939,7 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
       a.rmax = max_nk > 0 ? (max_nk + 2047) >> 11 : 1;
       a.k = k; a.k2 = k2; a.H = H; a.counter = counter_u; a.stat = counter_u + 8;
       a.out_rows = out_rows; a.out_stride = out_stride; a.out_status = out_status; a.status_stride = status_stride;
-      a.jump = jump_w1; a.unjump = unjump; a.jump_na = W1_JUMP_NA; a.qbuf = qbuf; a.merge = merge;   // (its own two-level table set)
+      a.jump = jump_w1; a.unjump = unjump; a.jump_na = W1_JUMP_NA; a.qbuf = qbuf; a.qcap = qcap; a.merge = merge;   // (its own two-level table set)
       const long long items = a.n_whole + a.n_tail * (long long)a.rmax;
       const int nb = (int)std::min<long long>(nblocks, (items + 3) / 4);
       const size_t lds1 = (size_t)H * 8 * 4 + lut_bytes;
@@ -2038,7 +1953,8 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
         static hipEvent_t pe0 = nullptr, pe1 = nullptr;
         if (!pe0) { (void)hipEventCreate(&pe0); (void)hipEventCreate(&pe1); }
         (void)hipEventRecord(pe0, st);
-        hipLaunchKernelGGL(minhash_w1_kernel<true>, dim3(nb), dim3(256), lds1, st, a);
+        if (qcap == BS_QCAP) hipLaunchKernelGGL((minhash_w1_kernel<true, true>), dim3(nb), dim3(256), lds1, st, a);
+        else hipLaunchKernelGGL((minhash_w1_kernel<true, false>), dim3(nb), dim3(256), lds1, st, a);
         (void)hipEventRecord(pe1, st);
         unsigned long long hp[8];
         (void)hipMemcpyAsync(hp, dprof1, sizeof(hp), hipMemcpyDeviceToHost, st);
@@ -2053,7 +1969,8 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
                 hp[5] ? (double)hp[1] / ((double)hp[5] * H) : 0.0, 100.0 * hp[2] / tot, hp[4] > hp[5] ? (double)hp[2] / ((double)(hp[4] - hp[5]) * H) : 0.0,
                 100.0 * hp[3] / tot, hp[4] ? (double)hp[6] / (double)hp[4] : 0.0);
       } else
-        hipLaunchKernelGGL(minhash_w1_kernel<false>, dim3(nb), dim3(256), lds1, st, a);
+        if (qcap == BS_QCAP) hipLaunchKernelGGL((minhash_w1_kernel<false, true>), dim3(nb), dim3(256), lds1, st, a);
+        else hipLaunchKernelGGL((minhash_w1_kernel<false, false>), dim3(nb), dim3(256), lds1, st, a);
       if (a.n_tail > 0)
         hipLaunchKernelGGL(minhash_w1_finish_kernel, dim3((unsigned)((a.n_tail * (long long)H + 255) / 256)), dim3(256), 0, st, a);
     }
