@@ -802,6 +802,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return leave(rc);
+        HPROF("first query tier done");
         const int32_t* dense_list = listA;
         unsigned long long n_dense = c5[6];
         if (t0 == 0 && use_mid && c5[0] <= cand_cap) {

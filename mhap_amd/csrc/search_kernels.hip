@@ -490,13 +490,25 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     // first tier: the buckets' lengths alone say whether this table can hold the hits — a repeat-rich query is handed over after
     // H loads instead of after counting until the table overflows
     unsigned long long tot = 0;
-    int itp = 0;
-    for (int s = threadIdx.x; s < sp.H; s += IQ_THREADS, itp++) {
+    // (two loops: the first IQ_PRE trips write the kept vectors with STATIC element indices.  As one loop with `if (itp < IQ_PRE)` the
+    //  element write was compiled to an indexed register move executed for every trip — beyond --num-hashes 768 it wrote past the vectors
+    //  into whatever registers followed, and from --num-hashes 2 752 on it hit a live pointer: a memory fault in this kernel, found
+    //  by a parameter sweep in round 5)
+#pragma unroll
+    for (int itp = 0; itp < IQ_PRE; itp++) {
+      const int s = (int)threadIdx.x + itp * IQ_THREADS;
+      if (s < sp.H) {
+        const uint32_t hvp = inv_mix((uint32_t)qrow[s]);
+        const uint32_t* E = ix.ends + (size_t)s * eper + (hvp >> ix.shift);
+        const uint32_t e0 = E[0], e1 = E[1];
+        tot += e1 - e0;
+        pre_hv[itp] = (int)hvp; pre_lo[itp] = (int)e0; pre_n[itp] = (int)(e1 - e0);
+      }
+    }
+    for (int s = (int)threadIdx.x + IQ_PRE * IQ_THREADS; s < sp.H; s += IQ_THREADS) {
       const uint32_t hvp = inv_mix((uint32_t)qrow[s]);
       const uint32_t* E = ix.ends + (size_t)s * eper + (hvp >> ix.shift);
-      const uint32_t e0 = E[0], e1 = E[1];
-      tot += e1 - e0;
-      if (itp < IQ_PRE) { pre_hv[itp] = (int)hvp; pre_lo[itp] = (int)e0; pre_n[itp] = (int)(e1 - e0); }
+      tot += E[1] - E[0];
     }
     pre_ok = true;
 #pragma unroll

@@ -46,6 +46,11 @@ def main(iters, seed0):
                   num_min_matches=rnd.choice([1, 2, 3, 5]), threshold=rnd.choice([0.0, 0.5, 0.78, 0.9]), max_shift=rnd.choice([0.05, 0.2, 0.4]),
                   min_store_length=rnd.choice([0, 0, 500, 2000]), min_olap_length=rnd.choice([0, 50, 116, 500]))
         kw["repeat_weight"] = rnd.choice([0.9, 0.9, 0.9, 0.5, 1.0, -1.0])
+        if os.environ.get("FUZZ_WIDE"):   # the corners beyond the everyday flags (a stream of its own: the default draws stay what they were)
+            rw = random.Random(seed0 * 7919 + it)
+            if rw.random() < 0.6: kw["num_hashes"] = rw.choice([700, 768, 769, 1024, 1500, 2047, 2752, 3000, 4096])
+            if rw.random() < 0.3: kw["ordered_sketch_size"] = rw.choice([1, 2, 2048, 2049, 4096, 8192])
+            if rw.random() < 0.2: kw["num_min_matches"] = rw.choice([7, 30, 200])
         p = MhapParams(**kw)
         flt = oflt = None
         if rnd.random() < 0.4:   # a -f filter over the reads' own k-mers: tf-idf weights, optionally the --supress-noise whitelist

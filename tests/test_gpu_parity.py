@@ -1199,3 +1199,15 @@ def test_minhash_at_1024_hashes_where_a_first_row_fills_the_queue():
     with ThreadPoolExecutor(16) as ex:
         bad = sum(ex.map(differs, range(len(seqs))))
     assert bad == 0, f"{bad} of {2 * len(seqs)} MinHash rows differ from the oracle at --num-hashes 1024"
+
+
+@pytest.mark.parametrize("H", [1024, 2048, 3000])
+def test_self_overlap_at_large_num_hashes(H):
+    """--num-hashes beyond the 768 the first query tier keeps its first look for, up into the range where its indexed-vector write ran past the
+    vectors (a memory fault from 2 752 on until round 5) and where a strand's first row fills the default candidate queue: the whole path —
+    sketches, index, every query handed to the dense tier, second stage — against the oracle (J/impl/MinHashSearch.java:150-251)."""
+    fa = mhap_amd.synth_reads(160, 3000, seed=4242 + H, error_rate=0.08)
+    p = MhapParams(num_hashes=H, ordered_sketch_size=512)
+    want = O.record_lines(O.run_self(fa, H=H, S=512, nthreads=16)["records"])
+    got, _ = _self_lines(fa, p)
+    assert got == want and len(want) > 100, (len(got), len(want))

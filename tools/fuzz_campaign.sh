@@ -16,4 +16,6 @@ run ${N4:-80} 53000 "MHAP_MINHASH=perchain" MHAP_MINHASH=perchain
 run ${N5:-100} 54000 "TEAM shape pinned + prune forced" MHAP_JOIN_MODE=team MHAP_OVERLAP_PRUNE=1
 run ${N6:-80} 55000 "128-query chunks (post stage on the worker thread)" MHAP_QUERY_CHUNK=128
 run ${N7:-80} 56000 "dense tier, class-ordered, 64-entry passes" MHAP_INDEX_DENSE=1 MHAP_INDEX_GROUP=1 MHAP_INDEX_GROUP_T=4 MHAP_INDEX_CLASS_LOG=6 MHAP_DENSE_RANGE_LOG=6
+
+run ${N8:-150} 70000 "FUZZ_WIDE corners (--num-hashes 700 .. 4096, --ordered-sketch-size 1 .. 8192, numMinMatches to 200)" FUZZ_WIDE=1
 cat $OUT
