@@ -15,9 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmhaphip.so")
 CLI = os.path.join(LIBDIR, "mhap-hip")
-SOURCES = ["sketch_kernels.hip", "search_kernels.hip", "mhap_capi.hip", "mhap_dist.hip", "mhap_ingest.hip", "host_util.cpp"]
+SOURCES = ["sketch_kernels.hip", "search_kernels.hip", "search_kernels_wide.hip", "search_kernels_wide2.hip", "mhap_capi.hip", "mhap_dist.hip", "mhap_ingest.hip", "host_util.cpp"]
 HEADERS = ["device_common.hpp", "kernels.hpp", "mhap_internal.hpp", "overlap_lane.hpp", os.path.join("..", "..", "include", "mhap_hip.h")]
 ARCH = "gfx950"
+EXTRA_DEPS = {"search_kernels_wide.hip": ["search_kernels.hip"], "search_kernels_wide2.hip": ["search_kernels.hip"]}   # (a translation unit that includes another one)
 
 
 def _hipcc():
@@ -87,7 +88,7 @@ def _compile_objects(hipcc, flags, only, tag, force, verbose):
         variant = bool(flags) and s in only
         obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + (f".{tag}" if variant else "") + ".o")
         cmd = [hipcc, f"--offload-arch={ARCH}", *[f for f in CFLAGS if f != "-shared"], *(flags if variant else []), "-c", os.path.join(CSRC, s), "-o", obj]
-        dg = _digest([os.path.join(CSRC, s)] + hdrs, cmd[1:])
+        dg = _digest([os.path.join(CSRC, s)] + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(s, [])] + hdrs, cmd[1:])
         objs.append(obj)
         if force or _stale(obj, dg):
             jobs.append((cmd, obj, dg))

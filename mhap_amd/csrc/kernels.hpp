@@ -145,6 +145,25 @@ void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const un
                     const int32_t* qmeta, const SearchParams& sp, const double* score_table, int32_t* scratch, int64_t scratch_per_lane,
                     DevRecord* recs, unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, int spread);
 // Second stage: one wavefront per candidate (equal-hash join); pairs it cannot decide exactly are appended to `slow`.
+// search_kernels_wide.hip: the join kernel compiled a second time with room for 512 joined k-mers per pair (second pass over what the first hands over)
+size_t overlap_join_wide_lds_bytes(int S, int shape);
+int overlap_join_wide_blocks_per_cu(int S, int shape);
+int overlap_join_wide_waves_per_block(int shape);
+int overlap_join_wide_capacity();
+void launch_overlap_join_wide(hipStream_t st, int shape, int nblocks, int chunk, const void* cand, const unsigned long long* cand_count,
+                              unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
+                              int64_t qord_stride, const int32_t* qmeta, const void* sp, const double* score_table, void* recs,
+                              unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, void* slow,
+                              unsigned long long* slow_count, unsigned long long* work, const uint16_t* ph, const uint16_t* qph, const int32_t* pass_min);
+size_t overlap_join_wide2_lds_bytes(int S, int shape);   // search_kernels_wide2.hip: ... and with room for 1 536 (third pass)
+int overlap_join_wide2_blocks_per_cu(int S, int shape);
+int overlap_join_wide2_waves_per_block(int shape);
+int overlap_join_wide2_capacity();
+void launch_overlap_join_wide2(hipStream_t st, int shape, int nblocks, int chunk, const void* cand, const unsigned long long* cand_count,
+                               unsigned long long cand_cap, const int32_t* ordered, int64_t ord_stride, const int32_t* meta, const int32_t* qordered,
+                               int64_t qord_stride, const int32_t* qmeta, const void* sp, const double* score_table, void* recs,
+                               unsigned long long* rec_count, unsigned long long rec_cap, unsigned long long* compared, void* slow,
+                               unsigned long long* slow_count, unsigned long long* work, const uint16_t* ph, const uint16_t* qph, const int32_t* pass_min);
 constexpr int OJ_MAX_S = 8192;   // largest ordered sketch the join path stages in LDS
 size_t overlap_join_lds_bytes(int S, int shape);     // shape: 0 every wave alone, 1 pairs of waves share a query, 2 teams of four + bucket table
 int overlap_join_blocks_per_cu(int S, int shape);

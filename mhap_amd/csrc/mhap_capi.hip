@@ -89,6 +89,8 @@ struct mhap_handle {
   hipStream_t own_stream = nullptr;
   int oj_per_cu[3] = {0, 0, 0}, oj_per_cu_S = -1;   // resident join-kernel workgroups per CU (per shape) at ordered sketch size oj_per_cu_S
   int join_mode = 0;                      // MHAP_JOIN_MODE: 0 = by the candidates per query, 1 = alone, 2 = pair, 3 = team
+  int join_wide = 2;                      // MHAP_JOIN_WIDE: further passes of the join kernel (512, then 1 536 joined k-mers) over the pairs handed over: 0, 1 or 2 of them
+  int ojw_per_cu[2] = {1, 1}, ojw_per_cu_S[2] = {-1, -1};
   hipStream_t mh_stream = nullptr;        // MinHash launch of the weighted strands, next to the launch of the weight-1 strands
   hipEvent_t ev_mh_fork = nullptr, ev_mh_join = nullptr, ev_ix_fork = nullptr, ev_ix_join = nullptr;
   // inverted index state: inv_ends / inv_items hold the index of entries [0, inv_ne) when inv_ready
@@ -134,7 +136,7 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big;
+  DevBuf qlist, rowstart, cand, slow_cand, slow_cand2, slow_cand3, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big;
   // post stage of a search chunk (record read-back, conversion, sink) on a worker thread, one chunk behind the kernels: two sets of buffers
   hipStream_t copy_stream = nullptr;
   uint8_t* pin_rec[2] = {nullptr, nullptr};
@@ -727,6 +729,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const int64_t per_lane = 3LL * (2LL * S + 2);
   const char* omode = getenv("MHAP_OVERLAP");
   const bool lane_only = omode && strcmp(omode, "lane") == 0;
+  { const char* jw = getenv("MHAP_JOIN_WIDE"); h->join_wide = !jw ? 2 : (jw[0] == '0' ? 0 : (jw[0] == '1' ? 1 : 2)); }
   { const char* jm = getenv("MHAP_JOIN_MODE"); h->join_mode = !jm ? 0 : (strcmp(jm, "alone") == 0 ? 1 : (strcmp(jm, "pair") == 0 ? 2 : (strcmp(jm, "team") == 0 ? 3 : 0))); }
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
   // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
@@ -773,7 +776,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     unsigned long long ncand = 0;
     for (;;) {
       SCHK(h->cand.ensure(cand_cap * sizeof(Candidate)));
-      SCHK(hipMemsetAsync(ctr, 0, 80, h->stream));
+      SCHK(hipMemsetAsync(ctr, 0, 104, h->stream));
       if (use_index) {
         SCHK(h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
@@ -869,6 +872,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     for (int i = 0; i < 3; i++) fits[i] = overlap_join_lds_bytes(S, i) <= 64 * 1024;
     const bool use_join = !lane_only && S <= OJ_MAX_S && (fits[0] || fits[1] || fits[2]);
     unsigned long long nslow = use_join ? 0 : ncand;
+    const Candidate* slow_list = nullptr; unsigned long long* slow_count_ptr = nullptr;   // (set when the wide second pass ran)
     unsigned long long cj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool have_counts = false;
     if (use_join) {
@@ -928,6 +932,44 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       if (rcj != MHAP_OK) return leave(rcj);
       nslow = cj[5];
       have_counts = nslow == 0;
+      // Further passes: the pairs the join kernel handed over — nearly all of them for MORE THAN 128 JOINED K-MERS, i.e. true overlaps of reads
+      // better than the 15 %-error ones MHAP was built for — go through the same kernel compiled with room for 512, and what that hands
+      // over through the one with room for 1 536 (search_kernels_wide.hip / _wide2.hip), every wave alone; only what is left then (the
+      // duplicated-hash group caps) takes the per-lane merge.  MHAP_JOIN_WIDE=0 switches the passes off, =1 keeps the first of them only.
+      for (int level = 0; level < h->join_wide && nslow > 0; level++) {
+        const size_t wl = level == 0 ? overlap_join_wide_lds_bytes(S, 0) : overlap_join_wide2_lds_bytes(S, 0);
+        if (wl > 64 * 1024) break;
+        DevBuf& in = level == 0 ? h->slow_cand : h->slow_cand2;
+        DevBuf& outb = level == 0 ? h->slow_cand2 : h->slow_cand3;
+        unsigned long long* in_count = level == 0 ? ctr + 5 : ctr + 10;
+        unsigned long long* out_count = level == 0 ? ctr + 10 : ctr + 11;
+        unsigned long long* work = level == 0 ? ctr + 9 : ctr + 12;
+        SCHK(outb.ensure((size_t)nslow * sizeof(Candidate)));
+        if (h->ojw_per_cu_S[level] != S) {
+          h->ojw_per_cu[level] = level == 0 ? overlap_join_wide_blocks_per_cu(S, 0) : overlap_join_wide2_blocks_per_cu(S, 0);
+          h->ojw_per_cu_S[level] = S;
+        }
+        const int wpbw = level == 0 ? overlap_join_wide_waves_per_block(0) : overlap_join_wide2_waves_per_block(0);
+        const int64_t residentw = (int64_t)h->num_cus * h->ojw_per_cu[level] * wpbw;
+        const int chunkw = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)nslow / std::max<int64_t>(residentw, 1)));
+        const int64_t wantw = ((int64_t)nslow + (int64_t)wpbw * chunkw - 1) / ((int64_t)wpbw * chunkw);
+        const int wblocks = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)h->num_cus * h->ojw_per_cu[level], wantw));
+        time_begin(h, MHAP_K_OVERLAP);
+        (level == 0 ? launch_overlap_join_wide : launch_overlap_join_wide2)(
+            h->stream, 0, wblocks, chunkw, in.as<Candidate>(), in_count, (unsigned long long)ncand, h->d_ordered, 2LL * S, h->d_meta, qs.d_ordered, qs.ord_stride,
+            qs.d_meta, &sp, h->score_tbl.as<double>(), recbuf.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2, outb.as<Candidate>(), out_count, work,
+            nullptr, nullptr, h->pass_min_tbl.as<int32_t>());
+        time_end(h);
+        SCHK(hipGetLastError());
+        unsigned long long cw[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        SCHK(hipMemcpyAsync(cw, ctr, 104, hipMemcpyDeviceToHost, h->stream));
+        const int rcw = sync_stream(h);
+        if (rcw != MHAP_OK) return leave(rcw);
+        for (int i = 0; i < 8; i++) cj[i] = cw[i];
+        nslow = level == 0 ? cw[10] : cw[11];
+        slow_list = outb.as<Candidate>(); slow_count_ptr = out_count;
+        have_counts = nslow == 0;
+      }
       h->stats.slow_pairs += (int64_t)nslow;
     }
     if (nslow > 0) {
@@ -939,7 +981,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       const int oblocks = (int)std::max<int64_t>(1, std::min<int64_t>(ovl_max_blocks, ((int64_t)nslow * spread + OVL_THREADS - 1) / OVL_THREADS));
       SCHK(h->ovl_scratch.ensure((size_t)oblocks * OVL_THREADS / (size_t)spread * (size_t)per_lane * 4));
       time_begin(h, MHAP_K_OVERLAP);
-      launch_overlap(h->stream, oblocks, use_join ? h->slow_cand.as<Candidate>() : h->cand.as<Candidate>(), use_join ? ctr + 5 : ctr + 0,
+      launch_overlap(h->stream, oblocks, slow_list ? slow_list : (use_join ? h->slow_cand.as<Candidate>() : h->cand.as<Candidate>()), slow_list ? slow_count_ptr : (use_join ? ctr + 5 : ctr + 0),
                      use_join ? (unsigned long long)ncand : (unsigned long long)cand_cap, h->d_ordered, 2LL * S, h->d_meta,
                      qs.d_ordered, qs.ord_stride, qs.d_meta, sp, h->score_tbl.as<double>(), h->ovl_scratch.as<int32_t>(), per_lane,
                      recbuf.as<DevRecord>(), ctr + 1, (unsigned long long)ncand, ctr + 2, spread);
@@ -1097,7 +1139,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->jump_w1_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big,
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->slow_cand2, &h->slow_cand3, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big,
                     &h->pass_min_tbl, &h->poshist, &h->q_poshist};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);

@@ -38,13 +38,37 @@ struct PlainView {
   __host__ __device__ inline void get(int i, int& h, int& pos) { h = p[2 * i]; pos = p[2 * i + 1]; }
 };
 
-// Utils.quickSelect, verbatim control flow, on scratch array 2.
+// Utils.quickSelect (J/utils/Utils.java:445-494) on scratch array 2: its control flow verbatim — while it behaves.  What it returns is the
+// k-th smallest value (0-based) of the array whatever the input (restated and checked against the sorted order statistic, duplicates
+// included: tests/test_oracle_kat.py), but its partition moves every element EQUAL to the pivot to the right, so on an array of equal
+// values — the shifts of two low-error reads that overlap: hundreds of joined k-mers, one shift — it narrows the range by one element per
+// pass: 885 000 steps for 1 536 equal values (20 000 error-free reads: 24 s of second stage, round 5).  So the literal loop runs on a
+// budget of steps (random input needs ~3 n, the worst seen on 20 000 duplicate-rich arrays 14 n) and, when that is spent, the same order
+// statistic is selected bit by bit from the array as the loop has left it (a permutation of the input): 32 counting passes, O(n).
+__host__ __device__ inline int32_t lane_select_bits(const LaneScratch& sc, int k, int length) {
+  uint32_t prefix = 0u, mask = 0u;
+  int kk = k;
+  for (int b = 31; b >= 0; b--) {
+    const uint32_t bit = 1u << b;
+    int zeros = 0;
+    for (int i = 0; i < length; i++) {
+      const uint32_t u = (uint32_t)sc.at(2, i) ^ 0x80000000u;     // signed order as unsigned order
+      zeros += ((u & mask) == prefix && !(u & bit)) ? 1 : 0;
+    }
+    if (kk >= zeros) { kk -= zeros; prefix |= bit; }
+    mask |= bit;
+  }
+  return (int32_t)(prefix ^ 0x80000000u);
+}
 __host__ __device__ inline int32_t lane_quickselect(const LaneScratch& sc, int k, int length) {
   if (length <= k) return INT32_MAX;
   int from = 0, to = length - 1;
+  long long budget = 24LL * length + 64;
   while (from < to) {
     int r = from, w = to;
     const int32_t mid = sc.at(2, (r + w) / 2);
+    budget -= (long long)(w - r);
+    if (budget < 0) return lane_select_bits(sc, k, length);
     while (r < w) {
       const int32_t ar = sc.at(2, r);
       if (ar >= mid) { const int32_t tmp = sc.at(2, w); sc.at(2, w) = ar; sc.at(2, r) = tmp; w--; }

@@ -1250,7 +1250,10 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
 #define MH_OJ_WAVES 4
 #endif
 constexpr int OJ_WAVES = MH_OJ_WAVES;
-constexpr int OJ_JCAP = 128;           // joined k-mers + group records kept per pair
+#ifndef MH_OJ_JCAP
+#define MH_OJ_JCAP 128
+#endif
+constexpr int OJ_JCAP = MH_OJ_JCAP;    // joined k-mers + group records kept per pair (a multiple of 64)
 constexpr int OJ_R = OJ_JCAP / 64;     // ... = rounds of one entry per lane
 #ifndef MH_OJ_GCAP
 #define MH_OJ_GCAP 16   // 12 / 16 with the 6-KB filter: C5 slice 50.6 / 46.9 ms (75 928 / 3 739 pairs handed to the per-lane kernel), c5rank 1004 / 996, C2 3.64 / 3.63

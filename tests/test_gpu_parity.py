@@ -1211,3 +1211,30 @@ def test_self_overlap_at_large_num_hashes(H):
     want = O.record_lines(O.run_self(fa, H=H, S=512, nthreads=16)["records"])
     got, _ = _self_lines(fa, p)
     assert got == want and len(want) > 100, (len(got), len(want))
+
+
+@pytest.mark.parametrize("err", [0.0, 0.01, 0.04, 0.08])
+def test_low_error_reads_take_the_wide_join_passes(err, monkeypatch):
+    """Reads better than the 15 %-error ones MHAP was built for: two overlapping reads then join hundreds of their bottom 12-mers (all of
+    them at error 0), more than the 128 the join kernel keeps per pair.  Such pairs go through the same kernel compiled with room for 512
+    and 1 536 (search_kernels_wide.hip / _wide2.hip) instead of the per-lane merge; records against the oracle
+    (J/sketch/BottomOverlapSketch.java:592-630), with the passes on (default), with one, and off — and nearly no pair is left for the lane kernel."""
+    fa = mhap_amd.synth_reads(260, 5000, seed=900 + int(err * 100), error_rate=err)
+    p = MhapParams()
+    want = O.record_lines(O.run_self(fa, nthreads=16)["records"])
+    assert len(want) > 200
+    for wide in (None, "1", "0"):
+        if wide is None:
+            monkeypatch.delenv("MHAP_JOIN_WIDE", raising=False)
+        else:
+            monkeypatch.setenv("MHAP_JOIN_WIDE", wide)
+        with MinHashSearch(p) as ms:
+            ms.add_data(fa)
+            got = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+            st = ms.stats()
+        assert got == want, (err, wide)
+        if wide is None and err <= 0.04:
+            assert st["slow_pairs"] * 20 <= st["candidates_compared"], (err, st["slow_pairs"], st["candidates_compared"])
+        if wide == "0" and err <= 0.01:
+            assert st["slow_pairs"] * 2 >= st["candidates_compared"]      # (without the passes most pairs are the lane kernel's: the test sees them)
+    monkeypatch.delenv("MHAP_JOIN_WIDE", raising=False)

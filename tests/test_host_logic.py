@@ -469,3 +469,21 @@ def test_early_reject_table_of_the_second_stage_is_exact():
                 assert acc.min() >= pm[:k + 1].max() or acc.min() >= pm[k], (thr, k)
                 assert all(acc.min() >= pm[kl] for kl in range(0, k + 1, max(1, k // 7)))
     assert pm[S + 1] == np.iinfo(np.int32).max
+
+
+def test_second_stage_lane_on_error_free_overlaps_takes_the_bounded_selection():
+    """Two error-free reads that overlap share every k-mer of the overlap at ONE shift: hundreds to 1 536 records with equal shifts, the input
+    on which Utils.quickSelect (J/utils/Utils.java:445-494) narrows its range by one element per pass.  The per-lane second stage runs the
+    literal loop on a step budget and then selects the same order statistic bit by bit (overlap_lane.hpp): results equal the oracle's."""
+    rnd = random.Random(5)
+    g = "".join(rnd.choice("ACGT") for _ in range(26000))
+    for off, la, lb in ((0, 10000, 10000), (1500, 10000, 12000), (9000, 10000, 10000), (4000, 15000, 3000)):
+        a, b = g[:la], g[off:off + lb]
+        _, A, lenA = O.ordered(a, 12, 1536)
+        _, B, lenB = O.ordered(b, 12, 1536)
+        want = O.overlap(A, lenA, B, lenB, max_shift=0.2)
+        got = _lane(A, lenA, B, lenB, max_shift=0.2, stride=64)
+        assert not want["empty"] and got["empty"] == 0
+        for key in ("a1", "a2", "b1", "b2", "inter", "k"):
+            assert got[key] == want[key], (off, key)
+        assert float(got["raw"]) == want["raw"] and want["raw"] > 100
