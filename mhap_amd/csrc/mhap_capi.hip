@@ -966,9 +966,11 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         const int rcw = sync_stream(h);
         if (rcw != MHAP_OK) return leave(rcw);
         for (int i = 0; i < 8; i++) cj[i] = cw[i];
+        const unsigned long long before = nslow;
         nslow = level == 0 ? cw[10] : cw[11];
         slow_list = outb.as<Candidate>(); slow_count_ptr = out_count;
         have_counts = nslow == 0;
+        if (nslow * 10 > before * 9) break;   // (handed over for the duplicated-hash group caps, not for their number of k-mers: a wider pass would hand them on again)
       }
       h->stats.slow_pairs += (int64_t)nslow;
     }
