@@ -3,7 +3,7 @@
 R=${ROUND:-r05}
 mkdir -p gpurun_out/$R
 OUT=gpurun_out/$R/${R}_fuzz_summary.txt
-echo "# tests/fuzz_parity.py against the round-5 kernels (MinHash class dispatch in assembly + the re-queue overflow fix, ordered kernel with LDS reads and batched fill / rank, collective-call rendezvous), run on an MI355X box:" > $OUT
+echo "# tests/fuzz_parity.py against the round-5 kernels (MinHash class dispatch in assembly, re-queue overflow fix, queue window growing with H; first query tier with static vector writes; three-pass join with the lane kernel's bounded selection; ordered kernel with LDS reads and batched fill / rank; collective-call rendezvous), run on an MI355X box:" > $OUT
 run() {  # draws seed label env...
   n=$1; seed=$2; label=$3; shift 3
   f=$(env "$@" timeout 3000 python tests/fuzz_parity.py $n $seed 2>/dev/null | tail -1)
@@ -18,4 +18,5 @@ run ${N6:-80} 55000 "128-query chunks (post stage on the worker thread)" MHAP_QU
 run ${N7:-80} 56000 "dense tier, class-ordered, 64-entry passes" MHAP_INDEX_DENSE=1 MHAP_INDEX_GROUP=1 MHAP_INDEX_GROUP_T=4 MHAP_INDEX_CLASS_LOG=6 MHAP_DENSE_RANGE_LOG=6
 
 run ${N8:-150} 70000 "FUZZ_WIDE corners (--num-hashes 700 .. 4096, --ordered-sketch-size 1 .. 8192, numMinMatches to 200)" FUZZ_WIDE=1
+run ${N9:-100} 91000 "wide join passes off (MHAP_JOIN_WIDE=0: the lane kernel with its bounded selection takes every pair of more than 128 joined k-mers)" MHAP_JOIN_WIDE=0
 cat $OUT
