@@ -776,7 +776,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     unsigned long long ncand = 0;
     for (;;) {
       SCHK(h->cand.ensure(cand_cap * sizeof(Candidate)));
-      SCHK(hipMemsetAsync(ctr, 0, 104, h->stream));
+      SCHK(hipMemsetAsync(ctr, 0, 160, h->stream));
       if (use_index) {
         SCHK(h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
@@ -873,7 +873,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     const bool use_join = !lane_only && S <= OJ_MAX_S && (fits[0] || fits[1] || fits[2]);
     unsigned long long nslow = use_join ? 0 : ncand;
     const Candidate* slow_list = nullptr; unsigned long long* slow_count_ptr = nullptr;   // (set when the wide second pass ran)
-    unsigned long long cj[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long cj[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     bool have_counts = false;
     if (use_join) {
       SCHK(h->slow_cand.ensure((size_t)ncand * sizeof(Candidate)));
@@ -927,7 +927,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       time_end(h);
       SCHK(hipGetLastError());
       // (one read-back for the pairs handed over and for the counts the tail needs: nothing else changes them when none were)
-      SCHK(hipMemcpyAsync(cj, ctr, 64, hipMemcpyDeviceToHost, h->stream));
+      SCHK(hipMemcpyAsync(cj, ctr, 160, hipMemcpyDeviceToHost, h->stream));
       int rcj = sync_stream(h);
       if (rcj != MHAP_OK) return leave(rcj);
       nslow = cj[5];
@@ -936,7 +936,11 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       // better than the 15 %-error ones MHAP was built for — go through the same kernel compiled with room for 512, and what that hands
       // over through the one with room for 1 536 (search_kernels_wide.hip / _wide2.hip), every wave alone; only what is left then (the
       // duplicated-hash group caps) takes the per-lane merge.  MHAP_JOIN_WIDE=0 switches the passes off, =1 keeps the first of them only.
+      unsigned long long group_bad = cj[13];   // of the pairs handed over: for the duplicated-hash group caps (ctr + 13 = the first pass's slow_count + 8)
       for (int level = 0; level < h->join_wide && nslow > 0; level++) {
+        // (pairs handed over for their duplicated-hash groups — repeat-rich reads of low error without a -f filter: hundreds of millions of
+        //  them — would be handed on by a wider pass too: 1.4 s of 9.6 wasted on 20 000 such reads)
+        if (group_bad * 10 > nslow * 9) break;
         const size_t wl = level == 0 ? overlap_join_wide_lds_bytes(S, 0) : overlap_join_wide2_lds_bytes(S, 0);
         if (wl > 64 * 1024) break;
         DevBuf& in = level == 0 ? h->slow_cand : h->slow_cand2;
@@ -961,13 +965,14 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
             nullptr, nullptr, h->pass_min_tbl.as<int32_t>());
         time_end(h);
         SCHK(hipGetLastError());
-        unsigned long long cw[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        SCHK(hipMemcpyAsync(cw, ctr, 104, hipMemcpyDeviceToHost, h->stream));
+        unsigned long long cw[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        SCHK(hipMemcpyAsync(cw, ctr, 160, hipMemcpyDeviceToHost, h->stream));
         const int rcw = sync_stream(h);
         if (rcw != MHAP_OK) return leave(rcw);
         for (int i = 0; i < 8; i++) cj[i] = cw[i];
         const unsigned long long before = nslow;
         nslow = level == 0 ? cw[10] : cw[11];
+        group_bad = level == 0 ? cw[18] : cw[19];
         slow_list = outb.as<Candidate>(); slow_count_ptr = out_count;
         have_counts = nslow == 0;
         if (nslow * 10 > before * 9) break;   // (handed over for the duplicated-hash group caps, not for their number of k-mers: a wider pass would hand them on again)

@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
       const uint2* brow = (const uint2*)(ordered + (int64_t)cd.m * ord_stride);
       // ---- join ----
       int nj = 0, ng = 0;
-      bool bad = false;
+      bool bad = false, bad_groups = false;   // bad_groups: handed over for the duplicated-hash group caps (a wider pass would hand the pair on again)
       oj_keep_t pbk[2];      // (keepb) positions of the other sketch: entry blk * 64 + lane in pbk[blk / 12][blk % 12]
       if (nA > 0 && nB > 0) {
         if constexpr (FILTER) {
@@ -1804,7 +1804,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               if (leader) grp = (l + 1 < nA && ah[l + 1] == hb) || (j + 1 < nB && hnext == hb);
               const bool reg = leader && !grp;
               const unsigned long long balr = __builtin_amdgcn_ballot_w64(reg), balg = __builtin_amdgcn_ballot_w64(grp);
-              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) { bad = true; OJ_STAT(ng + __popcll(balg) > OJ_GCAP ? 15 : 14, 1); }
+              if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) { bad = true; bad_groups = bad_groups || ng + __popcll(balg) > OJ_GCAP; OJ_STAT(ng + __popcll(balg) > OJ_GCAP ? 15 : 14, 1); }
               else {
                 if (reg) {
                   const int idx = nj + oj_mbcnt(balr);
@@ -1921,7 +1921,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
                 if (leader) grp = (l[u] + 1 < nA && ah[l[u] + 1] == hb) || (j + 1 < nB && hnext == hb);
                 const bool reg = leader && !grp;
                 const unsigned long long balr = __ballot(reg), balg = __ballot(grp);
-                if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) bad = true;
+                if (nj + __popcll(balr) > OJ_JCAP || ng + __popcll(balg) > OJ_GCAP) { bad = true; bad_groups = bad_groups || ng + __popcll(balg) > OJ_GCAP; }
                 else {
                   if (reg) {
                     const int idx = nj + oj_mbcnt(balr);
@@ -1965,7 +1965,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         const unsigned long long bala = __ballot(a_ok), balb = __ballot(b_ok);
         const int sh = 20 * (t < 3 ? t : 0);
         const int m = __popcll((bala >> sh) & 0x3FFULL), nn = __popcll((balb >> (sh + 10)) & 0x3FFULL);
-        if (__any(live && (m > OJ_GLEN || nn > OJ_GLEN))) { bad = true; OJ_STAT(16, 1); break; }
+        if (__any(live && (m > OJ_GLEN || nn > OJ_GLEN))) { bad = true; bad_groups = true; OJ_STAT(16, 1); break; }
         if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)be.y;
         int sz[3];   // entries of the round's groups (wave-uniform)
@@ -1984,7 +1984,7 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         const bool a_ok = lane <= OJ_GLEN && lo + x < nA && ah[lo + x] == h;
         const bool b_ok = lane >= 16 && lane <= 16 + OJ_GLEN && j + x < nB && (int)brow[j + x].x == h;
         const int m = __popcll(__ballot(a_ok)), nn = __popcll(__ballot(b_ok));
-        if (m > OJ_GLEN || nn > OJ_GLEN) { bad = true; break; }
+        if (m > OJ_GLEN || nn > OJ_GLEN) { bad = true; bad_groups = true; break; }
         if (a_ok) gpa[g * OJ_GLEN + x] = APOS ? ap[lo + x] : qrow[2 * (lo + x) + 1];
         if (b_ok) gpb[g * OJ_GLEN + x] = (int)brow[j + x].y;
         if (lane == 0) { gi[g * 6 + 2] = m; gi[g * 6 + 3] = nn; gi[g * 6 + 4] = nj + gtot; }
@@ -1993,7 +1993,8 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
       }
       if (!bad && nj + gtot > OJ_JCAP) { bad = true; OJ_STAT(17, 1); }
       if (bad) {
-        if (lane == 0) { const unsigned long long slot = atomicAdd(slow_count, 1ULL); slow[slot] = cd; }
+        // (slow_count[8]: how many of the pairs handed over were handed over for the group caps — what the host decides a wider pass by)
+        if (lane == 0) { const unsigned long long slot = atomicAdd(slow_count, 1ULL); slow[slot] = cd; if (bad_groups) atomicAdd(slow_count + 8, 1ULL); }
         return;
       }
       mine++;
