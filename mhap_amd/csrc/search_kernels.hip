@@ -1282,7 +1282,6 @@ constexpr int OJ_LDS_EXTRA = 3 * OJ_JCAP + OJ_GCAP * (6 + 2 * OJ_GLEN) + MH_OJ_P
 //  waves per SIMD: C2 4.78 -> 6.63 ms, C5 slice 69 -> 91; capped at 128 VGPRs (four waves): 5.24 / 74.8; at two waves 9.0 / 126.  The
 //  kernel's time stays inversely proportional to the waves a CU holds; instruction-level parallelism inside a wave does not replace them.)
 constexpr int OJ_KB = 24;              // blocks of the other sketch whose positions are kept (S <= 64 * OJ_KB)
-constexpr int OJ_KIT = (OJ_KB + OJ_U - 1) / OJ_U;
 
 __device__ __forceinline__ int oj_mbcnt(unsigned long long m) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -1629,44 +1628,15 @@ int overlap_join_filter_bits(int S, int waves) {
 typedef int oj_keep_t __attribute__((ext_vector_type(12)));   // (vectors, not an array: with a dynamic index an array of this size goes to scratch in this kernel; two of
                                                               //  twelve: a vector of 24 takes 32 registers, and up to eight elements the compiler picks by compare and select)
 static_assert(OJ_KB == 24 && 12 % OJ_U == 0, "two vectors of twelve blocks, whole trips each");
-template <int IT>
-__device__ __forceinline__ void oj_keep_store(oj_keep_t (&pbk)[2], const uint2 (&e)[OJ_U]) {
-#pragma unroll
-  for (int u = 0; u < OJ_U; u++) if (IT * OJ_U + u < OJ_KB) pbk[(IT * OJ_U + u) / 12][(IT * OJ_U + u) % 12] = (int)e[u].y;
-}
-template <int IT>
-__device__ __forceinline__ void oj_keep_load(const oj_keep_t (&pbk)[2], int (&posv)[OJ_U]) {
-#pragma unroll
-  for (int u = 0; u < OJ_U; u++) posv[u] = IT * OJ_U + u < OJ_KB ? pbk[(IT * OJ_U + u) / 12][(IT * OJ_U + u) % 12] : INT32_MIN;
-}
-// (a wave-uniform switch over static indices: the array stays in registers, no indirect addressing)
-#ifndef MH_OJ_KEEP_IDX
-#define MH_OJ_KEEP_IDX 1
-#endif
-#define OJ_KEEP_SWITCH(it, OP, ...)                                                                                              \
-  switch (it) {                                                                                                                  \
-    case 0: OP<0>(__VA_ARGS__); break; case 1: OP<1>(__VA_ARGS__); break; case 2: OP<2>(__VA_ARGS__); break; case 3: OP<3>(__VA_ARGS__); break;   \
-    case 4: OP<4>(__VA_ARGS__); break; case 5: OP<5>(__VA_ARGS__); break; case 6: OP<6>(__VA_ARGS__); break; case 7: OP<7>(__VA_ARGS__); break;   \
-    case 8: OP<8>(__VA_ARGS__); break; case 9: OP<9>(__VA_ARGS__); break; case 10: OP<10>(__VA_ARGS__); break; case 11: OP<11>(__VA_ARGS__); break; \
-    default: OP<12>(__VA_ARGS__); break;                                                                                         \
-  }
-static_assert(OJ_KIT <= 13, "OJ_KEEP_SWITCH covers 13 trips");
-// The kept positions are addressed by a wave-uniform trip number.  As a switch over static indices the array stayed in registers, but the
-// compiler merged the cases through copies of the WHOLE array — a dozen to two dozen v_mov per trip of the streaming loop (found in the ISA
-// when a probe showed that loop at 3.5 TB/s where bare row gathers reach 6.1: tools/row_gather_probe.hip).  A dynamic uniform index
-// compiles to s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off: three instructions per element.
-#if MH_OJ_KEEP_IDX
-#define OJ_KEEP_STORE(it, pbk, e) { const int b_ = (it) * OJ_U;                                                                 \
-    if (b_ < 12) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) pbk[0][b_ + u_] = (int)e[u_].y; }                          \
-    else if (b_ < 24) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) pbk[1][b_ - 12 + u_] = (int)e[u_].y; } }
+// The kept positions are addressed by a wave-uniform trip number: s_set_gpr_idx_on / v_mov / s_set_gpr_idx_off, three instructions per
+// element.  (History: a switch over static indices kept the array in registers too, but the compiler merged its cases through copies of the
+// WHOLE array, a dozen to two dozen v_mov per trip of the streaming loop — found in the ISA when a probe showed that loop at 3.5 TB/s where
+// bare row gathers reach 6.1, tools/row_gather_probe.hip; and the stores, written as `block < 12 ? first vector : second`, did the same
+// between the two vectors until the streaming loops were split by vector — see `trip` in the kernel.)
 #define OJ_KEEP_LOAD(it, pbk, posv) { const int b_ = (it) * OJ_U;                                                               \
     if (b_ < 12) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) posv[u_] = pbk[0][b_ + u_]; }                              \
     else if (b_ < 24) { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) posv[u_] = pbk[1][b_ - 12 + u_]; }                    \
     else { _Pragma("unroll") for (int u_ = 0; u_ < OJ_U; u_++) posv[u_] = INT32_MIN; } }
-#else
-#define OJ_KEEP_STORE(it, pbk, e) OJ_KEEP_SWITCH(it, oj_keep_store, pbk, e)
-#define OJ_KEEP_LOAD(it, pbk, posv) OJ_KEEP_SWITCH(it, oj_keep_load, pbk, posv)
-#endif
 
 // SHARED = true : a WORKGROUP pulls chunks of candidates; for every run of one query inside the chunk its WAVES waves stage the
 //                 query's hashes (and, TABLE, build the bucket table) together — one copy in LDS — then take the run's candidates one
@@ -1746,7 +1716,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
         uint2 en[OJ_U];
 #pragma unroll
         for (int u = 0; u < OJ_U; u++) { const int j = u * 64 + lane; en[u] = brow[j < nB ? j : nB - 1]; }
-        for (int j0 = 0;; j0 += 64 * OJ_U) {
+        // One trip of the streaming loop (returns false after the row's last one).  The kept positions of a trip go to ONE of the two
+        // twelve-element vectors, and which one is static at each of the three places the trip is instantiated from below: written as one
+        // loop with `block < 12 ? pbk[0] : pbk[1]` the compiler joined the two cases through copies of a whole vector — six to eighteen
+        // v_mov_b64 in every trip (read in the ISA, round 5).
+        auto trip = [&](const int j0, auto WHICH) -> bool {
+          constexpr int which = decltype(WHICH)::value;   // 0 / 1: the vector this trip's positions are kept in; 2: none (beyond OJ_KB blocks)
           const bool more = j0 < nB && !bad;
           if (more) {
             uint2 e[OJ_U];
@@ -1757,7 +1732,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               const int jn = j0 + (u + OJ_U) * 64 + lane;
               en[u] = brow[jn < nB ? jn : nB - 1];
             }
-            if (keepb) { OJ_KEEP_STORE(kit, pbk, e) kit++; }
+            if (keepb && which < 2) {
+              const int b_ = (kit - (12 / OJ_U) * which) * OJ_U;   // 0, 3, 6, 9 inside the vector
+#pragma unroll
+              for (int u = 0; u < OJ_U; u++) pbk[which < 2 ? which : 0][b_ + u] = (int)e[u].y;
+              kit++;
+            }
             uint32_t fb[OJ_U];
 #pragma unroll
             for (int u = 0; u < OJ_U; u++) { fb[u] = oj_filter_bit(e[u].x, (uint32_t)ts); w[u] = bm[fb[u] >> 5]; }
@@ -1820,7 +1800,16 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
               }
             }
           }
-          if (!more) break;
+          return more;
+        };
+        {
+          static_assert(12 % OJ_U == 0, "whole trips per kept vector");
+          constexpr int TPV = 12 / OJ_U;   // trips per kept vector
+          int j0 = 0;
+          bool go = true;
+          for (int t = 0; go && t < TPV; t++, j0 += 64 * OJ_U) go = trip(j0, std::integral_constant<int, 0>());
+          for (int t = 0; go && t < TPV; t++, j0 += 64 * OJ_U) go = trip(j0, std::integral_constant<int, 1>());
+          for (; go; j0 += 64 * OJ_U) go = trip(j0, std::integral_constant<int, 2>());
         }
         } else {
         int carry = 0;   // hash of the last entry of the previous OJ_U blocks (run detection across blocks)
@@ -1835,10 +1824,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
           for (int u = 0; u < OJ_U; u++) { acc += (int)en[u].x; const int jn = j0 + (u + OJ_U) * 64 + lane; en[u] = make_uint2(0u, 0u); if (jn < nB) en[u] = brow[jn]; }
           if (acc == 0x7fffffff) bad = true;
         }
-        for (int j0 = nB; j0 < nB && !bad; j0 += 64 * OJ_U) {
+        const int jstart = nB;
 #else
-        for (int j0 = 0; j0 < nB && !bad; j0 += 64 * OJ_U) {
+        const int jstart = 0;
 #endif
+        // (one trip; the vector its positions are kept in is static at each place it is instantiated from, as in the filter branch above)
+        auto trip = [&](const int j0, auto WHICH) {
+          constexpr int which = decltype(WHICH)::value;
           // OJ_U blocks of 64 entries at a time: their binary searches (dependent LDS reads) overlap each other and the loads
           // of the next OJ_U blocks
           uint2 e[OJ_U];
@@ -1850,7 +1842,12 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             en[u] = make_uint2(0u, 0u);
             if (jn < nB) en[u] = brow[jn];
           }
-          if (keepb) { OJ_KEEP_STORE(kit, pbk, e) kit++; }
+          if (keepb && which < 2) {
+            const int b_ = (kit - (12 / OJ_U) * which) * OJ_U;
+#pragma unroll
+            for (int u = 0; u < OJ_U; u++) pbk[which < 2 ? which : 0][b_ + u] = (int)e[u].y;
+            kit++;
+          }
           bool found[OJ_U];
           bool anyf = false;
           if constexpr (TABLE) {
@@ -1939,6 +1936,13 @@ __global__ __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WAVE
             }
           }
           carry = __builtin_amdgcn_readlane((int)e[OJ_U - 1].x, 63);
+        };
+        {
+          constexpr int TPV = 12 / OJ_U;
+          int j0 = jstart;
+          for (int t = 0; t < TPV && j0 < nB && !bad; t++, j0 += 64 * OJ_U) trip(j0, std::integral_constant<int, 0>());
+          for (int t = 0; t < TPV && j0 < nB && !bad; t++, j0 += 64 * OJ_U) trip(j0, std::integral_constant<int, 1>());
+          for (; j0 < nB && !bad; j0 += 64 * OJ_U) trip(j0, std::integral_constant<int, 2>());
         }
         }
       }
