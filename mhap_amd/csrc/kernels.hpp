@@ -70,7 +70,7 @@ void launch_kmer_weights(hipStream_t st, int num_cus, const ReadDesc* descs, int
                          const FilterTable& ft, double repeat_weight, StrandInfo* info, bool fused, const uint8_t* store,
                          const uint64_t* luts, const int32_t* order, int32_t* slist);   // order: read indices longest first (or null);
                          // slist: 2 x nstrands work lists of the MinHash launches (counts in counter[4], counter[5])
-void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+bool launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
                     const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, const uint64_t* jump_w1, unsigned long long* merge,

@@ -505,12 +505,14 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       if (rxo != MHAP_OK) return rxo;
     }
     const size_t t_mh = time_begin(h, MHAP_K_MINHASH);
-    launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
+    const bool mh_forked = launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
                    h->perm.as<uint32_t>(), h->info.as<StrandInfo>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k, k2, H, ctr, mh_rows, mh_stride,
                    meta_rows + 3, META_W, h->jump_tbl.as<uint64_t>(), h->jump_na, h->slist.as<int32_t>(), h->mhq.as<uint32_t>(), h->unjump_tbl.as<uint64_t>(), h->jump_w1_tbl.as<uint64_t>(),
                    h->mhmerge.as<unsigned long long>(), std::max(0, B.max_len - k + 1));
-    HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
+    if (mh_forked) {   // (the strands with weighted k-mers went to their own stream)
+      HIPCHK(h, hipEventRecord(h->ev_mh_join, h->mh_stream));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_mh_join, 0));
+    }
     time_end_at(h, t_mh);
     DBGSYNC(h, "minhash");
     launch_fix_status(h->stream, meta_rows, nb);   // statuses are final here (the ordered kernel only writes sizes)

@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
                                                       int64_t out_stride, int32_t* __restrict__ out_status, int64_t status_stride,
                                                       const uint64_t* __restrict__ jump, int jump_na, const int32_t* __restrict__ slist,
                                                       const unsigned long long* __restrict__ slist_count,
-                                                      uint32_t* __restrict__ qbuf, int qcap, unsigned long long* __restrict__ prof = nullptr) {
+                                                      uint32_t* __restrict__ qbuf, int qcap, unsigned long long* __restrict__ prof = nullptr, int split_arg = 0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (wave-uniform: scalar LDS / queue bases)
   // PROF: wave-clock attribution {strand total, first-row total, first-row argmin, first-row defer, later-row defer, key load+transpose,
@@ -1193,9 +1193,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
     bsq = (uint32_t*)(uintptr_t)(((unsigned long long)qhi << 32) | qlo);
   }
   const int32_t* besthi = (const int32_t*)best;   // high dword of best[s] = the hot loops' threshold
+  // SPLIT (a launch of a few strands only — a small job's handful of strands with repeated k-mers, which would otherwise hold the add for one
+  // strand's time on one wave, 0.63 ms of C1's 1.2): a work item is a strand for the WORKGROUP, its rows — bit-sliced and per-chain, numbered
+  // in one wave-uniform sequence — go round the four waves, each wave keeps minima of its own and the four tables meet in LDS at the end.
+  const bool split = WEIGHTED && BITSLICED && !PROF && split_arg != 0 && blockDim.x == 256;
+  const size_t wave_stride = (per_wave + 15) & ~(size_t)15;
+  unsigned long long* wgslot = (unsigned long long*)(smem + (size_t)MH_LUT_WORDS * 8 + 4 * wave_stride);   // (SPLIT: the workgroup's work item)
   for (;;) {
     unsigned long long tk = 0;
-    if (lane == 0) tk = atomicAdd(counter, 1ULL);
+    if (!split) { if (lane == 0) tk = atomicAdd(counter, 1ULL); }
+    else {
+      __syncthreads();   // (the previous strand's tables have been read)
+      if (threadIdx.x == 0) *wgslot = atomicAdd(counter, 1ULL);
+      __syncthreads();
+      tk = *wgslot;
+    }
     // readfirstlane: the strand index — and with it every descriptor field, pointer, count and loop bound below — is provably
     // wave-uniform, so the strand's control flow compiles to scalar branches instead of EXEC-mask bookkeeping
     long long sidx = (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tk >> 32)) << 32) |
@@ -1211,8 +1223,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
     const bool nosketch = strand_skipped(rd, rcs) || nk < 1 || rd.length - k2 + 1 < 1 || !si_valid;
     if (nosketch) {
       // too short (status 2) or ZeroNGramsFoundException from either sketch (status 1)
-      for (int s = lane; s < H; s += 64) orow[s] = 0;
-      if (lane == 0) out_status[sidx * status_stride] = strand_skipped(rd, rcs) ? 2 : 1;
+      if (!split || wv == 0) {
+        for (int s = lane; s < H; s += 64) orow[s] = 0;
+        if (lane == 0) out_status[sidx * status_stride] = strand_skipped(rd, rcs) ? 2 : 1;
+      }
     } else {   // (no `continue` above: the strand loop keeps a single back edge)
     const bool listed = WEIGHTED && si_mode == 0;
     KeySrc ks;
@@ -1226,7 +1240,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
     __builtin_amdgcn_wave_barrier();
 
     const unsigned long long ts0 = MHAP_TICK();
-    nst++;
+    if (!split || wv == 0) nst++;
+    int rowi = 0;              // rows of the strand so far (SPLIT: row r is wave r & 3's)
     const int ncls = listed ? BS_WCLASSES : 1;
     const int w_uniform = WEIGHTED ? si_mode : 1;
     // ---- bit-sliced rows: every weight class (or the whole strand at its common weight), 2048 chains per row ----
@@ -1242,6 +1257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
         off += count;
         if (w > BS_WMAX) continue;
         for (int base = 0; count - base >= BS_MINREM; base += 2048) {
+          if (split && ((rowi++) & 3) != wv) continue;
           uint32_t P[64];
           uint32_t ACT = 0;
           const unsigned long long tr0 = MHAP_TICK();
@@ -1295,6 +1311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
           first = false;
         }
       }
+      if (split) { bs_ok = __syncthreads_or(bs_ok ? 0 : 1) == 0; if (!bs_ok) rowi = 0; }   // (one wave's overflow: the whole strand again, per chain, on all four)
       if (!bs_ok) {
         for (int s = lane; s < H; s += 64) { best[s] = INT64_MAX; bpos[s] = INT32_MIN; }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1320,10 +1337,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
         if (BITSLICED && bs_ok && cl < ncls && w <= BS_WMAX) while (count - e0 >= BS_MINREM) e0 += 2048;   // done above
         while (e0 < count) {
           const int take = (64 * U - pfill) < (count - e0) ? (64 * U - pfill) : (count - e0);
+          const bool mine = !split || (rowi & 3) == wv;
 #pragma unroll
           for (int u = 0; u < U; u++) {
             const int e = u * 64 + lane - pfill;
-            if (e >= 0 && e < take) {
+            if (mine && e >= 0 && e < take) {
               const int pos = ks_pos(ks, e0 + e);
               pv[u] = pos;
               x[u] = ks_key(ks, pos);
@@ -1332,19 +1350,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
           }
           pfill += take; e0 += take;
           if (pfill == 64 * U) {
-            perchain_row<U>(best, bpos, besthi, H, x, pv, wt, lane);
+            if (mine) perchain_row<U>(best, bpos, besthi, H, x, pv, wt, lane);
 #pragma unroll
             for (int u = 0; u < U; u++) { x[u] = 0; wt[u] = 0; }
             pfill = 0;
+            rowi++;
           }
         }
       }
-      if (pfill > 0) perchain_row<U>(best, bpos, besthi, H, x, pv, wt, lane);
+      if (pfill > 0 && (!split || (rowi & 3) == wv)) perchain_row<U>(best, bpos, besthi, H, x, pv, wt, lane);
     }
     __builtin_amdgcn_wave_barrier();
     ks.perm = nullptr;
-    for (int s = lane; s < H; s += 64) {
-      const int32_t p = bpos[s];
+    if (split) __syncthreads();   // the four waves' tables are complete
+    for (int s = split ? (int)threadIdx.x : lane; s < H; s += split ? 256 : 64) {
+      int32_t p = bpos[s];
+      if (split) {   // the smallest of the four minima (equal values are one k-mer: the step is a bijection and the lists hold first occurrences)
+        const char* t0 = smem + (size_t)MH_LUT_WORDS * 8;
+        int64_t bv = INT64_MAX; p = INT32_MIN;
+        for (int w4 = 0; w4 < 4; w4++) {
+          const int64_t* b4 = (const int64_t*)(t0 + (size_t)w4 * wave_stride);
+          const int32_t pp = ((const int32_t*)(b4 + H))[s];
+          if (pp != INT32_MIN && (p == INT32_MIN || b4[s] < bv)) { bv = b4[s]; p = pp; }
+        }
+      }
       int32_t v = 0;
       if (p != INT32_MIN) {
         const uint64_t key = ks_key(ks, p);
@@ -1352,7 +1381,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_WAVES_EU
       }
       orow[s] = v;
     }
-    if (lane == 0) out_status[sidx * status_stride] = 0;
+    if (lane == 0 && (!split || wv == 0)) out_status[sidx * status_stride] = 0;
     if (PROF) tp[0] += MHAP_TICK() - ts0;
     }
   }
@@ -1867,14 +1896,15 @@ int64_t minhash_tail_strands(int nblocks, int64_t n_unweighted) {
 size_t minhash_merge_bytes(int nblocks, int H) { return (size_t)nblocks * 4 * (size_t)H * 8; }
 
 // MHAP_MINHASH=perchain selects the kernel without bit-sliced rows, MHAP_MINHASH=classic round 2's kernel for the weight-1 strands too (A/B measurements)
-void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
+bool launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_t n_unweighted, int64_t n_weighted, const ReadDesc* descs, int64_t nstrands, const int64_t* keys, const uint32_t* wts,
                     const uint32_t* perm, const StrandInfo* info, const uint8_t* store, const uint64_t* luts, int k, int k2, int H,
                     unsigned long long* counter, int32_t* out_rows, int64_t out_stride, int32_t* out_status, int64_t status_stride,
                     const uint64_t* jump, int jump_na, const int32_t* slist, uint32_t* qbuf, const uint64_t* unjump, const uint64_t* jump_w1, unsigned long long* merge, int max_nk) {
   // counter: the sketch phase's counter block — [1] / [2] work counters of the two launches, [4] / [5] lengths of their strand lists
   // (written by kmer_weight_kernel), [9] / [11] strands sketched.  qbuf: minhash_queue_bytes(2 * nblocks) (one half per launch);
-  // merge: minhash_merge_bytes(nblocks, H); max_nk: k-mers of the launch's longest strand
-  if (nstrands <= 0) return;
+  // merge: minhash_merge_bytes(nblocks, H); max_nk: k-mers of the launch's longest strand.  Returns whether anything was put on st_weighted
+  // (the caller joins that stream only then)
+  if (nstrands <= 0) return false;
   static int perchain = -1, classic = 0;
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; classic = (e && strcmp(e, "classic") == 0) ? 1 : 0; }
   size_t per_wave = (((size_t)H * 12 + 8) + 15) & ~(size_t)15;
@@ -1911,23 +1941,28 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
                 hp[8], tot / (double)hp[8], 100.0 * hp[1] / tot, 100.0 * hp[2] / tot, 100.0 * hp[3] / tot, 100.0 * hp[4] / tot, 100.0 * hp[5] / tot,
                 100.0 * hp[6] / tot, (double)hp[7] / (double)hp[8], hp[7] ? (double)hp[6] / (double)hp[7] : 0.0);
     }
-    return;
+    return false;
   }
   if (perchain) {
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, true>), dim3(nblocks), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
                        counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, qcap);
     hipLaunchKernelGGL((minhash_kernel<MH_U, false, false>), dim3(nblocks), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
                        counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, qcap);
+    return true;
   } else {
     // n_unweighted / n_weighted >= 0: the lengths of the two work lists (the caller read them back): each launch gets only the
     // workgroups its list can feed, the weighted one first, on its own stream — its few workgroups take their slots, the weight-1
     // launch fills the rest of the GPU, and nothing is left to run alone at the end.  < 0: unknown, full grids.
     const int waves_wg = (int)block.x / 64;
-    const int nb_w = n_weighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, (n_weighted + waves_wg - 1) / waves_wg);
+    // a few strands only: one WORKGROUP per strand, its rows going round the four waves (SPLIT in minhash_kernel); MHAP_MINHASH_SPLIT=0 turns it off
+    const char* split_env = getenv("MHAP_MINHASH_SPLIT");
+    const bool split_ok = !(split_env && atoi(split_env) == 0);
+    const bool split = split_ok && waves_wg == 4 && n_weighted > 0 && n_weighted * 4 <= nblocks;
+    const int nb_w = n_weighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, split ? n_weighted : (n_weighted + waves_wg - 1) / waves_wg);
     const int nb_u = n_unweighted < 0 ? nblocks : (int)std::min<int64_t>(nblocks, (n_unweighted + waves_wg - 1) / waves_wg);
     if (nb_w > 0)
-      hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nb_w), block, lds, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
-                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, qcap);
+      hipLaunchKernelGGL((minhash_kernel<MH_U, true, true>), dim3(nb_w), block, lds + 16, st_weighted, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
+                         counter_w, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist_w, counter + 5, qbuf_w, qcap, nullptr, split ? 1 : 0);
     if (nb_u > 0 && (classic || n_unweighted < 0 || waves_wg != 4)) {
       hipLaunchKernelGGL((minhash_kernel<MH_U, true, false>), dim3(nb_u), block, lds, st, descs, nstrands, keys, wts, perm, info, store, luts, k, k2, H,
                          counter_u, out_rows, out_stride, out_status, status_stride, jump, jump_na, slist, counter + 4, qbuf, qcap);
@@ -1974,6 +2009,7 @@ void launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
       if (a.n_tail > 0)
         hipLaunchKernelGGL(minhash_w1_finish_kernel, dim3((unsigned)((a.n_tail * (long long)H + 255) / 256)), dim3(256), 0, st, a);
     }
+    return nb_w > 0;
   }
 }
 

@@ -1130,6 +1130,27 @@ def test_weight_classes_and_large_weights():
     assert got == O.record_lines(want["records"])
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
+def test_few_weighted_strands_go_round_the_waves_of_a_workgroup(split, monkeypatch):
+    """A launch of a few strands with repeated k-mers (a small job: C1 has six) gives every strand a WORKGROUP whose four waves take the
+    strand's rows in turn — bit-sliced rows of 2 048 k-mers and per-chain rows alike — and merge their minima in LDS (SPLIT in
+    minhash_kernel); MHAP_MINHASH_SPLIT=0 keeps one wave per strand.  Strands of one to seven rows with tandem repeats of several
+    multiplicities, against the oracle (J/sketch/MinHashSketch.java:66-131), both ways."""
+    monkeypatch.setenv("MHAP_MINHASH_SPLIT", split)
+    rnd = random.Random(77)
+    seqs = []
+    for n, reps in ((1800, 2), (4300, 2), (6200, 3), (9000, 2), (14000, 5), (14000, 1), (2500, 9), (7000, 33)):
+        unit = _rand_seq(rnd, 45)
+        body = _rand_seq(rnd, n)
+        cut = n // 3
+        seqs.append(body[:cut] + unit * reps + body[cut:] + (unit if reps > 1 else ""))
+    seqs.append(_rand_seq(rnd, 5000))      # (weight-1 strands: the other launch)
+    seqs.append(_rand_seq(rnd, 300))
+    fa = FastaData.from_strings(seqs)
+    for H in (64, 512, 1100):
+        _assert_sketch_parity(fa, MhapParams(num_hashes=H, ordered_sketch_size=600))
+
+
 def test_random_flag_and_read_mixes():
     """A few draws of tests/fuzz_parity.py (random flags incl. k != 16 and odd k2, repeat families, N runs): 0 mismatches."""
     import fuzz_parity
