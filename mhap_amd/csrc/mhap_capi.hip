@@ -127,7 +127,11 @@ struct mhap_handle {
   size_t pin_cap = 0;
   uint8_t* pin_io = nullptr;      // pinned bounce buffer of the small device-to-host read-backs (meta rows, records)
   size_t pin_io_cap = 0;
-  std::vector<ReadDesc> h_descs;
+  ReadDesc* h_descs = nullptr; size_t h_descs_cap = 0;   // a batch's descriptors (pinned, grow-only: their upload is a DMA, not a staged copy)
+  // ids of an add in flight (mhap_index_add_*): mirrored and uploaded by sketch_staged while the GPU runs the add's kernels, so that
+  // finish_add has only the meta rows left to fetch; and whether the ids rise with the entries, kept for the searches of this generation
+  struct { int64_t first = 0, n = 0; const int64_t* ids = nullptr; bool done = false; } pend_ids;
+  uint64_t mono_gen = ~0ULL; bool mono_val = false;
   std::vector<ReadDesc> st_descs;   // staged reads (base_off/length/flags); packed bases resident in `store`
   std::vector<int64_t> st_ids;
   int64_t st_n = 0, st_bytes = 0;
@@ -345,6 +349,22 @@ static int inv_alloc(mhap_handle* h, int64_t ne) {
 }
 
 int ensure_inverted_index(mhap_handle* h, hipStream_t st = nullptr, int64_t ne_override = -1);
+// the ids of entries [first, first + 2 n): host mirror, device copy, and whether the ids of the whole index rise with the entries
+int fill_ids(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
+  h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
+  for (int64_t i = 0; i < n; i++) {
+    h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
+    h->fwd[(size_t)(first + 2 * i)] = 1; h->fwd[(size_t)(first + 2 * i + 1)] = 0;
+  }
+  HPROF("ids built");
+  HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)(2 * n) * 8, hipMemcpyHostToDevice));
+  HPROF("ids h2d");
+  bool mono = true;
+  for (int64_t e = 1; e < first + 2 * n && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
+  h->mono_val = mono; h->mono_gen = h->index_gen + 1;   // (finish_add starts the generation these ids belong to)
+  return MHAP_OK;
+}
+
 
 // eager_index_entries > 0 (an add that very likely completes the index): the inverted index of entries [0, eager_index_entries) —
 // the tables' rows up to the end of this add — is built as soon as the last batch's MinHash rows and statuses exist, on the side
@@ -354,6 +374,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
                   int64_t eager_index_entries = 0, bool eager_exchange = false, bool eager_first = false) {
   const int64_t n = h->st_n;
   if (n <= 0) { if (eager_exchange) { const int rx = dist_eager_begin(h, 0, nullptr, false); if (rx < 0) return rx; } return MHAP_OK; }
+  HPROF("sketch_staged begin");
   const int k = h->P.kmer_size, k2 = h->P.ordered_kmer_size, H = h->P.num_hashes, S = h->P.ordered_sketch_size;
   int64_t batch_bases = 1LL << 30;   // bases per launch group: 16 B of scratch per base (weights + class lists of both strands) = 16 GB of the 288 GB;
                                      // fewer, larger launches = fewer drain tails of the persistent MinHash waves (a strand takes ~2 ms)
@@ -407,9 +428,16 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     while (3 * se < 4LL * std::max(1, max_len_all - k + 1)) se <<= 1;
     HIPCHK(h, h->slabs.ensure((size_t)wb * (size_t)se * 4));
   }
+  HPROF("sketch: plan + scratch");
   for (const Batch& B : plan) {
     const int64_t nb = B.r1 - B.r0, nstr = 2 * nb;
-    h->h_descs.resize((size_t)nb);
+    if (h->h_descs_cap < (size_t)nb) {
+      if (h->h_descs) (void)hipHostFree(h->h_descs);
+      h->h_descs = nullptr; h->h_descs_cap = 0;
+      const size_t want = (size_t)nb + (size_t)nb / 4 + 64;
+      HIPCHK(h, hipHostMalloc((void**)&h->h_descs, want * sizeof(ReadDesc), hipHostMallocDefault));
+      h->h_descs_cap = want;
+    }
     int64_t key_elems = 0, h2_elems = 0, w_elems = 0;
     bool any_mat = false;
     int min_len_b = INT32_MAX, max_len_codes = 0;
@@ -452,7 +480,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     int32_t* meta_rows = d_meta + (2 * B.r0) * META_W;
     unsigned long long* ctr = h->counters.as<unsigned long long>();
     const ReadDesc* dd = h->descs.as<ReadDesc>();
-    HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs.data(), (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->descs.p, h->h_descs, (size_t)nb * sizeof(ReadDesc), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemsetAsync(h->counters.p, 0, 256, h->stream));
     const bool fused = k == 16 && k2 == 12;   // the table path exists: strands without MHAP_RD_MAT are hashed where their hashes are used
     if (any_mat) {
@@ -462,6 +490,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       time_end(h);
       DBGSYNC(h, "hash_kmers");
     }
+    HPROF("sketch: descriptors up");
     time_begin(h, MHAP_K_WEIGHT);
     launch_kmer_weights(h->stream, h->num_cus, dd, nstr, B.max_len, h->keys.as<int64_t>(), h->wts.as<uint32_t>(), h->perm.as<uint32_t>(),
                         h->slabs.as<uint32_t>(), slab_entries, ctr + 0, k, h->ft, h->P.repeat_weight, h->info.as<StrandInfo>(), fused,
@@ -483,6 +512,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     unsigned long long lens[2] = {0, 0};
     HIPCHK(h, hipMemcpyAsync(lens, ctr + 4, 16, hipMemcpyDeviceToHost, h->stream));
     { const int rs = sync_stream(h); if (rs != MHAP_OK) return rs; }
+    HPROF("sketch: list lengths back");
     // (Round 4 measured the ordered-sketch kernel — it only reads the strands — on a side stream next to the MinHash launch, with equal
     //  and with lowest priority, and next to the weight kernel: 107.4 -> 107.6-108.4 and 108.1 -> 110-111.6 ms at C2.  It trickles
     //  through the persistent MinHash grid's slots for 60-90 ms and slows that kernel by what it gains; the weight kernel and it both
@@ -530,8 +560,15 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     DBGSYNC(h, "ordered");
     HIPCHK(h, hipGetLastError());
     if (eager_launched) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ix_join, 0));
+    HPROF("sketch: all launched");
+    if (&B == &plan.back() && h->pend_ids.n > 0 && !h->pend_ids.done) {   // (host work and a copy the kernels do not touch: under the GPU's time)
+      const int rf = fill_ids(h, h->pend_ids.first, h->pend_ids.ids, h->pend_ids.n);
+      if (rf != MHAP_OK) { (void)sync_stream(h); return rf; }
+      h->pend_ids.done = true;
+    }
     int rc = sync_stream(h);   // h_descs is reused by the next batch
     if (rc != MHAP_OK) return rc;
+    HPROF("sketch: stream drained");
   }
   return MHAP_OK;
 }
@@ -1153,6 +1190,7 @@ void mhap_destroy(mhap_handle* h) {
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);
   if (h->pin_io) (void)hipHostFree(h->pin_io);
+  if (h->h_descs) (void)hipHostFree(h->h_descs);
   for (int i = 0; i < 2; i++) { if (h->pin_rec[i]) (void)hipHostFree(h->pin_rec[i]); free(h->out_recs2[i]); }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->ev_mh_fork) (void)hipEventDestroy(h->ev_mh_fork);
@@ -1256,15 +1294,10 @@ int mhap_index_add_reads(mhap_handle* h, const char* bases, const int64_t* offse
 // shared tail of mhap_index_add_reads / mhap_index_add_staged: host mirrors after the kernels ran
 static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   HPROF("finish_add begin");
+  const bool early = h->pend_ids.done && h->pend_ids.first == first && h->pend_ids.n == n && h->pend_ids.ids == ids;
+  h->pend_ids.done = false; h->pend_ids.n = 0;
+  if (!early) { const int rf = fill_ids(h, first, ids, n); if (rf != MHAP_OK) return rf; }
   h->inv_ready = false; h->ph_ready = false; h->index_gen++;   // the entry set changes
-  h->ids.resize((size_t)(first + 2 * n)); h->fwd.resize((size_t)(first + 2 * n));
-  for (int64_t i = 0; i < n; i++) {
-    h->ids[(size_t)(first + 2 * i)] = ids[i]; h->ids[(size_t)(first + 2 * i + 1)] = ids[i];
-    h->fwd[(size_t)(first + 2 * i)] = 1; h->fwd[(size_t)(first + 2 * i + 1)] = 0;
-  }
-  HPROF("ids built");
-  HIPCHK(h, hipMemcpy(h->d_ids.as<int64_t>() + first, h->ids.data() + first, (size_t)(2 * n) * 8, hipMemcpyHostToDevice));
-  HPROF("ids h2d");
   int rc = mirror_meta(h, h->d_meta, first, 2 * n);
   HPROF("meta mirrored");
   if (rc != MHAP_OK) return rc;
@@ -1311,9 +1344,10 @@ int mhap_index_add_staged(mhap_handle* h) {
   const bool likely_last = (first == 0 && 2 * h->reserve_reads <= after) || (h->reserve_reads > 0 && after == 2 * h->reserve_reads);
   // (a rank of a multi-GPU job with the eager exchange on: the add is collective; only the first add of an empty index can gather)
   const bool eager_exchange = h->dist != nullptr && dist_eager_wanted(h);
+  h->pend_ids.first = first; h->pend_ids.n = n; h->pend_ids.ids = h->st_ids.data(); h->pend_ids.done = false;
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W,
                      likely_last ? after : 0, eager_exchange, first == 0);
-  if (rc != MHAP_OK) return rc;
+  if (rc != MHAP_OK) { h->pend_ids.n = 0; h->pend_ids.done = false; return rc; }
   const bool built = h->inv_ready && h->inv_ne == after;
   rc = finish_add(h, first, h->st_ids.data(), n);
   if (rc == MHAP_OK && built) h->inv_ready = true;      // (finish_add drops the index of the OLD entry set; this one covers the new one)
@@ -1497,7 +1531,8 @@ static int self_search(mhap_handle* h, int64_t q_first, int64_t q_count, int64_t
     if (h->status[(size_t)e] == 0) ql.push_back((int32_t)e);   // AbstractMatchSearch.java:128-129
   }
   bool mono = true;
-  for (int64_t e = 1; e < h->n_entries && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
+  if (h->mono_gen == h->index_gen) mono = h->mono_val;   // (looked at when the ids arrived)
+  else for (int64_t e = 1; e < h->n_entries && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
   // tile skipping needs: ids sorted with entry order, every entry "long" (minStore == 0 -> only m.id < q.id survives)
   const bool tri = mono && h->P.min_store_length == 0 && !getenv("MHAP_NO_TRIANGULAR");
   QuerySide qs{h->d_minhash, h->Hrow, h->d_ordered, 2LL * h->P.ordered_sketch_size, h->d_meta, h->d_ids.as<int64_t>(), h->ids.data(), h->seqlen.data(), h->n_entries};
