@@ -131,7 +131,7 @@ struct mhap_handle {
   // ids of an add in flight (mhap_index_add_*): mirrored and uploaded by sketch_staged while the GPU runs the add's kernels, so that
   // finish_add has only the meta rows left to fetch; and whether the ids rise with the entries, kept for the searches of this generation
   struct { int64_t first = 0, n = 0; const int64_t* ids = nullptr; bool done = false; } pend_ids;
-  uint64_t mono_gen = ~0ULL; bool mono_val = false;
+  uint64_t mono_gen = ~0ULL; bool mono_val = false, mono_pending = false;   // (mono_val belongs to generation mono_gen: set by finish_add only)
   std::vector<ReadDesc> st_descs;   // staged reads (base_off/length/flags); packed bases resident in `store`
   std::vector<int64_t> st_ids;
   int64_t st_n = 0, st_bytes = 0;
@@ -361,7 +361,7 @@ int fill_ids(mhap_handle* h, int64_t first, const int64_t* ids, int64_t n) {
   HPROF("ids h2d");
   bool mono = true;
   for (int64_t e = 1; e < first + 2 * n && mono; e++) if (h->ids[(size_t)e] < h->ids[(size_t)(e - 1)]) mono = false;
-  h->mono_val = mono; h->mono_gen = h->index_gen + 1;   // (finish_add starts the generation these ids belong to)
+  h->mono_pending = mono;   // (finish_add starts the generation these ids belong to)
   return MHAP_OK;
 }
 
@@ -1298,6 +1298,7 @@ static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t
   h->pend_ids.done = false; h->pend_ids.n = 0;
   if (!early) { const int rf = fill_ids(h, first, ids, n); if (rf != MHAP_OK) return rf; }
   h->inv_ready = false; h->ph_ready = false; h->index_gen++;   // the entry set changes
+  h->mono_val = h->mono_pending; h->mono_gen = h->index_gen;
   int rc = mirror_meta(h, h->d_meta, first, 2 * n);
   HPROF("meta mirrored");
   if (rc != MHAP_OK) return rc;

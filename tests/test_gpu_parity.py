@@ -913,6 +913,32 @@ def test_index_table_reuse_and_incremental_adds():
     assert c == want and 0 < len(first) < len(want)
 
 
+def test_self_search_with_ids_that_do_not_rise_with_the_entries():
+    """The self search skips tiles by id order only while the ids rise with the entries — looked at once per generation of the index, when the
+    ids arrive (under the add's kernels since round 5), not in every search.  Ids descending, ids shuffled, and an index whose second add brings
+    ids BELOW the first's (the first generation's answer must not outlive it): records against the oracle (J/impl/MinHashSearch.java:204-214,
+    the `m.id < q.id` rule of the self search)."""
+    fa = mhap_amd.synth_reads(260, 3000, seed=515, error_rate=0.1)
+    p = MhapParams(num_hashes=256, ordered_sketch_size=600)
+    for kind in ("descending", "shuffled"):
+        ids = fa.ids[::-1].copy() if kind == "descending" else np.random.default_rng(5).permutation(fa.ids)
+        fb = FastaData(fa.bases, fa.offsets, fa.lengths, ids)
+        want = O.record_lines(O.run_self(fb, H=256, S=600, nthreads=8)["records"])
+        got, _ = _self_lines(fb, p)
+        assert got == want and len(want) > 50, kind
+    half = len(fa) // 2
+    hi, lo = fa.subset(np.arange(half, len(fa))), fa.subset(np.arange(half))   # the higher ids first
+    both = FastaData(np.concatenate([hi.bases, lo.bases]), np.concatenate([hi.offsets, lo.offsets + len(hi.bases)]),
+                     np.concatenate([hi.lengths, lo.lengths]), np.concatenate([hi.ids, lo.ids]))
+    want = O.record_lines(O.run_self(both, H=256, S=600, nthreads=8)["records"])
+    with MinHashSearch(p) as ms:
+        ms.add_data(hi)
+        first = ms.find_matches()                                          # (ids rising: tiles skipped)
+        ms.add_data(lo)
+        got = sorted(mhap_amd.records_to_lines(ms.find_matches()))
+    assert got == want and 0 < len(first) < len(want)
+
+
 def test_growing_batches_keep_the_read_back_buffer():
     """A small add followed by a much larger one re-allocates the pinned staging buffer; the (separate) pinned bounce buffer of
     the meta/record read-backs must survive it (round-1 use-after-free), and a destroyed handle frees both."""
