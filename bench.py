@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_SPEC = 256 * 4 * 32 * 2.4e9       # lane-ops/s at spec: 256 CUs x 4 SIMD-32 x 2.4 GHz = 7.86e13
 VALU_MEASURED = 6.5e13                 # tools/valu_ops.hip on MI355X (profiles/r01_valu_microbench.txt): sustained clock under an all-VALU load
 XORSHIFT_CEILING_PER_CHAIN = 4.79e12   # tools/valu_peak.hip: one chain per lane-register pair (2 v_lshlrev_b64 + 6 ops per step)
-BITSLICED_OPS_PER_32_STEPS = 107 + 9 + 4  # 43 v_xor + 64 v_xor/v_bitop3 per step of 32 chains + 9 ops of depth filter + compare/loop
+BITSLICED_OPS_PER_32_STEPS = 92 + 9 + 4   # 28 v_xor + 64 v_xor/v_bitop3 per step of 32 chains (tools/gen_bs_step92.py) + 9 ops of depth filter + compare/loop
 
 
 def sketch_bytes_per_read(L, H, S, k2):
@@ -359,10 +359,11 @@ def main():
         valu = {"bound": "valu", "kernel": "minhash_kernel<4,true,true> (+ minhash_w1_kernel)" if cfg.get("filter") else "minhash_w1_kernel", "xorshift_steps_per_s": round(xs_rate, 1),
                 "ceiling_spec_steps_per_s": round(ceil_spec, 1), "frac_of_spec_ceiling": round(xs_rate / ceil_spec, 4),
                 "ceiling_measured_clock_steps_per_s": round(ceil_meas, 1), "frac_of_measured_ceiling": round(xs_rate / ceil_meas, 4),
-                "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes): one step of 32 chains is 107 full-rate ops "
-                                "(43 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32) + 10 v_bitop3_b32 of depth filter + 3 of compare/loop = 120 (the compiled slot loop has exactly 120 VALU instructions).  Spec "
-                                "ceiling = 32 x (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 7.86e13 lane-ops/s) / 120; the measured one uses the "
-                                "6.5e13 lane-ops/s an all-VALU probe sustains (tools/valu_ops.hip).  Per-chain formulation: 4.79e12 steps/s",
+                "ceiling_note": "bit-sliced rows (32 chains per lane as 64 bit-planes): one step of 32 chains is 92 vector ops "
+                                "(28 v_xor_b32 + 64 v_xor_b32/v_bitop3_b32, 61 of the 92 three-input; 107 until the late-round-5 step) + 10 v_bitop3_b32 of depth filter + 3 of compare/loop = 105.  Spec "
+                                "ceiling = 32 x (256 CU x 4 SIMD x 32 lanes x 2.4 GHz = 7.86e13 lane-ops/s) / 105; the measured one uses the "
+                                "6.5e13 lane-ops/s an all-VALU probe of TWO-input ops sustains (tools/valu_ops.hip) — under the power cap the three-input mix of this step holds a lower clock "
+                                "(1.97 GHz against 2.2 with the 107-op step: MHAP_MINHASH_PROF), so the fraction fell while the kernel got faster.  Per-chain formulation: 4.79e12 steps/s",
                 "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4),
                 "weight_factor_assumed": wfac}
 

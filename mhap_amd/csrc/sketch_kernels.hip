@@ -818,6 +818,111 @@ constexpr int MH_LUT_WORDS = 512;   // k1 / k2 block-mix tables of the key hash 
 // (tools/gen_bs_step.py derives it and checks it against the 64-bit step).  Eight temporaries and, at the back edge of the
 // slot loop, four v_mov_b32 per step are gone with it.
 __device__ __forceinline__ uint32_t bs_xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+#ifndef MH_BS_STEP
+#define MH_BS_STEP 92
+#endif
+#if MH_BS_STEP == 92
+// 92 operations instead of 107.  With A[b] = x[b] ^ x[b-21] the outputs are C[b] = A[b] ^ A[b-4] (b >= 33: a three-input xor with one input
+// free), C[b] = A[b] ^ A[b-4] ^ A[b+31] (29..32), C[b] = A[b] ^ A[b-4] ^ C[b+35] (4..28), C[b] = A[b] ^ A[b+35] (0..3: one free).  An A[b]
+// whose readers all have a free input is never formed — the reader takes x[b] and x[b-21] itself: every other A along each chain b, b+4, ...
+// inside 33..59, fifteen of the forty-three.  tools/gen_bs_step92.py derives the list, finds an order that works IN PLACE (five A's are
+// written to temporaries instead of their planes, nothing is copied) and checks it against the 64-bit step.
+__device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
+  // 92 operations (61 three-input), in place, five temporaries and no copy: tools/gen_bs_step92.py
+  P[63] ^= P[42];
+  const uint32_t t62 = P[62] ^ P[41];
+  P[62] = bs_xor3(t62, P[58], P[37]);
+  P[61] ^= P[40];
+  P[60] ^= P[39];
+  P[56] ^= P[35];
+  P[55] ^= P[34];
+  P[54] ^= P[33];
+  P[58] = bs_xor3(P[58], P[37], P[54]);
+  P[54] = bs_xor3(P[54], P[50], P[29]);
+  const uint32_t t53 = P[53] ^ P[32];
+  P[53] = bs_xor3(t53, P[49], P[28]);
+  P[48] ^= P[27];
+  P[47] ^= P[26];
+  P[46] ^= P[25];
+  P[50] = bs_xor3(P[50], P[29], P[46]);
+  P[46] = bs_xor3(P[46], P[42], P[21]);
+  P[45] ^= P[24];
+  P[49] = bs_xor3(P[49], P[28], P[45]);
+  P[45] = bs_xor3(P[45], P[41], P[20]);
+  P[40] ^= P[19];
+  P[39] ^= P[18];
+  const uint32_t t37 = P[37] ^ P[16];
+  P[41] = bs_xor3(P[41], P[20], t37);
+  P[37] = bs_xor3(t37, P[33], P[12]);
+  const uint32_t t32 = P[32] ^ P[11];
+  P[29] ^= P[8];
+  P[33] = bs_xor3(P[33], P[12], P[29]);
+  P[28] ^= P[7];
+  P[32] = bs_xor3(t32, P[28], P[63]);
+  P[63] = bs_xor3(P[63], P[59], P[38]);
+  P[59] = bs_xor3(P[59], P[38], P[55]);
+  P[55] = bs_xor3(P[55], P[51], P[30]);
+  P[51] = bs_xor3(P[51], P[30], P[47]);
+  P[47] = bs_xor3(P[47], P[43], P[22]);
+  P[43] = bs_xor3(P[43], P[22], P[39]);
+  P[39] = bs_xor3(P[39], P[35], P[14]);
+  const uint32_t t38 = P[38] ^ P[17];
+  P[42] = bs_xor3(P[42], P[21], t38);
+  P[38] = bs_xor3(t38, P[34], P[13]);
+  P[30] ^= P[9];
+  P[34] = bs_xor3(P[34], P[13], P[30]);
+  P[27] ^= P[6];
+  P[26] ^= P[5];
+  P[30] = bs_xor3(P[30], P[26], P[61]);
+  P[61] = bs_xor3(P[61], P[57], P[36]);
+  P[57] = bs_xor3(P[57], P[36], t53);
+  P[25] ^= P[4];
+  P[29] = bs_xor3(P[29], P[25], P[60]);
+  P[60] ^= P[56];
+  P[56] = bs_xor3(P[56], P[52], P[31]);
+  P[52] = bs_xor3(P[52], P[31], P[48]);
+  P[48] = bs_xor3(P[48], P[44], P[23]);
+  P[44] = bs_xor3(P[44], P[23], P[40]);
+  P[40] = bs_xor3(P[40], P[36], P[15]);
+  P[31] ^= P[10];
+  P[24] ^= P[3];
+  P[28] = bs_xor3(P[28], P[24], P[63]);
+  P[24] = bs_xor3(P[24], P[20], P[59]);
+  P[23] ^= P[2];
+  P[22] ^= P[1];
+  P[26] = bs_xor3(P[26], P[22], P[61]);
+  P[22] = bs_xor3(P[22], P[18], P[57]);
+  P[21] ^= P[0];
+  P[25] = bs_xor3(P[25], P[21], P[60]);
+  P[21] = bs_xor3(P[21], P[17], P[56]);
+  P[20] = bs_xor3(P[20], P[16], P[55]);
+  P[18] = bs_xor3(P[18], P[14], P[53]);
+  P[17] = bs_xor3(P[17], P[13], P[52]);
+  P[16] = bs_xor3(P[16], P[12], P[51]);
+  P[13] = bs_xor3(P[13], P[9], P[48]);
+  P[12] = bs_xor3(P[12], P[8], P[47]);
+  P[9] = bs_xor3(P[9], P[5], P[44]);
+  P[8] = bs_xor3(P[8], P[4], P[43]);
+  P[5] = bs_xor3(P[5], P[1], P[40]);
+  P[4] = bs_xor3(P[4], P[0], P[39]);
+  P[1] = bs_xor3(P[1], P[36], P[15]);
+  P[36] = bs_xor3(P[36], P[15], t32);
+  P[0] = bs_xor3(P[0], P[35], P[14]);
+  P[35] = bs_xor3(P[35], P[14], P[31]);
+  P[31] = bs_xor3(P[31], P[27], t62);
+  P[27] = bs_xor3(P[27], P[23], P[62]);
+  P[23] = bs_xor3(P[23], P[19], P[58]);
+  P[19] = bs_xor3(P[19], P[15], P[54]);
+  P[15] = bs_xor3(P[15], P[11], P[50]);
+  P[14] = bs_xor3(P[14], P[10], P[49]);
+  P[11] = bs_xor3(P[11], P[7], P[46]);
+  P[10] = bs_xor3(P[10], P[6], P[45]);
+  P[7] = bs_xor3(P[7], P[3], P[42]);
+  P[6] = bs_xor3(P[6], P[2], P[41]);
+  P[3] ^= t38;
+  P[2] ^= t37;
+}
+#else
 __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
 #pragma unroll
   for (int b = 63; b >= 21; b--) P[b] ^= P[b - 21];                       // A
@@ -887,6 +992,7 @@ __device__ __forceinline__ void bs_step(uint32_t (&P)[64]) {
   P[4] = bs_xor3(P[4], P[0], P[39]);
   P[0] ^= T;
 }
+#endif
 
 // filter depth of a slot whose minimum has the high dword bhs: -1 = no negative minimum yet (every active chain is a candidate),
 // else the leading zero magnitude bits of the minimum, capped at BS_ZMAX
