@@ -411,20 +411,27 @@ def test_jni_shim_and_java_class_agree():
 
 
 def test_bit_sliced_step_order_matches_its_generator():
-    """bs_step() in sketch_kernels.hip is generated: tools/gen_bs_step.py derives the in-place evaluation order (topological sort,
-    one saved plane), checks it against the 64-bit xorshift step on random values, and prints the statements.  The kernel source
-    must hold exactly those statements."""
+    """bs_step() in sketch_kernels.hip is generated.  The shipped form (92 operations): tools/gen_bs_step92.py drops the intermediate
+    planes whose readers have a free xor input, orders the rest in place (five temporaries, no copy), checks the statements against the
+    64-bit xorshift step on random values and prints them.  The 107-operation form kept behind -DMH_BS_STEP=107: tools/gen_bs_step.py
+    (topological sort, one saved plane).  The kernel source must hold exactly those statements."""
     pytest.importorskip("networkx")
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "mhap_amd", "csrc", "sketch_kernels.hip")).read()
+    bodies = src[src.index("#if MH_BS_STEP == 92"):]
+    new_body, old_body = bodies[:bodies.index("#else")], bodies[bodies.index("#else"):bodies.index("#endif")]
+
+    def statements(text):
+        return [ln.strip() for ln in text.splitlines() if ln.strip().startswith(("const uint32_t t", "const uint32_t T", "P["))]
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_bs_step92.py")], capture_output=True, text=True, check=True).stdout
+    stmts = statements(gen)
+    assert len(stmts) == 92 and sum("bs_xor3" in x for x in stmts) == 61 and sum(x.startswith("const uint32_t t") for x in stmts) == 5
+    assert statements(new_body) == stmts
     gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_bs_step.py")], capture_output=True, text=True, check=True).stdout
     stmts = [ln.strip() for ln in gen.splitlines() if ln.strip()]
     assert len(stmts) == 65 and stmts[0] == "const uint32_t T = P[35];"
-    src = open(os.path.join(root, "mhap_amd", "csrc", "sketch_kernels.hip")).read()
-    body = src[src.index("__device__ __forceinline__ void bs_step("):]
-    body = body[:body.index("\n}\n")]
-    have = [ln.strip() for ln in body.splitlines() if ln.strip().startswith(("const uint32_t T", "P["))]
-    assert have == stmts
+    assert statements(old_body) == stmts
 
 
 def test_bench_preflight_without_a_gpu_reports_instead_of_hanging():
