@@ -353,6 +353,10 @@ int mhap_synth_reads_shard(uint64_t seed, int64_t n, int32_t len, double coverag
  * every rep_spacing-base stretch.  rep_len = 0 gives exactly mhap_synth_reads_shard's reads. */
 int mhap_synth_reads_repeats(uint64_t seed, int64_t n, int32_t len, double coverage, double error_rate, int64_t shard,
                              int64_t nshards, int32_t rep_len, int32_t rep_spacing, double rep_div, char* bases);
+/* Reads of given lengths from a SUPPLIED circular genome (one code 0..3 per byte), same error model; read r is written to
+ * bases[offsets[r] .. offsets[r] + lengths[r]).  Test / bench tooling (the E. coli-shaped stand-in of BASELINE configs[2]). */
+int mhap_synth_reads_genome(uint64_t seed, const uint8_t* genome, int64_t G, int64_t n, const int32_t* lengths, const int64_t* offsets,
+                            double error_rate, char* bases);
 
 /* murmur3_x64_128(seed 0).h1 of one k-mer line of a `-f` filter file, canonicalised when do_rc != 0
  * (HashUtils.computeSequenceHashesLong(str, len, 0, doRC)[0], J/sketch/FrequencyCounts.java:169). */

@@ -60,7 +60,7 @@ EXPORTED_SYMBOLS = [
     "mhap_format_record", "mhap_fasta_read", "mhap_fasta_free", "mhap_synth_reads", "mhap_hash_kmer",
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_pass_min", "mhap_selftest_xorshift_jump", "mhap_selftest_xorshift_unjump", "mhap_find_matches_sketches",
-    "mhap_synth_reads_repeats", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
+    "mhap_synth_reads_repeats", "mhap_synth_reads_genome", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
     "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing", "mhap_dist_info", "mhap_dist_selftest", "mhap_dist_set_eager", "mhap_dist_eager_searches",
     "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",
     "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats", "mhap_abi_version", "mhap_abi_sizes",
@@ -225,6 +225,23 @@ def synth_reads(n, length, seed=0x4D484150, coverage=30.0, error_rate=0.15, shar
     offsets = np.arange(m, dtype=np.int64) * length
     lengths = np.full(m, length, dtype=np.int32)
     return FastaData(bases[:m * length], offsets, lengths, idx + 1)
+
+
+def synth_reads_from_genome(genome, lengths, seed=0x4D484150, error_rate=0.15):
+    """Reads of the given lengths drawn from a supplied circular genome (uint8 codes 0..3): mhap_synth_reads_genome."""
+    lib = load_library()
+    genome = np.ascontiguousarray(genome, dtype=np.uint8)
+    lengths = np.ascontiguousarray(lengths, dtype=np.int32)
+    n = len(lengths)
+    offsets = np.zeros(n, dtype=np.int64)
+    if n > 1:
+        np.cumsum(lengths[:-1].astype(np.int64), out=offsets[1:])
+    bases = np.empty(max(int(lengths.astype(np.int64).sum()), 1), dtype=np.uint8)
+    rc = lib.mhap_synth_reads_genome(C.c_uint64(seed), _ptr(genome), C.c_int64(len(genome)), C.c_int64(n), _ptr(lengths), _ptr(offsets),
+                                     C.c_double(error_rate), _ptr(bases))
+    if rc != 0:
+        raise MhapError(f"mhap_synth_reads_genome failed ({rc})")
+    return FastaData(bases, offsets, lengths, np.arange(1, n + 1, dtype=np.int64))
 
 
 class FrequencyCounts:

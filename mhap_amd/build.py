@@ -46,6 +46,20 @@ def source_digest():
     return _digest(deps, ["sources"])
 
 
+def stale_objects():
+    """Translation units whose shipped object was built from other bytes than the sources here (no compiler needed: the digest of
+    (source, headers, command) is recomputed with the recorded compiler path left out of the comparison where it cannot be known)."""
+    out = []
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    for s in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(s)[0] + ".o")
+        cmd = [f"--offload-arch={ARCH}", *[f for f in CFLAGS if f != "-shared"], "-c", os.path.join(CSRC, s), "-o", obj]
+        dg = _digest([os.path.join(CSRC, s)] + [os.path.join(CSRC, d) for d in EXTRA_DEPS.get(s, [])] + hdrs, cmd)
+        if _stale(obj, dg):
+            out.append(s)
+    return out
+
+
 def _stale(target, digest):
     stamp = target + ".sha256"
     if not (os.path.exists(target) and os.path.exists(stamp)):
@@ -83,6 +97,9 @@ def _compile_objects(hipcc, flags, only, tag, force, verbose):
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJDIR, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    # a translation unit that textually includes a listed one is a variant too (-DMH_OJ_GCAP on search_kernels.hip alone left
+    # the two wider passes of the join kernel at the default and the A/B silently mixed configurations)
+    only = list(only) + [s for s, deps in EXTRA_DEPS.items() if s not in only and any(d in only for d in deps)]
     jobs, objs = [], []
     for s in SOURCES:
         variant = bool(flags) and s in only
@@ -128,6 +145,9 @@ def build(force=False, verbose=False, variants=()):
     except RuntimeError:
         if os.path.exists(LIB) and not force:   # a box without a compiler: the shipped artefact is all there is
             print(f"note: no hipcc here; using the shipped {LIB} (mhap_amd.load_library() checks its ABI version and struct sizes)", file=sys.stderr)
+            st = stale_objects()
+            if st:
+                print(f"warning: the shipped library is STALE against the sources here: {', '.join(st)} changed since their objects were built", file=sys.stderr)
             return LIB
         raise
     objs, _ = _compile_objects(hipcc, [], [], "", force, verbose)

@@ -354,6 +354,46 @@ int mhap_synth_reads_repeats(uint64_t seed, int64_t n, int32_t len, double cover
   return MHAP_OK;
 }
 
+// Reads of given lengths drawn from a SUPPLIED circular genome (codes 0..3, one per byte), same error model and per-read generators as
+// above.  The caller builds the genome — workloads.ecoli_like_genome plants rRNA-operon and IS-element copies in 4.6 Mbp — and the
+// length mix; read r goes to bases[offsets[r] .. offsets[r] + lengths[r]).
+int mhap_synth_reads_genome(uint64_t seed, const uint8_t* genome, int64_t G, int64_t n, const int32_t* lengths, const int64_t* offsets,
+                            double error_rate, char* bases) {
+  if (!genome || G < 1 || n < 0 || !lengths || !offsets || !bases || error_rate < 0.0 || error_rate >= 1.0) return MHAP_E_INVALID;
+  const double p_ins = error_rate * (0.1188 / 0.15), p_del = error_rate * (0.0183 / 0.15), p_sub = error_rate * (0.0129 / 0.15);
+  static const char ALPHA[4] = {'A', 'C', 'G', 'T'};
+  const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(mhap::usable_host_threads(32), n));
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; t++) {
+    th.emplace_back([&, t]() {
+      std::vector<uint8_t> tmp;
+      for (int64_t r = t; r < n; r += nthreads) {
+        const int len = lengths[r];
+        if (len <= 0) continue;
+        tmp.resize((size_t)len);
+        Xoshiro256ss g(SplitMix64{seed ^ (0x9e3779b97f4a7c15ULL * (uint64_t)(r + 1))}.next());
+        int64_t gp = (int64_t)g.below((uint64_t)G);
+        const bool rev = (g.next() >> 63) != 0;
+        int w = 0;
+        while (w < len) {
+          const double u = g.unit();
+          if (u < p_ins) { tmp[(size_t)w++] = (uint8_t)(g.next() >> 62); continue; }
+          const uint8_t b = genome[(size_t)gp] & 3;
+          gp++; if (gp == G) gp = 0;
+          if (u < p_ins + p_del) continue;
+          if (u < p_ins + p_del + p_sub) { tmp[(size_t)w++] = (uint8_t)((b + 1 + (g.next() >> 62) % 3) & 3); continue; }
+          tmp[(size_t)w++] = b;
+        }
+        char* dst = bases + offsets[r];
+        if (!rev) for (int i = 0; i < len; i++) dst[i] = ALPHA[tmp[(size_t)i]];
+        else for (int i = 0; i < len; i++) dst[i] = ALPHA[3 - tmp[(size_t)(len - 1 - i)]];
+      }
+    });
+  }
+  for (auto& x : th) x.join();
+  return MHAP_OK;
+}
+
 // new FrequencyCounts(reader, filterCutoff, offset, removeUnique, noTf, numThreads, range, doRC) (J/sketch/FrequencyCounts.java:63-229)
 int mhap_set_filter_file(mhap_handle* h, const char* path, double filter_cutoff, double offset, int32_t remove_unique, int32_t no_tf,
                          double range, int32_t do_rc, char* kmer_sizes, size_t kmer_sizes_cap) {

@@ -117,6 +117,9 @@ struct InvIndex {
   uint32_t grouped;      // != 0: every bucket longer than group_t postings is ordered by entry class (entry >> class_log): the dense query
                          // tier then streams, per pass over a range of entries, only the part of a long bucket that lies in it
   uint32_t group_t, class_log;   // (index_group_params: 256 and 15 unless MHAP_INDEX_GROUP_T / MHAP_INDEX_CLASS_LOG say otherwise — tests)
+  // round 6: the LINE table in front of ends / items — a lookup of the first query tier reads ONE 64-byte line (index_lines_kernel)
+  uint32_t* lines;       // [H][nl][16] or nullptr: line l of slot s packs the postings of buckets [l << lb, (l + 1) << lb)
+  uint32_t nl_log, line_lb, line_ebits;   // nl = 1 << nl_log lines per slot, lb = log2(buckets per line), entry bits of a packed posting
   // scratch of the build
   uint2* staged;         // [H][slot_stride]: the postings grouped by coarse bin
   uint32_t* tile_counts; // [H][tiles][coarse bins]
@@ -126,6 +129,8 @@ struct InvIndex {
 int index_tiles(int ne);
 void index_group_params(int64_t entries, InvIndex& ix);   // sets grouped / group_t / class_log for an index of this many entries
 int index_coarse_bins();
+bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t& lb, uint32_t& ebits);   // false: no line table for this index
+size_t index_line_bytes(int H, uint32_t nl_log);
 int index_max_buckets_log();
 void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,
                          unsigned long long* missing);   // self-check: postings that are not where a lookup would find them

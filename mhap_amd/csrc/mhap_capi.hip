@@ -140,7 +140,7 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, slow_cand2, slow_cand3, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big;
+  DevBuf qlist, rowstart, cand, slow_cand, slow_cand2, slow_cand3, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big, inv_lines;
   // post stage of a search chunk (record read-back, conversion, sink) on a worker thread, one chunk behind the kernels: two sets of buffers
   hipStream_t copy_stream = nullptr;
   uint8_t* pin_rec[2] = {nullptr, nullptr};
@@ -345,6 +345,14 @@ static int inv_alloc(mhap_handle* h, int64_t ne) {
   h->inv.slot_stride = (uint64_t)stride;
   h->inv.ne = (uint32_t)std::min<int64_t>(ne, 0xFFFFFFFFLL);
   index_group_params(ne, h->inv);
+  // the line table of the first query tier (round 6); an index it does not cover, or no memory for it: the tier reads ends / items
+  h->inv.lines = nullptr; h->inv.nl_log = 0; h->inv.line_lb = 0; h->inv.line_ebits = 0;
+  uint32_t nl_log = 0, lb = 0, eb = 0;
+  if (index_line_params(ne, (uint32_t)nb, nl_log, lb, eb)) {
+    if (h->inv_lines.ensure(index_line_bytes(H, nl_log)) == hipSuccess) {
+      h->inv.lines = h->inv_lines.as<uint32_t>(); h->inv.nl_log = nl_log; h->inv.line_lb = lb; h->inv.line_ebits = eb;
+    } else (void)hipGetLastError();
+  }
   return MHAP_OK;
 }
 
@@ -1185,7 +1193,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->jump_w1_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->slow_cand2, &h->slow_cand3, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big,
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->slow_cand2, &h->slow_cand3, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big, &h->inv_lines,
                     &h->pass_min_tbl, &h->poshist, &h->q_poshist};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);

@@ -377,6 +377,83 @@ __global__ __launch_bounds__(IB_GRP_THREADS) void index_group_kernel(InvIndex ix
   }
 }
 
+// Step 6 (round 6): the LINE table.  A lookup through ends / items is two dependent random accesses — the bucket's bounds, then its
+// postings — and in an N-GPU job every rank looks ALL N n queries up against its shard: the one term of a rank's step that does not
+// shrink with N.  Line l of slot s packs the postings of the buckets [l << lb, (l + 1) << lb) — 3.5 to 7 of them on average — into ONE
+// 64-byte line: the first-tier query reads that line and nothing else.  A packed posting is exact: the line index is the mix's top
+// nl_log bits, the posting keeps the other 32 - nl_log (the "tag") above the entry's ebits bits — at most 36 bits (index_line_params):
+//   words 0..13   the low 32 bits of 14 postings
+//   word 14       the top 4 bits of postings 0..7, word 15 bits 0..23 those of postings 8..13
+//   word 15 >> 24 the header: n = postings of the line's buckets (0..28), or 0xFF "look the bucket up in ends / items" (a long bucket: a
+//                 repeat — or, one line in ten thousand, more than a pair of lines holds)
+// n > 14: the postings beyond the 14th sit in the PARTNER line (l ^ 1: the other half of the same 128-byte block), behind the partner's
+// own (header of the partner = its own count < 14), as long as the pair's postings fit the pair's 28 places.
+constexpr int IL_CAP = 14;
+constexpr uint32_t IL_FALLBACK = 0xFFu;
+constexpr int IL_THREADS = 256;
+__global__ __launch_bounds__(IL_THREADS) void index_lines_kernel(InvIndex ix, int H) {
+  const size_t pairs = (size_t)1 << (ix.nl_log - 1);
+  const size_t t = (size_t)blockIdx.x * IL_THREADS + threadIdx.x;
+  if (t >= (size_t)H * pairs) return;
+  const size_t s = t >> (ix.nl_log - 1), pr = t & (pairs - 1);
+  const uint32_t* E = ix.ends + s * ((size_t)ix.nb + 1) + ((pr * 2) << ix.line_lb);
+  const uint32_t a = E[0], b = E[(size_t)1 << ix.line_lb], c = E[(size_t)2 << ix.line_lb];
+  const uint32_t n0 = b - a, n1 = c - b;
+  const bool fits = n0 + n1 <= 2u * IL_CAP;
+  const uint32_t h0 = n0 <= (uint32_t)IL_CAP ? n0 : (fits ? n0 : IL_FALLBACK), h1 = n1 <= (uint32_t)IL_CAP ? n1 : (fits ? n1 : IL_FALLBACK);
+  const uint2* P = ix.items + s * ix.slot_stride;
+  const uint32_t tmask = (ix.nl_log >= 32u) ? 0u : (0xFFFFFFFFu >> ix.nl_log), eb = ix.line_ebits;
+  uint32_t w0[16], w1[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { w0[i] = 0u; w1[i] = 0u; }
+  const uint32_t m0 = n0 < (uint32_t)IL_CAP ? n0 : (uint32_t)IL_CAP, m1 = n1 < (uint32_t)IL_CAP ? n1 : (uint32_t)IL_CAP;
+  const uint32_t x0 = (fits && n0 > (uint32_t)IL_CAP) ? n0 - IL_CAP : 0u;   // postings of line 0 that go to line 1, and the other way round
+  const uint32_t x1 = (fits && n1 > (uint32_t)IL_CAP) ? n1 - IL_CAP : 0u;
+#pragma unroll
+  for (int i = 0; i < IL_CAP; i++) {
+    // place i of line 0: its own i-th posting, or (behind its own) what line 1 could not hold; the same for line 1
+    uint32_t src0 = 0xFFFFFFFFu, src1 = 0xFFFFFFFFu;
+    if ((uint32_t)i < m0) src0 = a + (uint32_t)i; else if ((uint32_t)i - m0 < x1) src0 = b + (uint32_t)IL_CAP + ((uint32_t)i - m0);
+    if ((uint32_t)i < m1) src1 = b + (uint32_t)i; else if ((uint32_t)i - m1 < x0) src1 = a + (uint32_t)IL_CAP + ((uint32_t)i - m1);
+    if (src0 != 0xFFFFFFFFu && h0 != IL_FALLBACK) {
+      const uint2 x = P[src0];
+      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
+      w0[i] = (uint32_t)W;
+      if (i < 8) w0[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w0[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
+    }
+    if (src1 != 0xFFFFFFFFu && h1 != IL_FALLBACK) {
+      const uint2 x = P[src1];
+      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
+      w1[i] = (uint32_t)W;
+      if (i < 8) w1[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w1[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
+    }
+  }
+  w0[15] |= h0 << 24; w1[15] |= h1 << 24;
+  uint4* out = (uint4*)(ix.lines + ((s << ix.nl_log) + pr * 2) * 16);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = make_uint4(w0[4 * i], w0[4 * i + 1], w0[4 * i + 2], w0[4 * i + 3]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[4 + i] = make_uint4(w1[4 * i], w1[4 * i + 1], w1[4 * i + 2], w1[4 * i + 3]);
+}
+// lines per slot and posting layout for an index of `entries` entries in nb buckets per slot; false: no line table (a posting would not
+// fit its 36 bits, or MHAP_INDEX_LINES=0).  Average postings per line: 3.5 .. 7 (IL_CAP = 14 places, 28 with the partner's)
+bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t& lb, uint32_t& ebits) {
+  const char* e = getenv("MHAP_INDEX_LINES");
+  if (e && e[0] == '0') return false;
+  const int64_t per_line = []() { const char* v = getenv("MHAP_INDEX_LINE_LOAD"); const int x = v ? atoi(v) : 0; return (int64_t)(x >= 1 && x <= 14 ? x : 7); }();
+  uint32_t nbl = 0;
+  while ((1u << nbl) < nb) nbl++;
+  uint32_t l = 1;
+  while (l < nbl && ((int64_t)1 << l) * per_line < entries) l++;
+  if (((int64_t)1 << l) * per_line < entries) return false;          // (an index beyond nb * 7 entries: more than 7 M)
+  ebits = 1;
+  while (ebits < 32 && ((int64_t)1 << ebits) < entries) ebits++;     // entry < entries <= 2^ebits
+  if ((32 - l) + ebits > 36) return false;
+  nl_log = l; lb = nbl - l;
+  return true;
+}
+size_t index_line_bytes(int H, uint32_t nl_log) { return (size_t)H * ((size_t)64 << nl_log); }
+
 // Self-check (MHAP_DEBUG_INDEX=1, tests): every stored (entry, slot) finds its posting in its bucket; counts the ones that do not.
 __global__ void index_verify_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta, int ne, int H, InvIndex ix,
                                     unsigned long long* __restrict__ missing) {
@@ -395,11 +472,43 @@ __global__ void index_verify_kernel(const int32_t* __restrict__ minhash, int64_t
     }
   atomicAdd(missing, 1ULL);
 }
+// ... and, through the line table, by the rules of the first query tier (a line that says "see the buckets" counts as found)
+__global__ void index_verify_lines_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta, int ne, int H, InvIndex ix,
+                                          unsigned long long* __restrict__ missing) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)ne * H) return;
+  const int e = (int)(t / H), s = (int)(t % H);
+  if (meta[(int64_t)e * META_W + 3] != 0) return;
+  const uint32_t hv = inv_mix((uint32_t)minhash[(int64_t)e * row_stride + s]);
+  const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u;
+  const uint32_t line = hv >> lsh;
+  const uint32_t* L = ix.lines + (((size_t)s << ix.nl_log) + line) * 16;
+  const uint32_t hdr = L[15] >> 24;
+  if (hdr == IL_FALLBACK) return;
+  int found = 0;
+  auto scan = [&](const uint32_t* W, uint32_t from, uint32_t to) {
+    for (uint32_t i = from; i < to && i < (uint32_t)IL_CAP; i++) {
+      const uint32_t nib = ((i < 8 ? W[14] >> (4 * i) : W[15] >> (4 * (i - 8))) & 15u);
+      const unsigned long long P = ((unsigned long long)nib << 32) | W[i];
+      if ((uint32_t)(P >> eb) == (hv & tmask) && (uint32_t)(P & emk) == (uint32_t)e) found++;
+    }
+  };
+  scan(L, 0u, hdr);
+  if (hdr > (uint32_t)IL_CAP) {
+    const uint32_t* Q = ix.lines + (((size_t)s << ix.nl_log) + (line ^ 1u)) * 16;
+    const uint32_t pn = Q[15] >> 24;
+    if (pn >= (uint32_t)IL_CAP) { atomicAdd(missing, 1ULL); return; }
+    scan(Q, pn, pn + hdr - (uint32_t)IL_CAP);
+  }
+  if (found != 1) atomicAdd(missing, 1ULL);
+}
 void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix,
                          unsigned long long* missing) {
   const long long total = (long long)ne * H;
   if (total <= 0) return;
   hipLaunchKernelGGL(index_verify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, minhash, row_stride, meta, ne, H, ix, missing);
+  if (ix.lines)
+    hipLaunchKernelGGL(index_verify_lines_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, minhash, row_stride, meta, ne, H, ix, missing);
 }
 
 int index_tiles(int ne) { return (ne + IB_TE - 1) / IB_TE; }
@@ -415,6 +524,10 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
   hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
   hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
   if (ix.grouped) hipLaunchKernelGGL(index_group_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_GRP_THREADS), 0, st, ix);
+  if (ix.lines) {
+    const size_t threads = (size_t)H << (ix.nl_log - 1);
+    hipLaunchKernelGGL(index_lines_kernel, dim3((unsigned)((threads + IL_THREADS - 1) / IL_THREADS)), dim3(IL_THREADS), 0, st, ix, H);
+  }
 }
 // (called when the index is sized: an index the compact dense tier covers in one pass gains nothing from the order, and the class
 //  counters bound the size from above.  MHAP_INDEX_GROUP=0|1 never / always, MHAP_INDEX_GROUP_T, MHAP_INDEX_CLASS_LOG: tests, which
@@ -450,10 +563,15 @@ constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lan
 // appended to `big` and handed on: to the dense tier (index_query_dense_kernel), on a large index through <INV_CT_MID,
 // IQ_THREADS_MID> first.  big == nullptr (MHAP_INDEX_TIERS=1, tests): the hit set is split into hash-partition passes over the
 // stored entries instead (split in two until every part fits), which bounds a query's cost by its own postings.
+constexpr int IQ_OV = 64;    // line mode: slots of one query that may fall back to ends / items (more: the query is handed on)
+#ifndef MH_IQ_LB
+#define MH_IQ_LB 4
+#endif
+constexpr int IQ_LB = MH_IQ_LB;   // line mode: lines a lane has in flight
 constexpr int IQ_PRE = 12;   // slots per lane whose first look is kept (H <= 768 with 64 lanes; twelve elements: the compiler addresses such a vector by a uniform index)
 typedef int iq_pre_t __attribute__((ext_vector_type(IQ_PRE)));
-template <int INV_CT, int IQ_THREADS, int SPT>
-__global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
+template <int INV_CT, int IQ_THREADS, int SPT, bool LINES>
+__global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void index_query_kernel(InvIndex ix, const int32_t* __restrict__ qminhash, int64_t qrow_stride,
                                                           const int32_t* __restrict__ qlist, int nq, const int64_t* __restrict__ ids,
                                                           const int64_t* __restrict__ qids, const int32_t* __restrict__ meta,
                                                           const int32_t* __restrict__ qmeta, SearchParams sp,
@@ -486,7 +604,12 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
   //  trip ahead on top of it — with the mixed value recomputed, or the kernel drops to three waves per SIMD — gave nothing: 3.03 / 2.18)
   iq_pre_t pre_hv = 0, pre_lo = 0, pre_n = 0;
   bool pre_ok = false;
-  if (big != nullptr) {
+  // round 6: the index has a LINE table (index_lines_kernel) and this launch hands its large hit sets on: one 64-byte line per lookup
+  // instead of bucket bounds + postings; only slots whose line says "long bucket" (a repeat) go through ends / items below
+  constexpr bool lmode = LINES;   // (launch_index_query: big != nullptr && ix.lines != nullptr)
+  __shared__ uint32_t s_nov;
+  __shared__ uint32_t ovlist[IQ_OV];
+  if (big != nullptr && !lmode) {
     // first tier: the buckets' lengths alone say whether this table can hold the hits — a repeat-rich query is handed over after
     // H loads instead of after counting until the table overflows
     unsigned long long tot = 0;
@@ -534,7 +657,7 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
     if (threadIdx.x == 0) {
       if (s_top == 0) s_bits = 0xFFFFFFFFu;
       else { s_top--; s_prefix = stack[2 * s_top]; s_bits = stack[2 * s_top + 1]; }
-      s_distinct = 0; s_over = 0; s_nseg[0] = 0; s_nseg[1] = 0;
+      s_distinct = 0; s_over = 0; s_nseg[0] = 0; s_nseg[1] = 0; s_nov = 0;
     }
     for (int j = threadIdx.x; j < INV_CT; j += IQ_THREADS) tbl[j] = 0;
     __syncthreads();
@@ -569,11 +692,85 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       }
     };
     bool handed_over = false;
-    for (int s0 = 0, it = 0; s0 < sp.H; s0 += QCAP, it++) {   // workgroup-uniform trip count (barriers inside)
+    int nloop = sp.H;
+    if (lmode) {
+      const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u, hsh = 32u - eb;
+      const size_t lstride = (size_t)16 << ix.nl_log;   // words of one slot's lines
+      // a posting of place i of line words L: tag above the entry's bits; the place's top 4 bits sit in words 14 / 15
+#define IQ_LINE_SCAN(L, from, to, qtag)                                                                                   \
+      {                                                                                                                     \
+        const uint32_t lw_[14] = {L[0].x, L[0].y, L[0].z, L[0].w, L[1].x, L[1].y, L[1].z, L[1].w, L[2].x, L[2].y, L[2].z, L[2].w, L[3].x, L[3].y}; \
+        _Pragma("unroll") for (int i_ = 0; i_ < IL_CAP; i_++) {                                                              \
+          const uint32_t nib_ = ((i_ < 8 ? L[3].z >> (4 * i_) : L[3].w >> (4 * (i_ - 8))) & 15u);                            \
+          const uint32_t tag_ = (lw_[i_] >> eb) | (nib_ << hsh);                                                             \
+          if ((uint32_t)i_ >= (from) && (uint32_t)i_ < (to) && tag_ == (qtag)) { mine++; count_hit((int)(lw_[i_] & emk)); }    \
+        }                                                                                                                   \
+      }
+      for (int sb = (int)threadIdx.x; sb < sp.H; sb += IQ_LB * IQ_THREADS) {
+        uint4 L[IQ_LB][4];
+        uint32_t hvv[IQ_LB], nn[IQ_LB];
+        const uint32_t* lp[IQ_LB];
+#pragma unroll
+        for (int u = 0; u < IQ_LB; u++) {
+          const int s = sb + u * IQ_THREADS;
+          hvv[u] = 0; lp[u] = ix.lines;
+          L[u][3] = make_uint4(0u, 0u, 0u, 0u);
+          if (s < sp.H) {
+            hvv[u] = inv_mix((uint32_t)qrow[s]);
+            lp[u] = ix.lines + (size_t)s * lstride + ((size_t)(hvv[u] >> lsh) << 4);
+            const uint4* l4 = (const uint4*)lp[u];
+            L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
+          }
+        }
+        bool any_partner = false;
+#pragma unroll
+        for (int u = 0; u < IQ_LB; u++) {
+          const int s = sb + u * IQ_THREADS;
+          const uint32_t hdr = L[u][3].w >> 24;
+          nn[u] = 0;
+          if (s < sp.H) {
+            if (hdr == IL_FALLBACK) {
+              const uint32_t at = atomicAdd(&s_nov, 1u);
+              if (at < (uint32_t)IQ_OV) ovlist[at] = (uint32_t)s;
+            } else if (hdr) {
+              nn[u] = hdr;
+              const uint32_t qt = hvv[u] & tmask;
+              IQ_LINE_SCAN(L[u], 0u, hdr, qt);
+              if (hdr > (uint32_t)IL_CAP) any_partner = true;
+            }
+          }
+        }
+        if (any_partner) {
+          // what a line of more than 14 postings could not hold sits in its partner line, behind the partner's own
+#pragma unroll
+          for (int u = 0; u < IQ_LB; u++)
+            if (nn[u] > (uint32_t)IL_CAP) {
+              const uint4* l4 = (const uint4*)(ix.lines + (size_t)(sb + u * IQ_THREADS) * lstride + ((size_t)((hvv[u] >> lsh) ^ 1u) << 4));
+              L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
+            }
+#pragma unroll
+          for (int u = 0; u < IQ_LB; u++)
+            if (nn[u] > (uint32_t)IL_CAP) {
+              const uint32_t pn = L[u][3].w >> 24, qt = hvv[u] & tmask;
+              IQ_LINE_SCAN(L[u], pn, pn + nn[u] - (uint32_t)IL_CAP, qt);
+            }
+        }
+      }
+#undef IQ_LINE_SCAN
+      __syncthreads();
+      const uint32_t nov = s_nov;
+      if (nov > (uint32_t)IQ_OV) { if (threadIdx.x == 0) s_over = 1; nloop = 0; }   // (a query with that many long buckets is repeat-rich: handed on)
+      else nloop = (int)nov;
+      __syncthreads();
+    }
+    for (int s0 = 0, it = 0; s0 < nloop; s0 += QCAP, it++) {   // workgroup-uniform trip count (barriers inside)
       uint32_t hv[SPT], lo[SPT], n[SPT];
+      int sl[SPT];   // the slot a lane looks up: all of them in turn, or (line mode) the slots whose line said "see the buckets"
 #pragma unroll
       for (int u = 0; u < SPT; u++) {
-        const int s = s0 + u * IQ_THREADS + (int)threadIdx.x;
+        const int idx = s0 + u * IQ_THREADS + (int)threadIdx.x;
+        const int s = lmode ? (idx < nloop ? (int)ovlist[idx] : sp.H) : idx;
+        sl[u] = s;
         hv[u] = 0; lo[u] = 0; n[u] = 0;
         if (pre_ok && it * SPT + u < IQ_PRE) {
           if (s < sp.H) { hv[u] = (uint32_t)pre_hv[it * SPT + u]; lo[u] = (uint32_t)pre_lo[it * SPT + u]; n[u] = (uint32_t)pre_n[it * SPT + u]; }
@@ -586,14 +783,14 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
       uint2 w[SPT][4];                                                           // the usual bucket in one round trip
 #pragma unroll
       for (int u = 0; u < SPT; u++) {
-        const uint2* P = ix.items + (size_t)(s0 + u * IQ_THREADS + (int)threadIdx.x) * ix.slot_stride + lo[u];
+        const uint2* P = ix.items + (size_t)sl[u] * ix.slot_stride + lo[u];
         const uint32_t m = n[u] <= (uint32_t)IQ_INLINE ? n[u] : 0u;
 #pragma unroll
         for (int x = 0; x < 4; x++) w[u][x] = (uint32_t)x < m ? P[x] : make_uint2(~hv[u], 0u);
       }
 #pragma unroll
       for (int u = 0; u < SPT; u++) {
-        const int s = s0 + u * IQ_THREADS + (int)threadIdx.x;
+        const int s = sl[u];
         if (n[u] > (uint32_t)IQ_INLINE) {
           // a long bucket (a value many entries share): queued for the whole workgroup (a repeat's bucket holds tens of thousands
           // of postings: one lane would stream it alone)
@@ -640,7 +837,7 @@ __global__ __launch_bounds__(IQ_THREADS) void index_query_kernel(InvIndex ix, co
         // index with that many entries) are split before they are streamed: the pass would overflow after streaming everything
         // (the postings are still streamed, to count the ones that match — "table elements processed" — but no hit is counted)
         bool count_only = false;
-        if (big == nullptr && bits == 0 && s0 + QCAP >= sp.H && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; count_only = true; }
+        if (big == nullptr && bits == 0 && s0 + QCAP >= nloop && (total < ix.ne ? total : (unsigned long long)ix.ne) > 2ULL * (INV_CT * 3 / 4)) { if (threadIdx.x == 0) s_over = 1; count_only = true; }
         uint32_t g = 0;   // bucket of this lane's current posting (its postings come in ascending order)
         for (unsigned long long i0 = threadIdx.x; i0 - threadIdx.x < total; i0 += IQ_THREADS * 8) {
           uint2 e[8];
@@ -1130,11 +1327,14 @@ void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminh
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
                         unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, int tier) {
   if (nq <= 0) return;
-  if (tier == 0)
-    hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
+  if (tier == 0 && big != nullptr && ix.lines != nullptr)
+    hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT, true>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
+                       meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
+  else if (tier == 0)
+    hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT, false>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
                        meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
   else if (tier == 1)
-    hipLaunchKernelGGL((index_query_kernel<INV_CT_MID, IQ_THREADS_MID, 1>), dim3((unsigned)nq), dim3(IQ_THREADS_MID), 0, st, ix, qminhash, qrow_stride, qlist, nq,
+    hipLaunchKernelGGL((index_query_kernel<INV_CT_MID, IQ_THREADS_MID, 1, false>), dim3((unsigned)nq), dim3(IQ_THREADS_MID), 0, st, ix, qminhash, qrow_stride, qlist, nq,
                        ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
   else {
     const bool old_dense = []() { const char* e = getenv("MHAP_DENSE_TIER"); return e && strcmp(e, "counters") == 0; }();   // (the 16-bit-counter kernel for every case: tests)

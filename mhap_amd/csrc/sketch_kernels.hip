@@ -1809,6 +1809,10 @@ __device__ __forceinline__ void w1_row2(int64_t* best, uint2* __restrict__ q, in
 
 // FIXQ: the queue window has the default 4 096 words (every run up to --num-hashes 512): its capacity is then a literal in the enqueue and
 // the drain — as a kernel argument it cost the slot loops one more live scalar and 1.3 % (78.8 -> 79.8 ms at C2)
+#ifndef MH_W1_SEED_ROWS
+#define MH_W1_SEED_ROWS 1
+#endif
+constexpr bool W1_SEED_ROWS = MH_W1_SEED_ROWS != 0;
 template <bool PROF, bool FIXQ>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES_EU, 8))) void minhash_w1_kernel(W1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1858,12 +1862,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES
         ks.kp = (rd.flags & MHAP_RD_MAT) ? a.keys + rd.key_off + (rcs ? rd.key_stride : 0) : nullptr;
         ks.W = (const uint32_t*)(a.store + rd.base_off); ks.nd = (((rd.length + 3) >> 2) + 3) >> 2; ks.L = rd.length; ks.rcs = rcs;
         ks.lut = lut; ks.perm = nullptr;
-        for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;
+        // A row item of a strand whose earlier rows other waves have finished (the items are dealt row-major: every row 0 first) starts from
+        // THEIR minima, read from the merge buffer: any chain value of the strand's own k-mers is a valid upper bound of the slot's
+        // minimum, the result is the same minimum, and the row runs as a "later" row — class filter, a third of a first row's candidates
+        // (round 6: a rank of an 8-GPU job cuts a sixth of its strands into row items, every one of them was a first row)
+        bool seeded = !whole && row > 0 && W1_SEED_ROWS;
+        if (seeded) {
+          const unsigned long long* g = a.merge + (size_t)ti * (size_t)H;
+          bool all = true;
+          for (int s = lane; s < H; s += 64) {
+            const unsigned long long v = __hip_atomic_load(&g[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            best[s] = v == ~0ULL ? INT64_MAX : (int64_t)(v ^ 0x8000000000000000ULL);
+            all = all && v != ~0ULL;
+          }
+          seeded = __all(all);
+        } else
+          for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         bool ok = true;
         const int r0 = whole ? 0 : row, r1 = whole ? nrows : row + 1;
-        for (int r = r0; r < r1; r++) w1_row2<PROF>(best, (uint2*)q, qcap / 2 - 1, r << 11, nk, r == r0, H, ks, a.jump, lane, ok, tp);
+        for (int r = r0; r < r1; r++) w1_row2<PROF>(best, (uint2*)q, qcap / 2 - 1, r << 11, nk, r == r0 && !seeded, H, ks, a.jump, lane, ok, tp);
         // (a row whose candidates overflowed the queue — never seen — is redone one k-mer at a time: exact, slow)
         if (!ok) {
           for (int s = lane; s < H; s += 64) best[s] = INT64_MAX;

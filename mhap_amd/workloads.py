@@ -7,7 +7,7 @@ import os
 
 import numpy as np
 
-from .api import FastaData, MhapParams, synth_reads
+from .api import FastaData, MhapParams, synth_reads, synth_reads_from_genome
 
 SEED = 0x4D484150
 
@@ -51,6 +51,73 @@ def config_reads(name, shard=0, nshards=1, reads=None, length=None, error_rate=0
     n = reads or c["reads"]
     L = length or c["length"]
     return synth_reads(n, L, seed=c["seed"], error_rate=error_rate, shard=shard, nshards=nshards, repeats=c["repeats"])
+
+
+def _revcomp_codes(x):
+    return (3 - x[::-1]).astype(np.uint8)
+
+
+def ecoli_like_genome(seed=SEED ^ 3, size=4_600_000):
+    """A genome with the REPEAT STRUCTURE of E. coli K-12 (the genome behind BASELINE configs[2], whose real reads are in neither
+    tree): 4.6 Mbp of random sequence with seven copies of a ~5-kb rRNA-operon-like element at 99 % identity to their consensus (five
+    on one strand, two on the other, as rrnA-H sit around the origin) and twelve insertion-sequence copies of 0.8-1.3 kb in three
+    families at 99.5 % (IS1-, IS5-, IS3-like), either strand.  Returns (codes uint8[size], list of (name, start, length, strand))."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, size, dtype=np.uint8)
+    placed = []
+
+    def plant(name, elem, copies, div):
+        for c in range(copies):
+            x = elem.copy()
+            m = rng.random(len(x)) < div
+            x[m] = (x[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+            strand = int(rng.integers(0, 2)) if name != "rrn" else (0 if c < 5 else 1)
+            if strand:
+                x = _revcomp_codes(x)
+            for _ in range(1000):                                # a position clear of every earlier copy (by 20 kb)
+                at = int(rng.integers(0, size - len(x)))
+                if all(at + len(x) + 20000 <= a or a + n + 20000 <= at for _, a, n, _ in placed):
+                    break
+            g[at:at + len(x)] = x
+            placed.append((name, at, len(x), strand))
+
+    plant("rrn", rng.integers(0, 4, 5000, dtype=np.uint8), 7, 0.01)
+    plant("IS1", rng.integers(0, 4, 800, dtype=np.uint8), 5, 0.005)
+    plant("IS5", rng.integers(0, 4, 1200, dtype=np.uint8), 4, 0.005)
+    plant("IS3", rng.integers(0, 4, 1300, dtype=np.uint8), 3, 0.005)
+    # forty tandem repeats (REP / microsatellite-like: a unit of 3-60 bp repeated over 100-500 bp): the k-mers of one READ that occur
+    # more than once — what the default tf weighting (no -f) gives a weight > 1 (J/sketch/MinHashSketch.java:98-128)
+    for t in range(40):
+        unit = rng.integers(0, 4, int(rng.integers(3, 61)), dtype=np.uint8)
+        total = int(rng.integers(100, 501))
+        x = np.tile(unit, total // len(unit) + 1)[:total]
+        for _ in range(1000):
+            at = int(rng.integers(0, size - total))
+            if all(at + total + 2000 <= a or a + n + 2000 <= at for _, a, n, _ in placed):
+                break
+        g[at:at + total] = x
+        placed.append(("tandem", at, total, 0))
+    return g, placed
+
+
+def ecoli_like_reads(n=90000, seed=SEED ^ 3, lmax=45000, error_rate=0.15, short_every=997, n_runs_every=50):
+    """Stand-in for BASELINE configs[2] (E. coli PacBio P6-C4, ~90 k reads) with real repeat structure: reads of a log-normal length
+    mix (median ~8 kb, tail to 45 kb: reads past 24 591 bases take the materialised-hash path) drawn from ecoli_like_genome at 15 %
+    error, a few reads under --min-olap-length, a run of N in 2 % of the reads (raw-byte strands).  Default flags meet weights > 1
+    WITHOUT -f here (a read across an operon or an IS copy repeats no k-mer, but its MinHash buckets are shared by every read of every
+    copy: long buckets, seven-fold candidate sets, duplicated-hash groups in the join).  (reads, genome, placed copies)"""
+    g, placed = ecoli_like_genome(seed)
+    rng = np.random.default_rng(seed + 1)
+    L = np.clip(rng.lognormal(9.0, 0.55, n).astype(np.int32), 80, lmax)
+    if short_every:
+        L[::short_every] = rng.integers(10, 116, len(L[::short_every]))
+    fa = synth_reads_from_genome(g, L, seed=seed, error_rate=error_rate)
+    if n_runs_every:
+        for i in rng.choice(n, max(1, n // n_runs_every), replace=False):
+            w = int(rng.integers(5, 200))
+            o = int(fa.offsets[i]) + int(rng.integers(0, max(1, int(L[i]) - w)))
+            fa.bases[o:o + min(w, int(L[i]))] = ord("N")
+    return fa, g, placed
 
 
 def write_fasta(fasta, path, prefix="r"):

@@ -1054,35 +1054,87 @@ def test_full_config5_rank_properties_and_subset_parity(tmp_path):
           f"{len(want)} among the first {nsub} reads; kernel ms " + ", ".join(f"{k}={v['ms']:.0f}" for k, v in kt.items() if v["ms"] > 0))
 
 
-def test_config3_like_read_mix_at_scale_subset_parity():
-    """Stand-in for BASELINE configs[2] (real E. coli reads: the file is in neither tree) at its scale: 50 000 reads with a log-normal
-    length mix (median 8 kb, tail to 50 kb: reads past 24 591 bases take the materialised-hash path, short ones fall under
-    --min-olap-length), runs of N in 2 % of them (raw-byte strands), default flags.  Properties of every record and full parity with
-    the oracle on the pairs among the first 1 500 reads."""
-    N, LMAX = 50000, 50000
-    fa = mhap_amd.synth_reads(N, LMAX, seed=23, error_rate=0.15, coverage=30.0 * LMAX / 9000)
-    rng = np.random.default_rng(5)
-    L = np.clip(rng.lognormal(9.0, 0.55, N).astype(np.int32), 80, LMAX)
-    L[::997] = rng.integers(10, 116, len(L[::997]))                        # a few reads under --min-olap-length (and under k)
-    fa.lengths[:] = L
-    for i in rng.choice(N, N // 50, replace=False):                        # a run of N somewhere in the read
-        w = int(rng.integers(5, 200))
-        o = int(fa.offsets[i]) + int(rng.integers(0, max(1, int(L[i]) - w)))
-        fa.bases[o:o + min(w, int(L[i]))] = ord("N")
-    assert (L > 24591).sum() > 200 and (L < 116).sum() >= 1
+def _check_c3_records(recs, L, ids_ok=True):
+    """Properties every record of a default-flag self search must have (J/impl/MinHashSearch.java:215-241, MatchResult.java:46-65)."""
+    assert np.all(recs["to_id"] < recs["from_id"]) and np.all((recs["score"] >= 0.78) & (recs["score"] <= 1.0) & (recs["raw"] >= 3))
+    assert np.all(recs["alen"] == L[recs["from_id"] - 1]) and np.all(recs["blen"] == L[recs["to_id"] - 1])
+    assert np.all((recs["a1"] >= 0) & (recs["a1"] <= recs["a2"]) & (recs["a2"] <= recs["alen"] - 11) & (recs["b1"] >= -1) & (recs["b2"] <= recs["blen"]))
+    key = (recs["from_id"].astype(np.int64) << 32) | (recs["to_id"].astype(np.int64) << 1) | recs["to_rc"].astype(np.int64)
+    assert len(np.unique(key)) == len(recs)                                 # one record per (query, stored strand)
+
+
+def _subset_parity(fa, recs, idx, nthreads=16):
+    """GPU records among the reads `idx` of the full run == the oracle run on those reads alone (sketches and pair decisions do not
+    depend on the other reads without -f; the ids of a subset are the reads' own)."""
+    idx = np.unique(np.asarray(idx, dtype=np.int64))
+    sub = fa.subset(idx)
+    want = O.record_lines(O.run_self(sub, nthreads=nthreads, cap=1 << 22)["records"])
+    inset = np.zeros(int(fa.ids.max()) + 2, dtype=bool)
+    inset[sub.ids] = True
+    m = inset[recs["from_id"]] & inset[recs["to_id"]]
+    got = sorted(mhap_amd.records_to_lines(recs[m]))
+    assert got == want
+    return len(want)
+
+
+def test_config3_ecoli_shaped_reads_at_scale_subset_parity():
+    """Stand-in for BASELINE configs[2] (real E. coli P6-C4 reads: the file is in neither tree) at its scale AND with its repeat structure
+    (round 6; the round-5 stand-in had a repeat-free genome): 90 000 reads of a log-normal length mix (median 8 kb, tail to 45 kb: reads
+    past 24 591 bases take the materialised-hash path, short ones fall under --min-olap-length, runs of N make raw-byte strands) drawn
+    from a 4.6-Mbp genome with seven ~5-kb operon copies at 99 %, twelve IS copies of 0.8-1.3 kb in three families and forty tandem
+    repeats (k-mers of weight > 1 under the default tf weighting, no -f) — workloads.ecoli_like_reads.  Default flags.  Properties of
+    every record; full parity with the oracle on the pairs among the first 1 500 reads AND among the 500 reads with the most records
+    (the reads across operon / IS copies: seven-fold candidate sets, long buckets, duplicated-hash groups in the join)."""
+    fa, genome, placed = W.ecoli_like_reads(90000)
+    L = fa.lengths
+    assert (L > 24591).sum() > 300 and (L < 116).sum() >= 1 and len(placed) >= 19 + 40
+    with MinHashSearch(MhapParams()) as ms:
+        ms.add_data(fa)
+        recs = ms.find_matches()
+        st = ms.stats(); kt = ms.kernel_times()
+    assert st["queries_searched"] == int((L >= 116).sum()) and len(recs) > 100000
+    _check_c3_records(recs, L)
+    per_read = np.bincount(recs["from_id"], minlength=len(fa) + 2) + np.bincount(recs["to_id"], minlength=len(fa) + 2)
+    busiest = np.argsort(-per_read)[:500] - 1                              # ids are 1-based
+    # the repeat copies are really met: the busiest reads have several times the records of a read at unique 30x coverage
+    assert per_read[busiest + 1].min() > 2 * np.median(per_read[per_read > 0])
+    n1 = _subset_parity(fa, recs, np.arange(1500))
+    n2 = _subset_parity(fa, recs, busiest)
+    assert n1 >= 5 and n2 >= 2000
+    print(f"c3 stand-in (E. coli-shaped): {len(recs)} records from {st['candidates_compared']} candidates ({st['slow_pairs']} through the per-lane kernel); "
+          f"parity on {n1} records among the first 1500 reads and {n2} among the 500 busiest reads; {int((L > 24591).sum())} reads on the materialised-hash path; "
+          "kernel ms " + ", ".join(f"{k}={v['ms']:.0f}" for k, v in kt.items() if v["ms"] > 0))
+
+
+def test_config3_real_reads_when_supplied(tmp_path):
+    """BASELINE configs[2]: real E. coli PacBio P6-C4 reads, default parameters.  The file is in neither tree; a box that has it names it
+    in MHAP_C3_FASTA and this test is the parity gate that goes with `bench.py --config c3`: properties of every record, oracle parity
+    on the pairs among the first 1 500 reads and among the 500 busiest reads, and the native driver on the same file — identical
+    records, MHAP's stderr contract (J/main/MhapMain.java:463-476,576)."""
+    path = W.c3_fasta_path()
+    if path is None:
+        pytest.skip("C3 skipped: MHAP_C3_FASTA is not set / not readable")
+    import subprocess
+    fa = FastaData.from_file(path)
+    L = fa.lengths
     with MinHashSearch(MhapParams()) as ms:
         ms.add_data(fa)
         recs = ms.find_matches()
         st = ms.stats()
-    assert st["queries_searched"] == int((L >= 116).sum()) and len(recs) > 10000
-    assert np.all(recs["to_id"] < recs["from_id"]) and np.all((recs["score"] >= 0.78) & (recs["score"] <= 1.0) & (recs["raw"] >= 3))
-    assert np.all(recs["alen"] == L[recs["from_id"] - 1]) and np.all(recs["blen"] == L[recs["to_id"] - 1])
-    assert np.all((recs["a1"] >= 0) & (recs["a1"] <= recs["a2"]) & (recs["a2"] <= recs["alen"] - 11) & (recs["b1"] >= -1) & (recs["b2"] <= recs["blen"]))
-    nsub = 1500
-    want = O.record_lines(O.run_self(fa.subset(np.arange(nsub)), nthreads=16, cap=1 << 20)["records"])
-    m = (recs["from_id"] <= nsub) & (recs["to_id"] <= nsub)
-    assert sorted(mhap_amd.records_to_lines(recs[m])) == want and len(want) >= 5
-    print(f"c3-like: {len(recs)} records, {len(want)} among the first {nsub} reads, {int((L > 24591).sum())} reads on the materialised-hash path")
+    assert st["queries_searched"] == int((L >= 116).sum()) and len(recs) > 0
+    _check_c3_records(recs, L)
+    per_read = np.bincount(recs["from_id"], minlength=len(fa) + 2) + np.bincount(recs["to_id"], minlength=len(fa) + 2)
+    n1 = _subset_parity(fa, recs, np.arange(min(1500, len(fa))))
+    n2 = _subset_parity(fa, recs, np.argsort(-per_read)[:500] - 1 if len(fa) > 500 else np.arange(len(fa)))
+    cli = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mhap_amd", "lib", "mhap-hip")
+    r = subprocess.run([cli, "-s", path], capture_output=True, text=True, timeout=3600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted(l for l in r.stdout.split("\n") if l)
+    assert lines == sorted(mhap_amd.records_to_lines(recs))
+    nsk = 2 * int((L >= 116).sum())
+    assert f"Processed {nsk} unique sequences (fwd and rev)." in r.stderr and "Time (s) to read and hash from file:" in r.stderr
+    assert "Time (s) to score and output to self:" in r.stderr and f"Total matches found: {len(recs)}" in r.stderr
+    print(f"c3 (real reads, {len(fa)} reads): {len(recs)} records; parity on {n1} + {n2} records of the two subsets; native driver identical")
 
 
 def test_config4_read_shape_slice():
