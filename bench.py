@@ -90,6 +90,9 @@ def main():
                     help="after the timed region: repeat the step, untimed for `value`, for about this long and report the per-step spread "
                          "(settled clocks; also keeps the GPU busy long enough for a 5 s utilisation sampler to see it).  Default 8, "
                          "0 with --no-cpu-baseline")
+    ap.add_argument("--smi-trace", default="",
+                    help="write a clock / power trace of THIS rank's card (tools/smi_trace.py, picked by its PCI address) over the soak leg to "
+                         "this file and put its summary into the line's `soak.smi`; a capture without clock or power samples is reported as failed")
     ap.add_argument("--preflight", action="store_true",
                     help="check what an N-GPU run needs (devices, RCCL entry points, peer access, rendezvous variables) and print why "
                          "it cannot run instead of hanging in a collective; exit code 0 = ready")
@@ -302,6 +305,17 @@ def main():
         n_soak = int(max(1, min(2000, round(soak_s / sec_per_step))))
         per = []
         fence()
+        smi_proc = None
+        if args.smi_trace and rank == 0:
+            import subprocess as _sp
+            pr = torch.cuda.get_device_properties(dev)
+            try:
+                bdf = "%04x:%02x:%02x.0" % (int(pr.pci_domain_id), int(pr.pci_bus_id), int(pr.pci_device_id))
+            except AttributeError:
+                bdf = None
+            cmd = [sys.executable, os.path.join(ROOT, "tools", "smi_trace.py"), args.smi_trace, str(soak_s + 30.0)] + (["--bdf", bdf] if bdf else [])
+            smi_proc = _sp.Popen(cmd, stdout=_sp.PIPE, stderr=_sp.PIPE, text=True)
+            time.sleep(0.3)
         for _ in range(n_soak):
             ts = time.perf_counter()
             step()
@@ -312,6 +326,20 @@ def main():
         soak = {"steps": n_soak, "mean_ms_per_step": round(float(per_ms.mean()), 3), "median_ms_per_step": round(float(np.median(per_ms)), 3),
                 "min_ms": round(float(per_ms.min()), 3), "max_ms": round(float(per_ms.max()), 3),
                 "what": "the timed step repeated back to back after the timed region (this rank's wall time per step, no barrier in between)"}
+        if smi_proc is not None:
+            smi_proc.terminate()
+            try:
+                so, se = smi_proc.communicate(timeout=40)
+            except Exception:   # noqa: BLE001
+                smi_proc.kill(); so, se = "", "smi_trace did not stop"
+            try:
+                soak["smi"] = json.loads([l for l in so.splitlines() if l.startswith("{")][-1])
+            except Exception:   # noqa: BLE001
+                soak["smi"] = None
+            soak["smi_ok"] = smi_proc.returncode == 0
+            soak["smi_file"] = args.smi_trace
+            if smi_proc.returncode != 0:
+                print("bench: " + (se.strip().splitlines()[-1] if se.strip() else "smi_trace failed"), file=sys.stderr, flush=True)
 
     if rank == 0:
         K = max(args.steps, 1)
@@ -337,11 +365,16 @@ def main():
         # without -f) run minhash_w1_kernel, weighted ones minhash_kernel<4,true,true>; the PMC summary files both under "minhash_kernel"
         rocprof_name = {"minhash": "minhash_kernel<4,true,true> (+ minhash_w1_kernel)" if cfg.get("filter") else "minhash_w1_kernel",
                         "overlap": "overlap_join_kernel", "index_build": "index_tile_kernel + index_bins_kernel"}.get(dom, dom + "_kernel")
-        roofline = {"bound": "hbm", "kernel": rocprof_name, "pmc_summary_key": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # `bound` names what really bounds the dominant kernel: the sketch kernels are integer-VALU work, the index and
+        # second-stage kernels memory-side.  achieved / peak / unit / frac stay the SURVEY §8(d) recipe (algorithmic HBM bytes per launch
+        # over the launch time against 8 TB/s) whatever the bound, and are repeated under `hbm`; the VALU fraction is filled in below
+        real_bound = "valu" if dom in ("hash_kmers", "kmer_weight", "minhash", "ordered", "candidate") else "hbm"
+        roofline = {"bound": real_bound, "kernel": rocprof_name, "pmc_summary_key": dom + "_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                    "hbm": {"achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6)},
                     "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": int(launches),
-                    "note": "SURVEY §8(d) recipe (algorithmic HBM bytes / launch time vs 8 TB/s).  The dominant kernel is integer-VALU "
-                            "bound, not HBM bound: its honest ceiling is the `valu` object (bound: valu)"}
+                    "note": "achieved / peak / frac: the SURVEY §8(d) recipe (algorithmic HBM bytes / launch time vs 8 TB/s), tiny by construction "
+                            "for an integer-VALU kernel; `bound` names the real bound and `valu` (same object, and the line's `valu`) its fraction"}
         # measured HBM rate of every kernel (PMC bytes per launch x launches / its summed time): which ones are memory-side
         hbm_by_kernel = {}
         for kname in mhap_amd.KERNEL_NAMES:
@@ -366,6 +399,9 @@ def main():
                                 "(1.97 GHz against 2.2 with the 107-op step: MHAP_MINHASH_PROF), so the fraction fell while the kernel got faster.  Per-chain formulation: 4.79e12 steps/s",
                 "vs_per_chain_ceiling": round(xs_rate / XORSHIFT_CEILING_PER_CHAIN, 4),
                 "weight_factor_assumed": wfac}
+        if dom == "minhash":
+            roofline["valu"] = {"achieved": round(xs_rate, 1), "peak": round(ceil_spec, 1), "unit": "xorshift steps/s", "frac": round(xs_rate / ceil_spec, 4),
+                                "frac_of_measured_clock_ceiling": round(xs_rate / ceil_meas, 4)}
 
         # second stage: the stage whose honest bound IS HBM/L2 bandwidth — 8 S' bytes of the stored row per candidate
         # pair + 8 S' of the query row once per query; the time is the `overlap` slot (join kernel + the per-lane kernel of the

@@ -106,6 +106,31 @@ struct Transport {
   virtual int allgather(const void* send, void* recv, size_t bytes, hipStream_t st, std::string& err) = 0;
   // small host-side all-gather (counts)
   virtual int allgather_host(const void* in, void* out, size_t bytes, std::string& err) = 0;
+  // A rendezvous of the collective entry points: every rank contributes up to three words; the payload has ONE size whatever the call
+  // (four words) and starts with a tag = the kind of rendezvous + how many this transport has made.  Ranks that are out of step — one
+  // rank's add split into more ingest groups than another's, so an add's rendezvous meets a search's — then fail HERE with
+  // the two kinds named, instead of reading each other's differently sized payloads as counts.  all: nranks x 3 words.
+  enum { RV_SEARCH = 1, RV_SEARCH_ALLOC = 2, RV_ADD = 3, RV_ADD_ALLOC = 4, RV_SELFTEST = 5, RV_INGEST = 6 };
+  uint64_t rv_seq = 0;
+  int rendezvous(int kind, const int64_t (&mine)[3], int64_t* all, std::string& err) {
+    const int64_t tag = (int64_t)(((uint64_t)kind << 56) | (rv_seq++ & 0x00FFFFFFFFFFFFFFULL));
+    const int64_t out[4] = {tag, mine[0], mine[1], mine[2]};
+    std::vector<int64_t> in((size_t)nranks * 4, 0);
+    const int rc = allgather_host(out, in.data(), sizeof out, err);
+    if (rc != MHAP_OK) return rc;
+    for (int r = 0; r < nranks; r++) {
+      if (in[(size_t)r * 4] != tag) {
+        static const char* const names[] = {"?", "search", "search (buffers)", "add", "add (buffers)", "self-test", "ingest plan"};
+        const int kr = (int)(((uint64_t)in[(size_t)r * 4]) >> 56);
+        err = std::string("the ranks' collective calls are out of step: this rank is in its ") + names[kind] + " rendezvous no. " + std::to_string(rv_seq - 1) +
+              ", rank " + std::to_string(r) + " in a " + (kr >= 1 && kr <= 6 ? names[kr] : "?") + " rendezvous no. " +
+              std::to_string((unsigned long long)((uint64_t)in[(size_t)r * 4] & 0x00FFFFFFFFFFFFFFULL)) + " (every rank must make the same sequence of add / search calls)";
+        return MHAP_E_STATE;
+      }
+      for (int i = 0; i < 3; i++) all[(size_t)r * 3 + i] = in[(size_t)r * 4 + 1 + i];
+    }
+    return MHAP_OK;
+  }
   // every rank has drained its streams: send buffers may be rewritten
   virtual void quiesce() {}
   // this rank gives up: ranks of the same process waiting for it must not wait for ever
@@ -264,7 +289,7 @@ struct DistState {
   std::string gate_err;
   // eager exchange: eager = the host asked for it; eager_go = the add in progress gathers eagerly (every rank agreed); eager_valid = g_*
   // hold the forward rows of the index as it is now (eager_rows local rows, eager_npad per rank)
-  bool eager = false, eager_go = false, eager_done = false, eager_valid = false;
+  bool eager = false, eager_go = false, eager_done = false, eager_valid = false, eager_suspended = false;
   uint64_t eager_gen = 0;
   int64_t eager_searches = 0;    // searches that found their rows gathered by the add
   int64_t eager_rows = 0, eager_npad = 0;
@@ -343,11 +368,11 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
   int64_t n_pad = 0, total = 0;
   bool use_eager = eager_mine;
   {
-    const int64_t mine[2] = {rows, eager_mine ? 1 : 0};
-    std::vector<int64_t> all((size_t)N * 2, 0);
-    rc = tr->allgather_host(mine, all.data(), sizeof mine, *v.err);
+    const int64_t mine[3] = {rows, eager_mine ? 1 : 0, 0};
+    std::vector<int64_t> all((size_t)N * 3, 0);
+    rc = tr->rendezvous(Transport::RV_SEARCH, mine, all.data(), *v.err);
     if (rc != MHAP_OK) return rc;                         // (a failed rendezvous: ABORT)
-    for (int r = 0; r < N; r++) { n_pad = std::max(n_pad, all[(size_t)r * 2]); total += all[(size_t)r * 2]; use_eager = use_eager && all[(size_t)r * 2 + 1] != 0; }
+    for (int r = 0; r < N; r++) { n_pad = std::max(n_pad, all[(size_t)r * 3]); total += all[(size_t)r * 3]; use_eager = use_eager && all[(size_t)r * 3 + 1] != 0; }
   }
   if (use_eager && n_pad != d->eager_npad) use_eager = false;   // (cannot happen: every rank's count is the one its add announced)
   if (!use_eager) d->eager_valid = false;       // (the gather below overwrites the buffers)
@@ -366,12 +391,12 @@ int exchange_and_search(mhap_handle* h, DistState* d, const int32_t* d_mh, const
                      d->g_od.ensure((size_t)N * np * od_row) == hipSuccess && d->g_mt.ensure((size_t)N * np * mt_row) == hipSuccess &&
                      d->g_ids.ensure((size_t)N * np * 8) == hipSuccess;
     if (!got) (void)hipGetLastError();
-    const int64_t mine = got ? 0 : 1;
-    std::vector<int64_t> all((size_t)N, 0);
-    rc = tr->allgather_host(&mine, all.data(), sizeof mine, *v.err);
+    const int64_t mine[3] = {got ? 0 : 1, 0, 0};
+    std::vector<int64_t> all((size_t)N * 3, 0);
+    rc = tr->rendezvous(Transport::RV_SEARCH_ALLOC, mine, all.data(), *v.err);
     if (rc != MHAP_OK) return rc;
     int bad = -1;
-    for (int r = 0; r < N; r++) if (all[(size_t)r] != 0 && bad < 0) bad = r;
+    for (int r = 0; r < N; r++) if (all[(size_t)r * 3] != 0 && bad < 0) bad = r;
     if (bad >= 0) {
       leave = LEAVE_NONE; tr->quiesce();
       return dfail(v, MHAP_E_NOMEM, got ? "rank " + std::to_string(bad) + " is out of device memory for the exchange buffers" : std::string("out of device memory (exchange buffers)"));
@@ -456,12 +481,12 @@ int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool elig
   const int N = tr->nranks;
   d->eager_go = false; d->eager_done = false; d->eager_valid = false;
   // rendezvous: every rank's row count, negative = "I cannot" (not the first add of an empty index, or more than one launch group)
-  const int64_t mine = eligible ? rows : -1;
-  std::vector<int64_t> counts((size_t)N, 0);
-  int rc = tr->allgather_host(&mine, counts.data(), sizeof(int64_t), *v.err);
+  const int64_t mine[3] = {eligible ? rows : -1, 0, 0};
+  std::vector<int64_t> counts((size_t)N * 3, 0);
+  int rc = tr->rendezvous(Transport::RV_ADD, mine, counts.data(), *v.err);
   if (rc != MHAP_OK) { tr->abort(); return rc; }
   int64_t n_pad = 0, total = 0;
-  for (int64_t c : counts) { if (c < 0) return 0; n_pad = std::max(n_pad, c); total += c; }
+  for (int r = 0; r < N; r++) { const int64_t c = counts[(size_t)r * 3]; if (c < 0) return 0; n_pad = std::max(n_pad, c); total += c; }
   if (total == 0 || (int64_t)N * n_pad > (int64_t)INT32_MAX / 2) return 0;
   const size_t mh_row = (size_t)v.Hrow * 4, od_row = (size_t)v.S * 8, mt_row = (size_t)META_W * 4, np = (size_t)n_pad;
   auto chk = [&](hipError_t e) { return e == hipSuccess; };
@@ -472,11 +497,11 @@ int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool elig
                    chk(d->g_ids.ensure((size_t)N * np * 8));
   if (!got) (void)hipGetLastError();
   {
-    const int64_t flag = got ? 0 : 1;
-    std::vector<int64_t> all((size_t)N, 0);
-    rc = tr->allgather_host(&flag, all.data(), sizeof flag, *v.err);
+    const int64_t flag[3] = {got ? 0 : 1, 0, 0};
+    std::vector<int64_t> all((size_t)N * 3, 0);
+    rc = tr->rendezvous(Transport::RV_ADD_ALLOC, flag, all.data(), *v.err);
     if (rc != MHAP_OK) { tr->abort(); return rc; }
-    for (int64_t f : all) if (f != 0) return 0;
+    for (int r = 0; r < N; r++) if (all[(size_t)r * 3] != 0) return 0;
   }
   d->ids_local.assign(ids, ids + rows);
   d->eager_rows = rows; d->eager_npad = n_pad; d->eager_go = true;
@@ -663,15 +688,29 @@ int mhap_dist_selftest(mhap_handle* h, size_t bytes, double* ms_out) {
   Transport* tr = d->tr;
   const int N = tr->nranks;
   DevBuf sb, rb;
-  DCHK(v, sb.ensure(bytes)); DCHK(v, rb.ensure(bytes * (size_t)N));
-  struct Rel { DevBuf& a; DevBuf& b; ~Rel() { a.release(); b.release(); } } rel{sb, rb};
   hipStream_t cs = d->comm_stream;
-  DCHK(v, hipMemsetAsync(sb.p, (tr->rank + 1) & 0xFF, bytes, cs));
-  DCHK(v, hipMemsetAsync(rb.p, 0, bytes * (size_t)N, cs));
+  // (the guard first: a failed second allocation must not leak the first; and it drains the exchange stream before the buffers go —
+  //  a gather may still be queued on it when a later step fails.  ADVICE r05)
+  struct Rel { DevBuf& a; DevBuf& b; hipStream_t s; ~Rel() { (void)hipStreamSynchronize(s); a.release(); b.release(); } } rel{sb, rb, cs};
+  // this is a collective: a rank that cannot get its buffers (or fill them) says so in a rendezvous and ALL ranks return together —
+  // leaving alone would park the others in the gather until the watchdog's time-out
+  bool got = sb.ensure(bytes) == hipSuccess && rb.ensure(bytes * (size_t)N) == hipSuccess;
+  got = got && hipMemsetAsync(sb.p, (tr->rank + 1) & 0xFF, bytes, cs) == hipSuccess && hipMemsetAsync(rb.p, 0, bytes * (size_t)N, cs) == hipSuccess;
+  if (!got) (void)hipGetLastError();
+  {
+    const int64_t mine[3] = {got ? 0 : 1, (int64_t)bytes, 0};
+    std::vector<int64_t> all((size_t)N * 3, 0);
+    const int rc0 = tr->rendezvous(Transport::RV_SELFTEST, mine, all.data(), *v.err);
+    if (rc0 != MHAP_OK) { tr->abort(); return rc0; }
+    for (int r = 0; r < N; r++) {
+      if (all[(size_t)r * 3] != 0) return dfail(v, MHAP_E_NOMEM, "all-gather self-test: rank " + std::to_string(r) + " could not set its buffers up");
+      if (all[(size_t)r * 3 + 1] != (int64_t)bytes) return dfail(v, MHAP_E_INVALID, "all-gather self-test: rank " + std::to_string(r) + " asked for another size");
+    }
+  }
   const double t0 = now_ms();
   int rc = tr->allgather(sb.p, rb.p, bytes, cs, *v.err);
   if (rc != MHAP_OK) { tr->abort(); return rc; }
-  DCHK(v, hipEventRecord(d->ev_small, cs));
+  if (hipEventRecord(d->ev_small, cs) != hipSuccess) { (void)hipGetLastError(); tr->abort(); return dfail(v, MHAP_E_HIP, "all-gather self-test: hipEventRecord failed"); }
   rc = tr->wait_event(d->ev_small, *v.err);
   if (rc != MHAP_OK) return rc;
   if (ms_out) *ms_out = now_ms() - t0;

@@ -183,12 +183,13 @@ namespace mhap {
 
 // groups of <= group_bases bases (and <= 2^21 reads) over the subset start, start + stride, ...; for each group `consume(slot)` runs on
 // the calling thread while a producer thread packs the next group into the other slot
+// on_plan(groups): called once before anything is consumed, also for an empty subset (a collective caller agrees with its peers there)
 int ingest_pipeline(const FastaScanImpl& sc, int64_t start, int64_t stride, int min_olap, bool fwd_only,
-                    const std::function<int(Slot&)>& consume, std::string& err) {
+                    const std::function<int(Slot&)>& consume, std::string& err, const std::function<int(size_t)>& on_plan = nullptr) {
   std::vector<int64_t> idx;
   const int64_t nrec = (int64_t)sc.len.size();
   for (int64_t r = start; r < nrec; r += stride) idx.push_back(r);
-  if (idx.empty()) return MHAP_OK;
+  if (idx.empty()) return on_plan ? on_plan(0) : MHAP_OK;
   int64_t group_bases = 256LL << 20;
   if (const char* e = getenv("MHAP_INGEST_GROUP_BASES")) { const long long v = atoll(e); if (v > 0) group_bases = v; }
   // a quarter-size first group lets the GPU start early; after it the packing (15 GB/s on 16 threads) stays ahead of the kernels
@@ -202,6 +203,7 @@ int ingest_pipeline(const FastaScanImpl& sc, int64_t start, int64_t stride, int 
     groups.emplace_back(lo, hi);
     lo = hi;
   }
+  if (on_plan) { const int rp = on_plan(groups.size()); if (rp != MHAP_OK) return rp; }
   Slot slots[2];
   std::mutex mu; std::condition_variable cv;
   bool failed = false;
@@ -243,11 +245,16 @@ int ingest_add_subset(mhap_handle* h, const FastaScanImpl* scan, int64_t start, 
   HandleView v = handle_view(h);
   (void)hipSetDevice(v.device);
   std::string err;
+  // Under the eager exchange every add is a rendezvous of the ranks, and a rank's share may split into a different number of ingest groups
+  // than another's: the ranks agree on the plan FIRST — one rendezvous per call of this function whatever the group counts —
+  // and keep the eager exchange only when every rank adds exactly one group; otherwise it is suspended on all of them for this ingest
+  // (the exchange then happens at search time) and no add makes a rendezvous.
   const int rc = ingest_pipeline(*scan, start, stride, v.min_olap_length, false, [&](Slot& s) {
     int r = internal_stage_packed(h, s.descs.data(), s.ids.data(), (int64_t)s.descs.size(), s.pin, s.bytes);
     if (r == MHAP_OK) r = mhap_index_add_staged(h);
     return r;
-  }, err);
+  }, err, [&](size_t ngroups) { const int r = dist_ingest_scope(h, (int64_t)ngroups); return r < 0 ? r : MHAP_OK; });
+  dist_ingest_scope_end(h);
   if (rc != MHAP_OK && !err.empty()) *v.err = err;
   return rc;
 }

@@ -79,6 +79,11 @@ int dist_eager_begin(mhap_handle* h, int64_t rows, const int64_t* ids, bool elig
 int dist_eager_ordered(mhap_handle* h, hipStream_t producer, const int32_t* d_ordered_rows);   // rows of this add: [2 rows][S][2], forward = even
 int dist_eager_minhash(mhap_handle* h, hipStream_t producer, const int32_t* d_minhash_rows, const int32_t* d_meta_rows);
 bool dist_eager_wanted(mhap_handle* h);
+// An ingest of several adds (mhap_index_add_scan): COLLECTIVE when the eager exchange is on — the ranks exchange their group counts; 1 = every
+// rank adds exactly one group and the add's own rendezvous follow, 0 = the eager exchange is suspended on every rank until
+// dist_ingest_scope_end (no add makes a rendezvous), < 0 an error code.  Not a rank / eager off: 0 without any communication.
+int dist_ingest_scope(mhap_handle* h, int64_t ngroups);
+void dist_ingest_scope_end(mhap_handle* h);
 int dist_eager_reserve_wgs(mhap_handle* h);   // workgroup slots the persistent MinHash grid leaves free for the collective's own kernels (RCCL; 0: copy engines)
 void dist_eager_commit(mhap_handle* h);   // the add is complete (host mirrors included): what was gathered describes the index as it is now
 // install a group of reads that the caller packed itself (2 bits per base / raw bytes, laid out like stage_reads does) as the handle's

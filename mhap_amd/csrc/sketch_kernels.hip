@@ -1530,6 +1530,7 @@ struct W1Args {
   uint32_t* qbuf; int qcap;          // the waves' candidate queues: qcap words each (minhash_queue_words)
   unsigned long long* merge;         // n_tail x H words, filled with 0xFF: minima of the row items, sign bit flipped (unsigned order)
   unsigned long long* prof;          // MHAP_MINHASH_PROF: wave-clock sums {key load + transpose, first-row slots, later-row slots, drains, rows, first rows, candidates}
+  int stagger;                       // clocks a wave waits before its first item, times its slot number on its SIMD (mod 4): minhash_w1_kernel
 };
 
 // the key behind chain value x after n >= 1 steps: inverse tables for the next multiple of 4 (coarse, then fine), then up to 3 steps forward
@@ -1834,6 +1835,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MH_W1_WAVES
   unsigned long long nst = 0;
   unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const unsigned long long tk0 = MHAP_TICK();
+  // Round 6: the grid's waves all start a first row at the same moment, and a row is three phases — key load + transposes (memory
+  // and LDS latency), the slot loop (VALU), the drain (L2 tables, LDS atomics) — so the four waves of a SIMD sit in the SAME phase
+  // together, row after row: the VALU idles through everybody's loads and drains.  A long launch drifts apart by itself; a rank of an
+  // 8-GPU job has six strands per wave and stays in step to the end (MHAP_MINHASH_PROF: 679 k wave-clocks per row against 618 k, all of
+  // it in the two memory phases).  So the waves start a quarter of a row apart: slot number on the SIMD (HW_ID.WAVE_ID) x a.stagger clocks.
+  if (a.stagger > 0) {
+    const int slot = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) & 3u);   // HW_REG_HW_ID (4), bits 0..3 = WAVE_ID
+    const long long until = (long long)slot * a.stagger;
+    for (long long c = 0; c < until; c += 127 * 64) __builtin_amdgcn_s_sleep(127);
+  }
   for (;;) {
     unsigned long long tk = 0;
     if (lane == 0) tk = atomicAdd(a.counter, 1ULL);
@@ -2100,6 +2111,11 @@ bool launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
       a.k = k; a.k2 = k2; a.H = H; a.counter = counter_u; a.stat = counter_u + 8;
       a.out_rows = out_rows; a.out_stride = out_stride; a.out_status = out_status; a.status_stride = status_stride;
       a.jump = jump_w1; a.unjump = unjump; a.jump_na = W1_JUMP_NA; a.qbuf = qbuf; a.qcap = qcap; a.merge = merge;   // (its own two-level table set)
+      {   // a quarter of a row's ~1 300 clocks per slot (MHAP_W1_STAGGER: clocks per SIMD slot number; 0 = all waves start together)
+        static int stag = -2;
+        if (stag == -2) { const char* e = getenv("MHAP_W1_STAGGER"); stag = e ? atoi(e) : -1; }
+        a.stagger = stag >= 0 ? stag : H * 330;
+      }
       const long long items = a.n_whole + a.n_tail * (long long)a.rmax;
       const int nb = (int)std::min<long long>(nblocks, (items + 3) / 4);
       const size_t lds1 = (size_t)H * 8 * 4 + lut_bytes;

@@ -9,6 +9,7 @@ import pytest
 import oracle_lib as O
 import mhap_amd
 from mhap_amd import FastaData, MhapParams, MinHashSearch
+from mhap_amd import workloads as W
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -20,8 +20,14 @@ import sys
 import threading
 import time
 
-out = sys.argv[1] if len(sys.argv) > 1 else "smi_trace.txt"
-limit = float(sys.argv[2]) if len(sys.argv) > 2 else 600.0
+argv = list(sys.argv[1:])
+bdf = None
+if "--bdf" in argv:                       # the PCI address of the card to trace (bench.py --smi-trace passes the one HIP reports for device 0)
+    i = argv.index("--bdf")
+    bdf = argv[i + 1].lower()
+    del argv[i:i + 2]
+out = argv[0] if len(argv) > 0 else "smi_trace.txt"
+limit = float(argv[1]) if len(argv) > 1 else 600.0
 stop = threading.Event()
 signal.signal(signal.SIGTERM, lambda *_: stop.set())
 signal.signal(signal.SIGINT, lambda *_: stop.set())
@@ -58,7 +64,17 @@ def busiest_card(seconds=1.5):
     return max(cs, key=lambda c: tot[c])
 
 
-dev = busiest_card()
+def card_of_bdf(b):
+    for c in cards():
+        try:
+            if os.path.basename(os.path.realpath(c)).lower() == b:
+                return c
+        except OSError:
+            pass
+    return None
+
+
+dev = (card_of_bdf(bdf) if bdf else None) or busiest_card()
 hw = (glob.glob(os.path.join(dev, "hwmon", "hwmon*")) or [None])[0] if dev else None
 files = {}
 if hw:
@@ -140,3 +156,13 @@ with open(out, "w") as fh:
     for t, s in smi_rows:
         fh.write("%.3f %s\n" % (t - t0, s.replace("\n", " ")))
 print(json.dumps(summ))
+# Round 6: a trace without clock or power samples is a FAILED capture, said so loudly and by the exit code, so that it is
+# never committed as evidence (five of round 5's seven captures were empty and nobody noticed)
+have_clk = any(summ[k] for k in ("sclk_MHz_hwmon", "sclk_MHz_dpm"))
+have_pwr = any(summ[k] for k in ("power_W_average", "power_W_input"))
+if not (have_clk and have_pwr):
+    msg = "smi_trace FAILED: no %s samples (device %s, files %s)" % (" / ".join(n for n, h in (("clock", have_clk), ("power", have_pwr)) if not h), dev, sorted(files))
+    with open(out, "a") as fh:
+        fh.write("# " + msg + "\n")
+    print(msg, file=sys.stderr)
+    sys.exit(3)
