@@ -460,7 +460,26 @@ namespace mhap {
 bool dist_eager_wanted(mhap_handle* h) {
   HandleView v = handle_view(h);
   DistState* d = (DistState*)*v.dist;
-  return d && d->eager;
+  return d && d->eager && !d->eager_suspended;
+}
+int dist_ingest_scope(mhap_handle* h, int64_t ngroups) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d || !d->eager) return 0;
+  Transport* tr = d->tr;
+  const int64_t mine[3] = {ngroups, 0, 0};
+  std::vector<int64_t> all((size_t)tr->nranks * 3, 0);
+  const int rc = tr->rendezvous(Transport::RV_INGEST, mine, all.data(), *v.err);
+  if (rc != MHAP_OK) { tr->abort(); return rc; }
+  bool one_each = true;
+  for (int r = 0; r < tr->nranks; r++) one_each = one_each && all[(size_t)r * 3] == 1;
+  d->eager_suspended = !one_each;
+  return one_each ? 1 : 0;
+}
+void dist_ingest_scope_end(mhap_handle* h) {
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (d) d->eager_suspended = false;
 }
 // The ordered rows' all-gather and the persistent MinHash grid become runnable at the same moment (both wait for the ordered kernel).
 // A grid that takes every workgroup slot of every CU leaves an RCCL kernel nothing to run on until it ends — the gather would simply

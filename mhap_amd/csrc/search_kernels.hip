@@ -563,6 +563,9 @@ constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lan
 // appended to `big` and handed on: to the dense tier (index_query_dense_kernel), on a large index through <INV_CT_MID,
 // IQ_THREADS_MID> first.  big == nullptr (MHAP_INDEX_TIERS=1, tests): the hit set is split into hash-partition passes over the
 // stored entries instead (split in two until every part fits), which bounds a query's cost by its own postings.
+#ifndef MH_IQ_TIMING
+#define MH_IQ_TIMING 0   // timing builds of the first query tier (results wrong): 1 no `elements` atomic, 2 no hit counting, 4 no global atomic in the emit
+#endif
 constexpr int IQ_OV = 64;    // line mode: slots of one query that may fall back to ends / items (more: the query is handed on)
 #ifndef MH_IQ_LB
 #define MH_IQ_LB 4
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     const uint32_t cmax = ebits >= 32 ? 0u : (0xFFFFFFFFu >> ebits);
     const uint32_t sat = (uint32_t)sp.num_min_matches < cmax - (uint32_t)IQ_THREADS ? (uint32_t)sp.num_min_matches : cmax - (uint32_t)IQ_THREADS;
     auto count_hit = [&](int me) {
+      if (MH_IQ_TIMING & 2) return;
       const uint32_t hm = inv_mix((uint32_t)me);
       if (((hm >> CT_LOG) & pmask) != prefix) return;
       const uint32_t id = (uint32_t)me + 1u;
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     (void)handed_over;
     __syncthreads();
-    if (mine && !(s_over && big != nullptr)) atomicAdd(elements, mine);
+    if (!(MH_IQ_TIMING & 1) && mine && !(s_over && big != nullptr)) atomicAdd(elements, mine);
     if (s_over && big != nullptr) {
       // first tier: hand the query to the launch with the large count table (it starts over; nothing was emitted yet)
       if (threadIdx.x == 0) big[atomicAdd(big_count, 1ULL)] = qe;
@@ -901,7 +905,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     uint32_t local = 0;
     if (mycount) local = atomicAdd(&s_distinct, (uint32_t)mycount);
     __syncthreads();
-    if (threadIdx.x == 0) s_base = s_distinct ? atomicAdd(cand_count, (unsigned long long)s_distinct) : 0ULL;
+    if (threadIdx.x == 0) s_base = (s_distinct && !(MH_IQ_TIMING & 4)) ? atomicAdd(cand_count, (unsigned long long)s_distinct) : 0ULL;
     __syncthreads();
     unsigned long long slot = s_base + local;
 #pragma unroll
