@@ -96,6 +96,12 @@ def main():
     ap.add_argument("--preflight", action="store_true",
                     help="check what an N-GPU run needs (devices, RCCL entry points, peer access, rendezvous variables) and print why "
                          "it cannot run instead of hanging in a collective; exit code 0 = ready")
+    ap.add_argument("--exchange-only", action="store_true",
+                    help="the exchange of the chosen configuration by itself (VERDICT r05 item 6): every rank's real row volumes are all-gathered "
+                         "(a) with NO compute beside them (mhap_dist_selftest with the bytes of the ordered rows / of the MinHash + meta + id rows) and "
+                         "(b) by the eager add, UNDER the MinHash kernel (events on the exchange stream: mhap_dist_exchange_timing), with the part of "
+                         "(b) the search still had to wait for; one JSON line with every rank's numbers: fabric time and the interaction with a "
+                         "power-bound kernel come apart in the first record of a real N-GPU run.  Launch like the timed run")
     ap.add_argument("--dry-collective", action="store_true",
                     help="form the N-rank communicator exactly as the timed run does (torch only carries the unique id), all-gather 1 MB "
                          "per rank through the library's transport, check every rank's block and peer access, print one JSON line with "
@@ -106,6 +112,8 @@ def main():
         raise SystemExit(preflight(args.gpus))
     if args.dry_collective:
         raise SystemExit(dry_collective(args.gpus))
+    if args.exchange_only:
+        raise SystemExit(exchange_only(args))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -547,6 +555,87 @@ def dry_collective(n):
     if rank == 0:
         rep.update(ready=bool(ok), ranks=views if err is None else None, per_rank_results=alls)
         emit(rep)
+    ms.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def exchange_only(args):
+    """`bench.py --gpus N --exchange-only [--config c2]`: see --help.  One JSON line from rank 0."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--exchange-only --gpus {args.gpus}: launch with torch.distributed.run --nproc-per-node {args.gpus} (WORLD_SIZE is {world})")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    os.environ.setdefault("MHAP_DIST_TIMEOUT_S", "300")
+    cfg = W.CONFIGS[args.config]
+    H, S = args.hashes or cfg["hashes"], 1536
+    fa = W.config_reads(args.config, shard=rank, nshards=world, reads=args.reads or None, length=args.length or None, error_rate=args.error_rate)
+    n_local = len(fa)
+    flt = None
+    ms = MinHashSearch(W.params_for(args.config, device=local_rank, num_hashes=H), kmer_filter=flt)
+    ms.stage(fa)
+    ms.dist_init(rank, world, mdist.broadcast_unique_id(dist, rank, MinHashSearch.dist_unique_id))
+    n_pad = n_local
+    if dist is not None:
+        t = torch.tensor([n_local], dtype=torch.int64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        n_pad = int(t.item())
+    Hrow = ms.params.num_hashes
+    ord_bytes, small_bytes = n_pad * S * 8, n_pad * (Hrow * 4 + 16 + 8)
+    mine = {"rank": rank, "reads": n_local, "rows_padded": n_pad, "ordered_bytes_sent": ord_bytes, "small_bytes_sent": small_bytes, "error": None}
+    try:
+        ms.dist_selftest(1 << 20)                                        # (channels warm)
+        # (a) the fabric by itself: the same bytes per rank, nothing else on the chip (the self-test takes at most 1 GiB per rank)
+        alone_ord = [ms.dist_selftest(min(ord_bytes, 1 << 30)) for _ in range(3)]
+        alone_small = [ms.dist_selftest(max(1, min(small_bytes, 1 << 30))) for _ in range(3)]
+        # (b) the eager add: the gathers run under the add's kernels; then the search says what it still had to wait for
+        ms.dist_set_eager(True)
+        under = []
+        for _ in range(max(1, args.steps) + 1):
+            ms.clear()
+            t0 = time.perf_counter()
+            ms.add_staged(); ms.synchronize()
+            t_add = time.perf_counter() - t0
+            xt = ms.dist_exchange_timing()
+            t1 = time.perf_counter()
+            recs = ms.dist_find_matches()
+            t_search = time.perf_counter() - t1
+            tm = ms.dist_last_timing()
+            under.append({"add_ms": round(t_add * 1e3, 3), "ordered_gather_ms": round(xt["ordered_gather_ms"], 3), "small_gather_ms": round(xt["small_gather_ms"], 3),
+                          "search_ms": round(t_search * 1e3, 3), "exposed_ms": round(tm["gather_small_ms"] + tm["wait_ordered_ms"], 3),
+                          "eager_searches": ms.dist_eager_searches(), "records": len(recs)})
+        under = under[1:]                                                   # (the first step allocates)
+        gb = lambda b, ms_: round((world - 1) * b / (ms_ / 1e3) / 1e9, 2) if world > 1 and ms_ > 0 else None   # noqa: E731
+        mine.update(alone={"ordered_gather_ms": [round(x, 3) for x in alone_ord], "small_gather_ms": [round(x, 3) for x in alone_small],
+                           "ordered_GBps_received": gb(min(ord_bytes, 1 << 30), min(alone_ord))},
+                    under_the_add=under,
+                    hidden_ms=round(min(u["ordered_gather_ms"] + u["small_gather_ms"] - u["exposed_ms"] for u in under), 3),
+                    exposed_ms=round(min(u["exposed_ms"] for u in under), 3))
+    except Exception as e:   # noqa: BLE001
+        mine["error"] = repr(e)
+    alls = [mine]
+    if dist is not None:
+        alls = [None] * world
+        try:
+            dist.all_gather_object(alls, mine)
+        except Exception as e:   # noqa: BLE001
+            alls = [mine, {"error": "all_gather_object: " + repr(e)}]
+    ok = all(a and a.get("error") is None for a in alls)
+    if rank == 0:
+        emit({"exchange_only": True, "n_gpus": world, "config": args.config, "ok": bool(ok),
+              "what": "alone = mhap_dist_selftest with this rank's real row bytes and nothing else on the chip; under_the_add = the same gathers "
+                      "issued by the eager add while its kernels run (events on the exchange stream), exposed_ms = what the search still waited for "
+                      "(phase_wall_ms.exchange of the timed line), hidden_ms = gather time minus that",
+              "per_rank": alls})
     ms.close()
     if dist is not None:
         dist.barrier()

@@ -285,6 +285,11 @@ int mhap_dist_find_matches_reads(mhap_handle* h, const char* bases, const int64_
 int mhap_dist_set_eager(mhap_handle* h, int32_t on);
 int64_t mhap_dist_eager_searches(mhap_handle* h);   /* searches of this rank that found every rank's rows already gathered by the add */
 int mhap_dist_last_timing(mhap_handle* h, double* out3);
+/* The eager exchange of the last add as the exchange stream saw it (the gathers run UNDER the add's kernels): out4 = {ms of the ordered
+ * rows' all-gather, bytes this rank received in it, ms of the MinHash + meta + id rows' all-gathers, bytes received}; -1 ms = not run
+ * since the last call.  Waits for the gathers.  With mhap_dist_selftest (the same volume with no kernel beside it) this separates fabric
+ * time from the interaction with a power-bound compute kernel (bench.py --exchange-only).  No reference counterpart (§8e tooling). */
+int mhap_dist_exchange_timing(mhap_handle* h, double* out4);
 /* The transport's own view of this rank (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion), for a launcher that
  * wants to confirm that its N processes formed ONE communicator over N devices — the reference has nothing to compare: one JVM, one index
  * (AbstractMatchSearch.java:67-117).  out5 = {ranks, this rank, communicator's device, handle's device, RCCL version code};

@@ -61,7 +61,7 @@ EXPORTED_SYMBOLS = [
     "mhap_selftest_hash_windows", "mhap_selftest_overlap_lane", "mhap_stage_reads", "mhap_index_add_staged",
     "mhap_sketch_staged_device", "mhap_find_matches_self_shard", "mhap_synth_reads_shard", "mhap_selftest_transpose32", "mhap_selftest_pass_min", "mhap_selftest_xorshift_jump", "mhap_selftest_xorshift_unjump", "mhap_find_matches_sketches",
     "mhap_synth_reads_repeats", "mhap_synth_reads_genome", "mhap_find_matches_device", "mhap_set_filter_whitelist", "mhap_set_filter_file", "mhap_selftest_bloom", "mhap_set_second_stage_gate",
-    "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing", "mhap_dist_info", "mhap_dist_selftest", "mhap_dist_set_eager", "mhap_dist_eager_searches",
+    "mhap_dist_unique_id", "mhap_dist_init", "mhap_dist_finalize", "mhap_dist_find_matches_self", "mhap_dist_find_matches_reads", "mhap_dist_last_timing", "mhap_dist_exchange_timing", "mhap_dist_info", "mhap_dist_selftest", "mhap_dist_set_eager", "mhap_dist_eager_searches",
     "mhap_group_create", "mhap_group_destroy", "mhap_group_size", "mhap_group_rank", "mhap_group_last_error", "mhap_group_add_reads", "mhap_group_clear",
     "mhap_group_find_matches_self", "mhap_group_find_matches_reads", "mhap_group_get_stats", "mhap_abi_version", "mhap_abi_sizes",
     "mhap_index_reserve", "mhap_fasta_scan_open", "mhap_fasta_scan_free", "mhap_fasta_scan_reads", "mhap_fasta_scan_bases", "mhap_fasta_scan_info",
@@ -660,6 +660,12 @@ class MinHashSearch:
         ver = int(out[4])
         return {"comm_count": int(out[0]), "comm_user_rank": int(out[1]), "comm_device": int(out[2]), "handle_device": int(out[3]),
                 "rccl_version": (f"{ver // 10000}.{ver // 100 % 100}.{ver % 100}" if ver else None), "pci_bus_id": pci.value.decode() or None}
+
+    def dist_exchange_timing(self):
+        """The eager exchange of the last add as the exchange stream saw it: mhap_dist_exchange_timing."""
+        out = (C.c_double * 4)()
+        self._chk(self._lib.mhap_dist_exchange_timing(self._h, out))
+        return {"ordered_gather_ms": out[0], "ordered_bytes_received": out[1], "small_gather_ms": out[2], "small_bytes_received": out[3]}
 
     def dist_selftest(self, nbytes=1 << 20):
         """Collective: all-gather `nbytes` of a known pattern per rank through the handle's transport and check every block; returns the gather's ms."""

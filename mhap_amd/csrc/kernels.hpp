@@ -138,7 +138,9 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, int tier);
+                        unsigned long long* split_count, unsigned long long* elements_total, int32_t* big, unsigned long long* big_count, int tier,
+                        unsigned long long* elements_spread);   // elements_spread: index_elements_spread_words() zeroed words (scratch of the count)
+int index_elements_spread_words();
 int index_query_dense_ranges(int64_t entries);   // passes the dense tier makes over an index of this size
 bool index_query_tiers();
 bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches);   // tier 0 / 1: can its packed hit-count words hold this index and threshold?   // false: the build has no second tier (-DMH_IQ_BIG_CT=0)

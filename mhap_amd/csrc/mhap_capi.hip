@@ -140,7 +140,7 @@ struct mhap_handle {
   DevBuf q_minhash, q_ordered, q_meta, q_ids;
 
   // search scratch
-  DevBuf qlist, rowstart, cand, slow_cand, slow_cand2, slow_cand3, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big, inv_lines;
+  DevBuf qlist, rowstart, cand, slow_cand, slow_cand2, slow_cand3, recs, recs2, ovl_scratch, inv_ends, inv_items, inv_staged, inv_scratch, inv_big, inv_lines, iq_espread;
   // post stage of a search chunk (record read-back, conversion, sink) on a worker thread, one chunk behind the kernels: two sets of buffers
   hipStream_t copy_stream = nullptr;
   uint8_t* pin_rec[2] = {nullptr, nullptr};
@@ -826,6 +826,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       SCHK(hipMemsetAsync(ctr, 0, 160, h->stream));
       if (use_index) {
         SCHK(h->inv_big.ensure((size_t)nq * 8));   // two lists: handed on by the first tier / by the middle tier
+        // (the spread words of the "elements processed" count: zeroed once, every launch folds them into ctr[4] and leaves them zero)
+        if (!h->iq_espread.p) { SCHK(h->iq_espread.ensure((size_t)index_elements_spread_words() * 8)); SCHK(hipMemsetAsync(h->iq_espread.p, 0, (size_t)index_elements_spread_words() * 8, h->stream)); }
+        unsigned long long* espread = h->iq_espread.as<unsigned long long>();
         const char* tv = getenv("MHAP_INDEX_TIERS");   // "1": first tier only (large hit sets are split right away; tests)
         const bool tiers = index_query_tiers() && !(tv && tv[0] == '1');
         // (an index or a numMinMatches the first tier's packed hit-count words cannot hold: every query takes the dense tier)
@@ -845,7 +848,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         time_begin(h, MHAP_K_INDEX_QUERY);
         launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, h->qlist.as<int32_t>() + c0, nq,
                            h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && t0 < 2 ? listA : nullptr, ctr + 6, t0);
+                           (unsigned long long)cand_cap, ctr + 3, ctr + 4, tiers && t0 < 2 ? listA : nullptr, ctr + 6, t0, espread);
         time_end(h);
         SCHK(hipGetLastError());
         unsigned long long c5[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -862,7 +865,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
           if (c5[6] > 0) {
             time_begin(h, MHAP_K_INDEX_QUERY);
             launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, listA, (int)c5[6], h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp,
-                               h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, ctr + 3, ctr + 4, listB, ctr + 8, 1);
+                               h->cand.as<Candidate>(), ctr + 0, (unsigned long long)cand_cap, ctr + 3, ctr + 4, listB, ctr + 8, 1, espread);
             time_end(h);
             SCHK(hipGetLastError());
             SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
@@ -875,7 +878,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
           time_begin(h, MHAP_K_INDEX_QUERY);
           launch_index_query(h->stream, h->inv, qs.d_minhash, qs.mh_stride, dense_list, (int)n_dense,
                              h->d_ids.as<int64_t>(), qs.d_ids, h->d_meta, qs.d_meta, sp, h->cand.as<Candidate>(), ctr + 0,
-                             (unsigned long long)cand_cap, ctr + 3, ctr + 4, nullptr, nullptr, 2);
+                             (unsigned long long)cand_cap, ctr + 3, ctr + 4, nullptr, nullptr, 2, espread);
           time_end(h);
           SCHK(hipGetLastError());
           SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
@@ -1193,7 +1196,7 @@ void mhap_destroy(mhap_handle* h) {
   for (auto& p : h->free_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   DevBuf* bufs[] = {&h->f_keys, &h->f_vals, &h->f_bloom, &h->score_tbl, &h->jump_tbl, &h->hash_luts, &h->own_minhash, &h->own_ordered, &h->own_meta, &h->d_ids, &h->store, &h->descs,
                     &h->keys, &h->wts, &h->perm, &h->h32, &h->slist, &h->info, &h->slabs, &h->counters, &h->order, &h->mhq, &h->mhmerge, &h->unjump_tbl, &h->jump_w1_tbl, &h->q_minhash, &h->q_ordered, &h->q_meta, &h->q_ids,
-                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->slow_cand2, &h->slow_cand3, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big, &h->inv_lines,
+                    &h->qlist, &h->rowstart, &h->cand, &h->slow_cand, &h->slow_cand2, &h->slow_cand3, &h->recs, &h->recs2, &h->ovl_scratch, &h->inv_ends, &h->inv_items, &h->inv_staged, &h->inv_scratch, &h->inv_big, &h->inv_lines, &h->iq_espread,
                     &h->pass_min_tbl, &h->poshist, &h->q_poshist};
   for (DevBuf* b : bufs) b->release();
   if (h->pin_store) (void)hipHostFree(h->pin_store);

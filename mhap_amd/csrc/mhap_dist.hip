@@ -119,7 +119,8 @@ struct Transport {
     const int rc = allgather_host(out, in.data(), sizeof out, err);
     if (rc != MHAP_OK) return rc;
     for (int r = 0; r < nranks; r++) {
-      if (in[(size_t)r * 4] != tag) {
+      // (the KIND must agree; the counts may differ after a rank left an earlier call with an error of its own — they are for the message)
+      if ((((uint64_t)in[(size_t)r * 4]) >> 56) != (uint64_t)kind) {
         static const char* const names[] = {"?", "search", "search (buffers)", "add", "add (buffers)", "self-test", "ingest plan"};
         const int kr = (int)(((uint64_t)in[(size_t)r * 4]) >> 56);
         err = std::string("the ranks' collective calls are out of step: this rank is in its ") + names[kind] + " rendezvous no. " + std::to_string(rv_seq - 1) +
@@ -280,6 +281,9 @@ struct DistState {
   Transport* tr = nullptr;
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_pack = nullptr, ev_small = nullptr, ev_big = nullptr;
+  hipEvent_t ev_xt[4] = {nullptr, nullptr, nullptr, nullptr};   // timing events on the exchange stream: ordered rows' gather begin / end, MinHash + meta + id rows' begin / end
+  bool xt_ordered = false, xt_small = false;                   // ... recorded since the last read-out
+  double xt_bytes[2] = {0, 0};                                 // bytes this rank received in them
   DevBuf s_mh, s_od, s_mt, s_ids;      // this rank's forward rows, packed
   DevBuf g_mh, g_od, g_mt, g_ids;      // gathered rows of all ranks, rank after rank
   DevBuf q_mh, q_od, q_mt;             // -q mode: this rank's query sketches (both strand slots, forward filled)
@@ -301,6 +305,7 @@ struct DistState {
     if (ev_small) (void)hipEventDestroy(ev_small);
     if (ev_big) (void)hipEventDestroy(ev_big);
     if (ev_prod) (void)hipEventDestroy(ev_prod);
+    for (hipEvent_t e : ev_xt) if (e) (void)hipEventDestroy(e);
     if (comm_stream) (void)hipStreamDestroy(comm_stream);
     delete tr;
   }
@@ -537,8 +542,12 @@ int dist_eager_ordered(mhap_handle* h, hipStream_t producer, const int32_t* d_od
   DCHK(v, hipEventRecord(d->ev_prod, producer));
   DCHK(v, hipStreamWaitEvent(cs, d->ev_prod, 0));
   if (rows > 0) DCHK(v, hipMemcpy2DAsync(d->s_od.p, od_row, d_od, od_row * 2, od_row, (size_t)rows, hipMemcpyDeviceToDevice, cs));
+  for (auto& e : d->ev_xt) if (!e) DCHK(v, hipEventCreate(&e));
+  DCHK(v, hipEventRecord(d->ev_xt[0], cs));
   const int rc = d->tr->allgather(d->s_od.p, d->g_od.p, np * od_row, cs, *v.err);
   if (rc != MHAP_OK) { d->eager_go = false; d->tr->abort(); return rc; }
+  DCHK(v, hipEventRecord(d->ev_xt[1], cs));
+  d->xt_ordered = true; d->xt_bytes[0] = (double)(d->tr->nranks - 1) * (double)np * (double)od_row;
   DCHK(v, hipEventRecord(d->ev_big, cs));
   return MHAP_OK;
 }
@@ -563,10 +572,14 @@ int dist_eager_minhash(mhap_handle* h, hipStream_t producer, const int32_t* d_mh
     DCHK(v, hipMemsetAsync(d->s_mh.as<char>() + (size_t)rows * mh_row, 0, (size_t)(n_pad - rows) * mh_row, cs));
   }
   Transport* tr = d->tr;
+  for (auto& e : d->ev_xt) if (!e) DCHK(v, hipEventCreate(&e));
+  DCHK(v, hipEventRecord(d->ev_xt[2], cs));
   int rc = tr->allgather(d->s_mh.p, d->g_mh.p, np * mh_row, cs, *v.err);
   if (rc == MHAP_OK) rc = tr->allgather(d->s_mt.p, d->g_mt.p, np * mt_row, cs, *v.err);
   if (rc == MHAP_OK) rc = tr->allgather(d->s_ids.p, d->g_ids.p, np * 8, cs, *v.err);
   if (rc != MHAP_OK) { d->eager_go = false; tr->abort(); return rc; }
+  DCHK(v, hipEventRecord(d->ev_xt[3], cs));
+  d->xt_small = true; d->xt_bytes[1] = (double)(tr->nranks - 1) * (double)np * (double)(mh_row + mt_row + 8);
   DCHK(v, hipEventRecord(d->ev_small, cs));
   d->eager_go = false; d->eager_done = true;
   return MHAP_OK;
@@ -742,6 +755,24 @@ int mhap_dist_selftest(mhap_handle* h, size_t bytes, double* ms_out) {
     if (host[(size_t)r * bytes + bytes - 1] != want) return dfail(v, MHAP_E_STATE, "all-gather self-test: rank " + std::to_string(r) + "'s block arrived short");
   }
   tr->quiesce();
+  return MHAP_OK;
+}
+
+// The eager exchange of the last add, as the exchange stream saw it (events around the gathers, which run UNDER the add's kernels):
+// out4 = {ms of the ordered rows' gather, bytes this rank received in it, ms of the MinHash + meta + id rows' gathers, bytes received}.
+// -1 ms: that gather has not run since the last call (no eager add).  Waits for the gathers to finish.  (bench.py --exchange-only)
+int mhap_dist_exchange_timing(mhap_handle* h, double* out4) {
+  if (!h || !out4) return MHAP_E_INVALID;
+  HandleView v = handle_view(h);
+  DistState* d = (DistState*)*v.dist;
+  if (!d) return dfail(v, MHAP_E_STATE, "not a rank of a multi-GPU job");
+  (void)hipSetDevice(v.device);
+  out4[0] = out4[2] = -1.0; out4[1] = d->xt_bytes[0]; out4[3] = d->xt_bytes[1];
+  float ms = 0.f;
+  if (d->xt_ordered && hipEventSynchronize(d->ev_xt[1]) == hipSuccess && hipEventElapsedTime(&ms, d->ev_xt[0], d->ev_xt[1]) == hipSuccess) out4[0] = ms;
+  if (d->xt_small && hipEventSynchronize(d->ev_xt[3]) == hipSuccess && hipEventElapsedTime(&ms, d->ev_xt[2], d->ev_xt[3]) == hipSuccess) out4[2] = ms;
+  (void)hipGetLastError();
+  d->xt_ordered = d->xt_small = false;
   return MHAP_OK;
 }
 

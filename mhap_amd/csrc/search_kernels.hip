@@ -202,6 +202,24 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // workgroup (670 loads per wave in the second tier: r03 PMC pass).
 // =============================================================================================
 __device__ __forceinline__ uint32_t inv_mix(uint32_t v) { return fmix32(v); }
+// "table elements processed" (MinHashSearch.java:173) of a query, added to the launch's total.  Round 6: every LANE used to add its own count
+// to ONE word — a wave instruction of up to 64 atomic operations on one address, one per query, all through one L2 channel: the timing build
+// without it ran the first query tier of an 8-GPU rank in 1.03 ms instead of 1.98 (profiles/r06_iq_timing_builds.txt).  Now a wave adds its
+// sum once, to one of IQ_ELEM_SPREAD words picked by the workgroup; index_elements_sum_kernel folds them into the counter the host reads.
+constexpr int IQ_ELEM_SPREAD = 256;
+__device__ __forceinline__ void iq_add_elements(unsigned long long* __restrict__ spread, unsigned long long mine) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(spread + (blockIdx.x & (IQ_ELEM_SPREAD - 1)), mine);
+}
+__global__ __launch_bounds__(IQ_ELEM_SPREAD) void index_elements_sum_kernel(unsigned long long* __restrict__ spread, unsigned long long* __restrict__ total) {
+  unsigned long long v = spread[threadIdx.x];
+  spread[threadIdx.x] = 0ULL;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+int index_elements_spread_words() { return IQ_ELEM_SPREAD; }
 // (Round 4 tried an occupancy bitmap in front of the lookups — 4 bits per bucket, a clear bit ends a lookup after one load instead of two
 //  dependent ones; 82 % of the lookups of a C2 query find nothing.  It made the first tier SLOWER: 3.3 -> 4.8 ms at C2, 70.8 -> 78.4 at
 //  C4, 2.50 -> 2.42 for one rank of eight.  A wave is one query with eight slots per lane; nearly every wave holds some lane whose bit
@@ -700,67 +718,67 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     if (lmode) {
       const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u, hsh = 32u - eb;
       const size_t lstride = (size_t)16 << ix.nl_log;   // words of one slot's lines
-      // a posting of place i of line words L: tag above the entry's bits; the place's top 4 bits sit in words 14 / 15
-#define IQ_LINE_SCAN(L, from, to, qtag)                                                                                   \
-      {                                                                                                                     \
-        const uint32_t lw_[14] = {L[0].x, L[0].y, L[0].z, L[0].w, L[1].x, L[1].y, L[1].z, L[1].w, L[2].x, L[2].y, L[2].z, L[2].w, L[3].x, L[3].y}; \
-        _Pragma("unroll") for (int i_ = 0; i_ < IL_CAP; i_++) {                                                              \
-          const uint32_t nib_ = ((i_ < 8 ? L[3].z >> (4 * i_) : L[3].w >> (4 * (i_ - 8))) & 15u);                            \
-          const uint32_t tag_ = (lw_[i_] >> eb) | (nib_ << hsh);                                                             \
-          if ((uint32_t)i_ >= (from) && (uint32_t)i_ < (to) && tag_ == (qtag)) { mine++; count_hit((int)(lw_[i_] & emk)); }    \
-        }                                                                                                                   \
-      }
-      for (int sb = (int)threadIdx.x; sb < sp.H; sb += IQ_LB * IQ_THREADS) {
-        uint4 L[IQ_LB][4];
-        uint32_t hvv[IQ_LB], nn[IQ_LB];
-        const uint32_t* lp[IQ_LB];
+      // FOUR lanes per lookup, one 16-byte quarter of the line each: a wave's load instruction then touches 16 lines instead of 64 —
+      // tools/line_gather_probe.hip: the same 51.2 M lookups out of a 17-GB table (all of C4 on one GPU) take 2.6 ms with a line per lane
+      // and 1.06 ms with a line per quad; no difference at 0.13 / 1.1 GB (0.9 ms) — and a lookup in flight costs 4 registers, not 16.
+      // Lane 4 g + p holds places 4 p .. 4 p + 3 of group g's line (p = 3: places 12, 13, then the words with the places' top bits
+      // and the header, which the other three lanes fetch through a quad broadcast).
+      const int part = (int)(threadIdx.x & 3u), grp = (int)(threadIdx.x >> 2);
+      constexpr int GPI = IQ_THREADS / 4;     // lookups one wave instruction covers
+      auto bcast3 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xFF, 0xF, 0xF, true); };   // quad_perm [3,3,3,3]
+      // places [from, to) of the line quarter q (of the lane's part) against the query's tag
+      auto scan = [&](const uint4 q, uint32_t w14, uint32_t w15, uint32_t from, uint32_t to, uint32_t qt) {
+        const uint32_t nibs = ((part & 2) ? w15 : w14) >> ((part & 1) * 16);
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int jx = 0; jx < 4; jx++) {
+          const uint32_t place = (uint32_t)(part * 4 + jx);
+          const uint32_t tag = (w[jx] >> eb) | (((nibs >> (4 * jx)) & 15u) << hsh);
+          if (place < (uint32_t)IL_CAP && place >= from && place < to && tag == qt) { mine++; count_hit((int)(w[jx] & emk)); }
+        }
+      };
+      for (int sb = 0; sb < sp.H; sb += IQ_LB * GPI) {      // (workgroup-uniform bounds; no barrier inside)
+        uint4 L[IQ_LB];
+        uint32_t hvv[IQ_LB];
 #pragma unroll
         for (int u = 0; u < IQ_LB; u++) {
-          const int s = sb + u * IQ_THREADS;
-          hvv[u] = 0; lp[u] = ix.lines;
-          L[u][3] = make_uint4(0u, 0u, 0u, 0u);
+          const int s = sb + u * GPI + grp;
+          hvv[u] = 0; L[u] = make_uint4(0u, 0u, 0u, 0u);
           if (s < sp.H) {
             hvv[u] = inv_mix((uint32_t)qrow[s]);
-            lp[u] = ix.lines + (size_t)s * lstride + ((size_t)(hvv[u] >> lsh) << 4);
-            const uint4* l4 = (const uint4*)lp[u];
-            L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
+            L[u] = ((const uint4*)(ix.lines + (size_t)s * lstride + ((size_t)(hvv[u] >> lsh) << 4)))[part];
           }
         }
-        bool any_partner = false;
+        uint32_t more = 0;   // bit u: lookup u goes on in its partner line
+        uint32_t nn[IQ_LB];
 #pragma unroll
         for (int u = 0; u < IQ_LB; u++) {
-          const int s = sb + u * IQ_THREADS;
-          const uint32_t hdr = L[u][3].w >> 24;
-          nn[u] = 0;
-          if (s < sp.H) {
+          const int s = sb + u * GPI + grp;
+          const uint32_t w14 = bcast3(L[u].z), w15 = bcast3(L[u].w), hdr = w15 >> 24;
+          nn[u] = hdr;
+          if (s < sp.H && hdr) {
             if (hdr == IL_FALLBACK) {
-              const uint32_t at = atomicAdd(&s_nov, 1u);
-              if (at < (uint32_t)IQ_OV) ovlist[at] = (uint32_t)s;
-            } else if (hdr) {
-              nn[u] = hdr;
-              const uint32_t qt = hvv[u] & tmask;
-              IQ_LINE_SCAN(L[u], 0u, hdr, qt);
-              if (hdr > (uint32_t)IL_CAP) any_partner = true;
+              if (part == 0) { const uint32_t at = atomicAdd(&s_nov, 1u); if (at < (uint32_t)IQ_OV) ovlist[at] = (uint32_t)s; }
+            } else {
+              scan(L[u], w14, w15, 0u, hdr, hvv[u] & tmask);
+              if (hdr > (uint32_t)IL_CAP) more |= 1u << u;
             }
           }
         }
-        if (any_partner) {
+        if (__builtin_amdgcn_ballot_w64(more != 0u)) {
           // what a line of more than 14 postings could not hold sits in its partner line, behind the partner's own
 #pragma unroll
           for (int u = 0; u < IQ_LB; u++)
-            if (nn[u] > (uint32_t)IL_CAP) {
-              const uint4* l4 = (const uint4*)(ix.lines + (size_t)(sb + u * IQ_THREADS) * lstride + ((size_t)((hvv[u] >> lsh) ^ 1u) << 4));
-              L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
-            }
+            if ((more >> u) & 1u)
+              L[u] = ((const uint4*)(ix.lines + (size_t)(sb + u * GPI + grp) * lstride + ((size_t)((hvv[u] >> lsh) ^ 1u) << 4)))[part];
 #pragma unroll
-          for (int u = 0; u < IQ_LB; u++)
-            if (nn[u] > (uint32_t)IL_CAP) {
-              const uint32_t pn = L[u][3].w >> 24, qt = hvv[u] & tmask;
-              IQ_LINE_SCAN(L[u], pn, pn + nn[u] - (uint32_t)IL_CAP, qt);
-            }
+          for (int u = 0; u < IQ_LB; u++) {
+            // (the broadcasts run for the whole wave: a DPP read of a lane that is switched off returns nothing useful)
+            const uint32_t w14 = bcast3(L[u].z), w15 = bcast3(L[u].w);
+            if ((more >> u) & 1u) { const uint32_t pn = w15 >> 24; scan(L[u], w14, w15, pn, pn + nn[u] - (uint32_t)IL_CAP, hvv[u] & tmask); }
+          }
         }
       }
-#undef IQ_LINE_SCAN
       __syncthreads();
       const uint32_t nov = s_nov;
       if (nov > (uint32_t)IQ_OV) { if (threadIdx.x == 0) s_over = 1; nloop = 0; }   // (a query with that many long buckets is repeat-rich: handed on)
@@ -867,7 +885,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     }
     (void)handed_over;
     __syncthreads();
-    if (!(MH_IQ_TIMING & 1) && mine && !(s_over && big != nullptr)) atomicAdd(elements, mine);
+    if (!(MH_IQ_TIMING & 1)) iq_add_elements(elements, (s_over && big != nullptr) ? 0ULL : mine);   // (every wave of the workgroup gets here)
     if (s_over && big != nullptr) {
       // first tier: hand the query to the launch with the large count table (it starts over; nothing was emitted yet)
       if (threadIdx.x == 0) big[atomicAdd(big_count, 1ULL)] = qe;
@@ -1033,7 +1051,7 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
     }
 #undef DQ_COUNT_HIT
     __syncthreads();
-    if (pass == 0 && mine) atomicAdd(elements, mine);           // "table elements processed" (:173), counted once
+    if (pass == 0) iq_add_elements(elements, mine);           // "table elements processed" (:173), counted once
     if (pass > 0 && threadIdx.x == 0) atomicAdd(split_count, 1ULL);   // a pass beyond the first = the hit set was split
     // emit this range's candidates as ONE contiguous block (one global atomic)
     constexpr int PER = (1 << DQ_RANGE_LOG) / DQ_THREADS;      // 64 entries per lane: lane t owns entries t * 64 .. t * 64 + 63 of the range
@@ -1300,7 +1318,7 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
         }
       }
   }
-  if (mine) atomicAdd(elements, mine);           // "table elements processed" (:173): every posting with the query's value, once
+  iq_add_elements(elements, mine);           // "table elements processed" (:173): every posting with the query's value, once
 }
 
 bool index_query_tiers() { return MH_IQ_BIG_CT != 0; }
@@ -1329,8 +1347,11 @@ constexpr int INV_CT_MID = MH_IQ_MID_CT, IQ_THREADS_MID = MH_IQ_MID_THREADS;
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
-                        unsigned long long* split_count, unsigned long long* elements, int32_t* big, unsigned long long* big_count, int tier) {
+                        unsigned long long* split_count, unsigned long long* elements_total, int32_t* big, unsigned long long* big_count, int tier,
+                        unsigned long long* elements) {
+  // elements: index_elements_spread_words() zeroed words the kernels add to; folded into *elements_total (and zeroed again) behind the launch
   if (nq <= 0) return;
+  struct Fold { hipStream_t st; unsigned long long* s; unsigned long long* t; ~Fold() { hipLaunchKernelGGL(index_elements_sum_kernel, dim3(1), dim3(IQ_ELEM_SPREAD), 0, st, s, t); } } fold{st, elements, elements_total};
   if (tier == 0 && big != nullptr && ix.lines != nullptr)
     hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT, true>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
                        meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);

@@ -545,11 +545,16 @@ __global__ __launch_bounds__(WEIGHT_THREADS, WAVES_PER_SIMD) void kmer_weight_ke
   // own hash, so every strand is an item.
   const bool pairs = !reweigh;
   const int64_t nitems = pairs ? (nstrands >> 1) : nstrands;
+  // (round 6: the NEXT item is pulled while the current one is worked on — the atomic's answer used to be waited for by all 1 024
+  //  lanes at the top of every item, ~200 round trips to the counter per workgroup and launch.  The counter ends nblocks past the items.)
+  unsigned long long sx_next = 0;
+  if (threadIdx.x == 0) sx_next = atomicAdd(counter, 1ULL);
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned long long sx = atomicAdd(counter, 1ULL);
+      const unsigned long long sx = sx_next;
       svars[0] = (uint32_t)sx; svars[1] = (uint32_t)(sx >> 32);
+      if ((int64_t)sx < nitems) sx_next = atomicAdd(counter, 1ULL);
     }
     __syncthreads();
     // readfirstlane: the item — and with it the descriptor, every pointer and loop bound below — is provably uniform (scalar
@@ -2026,7 +2031,9 @@ size_t minhash_queue_bytes(int nblocks_total, int H) { return (size_t)nblocks_to
 // Strands of a weight-1 launch that are cut into row items (the others are taken whole): one strand's worth of rows per resident
 // wave at the end of the list evens the waves' finish times out to one row; a list shorter than that is all rows.
 int64_t minhash_tail_strands(int nblocks, int64_t n_unweighted) {
-  const int64_t waves = (int64_t)nblocks * 4;
+  static int div = 0;   // MHAP_W1_TAIL_DIV: 1 / 2 / 4 ... = a strand's worth of rows for every / every second / fourth resident wave (experiments)
+  if (div == 0) { const char* e = getenv("MHAP_W1_TAIL_DIV"); div = e && atoi(e) > 0 ? atoi(e) : 1; }
+  const int64_t waves = (int64_t)nblocks * 4 / div;
   return n_unweighted < waves ? n_unweighted : waves;
 }
 size_t minhash_merge_bytes(int nblocks, int H) { return (size_t)nblocks * 4 * (size_t)H * 8; }
@@ -2114,7 +2121,7 @@ bool launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
       {   // a quarter of a row's ~1 300 clocks per slot (MHAP_W1_STAGGER: clocks per SIMD slot number; 0 = all waves start together)
         static int stag = -2;
         if (stag == -2) { const char* e = getenv("MHAP_W1_STAGGER"); stag = e ? atoi(e) : -1; }
-        a.stagger = stag >= 0 ? stag : H * 330;
+        a.stagger = stag >= 0 ? stag : 0;   // (default off: measured without effect on a rank's launch — 10.83 / 10.70 ms with, 10.83 / 10.69 without: EXPERIMENTS round 6)
       }
       const long long items = a.n_whole + a.n_tail * (long long)a.rmax;
       const int nb = (int)std::min<long long>(nblocks, (items + 3) / 4);

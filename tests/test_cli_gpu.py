@@ -294,6 +294,24 @@ def test_bench_dry_collective_and_rank_views():
     assert bad.returncode != 0 and "torch.distributed.run" in (bad.stdout + bad.stderr)
 
 
+def test_bench_exchange_only_separates_fabric_time_from_the_time_under_the_add():
+    """bench.py --gpus 1 --exchange-only (one RCCL rank here): the real row volumes of a (reduced) C2 job gathered alone and by the eager
+    add under its kernels, the exposed part the search waited for, every rank's numbers in one JSON line."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--exchange-only", "--config", "c2", "--reads", "4000", "--steps", "2"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    d = json.loads(r.stdout.strip().split("\n")[-1])
+    assert d["exchange_only"] and d["ok"] and d["n_gpus"] == 1
+    m = d["per_rank"][0]
+    assert m["error"] is None and m["reads"] == 4000 and m["ordered_bytes_sent"] == 4000 * 1536 * 8
+    assert len(m["alone"]["ordered_gather_ms"]) == 3 and min(m["alone"]["ordered_gather_ms"]) > 0
+    assert len(m["under_the_add"]) == 2
+    for u in m["under_the_add"]:
+        assert u["ordered_gather_ms"] > 0 and u["small_gather_ms"] > 0 and u["records"] > 0 and u["exposed_ms"] >= 0
+    assert m["under_the_add"][-1]["eager_searches"] >= 2          # the searches found their rows gathered by the add
+
+
 def test_cli_gpus_flag_shards_the_index_and_keeps_the_records(tmp_path):
     """mhap-hip --devices 0,0[,0]: two and three ranks (sharing this box's one GPU) — reads dealt round-robin, one index shard
     per rank, the forward query rows gathered inside the library — print exactly the records of the one-GPU run, in self mode
