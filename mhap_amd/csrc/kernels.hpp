@@ -108,6 +108,8 @@ void launch_candidates(hipStream_t st, const int32_t* minhash, int64_t row_strid
 // Inverted index: one open-addressing table of 2^k (value, entry+1) words per MinHash slot; a value's entries beyond the run cap
 // are stored contiguously in the overflow pool (CSR: per-(slot, value) start / count in a second hash table).  During the build
 // they are appended to `tmp` and counted; launch_index_finalize lays them out once all entries are in.
+constexpr int MHAP_MAX_NUM_HASHES = 8192;   // --num-hashes limit (mhap_create); the MinHash kernels' queue entries keep the slot in 16 bits
+int minhash_waves_per_workgroup(int H);     // 4, fewer when --num-hashes is so large that four waves' minima do not fit a workgroup's LDS
 struct InvIndex {
   uint32_t* ends;        // [H][nb + 1]: postings of bucket b of slot s are items[s][ends[s][b] .. ends[s][b + 1]), ends[s][0] = 0
   uint2* items;          // [H][slot_stride]: (mix of the value, entry), grouped by bucket

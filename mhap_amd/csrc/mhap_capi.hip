@@ -509,7 +509,9 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     if (const char* e = getenv("MHAP_MINHASH_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 8) per_cu = v; }
     int mblocks = h->num_cus * per_cu;   // (each launch is trimmed to the workgroups its work list can feed)
     if (eager_x) mblocks = std::max(per_cu, mblocks - dist_eager_reserve_wgs(h));   // (room for the all-gather's own kernels: mhap_dist.hip)
-    HIPCHK(h, h->mhq.ensure(minhash_queue_bytes(2 * std::max(mblocks, 1), H) * 4));   // (x4: one wave per workgroup when --num-hashes is huge)
+    // (the slack factor only where the workgroups really have fewer than four waves — --num-hashes beyond ~3 000 — instead of 2 GB
+    //  of queue scratch at --num-hashes 2048 and 8.6 GB at 8192 for everybody)
+    HIPCHK(h, h->mhq.ensure(minhash_queue_bytes(2 * std::max(mblocks, 1), H) * (size_t)(minhash_waves_per_workgroup(H) < 4 ? 4 : 1)));
     HIPCHK(h, h->mhmerge.ensure(minhash_merge_bytes(std::max(mblocks, 1), H)));
     // The strands with weighted k-mers are a second launch (own instantiation).  On the same stream a handful of such strands (C2:
     // under 1 %) hold the GPU for one strand's duration (3 ms) after the weight-1 launch has drained.  So the two list lengths are
@@ -1118,7 +1120,7 @@ int mhap_create(const mhap_params* params, mhap_handle** out, char* err, size_t 
   const mhap_params& P = *params;
   if (P.kmer_size < 1 || P.kmer_size > 255) { seterr("k-mer size must be in [1,255]"); return MHAP_E_INVALID; }
   if (P.ordered_kmer_size < 1 || P.ordered_kmer_size > 255) { seterr("ordered k-mer size must be in [1,255]"); return MHAP_E_INVALID; }
-  if (P.num_hashes < 1 || P.num_hashes > 8192) { seterr("num-hashes must be in [1,8192]"); return MHAP_E_INVALID; }
+  if (P.num_hashes < 1 || P.num_hashes > MHAP_MAX_NUM_HASHES) { seterr("num-hashes must be in [1,8192]"); return MHAP_E_INVALID; }
   if (P.ordered_sketch_size < 1 || P.ordered_sketch_size > 8192) { seterr("ordered-sketch-size must be in [1,8192]"); return MHAP_E_INVALID; }
   if (P.num_min_matches < 1) { seterr("Minimum number of matches must be positive."); return MHAP_E_INVALID; }
   if (P.min_store_length < 0) { seterr("The minimum read length stored must be >=0."); return MHAP_E_INVALID; }
@@ -1307,12 +1309,16 @@ static int finish_add(mhap_handle* h, int64_t first, const int64_t* ids, int64_t
   HPROF("finish_add begin");
   const bool early = h->pend_ids.done && h->pend_ids.first == first && h->pend_ids.n == n && h->pend_ids.ids == ids;
   h->pend_ids.done = false; h->pend_ids.n = 0;
-  if (!early) { const int rf = fill_ids(h, first, ids, n); if (rf != MHAP_OK) return rf; }
-  h->inv_ready = false; h->ph_ready = false; h->index_gen++;   // the entry set changes
-  h->mono_val = h->mono_pending; h->mono_gen = h->index_gen;
+  // (nothing is committed before the add has succeeded — a failed id upload or meta mirror leaves the host mirrors at the
+  //  length of the entries that exist, and the generation / "ids rise with the entries" pair describes only ids that were committed)
+  auto undo = [&](int code) { h->ids.resize((size_t)first); h->fwd.resize((size_t)first); return code; };
+  if (!early) { const int rf = fill_ids(h, first, ids, n); if (rf != MHAP_OK) return undo(rf); }
+  h->inv_ready = false; h->ph_ready = false;                    // the entry set changes
   int rc = mirror_meta(h, h->d_meta, first, 2 * n);
   HPROF("meta mirrored");
-  if (rc != MHAP_OK) return rc;
+  if (rc != MHAP_OK) return undo(rc);
+  h->index_gen++;
+  h->mono_val = h->mono_pending; h->mono_gen = h->index_gen;
   h->n_entries = first + 2 * n;
   h->stats.strands_indexed = 0;
   for (int64_t e = 0; e < h->n_entries; e++) if (h->status[(size_t)e] == 0) h->stats.strands_indexed++;
@@ -1359,7 +1365,11 @@ int mhap_index_add_staged(mhap_handle* h) {
   h->pend_ids.first = first; h->pend_ids.n = n; h->pend_ids.ids = h->st_ids.data(); h->pend_ids.done = false;
   rc = sketch_staged(h, h->d_minhash + first * h->Hrow, h->Hrow, h->d_ordered + first * 2LL * S, 2LL * S, h->d_meta + first * META_W,
                      likely_last ? after : 0, eager_exchange, first == 0);
-  if (rc != MHAP_OK) { h->pend_ids.n = 0; h->pend_ids.done = false; return rc; }
+  if (rc != MHAP_OK) {   // (the early fill_ids inside sketch_staged may have grown the mirrors: back to the committed entries)
+    h->pend_ids.n = 0; h->pend_ids.done = false;
+    h->ids.resize((size_t)first); h->fwd.resize((size_t)first);
+    return rc;
+  }
   const bool built = h->inv_ready && h->inv_ne == after;
   rc = finish_add(h, first, h->st_ids.data(), n);
   if (rc == MHAP_OK && built) h->inv_ready = true;      // (finish_add drops the index of the OLD entry set; this one covers the new one)

@@ -18,6 +18,11 @@
 
 namespace mhap {
 
+// MH_OJ_WIDE_UNIT (search_kernels_wide.hip / _wide2.hip): this file compiled once more for the join kernel with room for more joined k-mers
+// per pair — ONLY the join kernel, its ALONE shape: the candidate, index and per-lane kernels are not compiled a second and third time
+// (round 5 built the whole unit three times: every search kernel triplicated in a 2.4-MB library)
+#ifndef MH_OJ_WIDE_UNIT
+
 // count += (a == b): exactly two VALU issues per slot pair (v_cmp_eq -> vcc, v_addc consumes vcc).  Left to the
 // compiler the compare lands in arbitrary SGPR pairs (v_cmp_e64 + v_cndmask + add) and spills SGPRs through
 // v_writelane/v_readlane inside the hot loop.
@@ -585,6 +590,10 @@ constexpr int IQ_INLINE = 16;     // a bucket up to this long is read by the lan
 #define MH_IQ_TIMING 0   // timing builds of the first query tier (results wrong): 1 no `elements` atomic, 2 no hit counting, 4 no global atomic in the emit
 #endif
 constexpr int IQ_OV = 64;    // line mode: slots of one query that may fall back to ends / items (more: the query is handed on)
+#ifndef MH_IQ_QUAD
+#define MH_IQ_QUAD 0   // line mode: 1 = four lanes share a line (one 16-byte quarter each), 0 = a line per lane (four 16-byte loads).  Measured (round 6,
+                       // emulated rank of eight at C2 / C2 on one GPU / rank of eight at C4): see EXPERIMENTS.md
+#endif
 #ifndef MH_IQ_LB
 #define MH_IQ_LB 4
 #endif
@@ -715,6 +724,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     };
     bool handed_over = false;
     int nloop = sp.H;
+#if MH_IQ_QUAD
     if (lmode) {
       const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u, hsh = 32u - eb;
       const size_t lstride = (size_t)16 << ix.nl_log;   // words of one slot's lines
@@ -779,6 +789,72 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
           }
         }
       }
+#else
+    if (lmode) {
+      const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u, hsh = 32u - eb;
+      const size_t lstride = (size_t)16 << ix.nl_log;   // words of one slot's lines
+      // a posting of place i of line words L: tag above the entry's bits; the place's top 4 bits sit in words 14 / 15
+#define IQ_LINE_SCAN(L, from, to, qtag)                                                                                   \
+      {                                                                                                                     \
+        const uint32_t lw_[14] = {L[0].x, L[0].y, L[0].z, L[0].w, L[1].x, L[1].y, L[1].z, L[1].w, L[2].x, L[2].y, L[2].z, L[2].w, L[3].x, L[3].y}; \
+        _Pragma("unroll") for (int i_ = 0; i_ < IL_CAP; i_++) {                                                              \
+          const uint32_t nib_ = ((i_ < 8 ? L[3].z >> (4 * i_) : L[3].w >> (4 * (i_ - 8))) & 15u);                            \
+          const uint32_t tag_ = (lw_[i_] >> eb) | (nib_ << hsh);                                                             \
+          if ((uint32_t)i_ >= (from) && (uint32_t)i_ < (to) && tag_ == (qtag)) { mine++; count_hit((int)(lw_[i_] & emk)); }    \
+        }                                                                                                                   \
+      }
+      for (int sb = (int)threadIdx.x; sb < sp.H; sb += IQ_LB * IQ_THREADS) {
+        uint4 L[IQ_LB][4];
+        uint32_t hvv[IQ_LB], nn[IQ_LB];
+        const uint32_t* lp[IQ_LB];
+#pragma unroll
+        for (int u = 0; u < IQ_LB; u++) {
+          const int s = sb + u * IQ_THREADS;
+          hvv[u] = 0; lp[u] = ix.lines;
+          L[u][3] = make_uint4(0u, 0u, 0u, 0u);
+          if (s < sp.H) {
+            hvv[u] = inv_mix((uint32_t)qrow[s]);
+            lp[u] = ix.lines + (size_t)s * lstride + ((size_t)(hvv[u] >> lsh) << 4);
+            const uint4* l4 = (const uint4*)lp[u];
+            L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
+          }
+        }
+        bool any_partner = false;
+#pragma unroll
+        for (int u = 0; u < IQ_LB; u++) {
+          const int s = sb + u * IQ_THREADS;
+          const uint32_t hdr = L[u][3].w >> 24;
+          nn[u] = 0;
+          if (s < sp.H) {
+            if (hdr == IL_FALLBACK) {
+              const uint32_t at = atomicAdd(&s_nov, 1u);
+              if (at < (uint32_t)IQ_OV) ovlist[at] = (uint32_t)s;
+            } else if (hdr) {
+              nn[u] = hdr;
+              const uint32_t qt = hvv[u] & tmask;
+              IQ_LINE_SCAN(L[u], 0u, hdr, qt);
+              if (hdr > (uint32_t)IL_CAP) any_partner = true;
+            }
+          }
+        }
+        if (any_partner) {
+          // what a line of more than 14 postings could not hold sits in its partner line, behind the partner's own
+#pragma unroll
+          for (int u = 0; u < IQ_LB; u++)
+            if (nn[u] > (uint32_t)IL_CAP) {
+              const uint4* l4 = (const uint4*)(ix.lines + (size_t)(sb + u * IQ_THREADS) * lstride + ((size_t)((hvv[u] >> lsh) ^ 1u) << 4));
+              L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
+            }
+#pragma unroll
+          for (int u = 0; u < IQ_LB; u++)
+            if (nn[u] > (uint32_t)IL_CAP) {
+              const uint32_t pn = L[u][3].w >> 24, qt = hvv[u] & tmask;
+              IQ_LINE_SCAN(L[u], pn, pn + nn[u] - (uint32_t)IL_CAP, qt);
+            }
+        }
+      }
+#undef IQ_LINE_SCAN
+#endif
       __syncthreads();
       const uint32_t nov = s_nov;
       if (nov > (uint32_t)IQ_OV) { if (threadIdx.x == 0) s_over = 1; nloop = 0; }   // (a query with that many long buckets is repeat-rich: handed on)
@@ -1453,6 +1529,8 @@ __global__ __launch_bounds__(OVL_THREADS) void overlap_kernel(const Candidate* _
   }
   if (mine) atomicAdd(compared, mine);
 }
+
+#endif   // MH_OJ_WIDE_UNIT
 
 // =============================================================================================
 // Second stage, one WAVEFRONT per candidate pair (default path).
@@ -2596,8 +2674,11 @@ size_t overlap_join_lds_bytes(int S, int shape) {
   return (sp + (MH_OJ_KEEP ? sp : 0) + aid + 4 + w * OJ_LDS_EXTRA) * 4;
 }
 template <class F> static auto oj_dispatch(int shape, F f) {
+#ifndef MH_OJ_WIDE_UNIT
   if (shape == OJ_TEAM) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_TEAM], !MH_OJ_FILTER, MH_OJ_FILTER != 0>);
   if (shape == OJ_PAIR) return f(overlap_join_kernel<true, OJ_SHAPE_WAVES[OJ_PAIR], false, MH_OJ_FILTER != 0>);
+#endif
+  (void)shape;   // (the wider passes run every wave alone)
   return f(overlap_join_kernel<false, OJ_SHAPE_WAVES[OJ_ALONE], false, false>);
 }
 // workgroups of the join kernel one CU holds at this sketch size
@@ -2622,6 +2703,7 @@ void launch_overlap_join(hipStream_t st, int shape, int nblocks, int chunk, cons
   });
 }
 
+#ifndef MH_OJ_WIDE_UNIT
 void oj_stats_dump() {
 #ifdef MH_OJ_STATS
   unsigned long long h[20];
@@ -2645,5 +2727,6 @@ void launch_overlap(hipStream_t st, int nblocks, const Candidate* cand, const un
   hipLaunchKernelGGL(overlap_kernel, dim3(nblocks), dim3(OVL_THREADS), 0, st, cand, cand_count, cand_cap, ordered, ord_stride, meta,
                      qordered, qord_stride, qmeta, sp, score_table, scratch, scratch_per_lane, recs, rec_count, rec_cap, compared, spread);
 }
+#endif   // MH_OJ_WIDE_UNIT
 
 }  // namespace mhap

@@ -10,7 +10,8 @@
 // time with MH_OJ_JCAP = 512 into a namespace of its own, and the search runs it as a second pass over the pairs the first pass hands over;
 // only what it hands over in turn (more than 512 joined k-mers, the group caps) goes to the per-lane kernel.
 //
-// Everything of search_kernels.hip is compiled again under the other namespace; only the wrappers at the end are used.
+// MH_OJ_WIDE_UNIT: only the join kernel (its ALONE shape) of search_kernels.hip is compiled again under the other namespace (round 6).
+#define MH_OJ_WIDE_UNIT 1
 #define mhap mhap_wide
 #define MH_OJ_JCAP 512
 #include "search_kernels.hip"

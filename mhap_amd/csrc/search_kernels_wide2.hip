@@ -1,5 +1,6 @@
 // search_kernels_wide2.hip — and a third time with room for 1 536 (the whole of a default ordered sketch): see search_kernels_wide.hip.
 // Eight times the first pass's cost per pair, a tenth of the per-lane kernel's: the pass for reads of a few per cent error and better.
+#define MH_OJ_WIDE_UNIT 1
 #define mhap mhap_wide2
 #define MH_OJ_JCAP 1536
 #include "search_kernels.hip"

@@ -2027,6 +2027,14 @@ int minhash_queue_words(int H) {
   return want > BS_QCAP ? want : BS_QCAP;
 }
 size_t minhash_queue_bytes(int nblocks_total, int H) { return (size_t)nblocks_total * 4 * (size_t)minhash_queue_words(H) * 4; }
+static_assert(MHAP_MAX_NUM_HASHES < 65536, "a weight-1 queue entry is slot | lane << 16 (w1_enqueue)");
+// waves (= strands in flight) of one MinHash workgroup: launch_minhash's own rule, for whoever sizes per-wave scratch
+int minhash_waves_per_workgroup(int H) {
+  const size_t per_wave = (((size_t)H * 12 + 8) + 15) & ~(size_t)15, lut_bytes = (size_t)MH_LUT_WORDS * 8;
+  int waves = 4;
+  while (waves > 1 && per_wave * waves + lut_bytes > 150 * 1024) waves >>= 1;
+  return waves;
+}
 
 // Strands of a weight-1 launch that are cut into row items (the others are taken whole): one strand's worth of rows per resident
 // wave at the end of the list evens the waves' finish times out to one row; a list shorter than that is all rows.
@@ -2052,8 +2060,7 @@ bool launch_minhash(hipStream_t st, hipStream_t st_weighted, int nblocks, int64_
   if (perchain < 0) { const char* e = getenv("MHAP_MINHASH"); perchain = (e && strcmp(e, "perchain") == 0) ? 1 : 0; classic = (e && strcmp(e, "classic") == 0) ? 1 : 0; }
   size_t per_wave = (((size_t)H * 12 + 8) + 15) & ~(size_t)15;
   const size_t lut_bytes = (size_t)MH_LUT_WORDS * 8;
-  int waves = 4;                                   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
-  while (waves > 1 && per_wave * waves + lut_bytes > 150 * 1024) waves >>= 1;
+  const int waves = minhash_waves_per_workgroup(H);   // waves (= strands in flight) per workgroup; fewer when --num-hashes is huge
   const size_t lds = per_wave * waves + lut_bytes;
   const dim3 block(64 * waves);
   nblocks = (int)(((int64_t)nblocks * 4 + waves - 1) / waves);

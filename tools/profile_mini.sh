@@ -1,7 +1,7 @@
 # the digest-stamped part of tools/profile_round.sh after a late kernel change: kernel stats, PMC traffic + pipe counters, the bench line and the
 # MinHash attribution of the default workload (about seven minutes on the box): ROUND=r05 bash tools/profile_mini.sh
 export TMPDIR=/tmp
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix gpurun_out/$R
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o prof --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_final/bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do

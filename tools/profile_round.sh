@@ -1,7 +1,7 @@
 # final profiles of a round: rocprofv3 kernel stats + PMC traffic on the default workload, the other configurations' bench lines, one rank of an
 # N-GPU job, the native driver end to end (run on the GPU box); ROUND=r04 bash tools/profile_round.sh
 export TMPDIR=/tmp
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 mkdir -p gpurun_out/prof_final gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_mix gpurun_out/$R
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_final -o prof --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_final/bench.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -23,9 +23,9 @@ cp gpurun_out/$R/${R}_pmc_pipes.json profiles/${R}_pmc_pipes.json
 cp gpurun_out/$R/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json   # bench.py reads the byte counts from profiles/ (same source digest)
 # the committed bench line, with a clock / power trace of the card under its soak leg (tools/smi_trace.py) and the MinHash kernel's own
 # wave-clock attribution + mean shader clock beside it
-(sleep 45; python tools/smi_trace.py gpurun_out/$R/smi_trace_raw.txt 60 > gpurun_out/$R/${R}_smi_trace_c2.txt 2>&1) &
-timeout 900 python bench.py --steps 20 --warmup 5 --soak-seconds 20 > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
-wait
+# (round 6: the sampler is started by the bench line itself, on the card HIP reports for device 0 — by PCI address, not by "the busiest card",
+#  which on a shared box was somebody else's — and a capture without clock or power samples is a failed capture: soak.smi_ok in the line)
+timeout 900 python bench.py --steps 20 --warmup 5 --soak-seconds 20 --smi-trace gpurun_out/$R/${R}_smi_trace_c2.txt > gpurun_out/$R/${R}_bench_final.json 2> gpurun_out/$R/bench_final.err
 MHAP_MINHASH_PROF=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --soak-seconds 0 2>&1 >/dev/null | grep "w1 prof" | tail -4 > gpurun_out/$R/${R}_minhash_prof.txt
 tail -1 gpurun_out/$R/${R}_bench_final.json | cut -c1-400
 MHAP_BENCH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29655 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/$R/${R}_bench_forcedist_rccl_1rank.json
@@ -58,5 +58,11 @@ d = json.loads(sys.stdin.read()); print('$c', '$v'.split('/')[-1], 'overlap kern
 fi
 # instruction mix of the join kernel (PMC pass of its own)
 (bash tools/pmc_kernel.sh overlap_join_kernel; CONFIG=c5slice bash tools/pmc_kernel.sh overlap_join_kernel) > gpurun_out/$R/${R}_pmc_join_instmix.txt 2>&1
+# round 6: the first query tier's floor (random 64-byte lines) and what its parts cost (timing builds: bash tools/build_variant.sh iqt1 -DMH_IQ_TIMING=1 --only search_kernels.hip ...)
+[ -x tools/bin/line_gather_probe ] && timeout 300 tools/bin/line_gather_probe > gpurun_out/$R/${R}_line_gather_probe.txt 2>&1
+if [ -f $V/libmhaphip_iqt1.so ]; then
+  (for v in mhap_amd/lib/libmhaphip.so $V/libmhaphip_iqt1.so $V/libmhaphip_iqt2.so $V/libmhaphip_iqt7.so; do echo "== $(basename $v)"; MHAP_LIB_PATH=$v timeout 300 python tools/emulate_rank.py 8 c2 4 2>/dev/null | tail -1; done) > gpurun_out/$R/${R}_iq_timing_builds.txt
+fi
+MHAP_BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29656 bench.py --gpus 1 --exchange-only --steps 3 2>/dev/null | tail -1 > gpurun_out/$R/${R}_exchange_only_1rank.json
 timeout 400 python tools/check_elements.py c5slice 2>/dev/null | tail -1 > gpurun_out/$R/${R}_check_elements_c5slice.txt
 ls -la gpurun_out/$R
