@@ -53,6 +53,8 @@ struct SearchParams {
   int32_t H, S, k2;
   int32_t num_min_matches, min_store_length;
   int32_t to_self;
+  int32_t own_queries;   // the query tables ARE the index's (a self search of one index): query entry q is stored entry q — its own H postings,
+                         // the one pair the id rule always drops (MinHashSearch.java:200-201), need not be counted (round 6)
   double max_shift, threshold;
 };
 

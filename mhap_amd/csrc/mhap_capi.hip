@@ -762,6 +762,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   SearchParams sp;
   sp.H = h->P.num_hashes; sp.S = S; sp.k2 = h->P.ordered_kmer_size;
   sp.num_min_matches = h->P.num_min_matches; sp.min_store_length = h->P.min_store_length; sp.to_self = to_self ? 1 : 0;
+  sp.own_queries = (to_self && qs.d_minhash == h->d_minhash && qs.d_meta == h->d_meta && !getenv("MHAP_COUNT_OWN")) ? 1 : 0;
   sp.max_shift = h->P.max_shift; sp.threshold = h->P.threshold;
   const int ne = (int)h->n_entries;
   int64_t qchunk = 262144;   // queries per candidate/overlap launch pair (bounds the candidate buffer)

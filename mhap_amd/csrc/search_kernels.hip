@@ -461,8 +461,14 @@ __global__ __launch_bounds__(IL_THREADS) void index_lines_kernel(InvIndex ix, in
 // lines per slot and posting layout for an index of `entries` entries in nb buckets per slot; false: no line table (a posting would not
 // fit its 36 bits, or MHAP_INDEX_LINES=0).  Average postings per line: 3.5 .. 7 (IL_CAP = 14 places, 28 with the partner's)
 bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t& lb, uint32_t& ebits) {
+  // Default: a line table for an index of up to 65 536 entries — a rank's shard of an 8- or 4-GPU C2 job, a small -q index: a table of a
+  // few hundred MB the Infinity Cache largely holds.  Measured in round 6 with a line per lane (EXPERIMENTS.md): rank of eight at C2
+  // (25 000 entries) index_query 1.47 -> 1.06 ms for +0.15 ms of build; rank of eight at C4 (250 000) 19.3 -> 15.6 for +1.35; C2 on one
+  // GPU (200 000 entries, every query counting its own strand) 2.39 -> 2.36 for +0.9 of build next to the ordered kernel: a loss.
+  // MHAP_INDEX_LINES=0 / 1: never / whenever the layout allows.
   const char* e = getenv("MHAP_INDEX_LINES");
   if (e && e[0] == '0') return false;
+  if (!(e && e[0] == '1') && entries > 65536) return false;
   const int64_t per_line = []() { const char* v = getenv("MHAP_INDEX_LINE_LOAD"); const int x = v ? atoi(v) : 0; return (int64_t)(x >= 1 && x <= 14 ? x : 7); }();
   uint32_t nbl = 0;
   while ((1u << nbl) < nb) nbl++;
@@ -707,6 +713,9 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
     const uint32_t sat = (uint32_t)sp.num_min_matches < cmax - (uint32_t)IQ_THREADS ? (uint32_t)sp.num_min_matches : cmax - (uint32_t)IQ_THREADS;
     auto count_hit = [&](int me) {
       if (MH_IQ_TIMING & 2) return;
+      // (a self search of one index: the query's own strand is stored — H hits on one table word per query, six in seven of all the hits a
+      //  C2 query counts, for the one pair the id rule drops anyway)
+      if (sp.own_queries && me == qe) return;
       const uint32_t hm = inv_mix((uint32_t)me);
       if (((hm >> CT_LOG) & pmask) != prefix) return;
       const uint32_t id = (uint32_t)me + 1u;

@@ -579,6 +579,44 @@ def _sorted_records(recs):
     return np.sort(a, order=names)
 
 
+def test_index_line_table_every_path_against_the_plain_index(monkeypatch):
+    """Round 6: the LINE table of the first query tier (one 64-byte line per lookup: index_lines_kernel) — lines of every filling (sparse,
+    the default 3.5-7 postings, packed so that many lines spill into their partner line or send the lookup to ends / items), long buckets
+    (a value thousands of entries share: 'see the buckets'), a query with more such slots than the tier keeps (handed to the next tier),
+    with the index self-check on (every stored posting must be found through its line) — records, statistics and the oracle all agree
+    with the search through bucket bounds + postings."""
+    rnd = random.Random(77)
+    fa1 = mhap_amd.synth_reads(1500, 3000, seed=77, error_rate=0.10)
+    rep = _rand_seq(rnd, 400)                                               # a repeat element in 300 more reads: long buckets
+    extra = [_rand_seq(rnd, 900) + rep + _rand_seq(rnd, 700) for _ in range(300)]
+    fa = FastaData.from_strings([fa1.sequence(i) for i in range(len(fa1))] + extra)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=500)
+    want = O.record_lines(O.run_self(fa, H=128, S=500, nthreads=16, cap=1 << 22)["records"])
+    monkeypatch.setenv("MHAP_DEBUG_INDEX", "1")
+    seen = {}
+    for tag, env in (("plain", {"MHAP_INDEX_LINES": "0"}), ("default", {}), ("sparse", {"MHAP_INDEX_LINES": "1", "MHAP_INDEX_LINE_LOAD": "1"}),
+                     ("packed", {"MHAP_INDEX_LINES": "1", "MHAP_INDEX_LINE_LOAD": "14"})):
+        for k in ("MHAP_INDEX_LINES", "MHAP_INDEX_LINE_LOAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lines, st = _self_lines(fa, p)
+        assert lines == want, tag
+        seen[tag] = (st["table_elements"], st["candidates_compared"], st["matches_found"])
+    assert len(set(seen.values())) == 1 and len(want) > 3000, seen
+    # -q style: the same index, queries from other tables (nothing to skip as "the query's own strand")
+    for k in ("MHAP_INDEX_LINES", "MHAP_INDEX_LINE_LOAD"):
+        monkeypatch.delenv(k, raising=False)
+    q = mhap_amd.synth_reads(200, 3000, seed=77, error_rate=0.12)
+    got = {}
+    for tag, env in (("plain", "0"), ("lines", "1")):
+        monkeypatch.setenv("MHAP_INDEX_LINES", env)
+        with MinHashSearch(p) as ms:
+            ms.add_data(fa)
+            got[tag] = sorted(mhap_amd.records_to_lines(ms.find_matches_stream(q)))
+    assert got["plain"] == got["lines"] and len(got["lines"]) > 50
+
+
 def test_candidate_paths_agree_and_overflow_fallback(monkeypatch):
     """Inverted-index candidates (default) == brute-force all-pairs candidates == oracle, including values shared by thousands
     of entries (run cap + overflow lists) and queries whose hit set overflows the per-query LDS count table (3072 distinct
