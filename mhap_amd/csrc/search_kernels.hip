@@ -621,8 +621,11 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   __shared__ uint32_t stack[2 * IQ_STACK];
   __shared__ uint32_t s_nseg[2];
   constexpr int QCAP = IQ_THREADS * SPT;   // a trip looks SPT slots per lane up (their loads in flight together) and may queue as many buckets
-  __shared__ uint2 seglist[QCAP];         // queued long buckets: (first posting within the slot, length),
-  __shared__ uint2 segkey[QCAP];          // ... (slot, the query's mix there)
+  __shared__ uint32_t segraw[QCAP * 4];
+  uint2* const seglist = (uint2*)segraw;  // queued long buckets: (first posting within the slot, length),
+  uint2* const segkey = seglist + QCAP;   // ... (slot, the query's mix there)
+  uint32_t* const hitq = segraw;          // (line mode, before any bucket is queued: the entries whose tag matched, waiting to be counted)
+  constexpr int IQ_HQ = QCAP * 4;
   __shared__ unsigned long long segpre[QCAP + 1];
   __shared__ unsigned long long wsum[IQ_THREADS / 64];
   __shared__ unsigned long long s_base;
@@ -800,8 +803,24 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       }
 #else
     if (lmode) {
+      static_assert(!LINES || IQ_THREADS == 64, "the line phase compacts its hits with wave ballots");
       const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u, hsh = 32u - eb;
       const size_t lstride = (size_t)16 << ix.nl_log;   // words of one slot's lines
+      // Hits are QUEUED, not counted where they are found: a match is one lane in a hundred per place, and counting it on the spot sent the
+      // whole wave through the hit-count table's probe loop (LDS atomics, their waits) 14 places x 8 lookups = 112 times a query — the timing
+      // build without the counting ran C2's first tier in 1.05 ms against 2.26 with it (round 6).  The scan is executed by all lanes together
+      // (a lane without a line scans the empty range), a ballot compacts the matching entries into hitq, and the queue is counted by a loop in
+      // which every lane has a hit to count.
+      int hbase = 0;                 // hits waiting in hitq (wave-uniform)
+      unsigned long long nhits = 0;  // ... and all hits so far ("table elements processed")
+      auto flush_hits = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = (int)threadIdx.x; i < hbase; i += IQ_THREADS) count_hit((int)hitq[i]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        hbase = 0;
+      };
       // a posting of place i of line words L: tag above the entry's bits; the place's top 4 bits sit in words 14 / 15
 #define IQ_LINE_SCAN(L, from, to, qtag)                                                                                   \
       {                                                                                                                     \
@@ -809,44 +828,46 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
         _Pragma("unroll") for (int i_ = 0; i_ < IL_CAP; i_++) {                                                              \
           const uint32_t nib_ = ((i_ < 8 ? L[3].z >> (4 * i_) : L[3].w >> (4 * (i_ - 8))) & 15u);                            \
           const uint32_t tag_ = (lw_[i_] >> eb) | (nib_ << hsh);                                                             \
-          if ((uint32_t)i_ >= (from) && (uint32_t)i_ < (to) && tag_ == (qtag)) { mine++; count_hit((int)(lw_[i_] & emk)); }    \
+          const bool hit_ = (uint32_t)i_ >= (from) && (uint32_t)i_ < (to) && tag_ == (qtag);                                  \
+          const unsigned long long bal_ = __builtin_amdgcn_ballot_w64(hit_);                                                  \
+          if (bal_) {                                                                                                        \
+            if (hit_) hitq[hbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal_, 0u))] = lw_[i_] & emk; \
+            const int np_ = __popcll(bal_);                                                                                  \
+            hbase += np_; nhits += (unsigned long long)np_;                                                                  \
+            if (hbase > IQ_HQ - 64) flush_hits();                                                                            \
+          }                                                                                                                 \
         }                                                                                                                   \
       }
-      for (int sb = (int)threadIdx.x; sb < sp.H; sb += IQ_LB * IQ_THREADS) {
+      for (int sb0 = 0; sb0 < sp.H; sb0 += IQ_LB * IQ_THREADS) {     // (wave-uniform trip count: the scans below are executed by all lanes)
+        const int sb = sb0 + (int)threadIdx.x;
         uint4 L[IQ_LB][4];
         uint32_t hvv[IQ_LB], nn[IQ_LB];
-        const uint32_t* lp[IQ_LB];
 #pragma unroll
         for (int u = 0; u < IQ_LB; u++) {
           const int s = sb + u * IQ_THREADS;
-          hvv[u] = 0; lp[u] = ix.lines;
-          L[u][3] = make_uint4(0u, 0u, 0u, 0u);
+          hvv[u] = 0;
+          L[u][0] = L[u][1] = L[u][2] = L[u][3] = make_uint4(0u, 0u, 0u, 0u);
           if (s < sp.H) {
             hvv[u] = inv_mix((uint32_t)qrow[s]);
-            lp[u] = ix.lines + (size_t)s * lstride + ((size_t)(hvv[u] >> lsh) << 4);
-            const uint4* l4 = (const uint4*)lp[u];
+            const uint4* l4 = (const uint4*)(ix.lines + (size_t)s * lstride + ((size_t)(hvv[u] >> lsh) << 4));
             L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
           }
         }
-        bool any_partner = false;
+        bool partner = false;
 #pragma unroll
         for (int u = 0; u < IQ_LB; u++) {
           const int s = sb + u * IQ_THREADS;
-          const uint32_t hdr = L[u][3].w >> 24;
+          const uint32_t hdr = L[u][3].w >> 24;      // (0 for a lane without a slot: nothing to scan)
           nn[u] = 0;
-          if (s < sp.H) {
-            if (hdr == IL_FALLBACK) {
-              const uint32_t at = atomicAdd(&s_nov, 1u);
-              if (at < (uint32_t)IQ_OV) ovlist[at] = (uint32_t)s;
-            } else if (hdr) {
-              nn[u] = hdr;
-              const uint32_t qt = hvv[u] & tmask;
-              IQ_LINE_SCAN(L[u], 0u, hdr, qt);
-              if (hdr > (uint32_t)IL_CAP) any_partner = true;
-            }
-          }
+          if (hdr == IL_FALLBACK) {
+            const uint32_t at = atomicAdd(&s_nov, 1u);
+            if (at < (uint32_t)IQ_OV) ovlist[at] = (uint32_t)s;
+          } else nn[u] = hdr;
+          const uint32_t qt = hvv[u] & tmask;
+          IQ_LINE_SCAN(L[u], 0u, nn[u], qt);
+          partner = partner || nn[u] > (uint32_t)IL_CAP;
         }
-        if (any_partner) {
+        if (__builtin_amdgcn_ballot_w64(partner)) {
           // what a line of more than 14 postings could not hold sits in its partner line, behind the partner's own
 #pragma unroll
           for (int u = 0; u < IQ_LB; u++)
@@ -855,13 +876,15 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
               L[u][0] = l4[0]; L[u][1] = l4[1]; L[u][2] = l4[2]; L[u][3] = l4[3];
             }
 #pragma unroll
-          for (int u = 0; u < IQ_LB; u++)
-            if (nn[u] > (uint32_t)IL_CAP) {
-              const uint32_t pn = L[u][3].w >> 24, qt = hvv[u] & tmask;
-              IQ_LINE_SCAN(L[u], pn, pn + nn[u] - (uint32_t)IL_CAP, qt);
-            }
+          for (int u = 0; u < IQ_LB; u++) {
+            const bool pm = nn[u] > (uint32_t)IL_CAP;
+            const uint32_t pn = pm ? L[u][3].w >> 24 : 0u, pe = pm ? pn + nn[u] - (uint32_t)IL_CAP : 0u, qt = hvv[u] & tmask;
+            IQ_LINE_SCAN(L[u], pn, pe, qt);
+          }
         }
       }
+      flush_hits();
+      if (threadIdx.x == 0) mine += nhits;
 #undef IQ_LINE_SCAN
 #endif
       __syncthreads();
