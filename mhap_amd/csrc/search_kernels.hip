@@ -290,6 +290,55 @@ __global__ __launch_bounds__(IB_BINS) void index_offsets_kernel(InvIndex ix, int
   for (int t = 0; t < tiles; t++) { const uint32_t v = c[(size_t)t * IB_BINS]; c[(size_t)t * IB_BINS] = run; run += v; }
 }
 
+// Step 4b (round 6; the tail of index_bins_kernel): the LINE table.  A lookup through ends / items is two dependent random accesses — the bucket's bounds, then its
+// postings — and in an N-GPU job every rank looks ALL N n queries up against its shard: the one term of a rank's step that does not
+// shrink with N.  Line l of slot s packs the postings of the buckets [l << lb, (l + 1) << lb) — 3.5 to 7 of them on average — into ONE
+// 64-byte line: the first-tier query reads that line and nothing else.  A packed posting is exact: the line index is the mix's top
+// nl_log bits, the posting keeps the other 32 - nl_log (the "tag") above the entry's ebits bits — at most 36 bits (index_line_params):
+//   words 0..13   the low 32 bits of 14 postings
+//   word 14       the top 4 bits of postings 0..7, word 15 bits 0..23 those of postings 8..13
+//   word 15 >> 24 the header: n = postings of the line's buckets (0..28), or 0xFF "look the bucket up in ends / items" (a long bucket: a
+//                 repeat — or, one line in ten thousand, more than a pair of lines holds)
+// n > 14: the postings beyond the 14th sit in the PARTNER line (l ^ 1: the other half of the same 128-byte block), behind the partner's
+// own (header of the partner = its own count < 14), as long as the pair's postings fit the pair's 28 places.
+constexpr int IL_CAP = 14;
+constexpr uint32_t IL_FALLBACK = 0xFFu;
+// the two lines of one pair: postings P[a .. b) belong to line 0's buckets, P[b .. c) to line 1's; out = the pair's 32 words
+__device__ __forceinline__ void il_build_pair(const uint2* __restrict__ P, uint32_t a, uint32_t b, uint32_t c, uint32_t tmask, uint32_t eb, uint4* __restrict__ out) {
+  const uint32_t n0 = b - a, n1 = c - b;
+  const bool fits = n0 + n1 <= 2u * IL_CAP;
+  const uint32_t h0 = n0 <= (uint32_t)IL_CAP ? n0 : (fits ? n0 : IL_FALLBACK), h1 = n1 <= (uint32_t)IL_CAP ? n1 : (fits ? n1 : IL_FALLBACK);
+  uint32_t w0[16], w1[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { w0[i] = 0u; w1[i] = 0u; }
+  const uint32_t m0 = n0 < (uint32_t)IL_CAP ? n0 : (uint32_t)IL_CAP, m1 = n1 < (uint32_t)IL_CAP ? n1 : (uint32_t)IL_CAP;
+  const uint32_t x0 = (fits && n0 > (uint32_t)IL_CAP) ? n0 - IL_CAP : 0u;   // postings of line 0 that go to line 1, and the other way round
+  const uint32_t x1 = (fits && n1 > (uint32_t)IL_CAP) ? n1 - IL_CAP : 0u;
+#pragma unroll
+  for (int i = 0; i < IL_CAP; i++) {
+    // place i of line 0: its own i-th posting, or (behind its own) what line 1 could not hold; the same for line 1
+    uint32_t src0 = 0xFFFFFFFFu, src1 = 0xFFFFFFFFu;
+    if ((uint32_t)i < m0) src0 = a + (uint32_t)i; else if ((uint32_t)i - m0 < x1) src0 = b + (uint32_t)IL_CAP + ((uint32_t)i - m0);
+    if ((uint32_t)i < m1) src1 = b + (uint32_t)i; else if ((uint32_t)i - m1 < x0) src1 = a + (uint32_t)IL_CAP + ((uint32_t)i - m1);
+    if (src0 != 0xFFFFFFFFu && h0 != IL_FALLBACK) {
+      const uint2 x = P[src0];
+      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
+      w0[i] = (uint32_t)W;
+      if (i < 8) w0[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w0[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
+    }
+    if (src1 != 0xFFFFFFFFu && h1 != IL_FALLBACK) {
+      const uint2 x = P[src1];
+      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
+      w1[i] = (uint32_t)W;
+      if (i < 8) w1[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w1[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
+    }
+  }
+  w0[15] |= h0 << 24; w1[15] |= h1 << 24;
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = make_uint4(w0[4 * i], w0[4 * i + 1], w0[4 * i + 2], w0[4 * i + 3]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[4 + i] = make_uint4(w1[4 * i], w1[4 * i + 1], w1[4 * i + 2], w1[4 * i + 3]);
+}
 // Step 4, one workgroup per (slot, bin): the bin's postings move from `staged` to `items` grouped by bucket; the buckets' ends are
 // written (ends[s][0] = 0 by bin 0).  sub = buckets per bin (a power of two, <= IB_SUB_MAX).
 constexpr int IB_SUB_MAX = 8192, IB_FIN_THREADS = 256;
@@ -330,6 +379,21 @@ __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix)
   for (uint32_t i = threadIdx.x; i < n; i += IB_FIN_THREADS) {
     const uint2 x = in[i];
     out[atomicAdd(&cnt[(x.x >> ix.shift) & smask], 1u)] = x;
+  }
+  if (ix.lines) {
+    // Step 4b: this bin's lines, from the postings just written (they come back out of the L2) and the buckets' ends, which the scatter's
+    // cursors have become: cnt[i] = end of bucket i within the bin.  (As a kernel of its own — round 6's first version — the line table
+    // read ends and items again: +0.9 ms of build at C2.)
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t lb = ix.line_lb, lpb = (uint32_t)sub >> lb;          // lines of this bin (even: index_line_params)
+    const uint32_t tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits;
+    uint4* lbase = (uint4*)(ix.lines + (((size_t)s << ix.nl_log) + (size_t)bin * lpb) * 16);
+    for (uint32_t pr = threadIdx.x; pr < lpb / 2; pr += IB_FIN_THREADS) {
+      const uint32_t f = (2u * pr) << lb;                                // first bucket of the pair's line 0
+      const uint32_t a = f ? cnt[f - 1] : 0u, b = cnt[f + (1u << lb) - 1], c = cnt[f + (2u << lb) - 1];
+      il_build_pair(out, a, b, c, tmask, eb, lbase + (size_t)pr * 8);
+    }
   }
 }
 
@@ -400,79 +464,21 @@ __global__ __launch_bounds__(IB_GRP_THREADS) void index_group_kernel(InvIndex ix
   }
 }
 
-// Step 6 (round 6): the LINE table.  A lookup through ends / items is two dependent random accesses — the bucket's bounds, then its
-// postings — and in an N-GPU job every rank looks ALL N n queries up against its shard: the one term of a rank's step that does not
-// shrink with N.  Line l of slot s packs the postings of the buckets [l << lb, (l + 1) << lb) — 3.5 to 7 of them on average — into ONE
-// 64-byte line: the first-tier query reads that line and nothing else.  A packed posting is exact: the line index is the mix's top
-// nl_log bits, the posting keeps the other 32 - nl_log (the "tag") above the entry's ebits bits — at most 36 bits (index_line_params):
-//   words 0..13   the low 32 bits of 14 postings
-//   word 14       the top 4 bits of postings 0..7, word 15 bits 0..23 those of postings 8..13
-//   word 15 >> 24 the header: n = postings of the line's buckets (0..28), or 0xFF "look the bucket up in ends / items" (a long bucket: a
-//                 repeat — or, one line in ten thousand, more than a pair of lines holds)
-// n > 14: the postings beyond the 14th sit in the PARTNER line (l ^ 1: the other half of the same 128-byte block), behind the partner's
-// own (header of the partner = its own count < 14), as long as the pair's postings fit the pair's 28 places.
-constexpr int IL_CAP = 14;
-constexpr uint32_t IL_FALLBACK = 0xFFu;
-constexpr int IL_THREADS = 256;
-__global__ __launch_bounds__(IL_THREADS) void index_lines_kernel(InvIndex ix, int H) {
-  const size_t pairs = (size_t)1 << (ix.nl_log - 1);
-  const size_t t = (size_t)blockIdx.x * IL_THREADS + threadIdx.x;
-  if (t >= (size_t)H * pairs) return;
-  const size_t s = t >> (ix.nl_log - 1), pr = t & (pairs - 1);
-  const uint32_t* E = ix.ends + s * ((size_t)ix.nb + 1) + ((pr * 2) << ix.line_lb);
-  const uint32_t a = E[0], b = E[(size_t)1 << ix.line_lb], c = E[(size_t)2 << ix.line_lb];
-  const uint32_t n0 = b - a, n1 = c - b;
-  const bool fits = n0 + n1 <= 2u * IL_CAP;
-  const uint32_t h0 = n0 <= (uint32_t)IL_CAP ? n0 : (fits ? n0 : IL_FALLBACK), h1 = n1 <= (uint32_t)IL_CAP ? n1 : (fits ? n1 : IL_FALLBACK);
-  const uint2* P = ix.items + s * ix.slot_stride;
-  const uint32_t tmask = (ix.nl_log >= 32u) ? 0u : (0xFFFFFFFFu >> ix.nl_log), eb = ix.line_ebits;
-  uint32_t w0[16], w1[16];
-#pragma unroll
-  for (int i = 0; i < 16; i++) { w0[i] = 0u; w1[i] = 0u; }
-  const uint32_t m0 = n0 < (uint32_t)IL_CAP ? n0 : (uint32_t)IL_CAP, m1 = n1 < (uint32_t)IL_CAP ? n1 : (uint32_t)IL_CAP;
-  const uint32_t x0 = (fits && n0 > (uint32_t)IL_CAP) ? n0 - IL_CAP : 0u;   // postings of line 0 that go to line 1, and the other way round
-  const uint32_t x1 = (fits && n1 > (uint32_t)IL_CAP) ? n1 - IL_CAP : 0u;
-#pragma unroll
-  for (int i = 0; i < IL_CAP; i++) {
-    // place i of line 0: its own i-th posting, or (behind its own) what line 1 could not hold; the same for line 1
-    uint32_t src0 = 0xFFFFFFFFu, src1 = 0xFFFFFFFFu;
-    if ((uint32_t)i < m0) src0 = a + (uint32_t)i; else if ((uint32_t)i - m0 < x1) src0 = b + (uint32_t)IL_CAP + ((uint32_t)i - m0);
-    if ((uint32_t)i < m1) src1 = b + (uint32_t)i; else if ((uint32_t)i - m1 < x0) src1 = a + (uint32_t)IL_CAP + ((uint32_t)i - m1);
-    if (src0 != 0xFFFFFFFFu && h0 != IL_FALLBACK) {
-      const uint2 x = P[src0];
-      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
-      w0[i] = (uint32_t)W;
-      if (i < 8) w0[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w0[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
-    }
-    if (src1 != 0xFFFFFFFFu && h1 != IL_FALLBACK) {
-      const uint2 x = P[src1];
-      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
-      w1[i] = (uint32_t)W;
-      if (i < 8) w1[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w1[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
-    }
-  }
-  w0[15] |= h0 << 24; w1[15] |= h1 << 24;
-  uint4* out = (uint4*)(ix.lines + ((s << ix.nl_log) + pr * 2) * 16);
-#pragma unroll
-  for (int i = 0; i < 4; i++) out[i] = make_uint4(w0[4 * i], w0[4 * i + 1], w0[4 * i + 2], w0[4 * i + 3]);
-#pragma unroll
-  for (int i = 0; i < 4; i++) out[4 + i] = make_uint4(w1[4 * i], w1[4 * i + 1], w1[4 * i + 2], w1[4 * i + 3]);
-}
 // lines per slot and posting layout for an index of `entries` entries in nb buckets per slot; false: no line table (a posting would not
 // fit its 36 bits, or MHAP_INDEX_LINES=0).  Average postings per line: 3.5 .. 7 (IL_CAP = 14 places, 28 with the partner's)
 bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t& lb, uint32_t& ebits) {
-  // Default: a line table for an index of up to 65 536 entries — a rank's shard of an 8- or 4-GPU C2 job, a small -q index: a table of a
-  // few hundred MB the Infinity Cache largely holds.  Measured in round 6 with a line per lane (EXPERIMENTS.md): rank of eight at C2
-  // (25 000 entries) index_query 1.47 -> 1.06 ms for +0.15 ms of build; rank of eight at C4 (250 000) 19.3 -> 15.6 for +1.35; C2 on one
-  // GPU (200 000 entries, every query counting its own strand) 2.39 -> 2.36 for +0.9 of build next to the ordered kernel: a loss.
+  // Default: a line table whenever the layout allows and the index has 8 192 entries or more.  Measured in round 6 (EXPERIMENTS.md), lines
+  // built by index_bins_kernel, hits queued: rank of eight at C2 (25 000 entries) index_query 1.47 -> 1.03 ms, C2 on one GPU (200 000) 2.36 ->
+  // 1.79, rank of eight at C4 (250 000) 19.5 -> 11.8; C1 (2 000 entries) 0.040 -> 0.052 and +0.01 of build: off there.
   // MHAP_INDEX_LINES=0 / 1: never / whenever the layout allows.
   const char* e = getenv("MHAP_INDEX_LINES");
   if (e && e[0] == '0') return false;
-  if (!(e && e[0] == '1') && entries > 65536) return false;
+  if (!(e && e[0] == '1') && entries < 8192) return false;   // (a tiny index: C1's 2 000 entries — the whole index sits in the L2 either way, the lines only cost their build)
   const int64_t per_line = []() { const char* v = getenv("MHAP_INDEX_LINE_LOAD"); const int x = v ? atoi(v) : 0; return (int64_t)(x >= 1 && x <= 14 ? x : 7); }();
   uint32_t nbl = 0;
   while ((1u << nbl) < nb) nbl++;
-  uint32_t l = 1;
+  uint32_t l = (uint32_t)IB_BINS_LOG + 1;   // (at least a pair of lines per coarse bin: the pair is built by the bin's workgroup)
+  if (l > nbl) return false;
   while (l < nbl && ((int64_t)1 << l) * per_line < entries) l++;
   if (((int64_t)1 << l) * per_line < entries) return false;          // (an index beyond nb * 7 entries: more than 7 M)
   ebits = 1;
@@ -553,10 +559,6 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
   hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
   hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
   if (ix.grouped) hipLaunchKernelGGL(index_group_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_GRP_THREADS), 0, st, ix);
-  if (ix.lines) {
-    const size_t threads = (size_t)H << (ix.nl_log - 1);
-    hipLaunchKernelGGL(index_lines_kernel, dim3((unsigned)((threads + IL_THREADS - 1) / IL_THREADS)), dim3(IL_THREADS), 0, st, ix, H);
-  }
 }
 // (called when the index is sized: an index the compact dense tier covers in one pass gains nothing from the order, and the class
 //  counters bound the size from above.  MHAP_INDEX_GROUP=0|1 never / always, MHAP_INDEX_GROUP_T, MHAP_INDEX_CLASS_LOG: tests, which
@@ -643,7 +645,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   //  trip ahead on top of it — with the mixed value recomputed, or the kernel drops to three waves per SIMD — gave nothing: 3.03 / 2.18)
   iq_pre_t pre_hv = 0, pre_lo = 0, pre_n = 0;
   bool pre_ok = false;
-  // round 6: the index has a LINE table (index_lines_kernel) and this launch hands its large hit sets on: one 64-byte line per lookup
+  // round 6: the index has a LINE table (index_bins_kernel, step 4b) and this launch hands its large hit sets on: one 64-byte line per lookup
   // instead of bucket bounds + postings; only slots whose line says "long bucket" (a repeat) go through ends / items below
   constexpr bool lmode = LINES;   // (launch_index_query: big != nullptr && ix.lines != nullptr)
   __shared__ uint32_t s_nov;
