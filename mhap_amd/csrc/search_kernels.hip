@@ -290,7 +290,7 @@ __global__ __launch_bounds__(IB_BINS) void index_offsets_kernel(InvIndex ix, int
   for (int t = 0; t < tiles; t++) { const uint32_t v = c[(size_t)t * IB_BINS]; c[(size_t)t * IB_BINS] = run; run += v; }
 }
 
-// Step 4b (round 6; the tail of index_bins_kernel): the LINE table.  A lookup through ends / items is two dependent random accesses — the bucket's bounds, then its
+// Step 6 (round 6): the LINE table.  A lookup through ends / items is two dependent random accesses — the bucket's bounds, then its
 // postings — and in an N-GPU job every rank looks ALL N n queries up against its shard: the one term of a rank's step that does not
 // shrink with N.  Line l of slot s packs the postings of the buckets [l << lb, (l + 1) << lb) — 3.5 to 7 of them on average — into ONE
 // 64-byte line: the first-tier query reads that line and nothing else.  A packed posting is exact: the line index is the mix's top
@@ -303,41 +303,47 @@ __global__ __launch_bounds__(IB_BINS) void index_offsets_kernel(InvIndex ix, int
 // own (header of the partner = its own count < 14), as long as the pair's postings fit the pair's 28 places.
 constexpr int IL_CAP = 14;
 constexpr uint32_t IL_FALLBACK = 0xFFu;
-// the two lines of one pair: postings P[a .. b) belong to line 0's buckets, P[b .. c) to line 1's; out = the pair's 32 words
-__device__ __forceinline__ void il_build_pair(const uint2* __restrict__ P, uint32_t a, uint32_t b, uint32_t c, uint32_t tmask, uint32_t eb, uint4* __restrict__ out) {
-  const uint32_t n0 = b - a, n1 = c - b;
-  const bool fits = n0 + n1 <= 2u * IL_CAP;
-  const uint32_t h0 = n0 <= (uint32_t)IL_CAP ? n0 : (fits ? n0 : IL_FALLBACK), h1 = n1 <= (uint32_t)IL_CAP ? n1 : (fits ? n1 : IL_FALLBACK);
-  uint32_t w0[16], w1[16];
+// one line: its own postings P[me_lo .. me_lo + n_me), and — behind them — what its partner line (n_pt postings from pt_lo) cannot hold
+__device__ __forceinline__ void il_build_line(const uint2* __restrict__ P, uint32_t me_lo, uint32_t n_me, uint32_t pt_lo, uint32_t n_pt, uint32_t tmask, uint32_t eb,
+                                              uint4* __restrict__ out) {
+  const bool fits = n_me + n_pt <= 2u * IL_CAP;
+  const uint32_t h = n_me <= (uint32_t)IL_CAP ? n_me : (fits ? n_me : IL_FALLBACK);
+  uint32_t w[16];
 #pragma unroll
-  for (int i = 0; i < 16; i++) { w0[i] = 0u; w1[i] = 0u; }
-  const uint32_t m0 = n0 < (uint32_t)IL_CAP ? n0 : (uint32_t)IL_CAP, m1 = n1 < (uint32_t)IL_CAP ? n1 : (uint32_t)IL_CAP;
-  const uint32_t x0 = (fits && n0 > (uint32_t)IL_CAP) ? n0 - IL_CAP : 0u;   // postings of line 0 that go to line 1, and the other way round
-  const uint32_t x1 = (fits && n1 > (uint32_t)IL_CAP) ? n1 - IL_CAP : 0u;
+  for (int i = 0; i < 16; i++) w[i] = 0u;
+  const uint32_t m = n_me < (uint32_t)IL_CAP ? n_me : (uint32_t)IL_CAP;
+  const uint32_t x = (fits && n_pt > (uint32_t)IL_CAP) ? n_pt - IL_CAP : 0u;   // postings of the partner that sit here
+  if (h != IL_FALLBACK) {
 #pragma unroll
-  for (int i = 0; i < IL_CAP; i++) {
-    // place i of line 0: its own i-th posting, or (behind its own) what line 1 could not hold; the same for line 1
-    uint32_t src0 = 0xFFFFFFFFu, src1 = 0xFFFFFFFFu;
-    if ((uint32_t)i < m0) src0 = a + (uint32_t)i; else if ((uint32_t)i - m0 < x1) src0 = b + (uint32_t)IL_CAP + ((uint32_t)i - m0);
-    if ((uint32_t)i < m1) src1 = b + (uint32_t)i; else if ((uint32_t)i - m1 < x0) src1 = a + (uint32_t)IL_CAP + ((uint32_t)i - m1);
-    if (src0 != 0xFFFFFFFFu && h0 != IL_FALLBACK) {
-      const uint2 x = P[src0];
-      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
-      w0[i] = (uint32_t)W;
-      if (i < 8) w0[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w0[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
-    }
-    if (src1 != 0xFFFFFFFFu && h1 != IL_FALLBACK) {
-      const uint2 x = P[src1];
-      const unsigned long long W = ((unsigned long long)(x.x & tmask) << eb) | (unsigned long long)x.y;
-      w1[i] = (uint32_t)W;
-      if (i < 8) w1[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w1[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
+    for (int i = 0; i < IL_CAP; i++) {
+      uint32_t src = 0xFFFFFFFFu;
+      if ((uint32_t)i < m) src = me_lo + (uint32_t)i; else if ((uint32_t)i - m < x) src = pt_lo + (uint32_t)IL_CAP + ((uint32_t)i - m);
+      if (src != 0xFFFFFFFFu) {
+        const uint2 v = P[src];
+        const unsigned long long W = ((unsigned long long)(v.x & tmask) << eb) | (unsigned long long)v.y;
+        w[i] = (uint32_t)W;
+        if (i < 8) w[14] |= ((uint32_t)(W >> 32) & 15u) << (4 * i); else w[15] |= ((uint32_t)(W >> 32) & 15u) << (4 * (i - 8));
+      }
     }
   }
-  w0[15] |= h0 << 24; w1[15] |= h1 << 24;
+  w[15] |= h << 24;
 #pragma unroll
-  for (int i = 0; i < 4; i++) out[i] = make_uint4(w0[4 * i], w0[4 * i + 1], w0[4 * i + 2], w0[4 * i + 3]);
-#pragma unroll
-  for (int i = 0; i < 4; i++) out[4 + i] = make_uint4(w1[4 * i], w1[4 * i + 1], w1[4 * i + 2], w1[4 * i + 3]);
+  for (int i = 0; i < 4; i++) out[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+// One thread per line.  (Built by index_bins_kernel's own workgroups right after their scatter — the postings come back out of the L2, the
+// buckets' ends are the scatter's cursors — it was SLOWER: a (slot, bin) workgroup has 16 to 128 pairs of lines for its 256 threads and every
+// thread walks its pair serially: index build 0.91 -> 1.11 ms for a rank of eight at C2, the ordered kernel beside it 0.80 -> 1.0; C1
+// 0.148 -> 0.242.  Round 6, EXPERIMENTS.md.)
+constexpr int IL_THREADS = 256;
+__global__ __launch_bounds__(IL_THREADS) void index_lines_kernel(InvIndex ix, int H) {
+  const size_t t = (size_t)blockIdx.x * IL_THREADS + threadIdx.x;
+  if (t >= ((size_t)H << ix.nl_log)) return;
+  const size_t s = t >> ix.nl_log, l = t & (((size_t)1 << ix.nl_log) - 1);
+  const uint32_t* E = ix.ends + s * ((size_t)ix.nb + 1) + ((l & ~(size_t)1) << ix.line_lb);   // ends at the pair's first bucket
+  const uint32_t a = E[0], b = E[(size_t)1 << ix.line_lb], c = E[(size_t)2 << ix.line_lb];
+  const bool odd = (l & 1) != 0;
+  il_build_line(ix.items + s * ix.slot_stride, odd ? b : a, odd ? c - b : b - a, odd ? a : b, odd ? b - a : c - b, 0xFFFFFFFFu >> ix.nl_log, ix.line_ebits,
+                (uint4*)(ix.lines + ((s << ix.nl_log) + l) * 16));
 }
 // Step 4, one workgroup per (slot, bin): the bin's postings move from `staged` to `items` grouped by bucket; the buckets' ends are
 // written (ends[s][0] = 0 by bin 0).  sub = buckets per bin (a power of two, <= IB_SUB_MAX).
@@ -379,21 +385,6 @@ __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix)
   for (uint32_t i = threadIdx.x; i < n; i += IB_FIN_THREADS) {
     const uint2 x = in[i];
     out[atomicAdd(&cnt[(x.x >> ix.shift) & smask], 1u)] = x;
-  }
-  if (ix.lines) {
-    // Step 4b: this bin's lines, from the postings just written (they come back out of the L2) and the buckets' ends, which the scatter's
-    // cursors have become: cnt[i] = end of bucket i within the bin.  (As a kernel of its own — round 6's first version — the line table
-    // read ends and items again: +0.9 ms of build at C2.)
-    __threadfence_block();
-    __syncthreads();
-    const uint32_t lb = ix.line_lb, lpb = (uint32_t)sub >> lb;          // lines of this bin (even: index_line_params)
-    const uint32_t tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits;
-    uint4* lbase = (uint4*)(ix.lines + (((size_t)s << ix.nl_log) + (size_t)bin * lpb) * 16);
-    for (uint32_t pr = threadIdx.x; pr < lpb / 2; pr += IB_FIN_THREADS) {
-      const uint32_t f = (2u * pr) << lb;                                // first bucket of the pair's line 0
-      const uint32_t a = f ? cnt[f - 1] : 0u, b = cnt[f + (1u << lb) - 1], c = cnt[f + (2u << lb) - 1];
-      il_build_pair(out, a, b, c, tmask, eb, lbase + (size_t)pr * 8);
-    }
   }
 }
 
@@ -468,7 +459,7 @@ __global__ __launch_bounds__(IB_GRP_THREADS) void index_group_kernel(InvIndex ix
 // fit its 36 bits, or MHAP_INDEX_LINES=0).  Average postings per line: 3.5 .. 7 (IL_CAP = 14 places, 28 with the partner's)
 bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t& lb, uint32_t& ebits) {
   // Default: a line table whenever the layout allows and the index has 8 192 entries or more.  Measured in round 6 (EXPERIMENTS.md), lines
-  // built by index_bins_kernel, hits queued: rank of eight at C2 (25 000 entries) index_query 1.47 -> 1.03 ms, C2 on one GPU (200 000) 2.36 ->
+  // hits queued: rank of eight at C2 (25 000 entries) index_query 1.47 -> 1.03 ms, C2 on one GPU (200 000) 2.36 ->
   // 1.79, rank of eight at C4 (250 000) 19.5 -> 11.8; C1 (2 000 entries) 0.040 -> 0.052 and +0.01 of build: off there.
   // MHAP_INDEX_LINES=0 / 1: never / whenever the layout allows.
   const char* e = getenv("MHAP_INDEX_LINES");
@@ -477,8 +468,7 @@ bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t&
   const int64_t per_line = []() { const char* v = getenv("MHAP_INDEX_LINE_LOAD"); const int x = v ? atoi(v) : 0; return (int64_t)(x >= 1 && x <= 14 ? x : 7); }();
   uint32_t nbl = 0;
   while ((1u << nbl) < nb) nbl++;
-  uint32_t l = (uint32_t)IB_BINS_LOG + 1;   // (at least a pair of lines per coarse bin: the pair is built by the bin's workgroup)
-  if (l > nbl) return false;
+  uint32_t l = 1;
   while (l < nbl && ((int64_t)1 << l) * per_line < entries) l++;
   if (((int64_t)1 << l) * per_line < entries) return false;          // (an index beyond nb * 7 entries: more than 7 M)
   ebits = 1;
@@ -559,6 +549,10 @@ void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stri
   hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
   hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
   if (ix.grouped) hipLaunchKernelGGL(index_group_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_GRP_THREADS), 0, st, ix);
+  if (ix.lines) {
+    const size_t threads = (size_t)H << ix.nl_log;
+    hipLaunchKernelGGL(index_lines_kernel, dim3((unsigned)((threads + IL_THREADS - 1) / IL_THREADS)), dim3(IL_THREADS), 0, st, ix, H);
+  }
 }
 // (called when the index is sized: an index the compact dense tier covers in one pass gains nothing from the order, and the class
 //  counters bound the size from above.  MHAP_INDEX_GROUP=0|1 never / always, MHAP_INDEX_GROUP_T, MHAP_INDEX_CLASS_LOG: tests, which
@@ -645,7 +639,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   //  trip ahead on top of it — with the mixed value recomputed, or the kernel drops to three waves per SIMD — gave nothing: 3.03 / 2.18)
   iq_pre_t pre_hv = 0, pre_lo = 0, pre_n = 0;
   bool pre_ok = false;
-  // round 6: the index has a LINE table (index_bins_kernel, step 4b) and this launch hands its large hit sets on: one 64-byte line per lookup
+  // round 6: the index has a LINE table (index_lines_kernel) and this launch hands its large hit sets on: one 64-byte line per lookup
   // instead of bucket bounds + postings; only slots whose line says "long bucket" (a repeat) go through ends / items below
   constexpr bool lmode = LINES;   // (launch_index_query: big != nullptr && ix.lines != nullptr)
   __shared__ uint32_t s_nov;
@@ -805,7 +799,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       }
 #else
     if (lmode) {
-      static_assert(!LINES || IQ_THREADS == 64, "the line phase compacts its hits with wave ballots");
+      // (the queue is per WAVE — ballots compact within a wave — so the 256-lane middle tier runs the same code: IQ_HQ / waves words each)
       const uint32_t lsh = 32u - ix.nl_log, tmask = 0xFFFFFFFFu >> ix.nl_log, eb = ix.line_ebits, emk = (1u << eb) - 1u, hsh = 32u - eb;
       const size_t lstride = (size_t)16 << ix.nl_log;   // words of one slot's lines
       // Hits are QUEUED, not counted where they are found: a match is one lane in a hundred per place, and counting it on the spot sent the
@@ -813,12 +807,16 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       // build without the counting ran C2's first tier in 1.05 ms against 2.26 with it (round 6).  The scan is executed by all lanes together
       // (a lane without a line scans the empty range), a ballot compacts the matching entries into hitq, and the queue is counted by a loop in
       // which every lane has a hit to count.
-      int hbase = 0;                 // hits waiting in hitq (wave-uniform)
+      int hbase = 0;                 // hits waiting in this wave's queue (wave-uniform)
       unsigned long long nhits = 0;  // ... and all hits so far ("table elements processed")
+      constexpr int HQW = IQ_HQ / (IQ_THREADS / 64);                 // words of one wave's queue (256)
+      static_assert(HQW >= 128, "a place adds up to 64 hits to a queue that is flushed beyond HQW - 64");
+      uint32_t* const hq = hitq + (threadIdx.x >> 6) * HQW;
+      const int wlane = (int)(threadIdx.x & 63u);
       auto flush_hits = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (int i = (int)threadIdx.x; i < hbase; i += IQ_THREADS) count_hit((int)hitq[i]);
+        for (int i = wlane; i < hbase; i += 64) count_hit((int)hq[i]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
         hbase = 0;
@@ -833,10 +831,10 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
           const bool hit_ = (uint32_t)i_ >= (from) && (uint32_t)i_ < (to) && tag_ == (qtag);                                  \
           const unsigned long long bal_ = __builtin_amdgcn_ballot_w64(hit_);                                                  \
           if (bal_) {                                                                                                        \
-            if (hit_) hitq[hbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal_, 0u))] = lw_[i_] & emk; \
+            if (hit_) hq[hbase + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal_, 0u))] = lw_[i_] & emk; \
             const int np_ = __popcll(bal_);                                                                                  \
             hbase += np_; nhits += (unsigned long long)np_;                                                                  \
-            if (hbase > IQ_HQ - 64) flush_hits();                                                                            \
+            if (hbase > HQW - 64) flush_hits();                                                                              \
           }                                                                                                                 \
         }                                                                                                                   \
       }
@@ -886,7 +884,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
         }
       }
       flush_hits();
-      if (threadIdx.x == 0) mine += nhits;
+      if (wlane == 0) mine += nhits;
 #undef IQ_LINE_SCAN
 #endif
       __syncthreads();
@@ -1468,6 +1466,9 @@ void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminh
   else if (tier == 0)
     hipLaunchKernelGGL((index_query_kernel<INV_CT, IQ_THREADS, IQ_SPT, false>), dim3((unsigned)nq), dim3(IQ_THREADS), 0, st, ix, qminhash, qrow_stride, qlist, nq, ids, qids,
                        meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
+  else if (tier == 1 && big != nullptr && ix.lines != nullptr)
+    hipLaunchKernelGGL((index_query_kernel<INV_CT_MID, IQ_THREADS_MID, 1, true>), dim3((unsigned)nq), dim3(IQ_THREADS_MID), 0, st, ix, qminhash, qrow_stride, qlist, nq,
+                       ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
   else if (tier == 1)
     hipLaunchKernelGGL((index_query_kernel<INV_CT_MID, IQ_THREADS_MID, 1, false>), dim3((unsigned)nq), dim3(IQ_THREADS_MID), 0, st, ix, qminhash, qrow_stride, qlist, nq,
                        ids, qids, meta, qmeta, sp, cand, cand_count, cand_cap, split_count, elements, big, big_count);
