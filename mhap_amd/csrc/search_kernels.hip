@@ -890,7 +890,28 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
       __syncthreads();
       const uint32_t nov = s_nov;
       if (nov > (uint32_t)IQ_OV) { if (threadIdx.x == 0) s_over = 1; nloop = 0; }   // (a query with that many long buckets is repeat-rich: handed on)
-      else nloop = (int)nov;
+      else {
+        nloop = (int)nov;
+        if (nov) {
+          // the long buckets' lengths say whether this table can hold their hits — the plain path's early hand-over, for the slots the
+          // lines sent here (without it a repeat-rich query with a few dozen long buckets streamed all of them before its table
+          // overflowed: C5 slice, first tier 4.6 -> 33 ms with the line table)
+          unsigned long long tot = 0;
+          for (uint32_t i = threadIdx.x; i < nov; i += IQ_THREADS) {
+            const uint32_t so = ovlist[i];
+            const uint32_t hvp = inv_mix((uint32_t)qrow[so]);
+            const uint32_t* E = ix.ends + (size_t)so * eper + (hvp >> ix.shift);
+            tot += E[1] - E[0];
+          }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+          if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = tot;
+          __syncthreads();
+          tot = 0;
+          for (unsigned w = 0; w < IQ_THREADS / 64; w++) tot += wsum[w];
+          if (tot + s_distinct > (5ULL * (INV_CT * 3 / 4)) / 4) { if (threadIdx.x == 0) s_over = 1; nloop = 0; }
+        }
+      }
       __syncthreads();
     }
     for (int s0 = 0, it = 0; s0 < nloop; s0 += QCAP, it++) {   // workgroup-uniform trip count (barriers inside)

@@ -1,15 +1,19 @@
-# tests/fuzz_parity.py against the round's final kernels on the GPU box: ROUND=r05 bash tools/fuzz_campaign.sh  ->  gpurun_out/$R/${R}_fuzz_summary.txt
+# tests/fuzz_parity.py against the round's final kernels on the GPU box: ROUND=r06 bash tools/fuzz_campaign.sh  ->  gpurun_out/$R/${R}_fuzz_summary.txt
 # (random flags, read mixes, repeat families, -f filters; sorted record lines GPU vs oracle; every line: draws, setting, failures)
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 mkdir -p gpurun_out/$R
 OUT=gpurun_out/$R/${R}_fuzz_summary.txt
-echo "# tests/fuzz_parity.py against the round-5 kernels (MinHash class dispatch in assembly, re-queue overflow fix, queue window growing with H; first query tier with static vector writes; three-pass join with the lane kernel's bounded selection; ordered kernel with LDS reads and batched fill / rank; collective-call rendezvous), run on an MI355X box:" > $OUT
+echo "# tests/fuzz_parity.py against the round-6 kernels (line table of the first and middle query tiers with queued hits, wave-reduced elements counter, seeded MinHash row items, join kernel's wide units compiled alone, tagged rendezvous), run on an MI355X box:" > $OUT
 run() {  # draws seed label env...
   n=$1; seed=$2; label=$3; shift 3
   f=$(env "$@" timeout 3000 python tests/fuzz_parity.py $n $seed 2>/dev/null | tail -1)
   echo "$n draws, $label: $f" >> $OUT
 }
 run ${N1:-400} 50000 "default"
+run ${NL1:-300} 60000 "line table forced on these small indexes (MHAP_INDEX_LINES=1)" MHAP_INDEX_LINES=1
+run ${NL2:-200} 61000 "line table, packed lines (MHAP_INDEX_LINE_LOAD=14: partner spills, 'see the buckets' lines)" MHAP_INDEX_LINES=1 MHAP_INDEX_LINE_LOAD=14
+run ${NL3:-150} 62000 "line table + middle tier forced" MHAP_INDEX_LINES=1 MHAP_INDEX_MID=1
+run ${NL4:-100} 63000 "line table, sparse lines, 128-query chunks" MHAP_INDEX_LINES=1 MHAP_INDEX_LINE_LOAD=1 MHAP_QUERY_CHUNK=128
 run ${N2:-150} 51000 "queue-overflow variant of the MinHash kernel (qcap64: every full row takes the exact redo)" MHAP_LIB_PATH=mhap_amd/lib/variants/libmhaphip_qcap64.so
 run ${N3:-100} 52000 "MHAP_MINHASH=classic (the general kernel for the weight-1 strands too)" MHAP_MINHASH=classic
 run ${N4:-80} 53000 "MHAP_MINHASH=perchain" MHAP_MINHASH=perchain
