@@ -458,13 +458,16 @@ __global__ __launch_bounds__(IB_GRP_THREADS) void index_group_kernel(InvIndex ix
 // lines per slot and posting layout for an index of `entries` entries in nb buckets per slot; false: no line table (a posting would not
 // fit its 36 bits, or MHAP_INDEX_LINES=0).  Average postings per line: 3.5 .. 7 (IL_CAP = 14 places, 28 with the partner's)
 bool index_line_params(int64_t entries, uint32_t nb, uint32_t& nl_log, uint32_t& lb, uint32_t& ebits) {
-  // Default: a line table whenever the layout allows and the index has 8 192 entries or more.  Measured in round 6 (EXPERIMENTS.md), lines
-  // hits queued: rank of eight at C2 (25 000 entries) index_query 1.47 -> 1.03 ms, C2 on one GPU (200 000) 2.36 ->
-  // 1.79, rank of eight at C4 (250 000) 19.5 -> 11.8; C1 (2 000 entries) 0.040 -> 0.052 and +0.01 of build: off there.
+  // Default: a line table for an index of 8 192 to 262 144 entries.  Measured in round 6 (EXPERIMENTS.md; hits queued, one build thread per
+  // line), index_query / index_build / step, without -> with: rank of eight at C2 (25 000 entries) 1.47 -> 1.03 / 0.78 -> 0.88 / 14.9 -> 14.4 ms;
+  // C2 on one GPU (200 000) 2.29 -> 1.79 / 2.94 -> 3.80 / 95.2 -> 94.8 (even: the build runs next to the ordered kernel); rank of eight at C4
+  // (250 000) 19.4 -> 11.7 / 3.7 -> 5.0 / 194 -> 189; C4 on one GPU (2 M entries: the middle tier) 76.8 -> 73.5 / 35.3 -> 44.4 / 1466 -> 1471;
+  // one rank's share of configs[4] (1.25 M, repeat-rich: the dense tier) 392 -> 405 / 23 -> 29 / 3314 -> 3362; C1 (2 000) 0.041 -> 0.051 /
+  // 0.139 -> 0.147 / 0.93 -> 0.98.  So: the sizes where the first tier does the work and the table stays near the caches.
   // MHAP_INDEX_LINES=0 / 1: never / whenever the layout allows.
   const char* e = getenv("MHAP_INDEX_LINES");
   if (e && e[0] == '0') return false;
-  if (!(e && e[0] == '1') && entries < 8192) return false;   // (a tiny index: C1's 2 000 entries — the whole index sits in the L2 either way, the lines only cost their build)
+  if (!(e && e[0] == '1') && (entries < 8192 || entries > 262144)) return false;
   const int64_t per_line = []() { const char* v = getenv("MHAP_INDEX_LINE_LOAD"); const int x = v ? atoi(v) : 0; return (int64_t)(x >= 1 && x <= 14 ? x : 7); }();
   uint32_t nbl = 0;
   while ((1u << nbl) < nb) nbl++;
