@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fills the measured numbers of DESIGN.md from the round's profile files, so that the document's tables and the committed evidence cannot
-drift apart: python tools/fill_design.py docs/DESIGN.template.md profiles r05 > DESIGN.md   (placeholders are @NAME@)."""
+drift apart: python tools/fill_design.py docs/DESIGN.template.md profiles r06 > DESIGN.md   (placeholders are @NAME@)."""
 import json
 import os
 import sys
@@ -49,6 +49,7 @@ def main():
                     if "ms_per_step" in d1 else "not measured")
     c1, c4s, c4, c5s, c5r = (last_json(P(f"bench_{c}.json")) for c in ("c1", "c4slice", "c4", "c5slice", "c5rank"))
     rep["C1"] = f"{c1['ms_per_step']:.2f} ms/step"
+    rep["C4IQ"] = f"{c4['kernel_ms_per_step']['index_query']:.1f}"
     rep["C4"] = f"{c4s['ms_per_step']:.1f} ms / {c4['ms_per_step'] / 1e3:.3f} s"
     rep["C5"] = f"{c5s['ms_per_step']:.0f} ms / {c5r['ms_per_step'] / 1e3:.2f} s ({c5r['value'] / 1e6:.1f} M overlaps/s, {c5r['records_per_step'] / 1e6:.1f} M records)"
     ranks = [json.loads(ln) for ln in open(P("emulate_rank.txt")) if ln.startswith("{")]
@@ -64,6 +65,16 @@ def main():
     rep["RANKTABLE"] = "\n".join(rows)
     rep["RANK8"] = "C2 %.1f ms, C4 %.0f ms, C5 %.1f s" % (r8["c2"]["rank_step_ms_without_comm"], r8["c4"]["rank_step_ms_without_comm"], r8["c5"]["rank_step_ms_without_comm"] / 1e3)
     model = r8["c2"]["rank_step_ms_without_comm"] + 0.4
+    rep["R8C2"] = f"{r8['c2']['rank_step_ms_without_comm']:.1f}"
+    rep["SPEEDUP_SHORT"] = f"{b['ms_per_step'] / model:.1f}× (N = 4: {b['ms_per_step'] / (next(r for r in ranks if r['world'] == 4 and r['config'] == 'c2')['rank_step_ms_without_comm'] + 0.3):.2f}×)"
+    rep["STAGE2_SHORT"] = f"{s2['frac']:.2f} of HBM peak, {k['overlap']:.2f} ms at C2"
+    smi = (b.get("soak") or {}).get("smi") or {}
+    if (b.get("soak") or {}).get("smi_ok") and smi.get("sclk_MHz_hwmon") and (smi.get("power_W_input") or smi.get("power_W_average")):
+        pw = smi.get("power_W_input") or smi.get("power_W_average")
+        rep["SMI"] = (f"{pw['mean']:.0f} W on average against the {smi['power_cap_W']['mean']:.0f}-W cap (max {pw['max']:.0f}) at a mean shader clock of "
+                      f"{smi['sclk_MHz_hwmon']['mean']:.0f} MHz ({smi['sclk_MHz_hwmon']['min']:.0f}-{smi['sclk_MHz_hwmon']['max']:.0f}) over the soak leg, {pw['n']} samples")
+    else:
+        rep["SMI"] = "the capture of this round FAILED (no clock or power samples on the box): soak.smi_ok false"
     rep["SPEEDUP"] = f"{b['ms_per_step']:.1f} / ({r8['c2']['rank_step_ms_without_comm']:.1f} + 0.4 exposed) = **{b['ms_per_step'] / model:.1f}×** (a model until a real run; C4: {one['c4'] / r8['c4']['rank_step_ms_without_comm']:.1f}× before the exchange)"
     text = open(tmpl).read()
     for inc in ("LIMITS", "SWITCHES", "LAYOUT"):
