@@ -1116,6 +1116,38 @@ def _subset_parity(fa, recs, idx, nthreads=16):
     return len(want)
 
 
+def test_config5_one_percent_family_subset_parity(tmp_path):
+    """The HARDER repeat structure of BASELINE configs[4]: the planted 300-bp family at 1 % divergence from its consensus (the c5rank / c5
+    configurations use 5 %, workloads.py says why; the 1 % family yields twelve times the candidates per read at a rank's size and was only
+    ever probed for time — VERDICT r05).  100 000 reads x 12 kb, generated -f file, --filter-threshold 1e-5: properties of every record, and
+    parity with the oracle under the same filter on the pairs among the first 1 500 reads."""
+    from mhap_amd import workloads as W
+    cfg = W.CONFIGS["c5rank"]
+    el, sp, _ = cfg["repeats"]
+    n = 100000
+    fa = mhap_amd.synth_reads(n, cfg["length"], seed=cfg["seed"], repeats=(el, sp, 0.01))
+    ffile = tmp_path / "kmers.txt"
+    W.write_filter_file(fa, str(ffile), max_reads=2000)
+    flt = mhap_amd.FrequencyCounts.from_file(str(ffile), filter_cutoff=1e-5, repeat_weight=0.9)
+    assert (flt.fractions >= 1e-5).sum() > 100
+    with MinHashSearch(MhapParams(), kmer_filter=flt) as ms:
+        ms.add_data(fa)
+        recs = ms.find_matches()
+        st, kt = ms.stats(), ms.kernel_times()
+    assert st["strands_indexed"] == 2 * n and st["queries_searched"] == n and len(recs) > 1000000
+    assert np.all(recs["to_id"] < recs["from_id"]) and np.all((recs["score"] >= 0.78) & (recs["score"] <= 1.0) & (recs["raw"] >= 3))
+    assert np.all((recs["a1"] >= 0) & (recs["a1"] <= recs["a2"]) & (recs["a2"] <= 12000 - 11) & (recs["alen"] == 12000) & (recs["blen"] == 12000))
+    key = (recs["from_id"].astype(np.int64) << 21) | (recs["to_id"].astype(np.int64) << 1) | recs["to_rc"].astype(np.int64)
+    assert len(np.unique(key)) == len(recs)
+    nsub = 1500
+    oflt = O.Filter(flt.hashes, flt.fractions, 1e-5, 0.9, 3.0, False)
+    want = O.record_lines(O.run_self(fa.subset(np.arange(nsub)), nthreads=16, flt=oflt, cap=1 << 22)["records"])
+    m = (recs["from_id"] <= nsub) & (recs["to_id"] <= nsub)
+    assert sorted(mhap_amd.records_to_lines(recs[m])) == want and len(want) >= 20
+    print(f"c5, 1 % family, {n} reads: {len(recs)} records from {st['candidates_compared']} candidates ({st['candidates_compared'] / n:.0f} per read, "
+          f"{st['slow_pairs']} through the per-lane kernel), {len(want)} among the first {nsub} reads; kernel ms " + ", ".join(f"{k}={v['ms']:.0f}" for k, v in kt.items() if v["ms"] > 0))
+
+
 def test_config3_ecoli_shaped_reads_at_scale_subset_parity():
     """Stand-in for BASELINE configs[2] (real E. coli P6-C4 reads: the file is in neither tree) at its scale AND with its repeat structure
     (round 6; the round-5 stand-in had a repeat-free genome): 90 000 reads of a log-normal length mix (median 8 kb, tail to 45 kb: reads
