@@ -130,6 +130,7 @@ struct InvIndex {
   uint32_t* bin_start;   // [H][coarse bins + 1]
   uint32_t* bin_long;    // [H][coarse bins]: the bin holds a bucket longer than group_t (written by step 4 for step 5)
 };
+void launch_query_iota(hipStream_t st, int32_t* qlist, int first, int n);
 int index_tiles(int ne);
 void index_group_params(int64_t entries, InvIndex& ix);   // sets grouped / group_t / class_log for an index of this many entries
 int index_coarse_bins();

@@ -635,6 +635,12 @@ struct QuerySide {
   const int64_t* d_ids;
   const int64_t* h_ids; const int32_t* h_seqlen;
   int64_t n_rows;   // rows of the query tables
+  // Round 6 — device-resident query rows (mhap_find_matches_device, the sharded search): `identity` = every row is a query unless its status
+  // word says "not sketched", which the first tier checks itself; the list is then made on the device and the first kernels are launched
+  // BEFORE the rows' meta words have reached the host.  `prep` (run once, behind the first launch) waits for them and fills h_seqlen / h_valid.
+  bool identity = false;
+  std::function<int(QuerySide&)> prep;
+  const uint8_t* h_valid = nullptr;
 };
 
 // Run candidate + second stage for the query entries in `ql` (entry indices into the query side).
@@ -755,9 +761,27 @@ struct PostStage {
   ~PostStage() { (void)drain(); }
 };
 
-int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>& ql, bool to_self, bool triangular_ok,
+int search_core(mhap_handle* h, QuerySide& qs, const std::vector<int32_t>& ql_in, bool to_self, bool triangular_ok,
                 mhap_record_sink sink, void* user) {
-  if (ql.empty() || h->n_entries == 0) { h->stats.queries_searched += (int64_t)ql.size(); return MHAP_OK; }
+  // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
+  const char* cmode = getenv("MHAP_CANDIDATES");
+  const bool use_index = !(cmode && strcmp(cmode, "bruteforce") == 0);
+  bool prep_done = !qs.prep;
+  auto run_prep = [&]() -> int { if (prep_done) return MHAP_OK; prep_done = true; return qs.prep(qs); };
+  auto count_valid = [&](int64_t a, int64_t n) { int64_t c = 0; for (int64_t e = a; e < a + n; e++) c += qs.h_valid[(size_t)e] ? 1 : 0; return c; };
+  // the list on the device (identity) unless the brute-force tiles want it sorted out on the host, the index is empty, or MHAP_QUERY_LIST_HOST=1 (A/B, tests)
+  bool ident = qs.identity;
+  std::vector<int32_t> ql_made;
+  if (ident && (!use_index || h->n_entries == 0 || getenv("MHAP_QUERY_LIST_HOST"))) {
+    const int rp = run_prep();
+    if (rp != MHAP_OK) return rp;
+    ql_made.reserve((size_t)qs.n_rows);
+    for (int64_t e = 0; e < qs.n_rows; e++) if (qs.h_valid[(size_t)e]) ql_made.push_back((int32_t)e);
+    ident = false;
+  }
+  const std::vector<int32_t>& ql = qs.identity && !ident ? ql_made : ql_in;
+  const int64_t nql = ident ? qs.n_rows : (int64_t)ql.size();
+  if (nql == 0 || h->n_entries == 0) { h->stats.queries_searched += nql; return MHAP_OK; }
   const int S = h->P.ordered_sketch_size;
   SearchParams sp;
   sp.H = h->P.num_hashes; sp.S = S; sp.k2 = h->P.ordered_kmer_size;
@@ -767,8 +791,9 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const int ne = (int)h->n_entries;
   int64_t qchunk = 262144;   // queries per candidate/overlap launch pair (bounds the candidate buffer)
   if (const char* e = getenv("MHAP_QUERY_CHUNK")) { long long v = atoll(e); if (v >= CAND_TQ) qchunk = (v / CAND_TQ) * CAND_TQ; }
-  HIPCHK(h, h->qlist.ensure(ql.size() * 4));
-  HIPCHK(h, hipMemcpyAsync(h->qlist.p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, h->qlist.ensure((size_t)nql * 4));
+  if (ident) { launch_query_iota(h->stream, h->qlist.as<int32_t>(), 0, (int)nql); HIPCHK(h, hipGetLastError()); }
+  else HIPCHK(h, hipMemcpyAsync(h->qlist.p, ql.data(), ql.size() * 4, hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, h->counters.ensure(256));
   unsigned long long* ctr = h->counters.as<unsigned long long>();
   size_t cand_cap = std::max<size_t>(h->cand.cap / sizeof(Candidate), (size_t)4 << 20);
@@ -782,9 +807,6 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   { const char* jw = getenv("MHAP_JOIN_WIDE"); h->join_wide = !jw ? 2 : (jw[0] == '0' ? 0 : (jw[0] == '1' ? 1 : 2)); }
   { const char* jm = getenv("MHAP_JOIN_MODE"); h->join_mode = !jm ? 0 : (strcmp(jm, "alone") == 0 ? 1 : (strcmp(jm, "pair") == 0 ? 2 : (strcmp(jm, "team") == 0 ? 3 : 0))); }
   const int ntu = (ne + CAND_TM - 1) / CAND_TM;
-  // candidate generation: GPU inverted index (default) or brute-force all-pairs (MHAP_CANDIDATES=bruteforce)
-  const char* cmode = getenv("MHAP_CANDIDATES");
-  const bool use_index = !(cmode && strcmp(cmode, "bruteforce") == 0);
   if (use_index) {
     int rcb = ensure_inverted_index(h);
     if (rcb != MHAP_OK) return rcb;
@@ -802,8 +824,8 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
   const char* ppe = getenv("MHAP_SEARCH_PIPELINE");   // "0": the tail of every chunk inline (tests / A-B)
   const bool pipeline = !(ppe && ppe[0] == '0');
   int slot = 0;   // the record buffers (device + host) this chunk's kernels and tail use; flips with every tail handed over
-  for (int64_t c0 = 0, adv = 0; c0 < (int64_t)ql.size(); c0 += adv, chunk_no++) {
-    const int nq = (int)std::min<int64_t>(qchunk, (int64_t)ql.size() - c0);
+  for (int64_t c0 = 0, adv = 0; c0 < nql; c0 += adv, chunk_no++) {
+    const int nq = (int)std::min<int64_t>(qchunk, nql - c0);
     adv = nq;
     const int ntq = (nq + CAND_TQ - 1) / CAND_TQ;
     const long long* d_rowstart = nullptr;
@@ -821,7 +843,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       SCHK(hipMemcpyAsync(h->rowstart.p, rs.data(), rs.size() * 8, hipMemcpyHostToDevice, h->stream));
       SCHK(hipStreamSynchronize(h->stream));  // rs is a stack vector
       d_rowstart = h->rowstart.as<long long>();
-      if (nblocks_tri == 0) { h->stats.queries_searched += nq; continue; }
+      if (nblocks_tri == 0) { h->stats.queries_searched += nq; continue; }   // (never the identity list: that needs the index)
     }
     unsigned long long ncand = 0;
     for (;;) {
@@ -856,6 +878,11 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
         SCHK(hipGetLastError());
         unsigned long long c5[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         SCHK(hipMemcpyAsync(c5, ctr, 72, hipMemcpyDeviceToHost, h->stream));
+        if (!prep_done) {   // (the rows' meta words, under the first tier's time)
+          const int rp = run_prep();
+          if (rp != MHAP_OK) { (void)sync_stream(h); return leave(rp); }
+          HPROF("query meta on the host");
+        }
         int rc = sync_stream(h);
         if (rc != MHAP_OK) return leave(rc);
         HPROF("first query tier done");
@@ -909,7 +936,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
       if (ncand <= cand_cap) break;
       cand_cap = (size_t)ncand + (size_t)(ncand / 4) + 1024;   // overflow: grow and redo this chunk
     }
-    h->stats.queries_searched += nq;
+    h->stats.queries_searched += ident ? count_valid(c0, nq) : (int64_t)nq;
     if (ncand == 0) continue;
     // a candidate-rich search (repeats): smaller chunks from here on — smaller candidate / record buffers, and the tail of a chunk
     // (read-back, conversion, sink: PostStage) hides behind the next chunk's kernels, so less of it is left over at the end
@@ -1060,7 +1087,7 @@ int search_core(mhap_handle* h, const QuerySide& qs, const std::vector<int32_t>&
     h->stats.candidates_compared += (int64_t)counts[2];
     if (nrec == 0) continue;
     // the chunk's tail: inline when it is the last chunk with no worker running (nothing left to hide it behind), else on the worker
-    const bool last = c0 + nq >= (int64_t)ql.size();
+    const bool last = c0 + nq >= nql;
     const int rp = post.submit(slot, nrec, !pipeline || last);
     if (rp != MHAP_OK) return leave(fail(h, rp, post.err));
     slot ^= 1;
@@ -1652,24 +1679,34 @@ static int find_matches_device_impl(mhap_handle* h, const void* d_q_minhash, con
   // the rows' meta words come to the host through the pinned bounce buffer (lengths for the records, statuses for the query list), and
   // the ids go up — unless they are on the device already — while the host walks them: on one rank of eight this preparation was
   // 0.4 ms of a 3.9 ms search
-  const size_t mbytes = (size_t)m * META_W * 4;
-  const int32_t* meta = (const int32_t*)pinned_io(h, mbytes);
-  if (!meta) return fail(h, MHAP_E_HIP, "cannot allocate pinned host memory");
+  // Round 6: the first kernels no longer wait for any of it — the ids are staged through the pinned buffer (an asynchronous copy), the query
+  // list is made on the device, and the meta words are waited for behind the first tier's launch (QuerySide::prep): 0.35 -> 0.06 ms between
+  // the call and the first kernel on one rank of eight.
+  const size_t mbytes = (size_t)m * META_W * 4, idbytes = d_ids_dev ? 0 : (size_t)m * 8;
+  char* pin = (char*)pinned_io(h, mbytes + idbytes);
+  if (!pin) return fail(h, MHAP_E_HIP, "cannot allocate pinned host memory");
+  const int32_t* meta = (const int32_t*)pin;
   if (!d_ids_dev) {
     HIPCHK(h, h->q_ids.ensure((size_t)m * 8));
-    HIPCHK(h, hipMemcpyAsync(h->q_ids.p, ids, (size_t)m * 8, hipMemcpyHostToDevice, h->stream));   // (ordered before the search's kernels)
+    memcpy(pin + mbytes, ids, idbytes);
+    HIPCHK(h, hipMemcpyAsync(h->q_ids.p, pin + mbytes, idbytes, hipMemcpyHostToDevice, h->stream));   // (ordered before the search's kernels)
   }
   HIPCHK(h, hipMemcpyAsync((void*)meta, d_q_meta, mbytes, hipMemcpyDeviceToHost, h->copy_stream));
-  HIPCHK(h, hipStreamSynchronize(h->copy_stream));
   std::vector<int32_t> qlen((size_t)m), ql;
-  ql.reserve((size_t)m);
-  for (int64_t e = 0; e < m; e++) {
-    qlen[(size_t)e] = meta[(size_t)e * META_W + 2];
-    if (meta[(size_t)e * META_W + 3] == 0) ql.push_back((int32_t)e);
-  }
+  std::vector<uint8_t> valid((size_t)m);
   QuerySide qs{(const int32_t*)d_q_minhash, h->Hrow, (const int32_t*)d_q_ordered, 2LL * S, (const int32_t*)d_q_meta,
                d_ids_dev ? d_ids_dev : h->q_ids.as<int64_t>(), ids, qlen.data(), m};
-  return search_core(h, qs, ql, to_self != 0, false, sink, user);
+  qs.identity = true;
+  qs.prep = [&](QuerySide& q) -> int {
+    const hipError_t e = hipStreamSynchronize(h->copy_stream);
+    if (e != hipSuccess) return fail(h, MHAP_E_HIP, std::string("read-back of the query rows' meta words: ") + hipGetErrorString(e));
+    for (int64_t i = 0; i < m; i++) { qlen[(size_t)i] = meta[(size_t)i * META_W + 2]; valid[(size_t)i] = meta[(size_t)i * META_W + 3] == 0 ? 1 : 0; }
+    q.h_valid = valid.data();
+    return MHAP_OK;
+  };
+  const int rcs = search_core(h, qs, ql, to_self != 0, false, sink, user);
+  if (qs.prep) (void)hipStreamSynchronize(h->copy_stream);   // (the copy targets this call's buffers: never left in flight)
+  return rcs;
 }
 
 int mhap_find_matches_device(mhap_handle* h, const void* d_q_minhash, const void* d_q_ordered, const void* d_q_meta, const int64_t* ids,

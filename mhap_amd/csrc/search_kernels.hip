@@ -237,12 +237,12 @@ constexpr int IB_BINS_LOG = MH_IB_BINS_LOG, IB_BINS = 1 << IB_BINS_LOG;   // coa
                                                                           // contiguous bytes (512 bins, 64-byte shares: the scatter took 2.6 ms at C2, its
                                                                           // half-written lines leaving the L2 before their neighbours arrived)
 constexpr int IB_S = 8;                                      // slots of one workgroup (32 bytes of every MinHash row it reads)
-constexpr int IB_TE = 4096;                                  // entries of one tile
+constexpr int IB_TE = 4096;                                  // entries of one tile (index_tile_entries: 1024 for a small index)
 constexpr int IB_THREADS = 256;
 // Steps 1 and 3.  Slot-group-major grid: consecutive workgroups are the tiles of one group of IB_S slots.
 template <bool SCATTER>
 __global__ __launch_bounds__(IB_THREADS) void index_tile_kernel(const int32_t* __restrict__ minhash, int64_t row_stride, const int32_t* __restrict__ meta,
-                                                                int ne, int H, int tiles, InvIndex ix) {
+                                                                int ne, int H, int tiles, int te, InvIndex ix) {
   __shared__ uint32_t bins[IB_S][IB_BINS];
   const int g = (int)(blockIdx.x / (unsigned)tiles), tile = (int)(blockIdx.x % (unsigned)tiles);
   const int sl = (int)(threadIdx.x % IB_S), s = g * IB_S + sl;
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(IB_THREADS) void index_tile_kernel(const int32_t* _
   }
   __syncthreads();
   if (s < H) {
-    const int e1 = min(ne, (tile + 1) * IB_TE);
-    for (int e = tile * IB_TE + (int)(threadIdx.x / IB_S); e < e1; e += IB_THREADS / IB_S) {
+    const int e1 = min(ne, (tile + 1) * te);
+    for (int e = tile * te + (int)(threadIdx.x / IB_S); e < e1; e += IB_THREADS / IB_S) {
       if (meta[(int64_t)e * META_W + 3] != 0) continue;                  // skipped strands are not stored (addSequence never sees them)
       const uint32_t hv = inv_mix((uint32_t)minhash[(int64_t)e * row_stride + s]);
       const uint32_t at = atomicAdd(&bins[sl][hv >> (32 - IB_BINS_LOG)], 1u);
@@ -347,9 +347,14 @@ __global__ __launch_bounds__(IL_THREADS) void index_lines_kernel(InvIndex ix, in
 }
 // Step 4, one workgroup per (slot, bin): the bin's postings move from `staged` to `items` grouped by bucket; the buckets' ends are
 // written (ends[s][0] = 0 by bin 0).  sub = buckets per bin (a power of two, <= IB_SUB_MAX).
-constexpr int IB_SUB_MAX = 8192, IB_FIN_THREADS = 256;
+// (Round 6: the kernel is compiled for three sizes of a bin.  It used to reserve the counters of the largest — 32 KB, five workgroups of 256 lanes
+//  per CU — whatever the index: one rank's shard of an 8-GPU job at C2 has 256 buckets and ~195 postings per (slot, bin), 65 536 workgroups of
+//  which 1 280 were resident, most of their lanes without a posting: 0.46 ms where an eighth of the one-GPU build is 0.16.  Small bins now take one
+//  wavefront and 2 KB each, 32 of them per CU.)
+constexpr int IB_SUB_MAX = 8192;
+template <int SUBCAP, int IB_FIN_THREADS>
 __global__ __launch_bounds__(IB_FIN_THREADS) void index_bins_kernel(InvIndex ix) {
-  __shared__ uint32_t cnt[IB_SUB_MAX];
+  __shared__ uint32_t cnt[SUBCAP];
   __shared__ uint32_t wsum[IB_FIN_THREADS / 64];
   __shared__ uint32_t s_carry, s_long;
   const int s = blockIdx.x >> IB_BINS_LOG, bin = blockIdx.x & (IB_BINS - 1);
@@ -539,18 +544,33 @@ void launch_index_verify(hipStream_t st, const int32_t* minhash, int64_t row_str
     hipLaunchKernelGGL(index_verify_lines_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, minhash, row_stride, meta, ne, H, ix, missing);
 }
 
-int index_tiles(int ne) { return (ne + IB_TE - 1) / IB_TE; }
+// (Round 6: a small index — one rank's shard of an 8-GPU job at C2: 25 000 entries — had 7 tiles x 64 slot groups = 448 workgroups for 256 CUs;
+//  tiles of 1 024 entries give it four times as many.  Their shares of a bin are 64 bytes: the scatter's half-written lines — what made 512
+//  coarse bins slow at C2 — meet in the caches while the whole staging area is a few hundred MB.)
+static int index_tile_entries(int ne) {
+  static const int force = []() { const char* e = getenv("MHAP_INDEX_TILE"); const int v = e ? atoi(e) : 0; return v >= 256 && v <= IB_TE ? v : 0; }();
+  return force ? force : (ne <= 65536 ? 1024 : IB_TE);
+}
+int index_tiles(int ne) { const int te = index_tile_entries(ne); return (ne + te - 1) / te; }
 int index_coarse_bins() { return IB_BINS; }
 int index_max_buckets_log() { return IB_BINS_LOG + 13; }   // IB_SUB_MAX buckets per coarse bin
 // (re)build the index for entries [0, ne): ix.ends / items / staged / tile_counts / bin_start sized by the caller (index_tiles)
 void launch_index_build(hipStream_t st, const int32_t* minhash, int64_t row_stride, const int32_t* meta, int ne, int H, const InvIndex& ix) {
   if ((int64_t)ne * H <= 0) return;
-  const int tiles = index_tiles(ne);
+  const int tiles = index_tiles(ne), te = index_tile_entries(ne);
   const unsigned grid = (unsigned)tiles * (unsigned)((H + IB_S - 1) / IB_S);
-  hipLaunchKernelGGL(index_tile_kernel<false>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
+  hipLaunchKernelGGL(index_tile_kernel<false>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, te, ix);
   hipLaunchKernelGGL(index_offsets_kernel, dim3((unsigned)H), dim3(IB_BINS), 0, st, ix, tiles);
-  hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, ix);
-  hipLaunchKernelGGL(index_bins_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_FIN_THREADS), 0, st, ix);
+  hipLaunchKernelGGL(index_tile_kernel<true>, dim3(grid), dim3(IB_THREADS), 0, st, minhash, row_stride, meta, ne, H, tiles, te, ix);
+  {
+    const int sub = (int)(ix.nb >> IB_BINS_LOG);
+    const dim3 g((unsigned)H << IB_BINS_LOG);
+    static const int force = []() { const char* e = getenv("MHAP_INDEX_BINS_SHAPE"); return e ? atoi(e) : -1; }();   // 0 / 1 / 2: pin a shape that fits (A/B)
+    const int shape = force >= 0 ? force : (sub <= 512 ? 0 : (sub <= 2048 ? 1 : 2));
+    if (shape == 0 && sub <= 512) hipLaunchKernelGGL((index_bins_kernel<512, 64>), g, dim3(64), 0, st, ix);
+    else if (shape <= 1 && sub <= 2048) hipLaunchKernelGGL((index_bins_kernel<2048, 256>), g, dim3(256), 0, st, ix);
+    else hipLaunchKernelGGL((index_bins_kernel<IB_SUB_MAX, 256>), g, dim3(256), 0, st, ix);
+  }
   if (ix.grouped) hipLaunchKernelGGL(index_group_kernel, dim3((unsigned)H << IB_BINS_LOG), dim3(IB_GRP_THREADS), 0, st, ix);
   if (ix.lines) {
     const size_t threads = (size_t)H << ix.nl_log;
@@ -632,6 +652,7 @@ __global__ __launch_bounds__(IQ_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8
   if (qi >= nq) return;
   const int qe = qlist[qi];
   const int32_t* qm = qmeta + (int64_t)qe * META_W;
+  if (qm[3] != 0) return;   // (a strand that was not sketched is no query: a list made on the device — launch_query_iota — names every row)
   const int64_t qid = qids[qe];
   const int qlen = qm[2];
   const int32_t* qrow = qminhash + (int64_t)qe * qrow_stride;
@@ -1101,6 +1122,7 @@ __global__ __launch_bounds__(DQ_THREADS) void index_query_dense_kernel(InvIndex 
   if (qi >= nq) return;
   const int qe = qlist[qi];
   const int32_t* qm = qmeta + (int64_t)qe * META_W;
+  if (qm[3] != 0) return;   // (a strand that was not sketched is no query: a list made on the device — launch_query_iota — names every row)
   const int64_t qid = qids[qe];
   const int qlen = qm[2];
   const int32_t* qrow = qminhash + (int64_t)qe * qrow_stride;
@@ -1247,6 +1269,7 @@ __global__ __launch_bounds__(DQ2_THREADS) void index_query_dense4_kernel(InvInde
   if (qi >= nq) return;
   const int qe = qlist[qi];
   const int32_t* qm = qmeta + (int64_t)qe * META_W;
+  if (qm[3] != 0) return;   // (a strand that was not sketched is no query: a list made on the device — launch_query_iota — names every row)
   const int64_t qid = qids[qe];
   const int qlen = qm[2];
   const int32_t* qrow = qminhash + (int64_t)qe * qrow_stride;
@@ -1476,6 +1499,16 @@ bool index_query_tier_ok(int tier, int64_t entries, int num_min_matches) {
 #define MH_IQ_MID_THREADS 256
 #endif
 constexpr int INV_CT_MID = MH_IQ_MID_CT, IQ_THREADS_MID = MH_IQ_MID_THREADS;
+// the query list "every row": qlist[i] = first + i (the kernels above skip the rows whose status says "not sketched").  Round 6: the search of
+// device-resident query rows used to wait for the rows' meta words on the host, a host loop over them and the upload of the list it made
+// before its first kernel: 0.35 ms of a 2.1-ms search on one rank of eight.
+__global__ __launch_bounds__(256) void query_iota_kernel(int32_t* __restrict__ qlist, int first, int n) {
+  const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (i < n) qlist[i] = first + i;
+}
+void launch_query_iota(hipStream_t st, int32_t* qlist, int first, int n) {
+  if (n > 0) hipLaunchKernelGGL(query_iota_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qlist, first, n);
+}
 void launch_index_query(hipStream_t st, const InvIndex& ix, const int32_t* qminhash, int64_t qrow_stride,
                         const int32_t* qlist, int nq, const int64_t* ids, const int64_t* qids, const int32_t* meta, const int32_t* qmeta,
                         const SearchParams& sp, Candidate* cand, unsigned long long* cand_count, unsigned long long cand_cap,
