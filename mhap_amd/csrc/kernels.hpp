@@ -97,7 +97,7 @@ void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads);
 size_t ordered_lds_bytes(int cap, int code_words, int stage_wide);
 void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len_codes, int max_len, const int32_t* h32,
                     const uint8_t* store, const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_meta, int64_t meta_stride);
+                    int32_t* out_meta, int64_t meta_stride, int64_t first = 0, int64_t count = -1);
 
 // ---- search_kernels.hip ----
 // All-pairs slot-equality count between query entries qlist[0..nq) and index entries [0..ne).

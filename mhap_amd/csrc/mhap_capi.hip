@@ -528,21 +528,57 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     //  through the persistent MinHash grid's slots for 60-90 ms and slows that kernel by what it gains; the weight kernel and it both
     //  live on the LDS pipe.  One stream it is.)
     const hipStream_t ost = h->stream;
-    auto do_ordered = [&]() -> int {
+    auto do_ordered = [&](int64_t first, int64_t count) -> int {
       time_begin(h, MHAP_K_ORDERED, ost);
       launch_ordered(ost, dd, nstr, max_len_codes, B.max_len, h->h32.as<int32_t>(), h->store.as<uint8_t>(), h->hash_luts.as<uint64_t>(), k2, S, h->ord_cap,
-                     ord_rows, ord_stride, meta_rows, META_W);
+                     ord_rows, ord_stride, meta_rows, META_W, first, count);
       time_end(h, ost);
       return MHAP_OK;
     };
+    // Round 6: PART of the ordered kernel runs between the weight kernel's read-back and the weight-1 MinHash launch, and the weighted strands'
+    // MinHash launch (its own stream) runs NEXT TO THAT PART instead of next to the weight-1 launch's start.  Measured, not derived (EXPERIMENTS.md,
+    // round 6, "the MinHash launch's clock"): the weight-1 launch of C2 — 75 ms at the card's power limit — holds whatever clock the power
+    // management settles on when it starts.  Started into an idle GPU (the read-back is a host round trip) together with the weighted launch it held
+    // 1 820-2 126 MHz from step to step; started alone, right behind a running, moderately busy kernel, 2 164-2 179 MHz every time
+    // (MHAP_MINHASH_PROF): 76.2-76.8 -> 72.1-72.4 ms, the C2 step 93.4-94.6 -> 90.5-91.3 ms on one box.  With the weighted launch made to wait for
+    // the ordered part the gain is gone (76.1-76.3); behind memory fills the clock is 1 800; with an idle gap behind the ordered part 1 850-2 030.
+    // The rest of the strands' ordered rows are made behind the MinHash launch, next to the index build as before (the build takes about as long as
+    // 0.45 of the ordered kernel beside it).  Only where a LONG weight-1 launch is the job: a launch group of 0.9 G bases of reads or more (a
+    // MinHash launch of 60 ms and more: C2 on one GPU, the launch groups of C4) with at most a fifth of the strands weighted.  Shorter launches
+    // lose by it — one rank's share of an N-GPU C2 job, same box, alternating: N = 2 / 4 / 8 rank step 50.5 -> 50.7 / 26.85 -> 27.6 / 14.8 -> 15.2 ms —
+    // and a -f run's strands are all weighted (its MinHash launch would run under the ordered part from the start: c5slice 180.3 -> 180.5 / 184.6).
+    // MHAP_ORDERED_SPLIT = per cent of the strands in the first part (0 = rounds 1-5's order, 100 = all of them); MHAP_ORDERED_NOWAIT=0 makes the
+    // weighted launch wait for the first part; MHAP_ORDERED_FIRST=1 / 2 = all of it first / and an idle gap behind it (the experiments).
+    static const int ord_first_env = []() { const char* e = getenv("MHAP_ORDERED_FIRST"); return e ? atoi(e) : 0; }();
+    static const int ord_split_env = []() { const char* e = getenv("MHAP_ORDERED_SPLIT"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();
+    int64_t batch_read_bases = 0;
+    for (int64_t i = 0; i < nb; i++) batch_read_bases += h->h_descs[(size_t)i].length;
+    const bool split_pays = batch_read_bases >= 900000000LL && (int64_t)lens[0] >= 4 * (int64_t)lens[1];
+    int64_t ord_pre = ord_first_env ? nstr : (nstr * (int64_t)(ord_split_env >= 0 ? ord_split_env : (split_pays ? 55 : 0))) / 100;
+    ord_pre &= ~(int64_t)1;   // (both strands of a read in one part)
     bool ordered_done = false;
+    if (ord_pre > 0 && !eager_x) {
+      (void)do_ordered(0, ord_pre);
+      ordered_done = ord_pre >= nstr;
+      static const int nowait = []() { const char* e = getenv("MHAP_ORDERED_NOWAIT"); return e ? atoi(e) : 1; }();
+      if (!nowait) {
+        HIPCHK(h, hipEventRecord(h->ev_mh_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->mh_stream, h->ev_mh_fork, 0));
+      }
+    } else ord_pre = 0;
     if (eager_x) {
       // eager exchange: the ordered rows first (they do not depend on the MinHash rows), so that their all-gather — 6/7 of the bytes
       // a rank sends — runs under the MinHash kernel; its copy engines / RCCL workgroups are in place before the persistent grid starts
-      (void)do_ordered();
+      (void)do_ordered(0, nstr);
       ordered_done = true;
       const int rxo = dist_eager_ordered(h, h->stream, ord_rows);
       if (rxo != MHAP_OK) return rxo;
+    }
+    {   // experiments (round 6, EXPERIMENTS.md "the MinHash launch's clock"): MHAP_ORDERED_FIRST=2 = an idle gap between the ordered kernel and the
+        // MinHash launch; MHAP_W1_PREFILL=n = n fills of the queue buffer in front of the MinHash launch (it is enqueued behind running work)
+      static const int prefill = []() { const char* e = getenv("MHAP_W1_PREFILL"); return e ? atoi(e) : 0; }();
+      if (ord_first_env == 2) (void)hipStreamSynchronize(h->stream);
+      for (int i = 0; i < prefill; i++) (void)hipMemsetAsync(h->mhq.p, 0, h->mhq.cap, h->stream);
     }
     const size_t t_mh = time_begin(h, MHAP_K_MINHASH);
     const bool mh_forked = launch_minhash(h->stream, h->mh_stream, mblocks, (int64_t)lens[0], (int64_t)lens[1], dd, nstr, h->keys.as<int64_t>(), h->wts.as<uint32_t>(),
@@ -566,7 +602,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
       HIPCHK(h, hipEventRecord(h->ev_ix_join, h->mh_stream));
       eager_launched = true;
     }
-    if (!ordered_done) (void)do_ordered();
+    if (!ordered_done) (void)do_ordered(ord_pre, nstr - ord_pre);
     DBGSYNC(h, "ordered");
     HIPCHK(h, hipGetLastError());
     if (eager_launched) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_ix_join, 0));

@@ -2195,7 +2195,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
                                                               const int32_t* __restrict__ h32, const uint8_t* __restrict__ store,
                                                               const uint64_t* __restrict__ luts, int code_words, int stage_wide, int k2, int S, int cap,
                                                               int32_t* __restrict__ out_rows, int64_t out_stride,
-                                                              int32_t* __restrict__ out_meta, int64_t meta_stride) {
+                                                              int32_t* __restrict__ out_meta, int64_t meta_stride, int64_t first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* hist = (uint32_t*)smem;                       // ORD_BINS
   uint32_t* part = hist + ORD_BINS;                       // ORD_THREADS partial sums
@@ -2212,7 +2212,7 @@ __global__ __launch_bounds__(ORD_THREADS) void ordered_kernel(const ReadDesc* __
   uint64_t* lut = (uint64_t*)(smem + lut_off);
   uint32_t* codes = (uint32_t*)(lut + 256);
   uint32_t& s_bin = svars[0]; uint32_t& s_below = svars[1]; uint32_t& s_cnt = svars[2]; uint32_t& s_fill = svars[3];
-  const int64_t strand = blockIdx.x;
+  const int64_t strand = first + (int64_t)blockIdx.x;   // (a launch covers the strands [first, first + gridDim.x): sketch_staged runs the kernel in two parts)
   if (strand >= nstrands) return;
 #ifdef MH_ORD_PROF
   unsigned long long ord_t0 = wall_clock64();
@@ -2576,12 +2576,14 @@ void launch_fix_status(hipStream_t st, int32_t* meta, int64_t nreads) {
 // max_len = longest read of the launch
 void launch_ordered(hipStream_t st, const ReadDesc* descs, int64_t nstrands, int max_len_codes, int max_len, const int32_t* h32,
                     const uint8_t* store, const uint64_t* luts, int k2, int S, int cap, int32_t* out_rows, int64_t out_stride,
-                    int32_t* out_meta, int64_t meta_stride) {
-  if (nstrands <= 0) return;
+                    int32_t* out_meta, int64_t meta_stride, int64_t first, int64_t count) {
+  // strands [first, first + count) of the launch's nstrands (count < 0: all of them from `first` on)
+  if (count < 0 || first + count > nstrands) count = nstrands - first;
+  if (nstrands <= 0 || count <= 0) return;
   const int code_words = max_len_codes > 0 ? (max_len_codes + 15) / 16 + 4 : 0;
   const int stage_wide = max_len - k2 + 1 > 65535 ? 1 : 0;
-  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)nstrands), dim3(ORD_THREADS), ordered_lds_bytes(cap, code_words, stage_wide), st, descs, nstrands, h32,
-                     store, luts, code_words, stage_wide, k2, S, cap, out_rows, out_stride, out_meta, meta_stride);
+  hipLaunchKernelGGL(ordered_kernel, dim3((unsigned)count), dim3(ORD_THREADS), ordered_lds_bytes(cap, code_words, stage_wide), st, descs, nstrands, h32,
+                     store, luts, code_words, stage_wide, k2, S, cap, out_rows, out_stride, out_meta, meta_stride, first);
 #ifdef MH_ORD_PROF
   (void)hipStreamSynchronize(st);
   unsigned long long hp[8];
