@@ -549,8 +549,9 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     // and a -f run's strands are all weighted (its MinHash launch would run under the ordered part from the start: c5slice 180.3 -> 180.5 / 184.6).
     // MHAP_ORDERED_SPLIT = per cent of the strands in the first part (0 = rounds 1-5's order, 100 = all of them); MHAP_ORDERED_NOWAIT=0 makes the
     // weighted launch wait for the first part; MHAP_ORDERED_FIRST=1 / 2 = all of it first / and an idle gap behind it (the experiments).
-    static const int ord_first_env = []() { const char* e = getenv("MHAP_ORDERED_FIRST"); return e ? atoi(e) : 0; }();
-    static const int ord_split_env = []() { const char* e = getenv("MHAP_ORDERED_SPLIT"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();
+    // (read at every launch group: tests switch them inside one process)
+    const int ord_first_env = []() { const char* e = getenv("MHAP_ORDERED_FIRST"); return e ? atoi(e) : 0; }();
+    const int ord_split_env = []() { const char* e = getenv("MHAP_ORDERED_SPLIT"); const int v = e ? atoi(e) : -1; return v > 100 ? 100 : v; }();
     int64_t batch_read_bases = 0;
     for (int64_t i = 0; i < nb; i++) batch_read_bases += h->h_descs[(size_t)i].length;
     const bool split_pays = batch_read_bases >= 900000000LL && (int64_t)lens[0] >= 4 * (int64_t)lens[1];
@@ -560,7 +561,7 @@ int sketch_staged(mhap_handle* h, int32_t* d_minhash, int64_t mh_stride, int32_t
     if (ord_pre > 0 && !eager_x) {
       (void)do_ordered(0, ord_pre);
       ordered_done = ord_pre >= nstr;
-      static const int nowait = []() { const char* e = getenv("MHAP_ORDERED_NOWAIT"); return e ? atoi(e) : 1; }();
+      const int nowait = []() { const char* e = getenv("MHAP_ORDERED_NOWAIT"); return e ? atoi(e) : 1; }();
       if (!nowait) {
         HIPCHK(h, hipEventRecord(h->ev_mh_fork, h->stream));
         HIPCHK(h, hipStreamWaitEvent(h->mh_stream, h->ev_mh_fork, 0));

@@ -267,6 +267,59 @@ def test_search_with_query_sketches_already_in_device_memory():
     assert len(want) > 100 and got == want and cnt == len(want)
 
 
+def test_ordered_kernel_in_two_launches_and_the_host_made_query_list(monkeypatch):
+    """Round 6: (a) long weight-1 launches run the ordered kernel in two parts, one in front of the MinHash launch (with the weighted strands'
+    launch beside it) and one behind it — forced here on a small data set with repeats (so that there ARE weighted strands), for every split
+    incl. an odd one and with the weighted launch waiting; sketches and records must not notice.  (b) the search of device-resident rows
+    with its query list made on the host, as rounds 1-5 did (MHAP_QUERY_LIST_HOST=1), gives the device-made list's records — with rows
+    that were not sketched (too short) among the queries."""
+    import torch
+    fa0 = mhap_amd.synth_reads(260, 4000, seed=4242, error_rate=0.05, repeats=(300, 1500, 0.01))
+    short = mhap_amd.synth_reads(6, 100, seed=5, error_rate=0.05)     # below the minimum overlap length (116): status 2, no query
+    bases = np.concatenate([fa0.bases, short.bases]); lengths = np.concatenate([fa0.lengths, short.lengths])
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    fa = mhap_amd.FastaData(bases, offsets, lengths.astype(np.int32), np.arange(len(lengths), dtype=np.int64) + 1)
+    p = MhapParams(num_hashes=128, ordered_sketch_size=512, device=0)
+    want = O.record_lines(O.run_self(fa, H=128, S=512, nthreads=8)["records"])
+    assert len(want) > 100
+    n, H, S = len(fa), 128, 512
+    dev = torch.device("cuda", 0)
+    ref = None
+    for env in ({"MHAP_ORDERED_SPLIT": "0"}, {"MHAP_ORDERED_SPLIT": "55"}, {"MHAP_ORDERED_SPLIT": "33"}, {"MHAP_ORDERED_SPLIT": "100"},
+                {"MHAP_ORDERED_SPLIT": "55", "MHAP_ORDERED_NOWAIT": "0"}, {"MHAP_ORDERED_FIRST": "1"}):
+        for k in ("MHAP_ORDERED_SPLIT", "MHAP_ORDERED_NOWAIT", "MHAP_ORDERED_FIRST"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mh = torch.empty((2 * n, H), dtype=torch.int32, device=dev); od = torch.full((2 * n, S, 2), -7, dtype=torch.int32, device=dev)
+        mt = torch.empty((2 * n, 4), dtype=torch.int32, device=dev)
+        with MinHashSearch(p) as ms:
+            ms.stage(fa); ms.sketch_staged_device(mh.data_ptr(), od.data_ptr(), mt.data_ptr()); ms.synchronize()
+            tabs = (mh.cpu().numpy().copy(), od.cpu().numpy().copy(), mt.cpu().numpy().copy())
+            ms.add_staged()
+            assert sorted(mhap_amd.records_to_lines(ms.find_matches())) == want, env
+            if ref is None:
+                ref = tabs
+                q = (mh[0::2].contiguous(), od[0::2].contiguous(), mt[0::2].contiguous())
+                assert int((q[2][:, 3] != 0).sum()) >= 6                      # the short reads' rows are among the queries
+                dev_list = sorted(mhap_amd.records_to_lines(ms.find_matches_device(q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), fa.ids, to_self=True)))
+                st0 = ms.stats()["queries_searched"]
+                monkeypatch.setenv("MHAP_QUERY_LIST_HOST", "1")
+                host_list = sorted(mhap_amd.records_to_lines(ms.find_matches_device(q[0].data_ptr(), q[1].data_ptr(), q[2].data_ptr(), fa.ids, to_self=True)))
+                st1 = ms.stats()["queries_searched"]
+                monkeypatch.delenv("MHAP_QUERY_LIST_HOST")
+                assert dev_list == want and host_list == want
+                assert st1 - st0 == n - 6 and st0 > 0                        # both paths count the sketched rows only
+            else:
+                for a, b, name in zip(ref, tabs, ("minhash", "ordered", "meta")):
+                    sized = tabs[2][:, 0]                                    # ordered rows are defined up to their size (meta word 0)
+                    if name == "ordered":
+                        for e in range(2 * n):
+                            assert np.array_equal(a[e, :sized[e]], b[e, :sized[e]]), (env, e)
+                    else:
+                        assert np.array_equal(a, b), (env, name)
+
+
 def test_group_of_ranks_on_one_device_matches_the_oracle(monkeypatch):
     """The multi-GPU path inside the library (mhap_group_*: reads dealt round-robin, one index shard per rank, forward query rows
     gathered by peer copies, every rank scoring all queries against its shard under the toSelf id rules) with 2, 3 and 4 ranks
