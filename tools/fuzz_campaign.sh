@@ -3,7 +3,7 @@
 R=${ROUND:-r06}
 mkdir -p gpurun_out/$R
 OUT=gpurun_out/$R/${R}_fuzz_summary.txt
-echo "# tests/fuzz_parity.py against the round-6 kernels (line table of the first and middle query tiers with queued hits, wave-reduced elements counter, seeded MinHash row items, join kernel's wide units compiled alone, tagged rendezvous), run on an MI355X box:" > $OUT
+echo "# tests/fuzz_parity.py against the round-6 kernels (line table of the first and middle query tiers with queued hits, wave-reduced elements counter, seeded MinHash row items, join kernel's wide units compiled alone, tagged rendezvous, small-shard index build shapes, the ordered kernel's two launches), run on an MI355X box:" > $OUT
 run() {  # draws seed label env...
   n=$1; seed=$2; label=$3; shift 3
   f=$(env "$@" timeout 3000 python tests/fuzz_parity.py $n $seed 2>/dev/null | tail -1)
@@ -22,5 +22,9 @@ run ${N6:-80} 55000 "128-query chunks (post stage on the worker thread)" MHAP_QU
 run ${N7:-80} 56000 "dense tier, class-ordered, 64-entry passes" MHAP_INDEX_DENSE=1 MHAP_INDEX_GROUP=1 MHAP_INDEX_GROUP_T=4 MHAP_INDEX_CLASS_LOG=6 MHAP_DENSE_RANGE_LOG=6
 
 run ${N8:-150} 70000 "FUZZ_WIDE corners (--num-hashes 700 .. 4096, --ordered-sketch-size 1 .. 8192, numMinMatches to 200)" FUZZ_WIDE=1
+run ${NS1:-150} 92000 "ordered kernel in two launches forced on these small jobs (MHAP_ORDERED_SPLIT=55, the weighted MinHash launch beside the first)" MHAP_ORDERED_SPLIT=55
+run ${NS2:-100} 93000 "the same with the weighted launch waiting, odd split (MHAP_ORDERED_SPLIT=33 MHAP_ORDERED_NOWAIT=0)" MHAP_ORDERED_SPLIT=33 MHAP_ORDERED_NOWAIT=0
+run ${NS3:-100} 94000 "index build: 256-entry tiles, the 8-KB bins shape (MHAP_INDEX_TILE=256 MHAP_INDEX_BINS_SHAPE=1)" MHAP_INDEX_TILE=256 MHAP_INDEX_BINS_SHAPE=1
+run ${NS4:-60} 95000 "index build: 4096-entry tiles, the 32-KB bins shape (rounds 1-5)" MHAP_INDEX_TILE=4096 MHAP_INDEX_BINS_SHAPE=2
 run ${N9:-100} 91000 "wide join passes off (MHAP_JOIN_WIDE=0: the lane kernel with its bounded selection takes every pair of more than 128 joined k-mers)" MHAP_JOIN_WIDE=0
 cat $OUT

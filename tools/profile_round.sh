@@ -34,7 +34,15 @@ for c in c4slice c5slice; do timeout 600 python bench.py --config $c > gpurun_ou
 # configs[3] in full and one rank's share of configs[4] on one GPU, one rank of an N-GPU job (gathered rows of the other ranks in HBM), the native driver end to end
 timeout 900 python bench.py --config c4 --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c4.json 2>/dev/null
 timeout 1200 python bench.py --config c5rank --steps 2 --warmup 1 > gpurun_out/$R/${R}_bench_c5rank.json 2>/dev/null
-(for n in 2 4 8; do python tools/emulate_rank.py $n c2 4 2>/dev/null | tail -1; done; python tools/emulate_rank.py 8 c4 3 2>/dev/null | tail -1; python tools/emulate_rank.py 8 c5 1 count 2>/dev/null | tail -1) > gpurun_out/$R/${R}_emulate_rank.txt
+# (medians over the iterations after the first; the last C2 line: the eager add's kernel order — the ordered kernel in front of the MinHash launch, what a real N-GPU run does for its exchange)
+(for n in 2 4 8; do python tools/emulate_rank.py $n c2 10 2>/dev/null | tail -1; done; python tools/emulate_rank.py 8 c4 4 2>/dev/null | tail -1; python tools/emulate_rank.py 8 c5 1 count 2>/dev/null | tail -1
+ echo "# N = 8 at C2 with MHAP_ORDERED_FIRST=1 (the eager add's kernel order)"; MHAP_ORDERED_FIRST=1 python tools/emulate_rank.py 8 c2 10 2>/dev/null | tail -1) > gpurun_out/$R/${R}_emulate_rank.txt
+# round 6: the MinHash launch's clock by what runs in front of it (final source; alternating): rounds 1-5's order, the shipped split, all of the ordered kernel first
+(for rep in 1 2 3; do for v in "MHAP_ORDERED_SPLIT=0" "MHAP_ORDERED_SPLIT=55" "MHAP_ORDERED_SPLIT=100"; do
+   echo "== $v"; env $v MHAP_MINHASH_PROF=1 timeout 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --soak-seconds 0 2>&1 >/dev/null | grep "w1 prof\] launch" | tail -3
+   env $v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --soak-seconds 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('step', d['ms_per_step'], d['kernel_ms_per_step'])"
+ done; done) > gpurun_out/$R/${R}_minhash_clock_order_final.txt 2>&1
+(echo "# tools/w1_clock_probe.py 8 c2 on the final source: [add wall ms, MinHash kernel ms] after 100 ms of idle / behind one add / behind three adds"; timeout 600 python tools/w1_clock_probe.py 8 c2 2>/dev/null | tail -1) > gpurun_out/$R/${R}_w1_clock_probe_final.txt
 (bash tools/e2e_probe.sh c2; bash tools/e2e_probe.sh c4) > gpurun_out/$R/${R}_e2e_probe.txt 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -o p --output-format csv -- python bench.py --no-cpu-baseline --steps 1 --warmup 1 --config c5rank > /dev/null 2>&1
 cp $(find /tmp/prof_c5 -name '*kernel_stats.csv' | head -1) gpurun_out/$R/${R}_rocprofv3_kernel_stats_c5rank.csv
