@@ -35,7 +35,7 @@ def main():
     rep = {
         "WEIGHT_MS": f"{k['kmer_weight']:.2f}", "WEIGHT_CEIL": ceil("kmer_weight"),
         "MINHASH_MS": f"{k['minhash']:.1f}", "MINHASH_CEIL": ceil("minhash") + f"; {v['xorshift_steps_per_s']:.3g} chain steps/s = {v['frac_of_spec_ceiling']:.2f} of the spec-clock ceiling, {v['frac_of_measured_ceiling']:.2f} of the measured-clock one",
-        "ORDERED_MS": f"{k['ordered']:.2f} (next to the index build)", "ORDERED_CEIL": ceil("ordered"),
+        "ORDERED_MS": f"{k['ordered']:.2f} (both launches, the weighted MinHash launch inside the first's time)", "ORDERED_CEIL": ceil("ordered"),
         "IBUILD_MS": f"{k['index_build']:.2f}", "IBUILD_CEIL": ceil("index_build"),
         "IQUERY_MS": f"{k['index_query']:.2f}", "IQUERY_CEIL": ceil("index_query"),
         "JOIN_MS": f"{k['overlap']:.2f}", "STAGE2": f"{s2['frac']:.2f} of HBM peak ({s2['achieved'] / 1e3:.2f} TB/s algorithmic, {s2['pairs_per_s'] / 1e6:.0f} M pairs/s); " + ceil("overlap"),
@@ -86,7 +86,9 @@ def main():
     rep["R8C2EAGER"] = f"{eager[-1]['rank_step_ms_without_comm']:.1f}" if len(eager) > 1 else "not measured"
     rep["N8_OVERLAPS"] = f"{b['records_per_step'] / ((r8['c2']['rank_step_ms_without_comm'] + 0.4) * 1e-3) / 1e6:.2f} M"
     rep["N1_OVERLAPS"] = f"{b['value'] / 1e6:.3f} M"
-    rep["SPEEDUP"] = f"{b['ms_per_step']:.1f} / ({r8['c2']['rank_step_ms_without_comm']:.1f} + 0.4 exposed) = **{b['ms_per_step'] / model:.1f}×** (a model until a real run; C4: {one['c4'] / r8['c4']['rank_step_ms_without_comm']:.1f}× before the exchange)"
+    eager_part = (f"; with the eager add's kernel order, which is what a real run executes: {b['ms_per_step']:.1f} / ({eager[-1]['rank_step_ms_without_comm']:.1f} + 0.4) = **{b['ms_per_step'] / (eager[-1]['rank_step_ms_without_comm'] + 0.4):.1f}×**"
+                  if len(eager) > 1 else "")
+    rep["SPEEDUP"] = f"{b['ms_per_step']:.1f} / ({r8['c2']['rank_step_ms_without_comm']:.1f} + 0.4 exposed) = **{b['ms_per_step'] / model:.1f}×**{eager_part} (a model until a real run; C4: {one['c4'] / r8['c4']['rank_step_ms_without_comm']:.1f}× before the exchange)"
     text = open(tmpl).read()
     for inc in ("LIMITS", "SWITCHES", "LAYOUT"):
         pth = os.path.join(os.path.dirname(tmpl), f"DESIGN.{inc.lower()}.md")
