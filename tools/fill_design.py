@@ -70,6 +70,7 @@ def main():
         if r["world"] == 8:
             r8[r["config"]] = r
     rep["RANKTABLE"] = "\n".join(rows)
+    rep["C5HBM"] = f"{r8['c5']['hbm_gb']['in_use']:.0f}" if "c5" in r8 else "?"
     rep["RANK8"] = "C2 %.1f ms, C4 %.0f ms, C5 %.1f s" % (r8["c2"]["rank_step_ms_without_comm"], r8["c4"]["rank_step_ms_without_comm"], r8["c5"]["rank_step_ms_without_comm"] / 1e3)
     model = r8["c2"]["rank_step_ms_without_comm"] + 0.4
     rep["R8C2"] = f"{r8['c2']['rank_step_ms_without_comm']:.1f}"
