@@ -2,10 +2,10 @@
 # (random flags, read mixes, repeat families, -f filters; sorted record lines GPU vs oracle; every line: draws, setting, failures)
 R=${ROUND:-r06}
 mkdir -p gpurun_out/$R
-OUT=gpurun_out/$R/${R}_fuzz_summary.txt
+OUT=gpurun_out/$R/${R}_fuzz_${FUZZ_TAG:-summary}.txt
 echo "# tests/fuzz_parity.py against the round-6 kernels (line table of the first and middle query tiers with queued hits, wave-reduced elements counter, seeded MinHash row items, join kernel's wide units compiled alone, tagged rendezvous, small-shard index build shapes, the ordered kernel's two launches), run on an MI355X box:" > $OUT
 run() {  # draws seed label env...
-  n=$1; seed=$2; label=$3; shift 3
+  n=$1; seed=$(( $2 + ${SEED_OFFSET:-0} )); label=$3; shift 3   # (SEED_OFFSET: a second campaign with draws of its own)
   f=$(env "$@" timeout 3000 python tests/fuzz_parity.py $n $seed 2>/dev/null | tail -1)
   echo "$n draws, $label: $f" >> $OUT
 }
